@@ -1,0 +1,16 @@
+"""fgoicp_amd — MI355X-native (gfx950) Go-ICP hot path behind the reference's operator interface.
+
+    Registration / IterativeClosestPoint3D / FastGoICP   mirror icp::* of solemnwind/fast-go-icp
+    libfgoicp_amd.so                                    C ABI (include/fgoicp_amd.h), hand-written HIP
+
+There is no CPU implementation in this package: every operator raises if the HIP library is
+missing or no MI355X is visible."""
+from . import _lib, build, nodes, synth  # noqa: F401
+from ._lib import (FLAG_NO_MORTON, FLAG_NO_WEIGHT_QUANT, FLAG_PROFILE, SCHEDULE_ROUND, SCHEDULE_SERIAL, FgoicpError)  # noqa: F401
+from .registration import IterativeClosestPoint3D, Registration, StreamPool  # noqa: F401
+from .nodes import Rotation, RotNode, TransNode, from_glm, to_glm  # noqa: F401
+
+try:  # the driver mirror needs nothing beyond the C ABI, but keep import errors local to it
+    from .fgoicp import FastGoICP  # noqa: F401
+except ImportError:  # pragma: no cover
+    pass

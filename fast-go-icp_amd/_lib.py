@@ -1,0 +1,110 @@
+"""ctypes binding of libfgoicp_amd.so (include/fgoicp_amd.h).  Loading fails loudly when the
+library has not been built; there is no Python or CPU fallback for any operator."""
+import ctypes as C
+import os
+
+from . import build as _build
+
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int)
+
+
+class Exchange(C.Structure):
+    ALLREDUCE_MIN = C.CFUNCTYPE(C.c_int, c_float_p, C.c_size_t, C.c_void_p)
+    ALLGATHER = C.CFUNCTYPE(C.c_int, c_float_p, c_float_p, C.c_size_t, C.c_void_p)
+    _fields_ = [("rank", C.c_int), ("world_size", C.c_int), ("allreduce_min", ALLREDUCE_MIN),
+                ("allgather", ALLGATHER), ("user", C.c_void_p)]
+
+
+class SolverOpts(C.Structure):
+    _fields_ = [("schedule", C.c_int), ("round_width", C.c_int), ("ctx_flags", C.c_uint), ("device", C.c_int)]
+
+
+class RunStats(C.Structure):
+    _fields_ = [("trans_cubes", C.c_uint64), ("bounds_calls", C.c_uint64), ("rot_cubes", C.c_uint64),
+                ("icp_runs", C.c_uint64), ("icp_iters", C.c_uint64), ("inner_bnb", C.c_uint64),
+                ("rounds", C.c_uint64), ("seconds_total", C.c_double), ("seconds_bnb", C.c_double),
+                ("seconds_icp", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+FLAG_NO_WEIGHT_QUANT = 1 << 0
+FLAG_NO_MORTON = 1 << 1
+FLAG_PROFILE = 1 << 2
+SCHEDULE_SERIAL = 0
+SCHEDULE_ROUND = 1
+
+_SIGS = {
+    "fgoicp_last_error": (C.c_char_p, []),
+    "fgoicp_version": (C.c_char_p, []),
+    "fgoicp_ctx_create": (C.c_int, [c_float_p, C.c_size_t, c_float_p, C.c_size_t, c_float_p, C.c_float, C.c_int, C.c_uint,
+                                    C.POINTER(C.c_void_p)]),
+    "fgoicp_ctx_destroy": (None, [C.c_void_p]),
+    "fgoicp_lut_dims": (C.c_int, [C.c_void_p, c_int_p]),
+    "fgoicp_lut_read": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t]),
+    "fgoicp_lut_search": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t, c_float_p]),
+    "fgoicp_bounds_batch": (C.c_int, [C.c_void_p, c_float_p, C.c_float, c_float_p, C.c_int, C.c_int, c_float_p, c_float_p]),
+    "fgoicp_bounds_multi": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_int_p, c_int_p, c_float_p, c_float_p,
+                                      c_float_p]),
+    "fgoicp_sse": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_float_p]),
+    "fgoicp_icp": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_size_t, C.c_float, c_float_p, c_float_p, c_float_p, c_int_p]),
+    "fgoicp_procrustes": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_int_p]),
+    "fgoicp_ctx_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
+    "fgoicp_ctx_ns": (C.c_size_t, [C.c_void_p]),
+    "fgoicp_ctx_nt": (C.c_size_t, [C.c_void_p]),
+    "fgoicp_solver_create": (C.c_int, [c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_float, C.c_float,
+                                       C.POINTER(SolverOpts), C.POINTER(C.c_void_p)]),
+    "fgoicp_solver_destroy": (None, [C.c_void_p]),
+    "fgoicp_solver_set_exchange": (C.c_int, [C.c_void_p, C.POINTER(Exchange)]),
+    "fgoicp_solver_run": (C.c_int, [C.c_void_p, c_float_p, c_float_p]),
+    "fgoicp_solver_best_error": (C.c_int, [C.c_void_p, c_float_p]),
+    "fgoicp_solver_best_transform": (C.c_int, [C.c_void_p, c_float_p, c_float_p]),
+    "fgoicp_solver_last_transform": (C.c_int, [C.c_void_p, c_float_p, c_float_p]),
+    "fgoicp_solver_stats": (C.c_int, [C.c_void_p, C.POINTER(RunStats)]),
+    "fgoicp_solver_preproc": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_float_p]),
+    "fgoicp_solver_ctx": (C.c_void_p, [C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Returns the loaded library; raises if it is missing (build it with __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: the HIP extension has not been built (python __graft_entry__.py build). "
+            "fgoicp_amd has no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError here = the ABI header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+class FgoicpError(RuntimeError):
+    def __init__(self, status, where):
+        lib = load()
+        msg = lib.fgoicp_last_error().decode(errors="replace")
+        super().__init__(f"{where} failed with status {status}: {msg}")
+        self.status = status
+
+
+def check(status, where):
+    if status != 0:
+        raise FgoicpError(status, where)

@@ -1,0 +1,69 @@
+"""Builds libfgoicp_amd.so (HIP kernels for gfx950 + C ABI + host driver) in-tree with hipcc.
+
+hipcc cross-compiles gfx950 code objects without a GPU, so this runs in the CPU-only container
+as the "does it build" check and the resulting .so travels to the GPU box with the snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(PKG_DIR)
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_DIR = os.path.join(PKG_DIR, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libfgoicp_amd.so")
+CLI_PATH = os.path.join(LIB_DIR, "fast-go-icp")
+
+SOURCES = [
+    os.path.join(CSRC, "device", "kernels.hip"),
+    os.path.join(CSRC, "device", "ctx.hip"),
+    os.path.join(CSRC, "host", "solver.cpp"),
+]
+CLI_SOURCES = [os.path.join(CSRC, "cli", "main.cpp")]
+
+# -ffp-contract=off: the arithmetic contract with oracle/ spells out every fma (kernels.hip header)
+COMMON_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+                "-I" + os.path.join(REPO, "include")]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: fgoicp_amd needs ROCm to build")
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    for d in deps:
+        for root, _, files in os.walk(d) if os.path.isdir(d) else [(os.path.dirname(d), [], [os.path.basename(d)])]:
+            for f in files:
+                if os.path.getmtime(os.path.join(root, f)) > t:
+                    return False
+    return True
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIB_DIR, exist_ok=True)
+    deps = [CSRC, os.path.join(REPO, "include")]
+    srcs = [s for s in SOURCES if os.path.exists(s)]
+    if force or not _newer(LIB_PATH, deps):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-x", "hip", *COMMON_FLAGS, "-shared", "-o", LIB_PATH, *srcs]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    cli_srcs = [s for s in CLI_SOURCES if os.path.exists(s)]
+    if cli_srcs and (force or not _newer(CLI_PATH, deps)):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-x", "hip", *COMMON_FLAGS, "-o", CLI_PATH, *cli_srcs,
+               "-L" + LIB_DIR, "-lfgoicp_amd", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,477 @@
+// Operator-level C ABI (include/fgoicp_amd.h): one context = one HIP device + one stream + all
+// device memory of icp::Registration / icp::NearestNeighborLUT / icp::IterativeClosestPoint3D.
+// No CPU fallback: without a HIP device fgoicp_ctx_create fails with FGOICP_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../../include/fgoicp_amd.h"
+#include "../host/math3.hpp"
+#include "ctx.hpp"
+#include "kernels.hpp"
+
+namespace fgoicp {
+
+thread_local std::string g_last_error;
+void set_error(const std::string& s) { g_last_error = s; }
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            set_error(std::string(#expr) + " failed: " + hipGetErrorString(e_));                        \
+            return e_ == hipErrorOutOfMemory ? FGOICP_ERR_OOM : FGOICP_ERR_HIP;                         \
+        }                                                                                              \
+    } while (0)
+
+namespace {
+
+// 30-bit Morton code of a point inside [lo, hi]^3 — neighbouring lanes then stay in neighbouring
+// LUT voxels under any rigid motion (the LUT gathers of one wave share cache lines).
+uint32_t expand10(uint32_t v) {
+    v &= 0x3ff;
+    v = (v | (v << 16)) & 0x030000FF;
+    v = (v | (v << 8)) & 0x0300F00F;
+    v = (v | (v << 4)) & 0x030C30C3;
+    v = (v | (v << 2)) & 0x09249249;
+    return v;
+}
+
+std::vector<uint32_t> morton_order(const float* xyz, size_t n) {
+    std::vector<uint32_t> perm(n);
+    std::iota(perm.begin(), perm.end(), 0u);
+    if (n == 0) return perm;
+    float lo[3] = {xyz[0], xyz[1], xyz[2]}, hi[3] = {xyz[0], xyz[1], xyz[2]};
+    for (size_t i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], xyz[3 * i + a]);
+            hi[a] = std::max(hi[a], xyz[3 * i + a]);
+        }
+    float ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
+    if (!(ext > 0)) return perm;
+    std::vector<uint32_t> code(n);
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t c[3];
+        for (int a = 0; a < 3; ++a) {
+            float f = (xyz[3 * i + a] - lo[a]) / ext * 1023.0f;
+            c[a] = (uint32_t)std::min(1023.0f, std::max(0.0f, f));
+        }
+        code[i] = expand10(c[0]) | (expand10(c[1]) << 1) | (expand10(c[2]) << 2);
+    }
+    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return code[a] < code[b]; });
+    return perm;
+}
+
+}  // namespace
+
+int ctx_flush_profile(fgoicp_ctx* c) {
+    for (int i = 0; i < c->ev_used; ++i) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev_start[i], c->ev_stop[i]));
+        c->prof_ms += ms;
+    }
+    c->ev_used = 0;
+    return FGOICP_OK;
+}
+
+// -------------------------------------------------------------------------------------------
+// Registration::compute_sse_error(RotNode&, vector<TransNode>&, bool, StreamPool&) for G groups.
+// -------------------------------------------------------------------------------------------
+int ctx_bounds_multi(fgoicp_ctx* c, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets,
+                     const float* tn4, float* lb_out, float* ub_out) {
+    HIPCHK(hipSetDevice(c->device));
+    struct Piece { int g, pos, B; };
+    std::vector<Piece> pieces;
+    for (int g = 0; g < G; ++g)
+        for (int pos = offsets[g]; pos < offsets[g + 1]; pos += kMaxBatch) pieces.push_back({g, pos, std::min(kMaxBatch, offsets[g + 1] - pos)});
+    size_t pi = 0;
+    while (pi < pieces.size()) {
+        // one window = at most max_subcubes rows of `partials`, one finalize, one host sync
+        const int first = pieces[pi].pos;
+        int rows = 0;
+        while (pi < pieces.size() && rows + pieces[pi].B <= c->max_subcubes) {
+            const Piece& pc = pieces[pi];
+            BoundsArgs a;
+            std::memcpy(a.R, R9 + 9 * pc.g, sizeof(a.R));
+            const float half_angle = rot_span[pc.g] * kSqrt3 * kPi / 2.0f;  // registration.cu:42
+            a.sin_half = std::sin(half_angle);
+            a.fix_rot = fix_rot[pc.g] ? 1 : 0;
+            a.B = pc.B;
+            a.out_base = rows;
+            a.pad_ = 0;
+            std::memcpy(a.tn, tn4 + 4 * (size_t)pc.pos, sizeof(float) * 4 * pc.B);
+            const bool prof = c->profile;
+            if (prof) {
+                if (c->ev_used == (int)c->ev_start.size()) {
+                    HIPCHK(hipStreamSynchronize(c->stream));
+                    int rc = ctx_flush_profile(c);
+                    if (rc) return rc;
+                }
+                HIPCHK(hipEventRecord(c->ev_start[c->ev_used], c->stream));
+            }
+            launch_bounds(c->d_src, (int)c->ns, c->d_lut, c->geom, a, c->d_partials, c->nchunk, c->pts_per_thread, c->stream);
+            if (prof) {
+                HIPCHK(hipEventRecord(c->ev_stop[c->ev_used], c->stream));
+                c->ev_used++;
+                c->prof_launches++;
+                c->prof_subcubes += pc.B;
+            }
+            rows += pc.B;
+            ++pi;
+        }
+        launch_bounds_finalize(c->d_partials, c->nchunk, rows, c->hd_lb, c->hd_ub, c->stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));
+        std::memcpy(lb_out + first, c->h_lb, sizeof(float) * rows);
+        std::memcpy(ub_out + first, c->h_ub, sizeof(float) * rows);
+        if (c->profile) {
+            int rc = ctx_flush_profile(c);
+            if (rc) return rc;
+        }
+    }
+    return FGOICP_OK;
+}
+
+// float Registration::compute_sse_error(glm::mat3, glm::vec3) — registration.cu:62-86
+int ctx_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out) {
+    HIPCHK(hipSetDevice(c->device));
+    const int ns = (int)c->ns;
+    launch_fill_u32(c->d_min_bits, 0x501502F9u /* bits(1e10f) */, c->ns, c->stream);
+    launch_nn_min(c->d_src, ns, c->d_tgt, (int)c->nt, R9, t3, 1, c->d_min_bits, c->stream);
+    const int nb = reduce_blocks_for(ns);
+    launch_sum_f32_as_f64(c->d_min_bits, ns, c->d_bp, nb, c->stream);
+    launch_sum_partials(c->d_bp, nb, 1, c->hd_sums, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *sse_out = (float)c->h_sums[0];
+    return FGOICP_OK;
+}
+
+// IterativeClosestPoint3D::procrustes() on c->d_work — icp3d.cu:140-172
+int ctx_procrustes_device(fgoicp_ctx* c, Mat3f* R_out, Vec3f* t_out, float* centroids6_out, Mat3f* ABt_out) {
+    const int ns = (int)c->ns, nt = (int)c->nt;
+    // kernFindNearestNeighbor (icp3d.cu:11-28): min distance, tie set, lowest index
+    launch_fill_u32(c->d_min_bits, 0x501502F9u, c->ns, c->stream);
+    launch_fill_u32(c->d_first_idx, 0x7fffffffu, c->ns, c->stream);
+    launch_nn_min(c->d_work, ns, c->d_tgt, nt, nullptr, nullptr, 0, c->d_min_bits, c->stream);
+    launch_nn_tie_threshold(c->d_min_bits, ns, c->d_thr_bits, c->stream);
+    launch_nn_first_index(c->d_work, ns, c->d_tgt, nt, c->d_thr_bits, c->d_first_idx, c->stream);
+    const int nb = reduce_blocks_for(ns);
+    launch_icp_sums(c->d_work, c->d_tgt, c->d_first_idx, ns, c->d_bp, nb, c->stream);
+    launch_sum_partials(c->d_bp, nb, 6, c->hd_sums, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const float fn = static_cast<float>(c->ns);
+    float cen[6];
+    for (int k = 0; k < 6; ++k) cen[k] = (float)c->h_sums[k] / fn;  // icp3d.cu:155-156
+    launch_icp_cov(c->d_work, c->d_tgt, c->d_first_idx, ns, cen, c->d_bp, nb, c->stream);
+    launch_sum_partials(c->d_bp, nb, 9, c->hd_sums, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    Mat3f ABt;
+    for (int k = 0; k < 9; ++k) ABt.m[k] = (float)c->h_sums[k];
+    const Mat3f Rn = closest_orthogonal_approximation(ABt);  // icp3d.cu:168
+    const Vec3f sc{cen[0], cen[1], cen[2]}, cc{cen[3], cen[4], cen[5]};
+    *R_out = Rn;
+    *t_out = cc - Rn * sc;  // icp3d.cu:169
+    if (centroids6_out) std::memcpy(centroids6_out, cen, sizeof(cen));
+    if (ABt_out) *ABt_out = ABt;
+    return FGOICP_OK;
+}
+
+// IterativeClosestPoint3D ctor + run() — icp3d.cu:55-108
+int ctx_icp(fgoicp_ctx* c, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3,
+            int* iters_out) {
+    HIPCHK(hipSetDevice(c->device));
+    const int ns = (int)c->ns;
+    HIPCHK(hipMemcpyAsync(c->d_work, c->d_src, sizeof(float4) * c->ns, hipMemcpyDeviceToDevice, c->stream));
+    launch_transform_inplace(c->d_work, ns, R0, t0, c->stream);  // icp3d.cu:85
+    Mat3f R = Mat3f::from(R0);
+    Vec3f t{t0[0], t0[1], t0[2]};
+    size_t iter = 0;
+    float sse = kInf, last_sse = 2.0f * kInf;
+    Mat3f last_R = Mat3f::identity();
+    Vec3f last_t{0, 0, 0};
+    int iters = 0;
+    while (iter++ < max_iter && (last_sse - sse) > thr * last_sse) {  // icp3d.cu:94
+        last_sse = sse;
+        last_R = R;
+        last_t = t;
+        Mat3f Rn;
+        Vec3f tn;
+        int rc = ctx_procrustes_device(c, &Rn, &tn, nullptr, nullptr);
+        if (rc) return rc;
+        const float tn3[3] = {tn.x, tn.y, tn.z};
+        launch_transform_inplace(c->d_work, ns, Rn.m, tn3, c->stream);  // :100
+        R = Rn * R;                                                      // :101
+        t = Rn * t + tn;                                                 // :102
+        const float t3[3] = {t.x, t.y, t.z};
+        rc = ctx_sse(c, R.m, t3, &sse);                                  // :103
+        if (rc) return rc;
+        ++iters;
+    }
+    const bool cur = sse < last_sse;  // :106-107
+    *sse_out = cur ? sse : last_sse;
+    const Mat3f& Ro = cur ? R : last_R;
+    const Vec3f& to = cur ? t : last_t;
+    std::memcpy(R_out9, Ro.m, sizeof(Ro.m));
+    t_out3[0] = to.x; t_out3[1] = to.y; t_out3[2] = to.z;
+    if (iters_out) *iters_out = iters;
+    return FGOICP_OK;
+}
+
+}  // namespace fgoicp
+
+using namespace fgoicp;
+
+extern "C" {
+
+const char* fgoicp_last_error(void) { return g_last_error.c_str(); }
+const char* fgoicp_version(void) { return "fgoicp_amd 0.1 (gfx950)"; }
+
+int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, size_t ns, const float* bounds6, float lut_resolution,
+                      int device, unsigned flags, fgoicp_ctx** out) {
+    if (!out) return FGOICP_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!tgt_xyz || !src_xyz || !bounds6 || nt == 0 || ns == 0 || !(lut_resolution > 0) || nt > 0x7ffffffeull || ns > 0x7ffffffeull) {
+        set_error("fgoicp_ctx_create: invalid argument");
+        return FGOICP_ERR_INVALID_ARG;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        set_error(std::string("no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+                  "); fgoicp_amd has no CPU path");
+        return FGOICP_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) {
+        set_error("fgoicp_ctx_create: device ordinal out of range");
+        return FGOICP_ERR_INVALID_ARG;
+    }
+    HIPCHK(hipSetDevice(device));
+    fgoicp_ctx* c = new fgoicp_ctx();
+    c->device = device;
+    c->ns = ns;
+    c->nt = nt;
+    c->profile = (flags & FGOICP_FLAG_PROFILE) != 0;
+    auto fail = [&](int rc) { fgoicp_ctx_destroy(c); return rc; };
+#define CHK(expr) do { hipError_t e2_ = (expr); if (e2_ != hipSuccess) { set_error(std::string(#expr) + " failed: " + hipGetErrorString(e2_)); return fail(e2_ == hipErrorOutOfMemory ? FGOICP_ERR_OOM : FGOICP_ERR_HIP); } } while (0)
+    CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+
+    // LUT geometry — NearestNeighborLUT ctor, registration.cu:186-204
+    LutGeom& g = c->geom;
+    g.resolution = lut_resolution;
+    g.dx = (int)std::ceil((bounds6[1] - bounds6[0]) / lut_resolution);
+    g.dy = (int)std::ceil((bounds6[3] - bounds6[2]) / lut_resolution);
+    g.dz = (int)std::ceil((bounds6[5] - bounds6[4]) / lut_resolution);
+    if (g.dx < 1 || g.dy < 1 || g.dz < 1 || g.dx > 4094 || g.dy > 4094 || g.dz > 4094) {
+        set_error("fgoicp_ctx_create: LUT dims out of range (" + std::to_string(g.dx) + "," + std::to_string(g.dy) + "," + std::to_string(g.dz) + ")");
+        return fail(FGOICP_ERR_INVALID_ARG);
+    }
+    g.px = g.dx + 2; g.py = g.dy + 2; g.pz = g.dz + 2;
+    g.scale = 1.0f / lut_resolution;
+    g.off_x = -bounds6[0]; g.off_y = -bounds6[2]; g.off_z = -bounds6[4];
+    g.quantize = (flags & FGOICP_FLAG_NO_WEIGHT_QUANT) ? 0 : 1;
+
+    // clouds: float4 on the device.  Source: Morton order, w = x*x+y*y+z*z in the device
+    // contraction order (registration.cu:39-41).  Target: caller order (index tie rule), w = 0.
+    c->perm.resize(ns);
+    if (flags & FGOICP_FLAG_NO_MORTON) std::iota(c->perm.begin(), c->perm.end(), 0u);
+    else c->perm = morton_order(src_xyz, ns);
+    {
+        std::vector<float4> h(ns);
+        for (size_t i = 0; i < ns; ++i) {
+            const float* p = src_xyz + 3 * (size_t)c->perm[i];
+            h[i] = make_float4(p[0], p[1], p[2], std::fmaf(p[2], p[2], std::fmaf(p[1], p[1], p[0] * p[0])));
+        }
+        CHK(hipMalloc(&c->d_src, sizeof(float4) * ns));
+        CHK(hipMemcpy(c->d_src, h.data(), sizeof(float4) * ns, hipMemcpyHostToDevice));
+        CHK(hipMalloc(&c->d_work, sizeof(float4) * ns));
+    }
+    float4* d_tgt_shift = nullptr;
+    {
+        std::vector<float4> h(nt), hs(nt);
+        for (size_t i = 0; i < nt; ++i) {
+            const float* p = tgt_xyz + 3 * i;
+            h[i] = make_float4(p[0], p[1], p[2], 0.f);
+            hs[i] = make_float4(p[0] + g.off_x, p[1] + g.off_y, p[2] + g.off_z, 0.f);  // registration.cu:289-296
+        }
+        CHK(hipMalloc(&c->d_tgt, sizeof(float4) * nt));
+        CHK(hipMemcpy(c->d_tgt, h.data(), sizeof(float4) * nt, hipMemcpyHostToDevice));
+        CHK(hipMalloc(&d_tgt_shift, sizeof(float4) * nt));
+        hipError_t e3 = hipMemcpy(d_tgt_shift, hs.data(), sizeof(float4) * nt, hipMemcpyHostToDevice);
+        if (e3 != hipSuccess) { (void)hipFree(d_tgt_shift); set_error("upload of shifted target failed"); return fail(FGOICP_ERR_HIP); }
+    }
+    // LUT build — buildLUTKernel, registration.cu:258-318
+    {
+        const size_t total = (size_t)g.px * g.py * g.pz;
+        hipError_t e3 = hipMalloc(&c->d_lut, total * sizeof(float));
+        if (e3 == hipSuccess) {
+            launch_lut_build(d_tgt_shift, (int)nt, g, c->d_lut, c->stream);
+            e3 = hipGetLastError();
+            if (e3 == hipSuccess) e3 = hipStreamSynchronize(c->stream);
+        }
+        (void)hipFree(d_tgt_shift);
+        if (e3 != hipSuccess) { set_error(std::string("LUT build failed: ") + hipGetErrorString(e3)); return fail(e3 == hipErrorOutOfMemory ? FGOICP_ERR_OOM : FGOICP_ERR_HIP); }
+    }
+    // bounds scratch: P points per thread so that one 32-subcube launch has >= ~2048 blocks
+    {
+        int P = 8;
+        while (P > 1 && ((ns + (size_t)kBlock * P - 1) / ((size_t)kBlock * P)) * kMaxBatch < 2048) P >>= 1;
+        c->pts_per_thread = P;
+        c->nchunk = (int)((ns + (size_t)kBlock * P - 1) / ((size_t)kBlock * P));
+        c->max_subcubes = 4096;
+        CHK(hipMalloc(&c->d_partials, sizeof(double2) * (size_t)c->max_subcubes * c->nchunk));
+        CHK(hipHostMalloc((void**)&c->h_lb, sizeof(float) * c->max_subcubes, hipHostMallocMapped));
+        CHK(hipHostMalloc((void**)&c->h_ub, sizeof(float) * c->max_subcubes, hipHostMallocMapped));
+        CHK(hipHostGetDevicePointer((void**)&c->hd_lb, c->h_lb, 0));
+        CHK(hipHostGetDevicePointer((void**)&c->hd_ub, c->h_ub, 0));
+    }
+    // exact-NN / ICP scratch
+    CHK(hipMalloc(&c->d_min_bits, sizeof(uint32_t) * ns));
+    CHK(hipMalloc(&c->d_thr_bits, sizeof(uint32_t) * ns));
+    CHK(hipMalloc(&c->d_first_idx, sizeof(uint32_t) * ns));
+    CHK(hipMalloc(&c->d_bp, sizeof(double) * 1024 * 16));
+    CHK(hipHostMalloc((void**)&c->h_sums, sizeof(double) * 16, hipHostMallocMapped));
+    CHK(hipHostGetDevicePointer((void**)&c->hd_sums, c->h_sums, 0));
+    if (c->profile) {
+        c->ev_start.resize(1024);
+        c->ev_stop.resize(1024);
+        for (size_t i = 0; i < c->ev_start.size(); ++i) {
+            CHK(hipEventCreate(&c->ev_start[i]));
+            CHK(hipEventCreate(&c->ev_stop[i]));
+        }
+    }
+#undef CHK
+    *out = c;
+    return FGOICP_OK;
+}
+
+void fgoicp_ctx_destroy(fgoicp_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& e : c->ev_start) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_stop) if (e) (void)hipEventDestroy(e);
+    (void)hipFree(c->d_src); (void)hipFree(c->d_work); (void)hipFree(c->d_tgt); (void)hipFree(c->d_lut);
+    (void)hipFree(c->d_partials); (void)hipFree(c->d_min_bits); (void)hipFree(c->d_thr_bits); (void)hipFree(c->d_first_idx);
+    (void)hipFree(c->d_bp);
+    if (c->h_lb) (void)hipHostFree(c->h_lb);
+    if (c->h_ub) (void)hipHostFree(c->h_ub);
+    if (c->h_sums) (void)hipHostFree(c->h_sums);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int fgoicp_lut_dims(const fgoicp_ctx* c, int* dims3) {
+    if (!c || !dims3) return FGOICP_ERR_INVALID_ARG;
+    dims3[0] = c->geom.dx; dims3[1] = c->geom.dy; dims3[2] = c->geom.dz;
+    return FGOICP_OK;
+}
+
+int fgoicp_lut_read(fgoicp_ctx* c, float* out, size_t capacity) {
+    if (!c || !out) return FGOICP_ERR_INVALID_ARG;
+    const size_t total = (size_t)c->geom.dx * c->geom.dy * c->geom.dz;
+    if (capacity < total) { set_error("fgoicp_lut_read: buffer too small"); return FGOICP_ERR_INVALID_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    float* d = nullptr;
+    HIPCHK(hipMalloc(&d, total * sizeof(float)));
+    launch_lut_unpad(c->d_lut, c->geom, d, c->stream);
+    hipError_t e = hipMemcpyAsync(out, d, total * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    HIPCHK(e);
+    return FGOICP_OK;
+}
+
+int fgoicp_lut_search(fgoicp_ctx* c, const float* q, size_t n, float* out) {
+    if (!c || !q || !out) return FGOICP_ERR_INVALID_ARG;
+    if (n == 0) return FGOICP_OK;
+    HIPCHK(hipSetDevice(c->device));
+    float *dq = nullptr, *dout = nullptr;
+    HIPCHK(hipMalloc(&dq, 3 * n * sizeof(float)));
+    hipError_t e = hipMalloc(&dout, n * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(dq, q, 3 * n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) { launch_lut_search(c->d_lut, c->geom, dq, n, dout, c->stream); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dout, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dq); (void)hipFree(dout);
+    HIPCHK(e);
+    return FGOICP_OK;
+}
+
+int fgoicp_bounds_multi(fgoicp_ctx* c, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets,
+                        const float* tn4, float* lb_out, float* ub_out) {
+    if (!c || G < 0 || (G > 0 && (!R9 || !rot_span || !fix_rot || !offsets || !tn4 || !lb_out || !ub_out))) return FGOICP_ERR_INVALID_ARG;
+    if (G == 0) return FGOICP_OK;
+    for (int g = 0; g < G; ++g)
+        if (offsets[g + 1] < offsets[g] || offsets[0] != 0) { set_error("fgoicp_bounds_multi: offsets must start at 0 and be non-decreasing"); return FGOICP_ERR_INVALID_ARG; }
+    if (offsets[G] == 0) return FGOICP_OK;
+    return ctx_bounds_multi(c, G, R9, rot_span, fix_rot, offsets, tn4, lb_out, ub_out);
+}
+
+int fgoicp_bounds_batch(fgoicp_ctx* c, const float* R9, float rot_span, const float* tn4, int B, int fix_rot, float* lb_out, float* ub_out) {
+    if (B < 0) return FGOICP_ERR_INVALID_ARG;
+    const int offsets[2] = {0, B};
+    return fgoicp_bounds_multi(c, 1, R9, &rot_span, &fix_rot, offsets, tn4, lb_out, ub_out);
+}
+
+int fgoicp_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out) {
+    if (!c || !R9 || !t3 || !sse_out) return FGOICP_ERR_INVALID_ARG;
+    return ctx_sse(c, R9, t3, sse_out);
+}
+
+int fgoicp_icp(fgoicp_ctx* c, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3,
+               int* iters_out) {
+    if (!c || !R0 || !t0 || !sse_out || !R_out9 || !t_out3) return FGOICP_ERR_INVALID_ARG;
+    return ctx_icp(c, R0, t0, max_iter, thr, sse_out, R_out9, t_out3, iters_out);
+}
+
+int fgoicp_procrustes(fgoicp_ctx* c, const float* working_xyz, float* R_out9, float* t_out3, float* centroids6, float* ABt9, int* corr_idx) {
+    if (!c || !working_xyz || !R_out9 || !t_out3) return FGOICP_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<float4> h(c->ns);
+    for (size_t i = 0; i < c->ns; ++i) {
+        const float* p = working_xyz + 3 * (size_t)c->perm[i];
+        h[i] = make_float4(p[0], p[1], p[2], 0.f);
+    }
+    HIPCHK(hipMemcpy(c->d_work, h.data(), sizeof(float4) * c->ns, hipMemcpyHostToDevice));
+    Mat3f R, ABt;
+    Vec3f t;
+    int rc = ctx_procrustes_device(c, &R, &t, centroids6, &ABt);
+    if (rc) return rc;
+    std::memcpy(R_out9, R.m, sizeof(R.m));
+    t_out3[0] = t.x; t_out3[1] = t.y; t_out3[2] = t.z;
+    if (ABt9) std::memcpy(ABt9, ABt.m, sizeof(ABt.m));
+    if (corr_idx) {
+        std::vector<uint32_t> idx(c->ns);
+        HIPCHK(hipMemcpy(idx.data(), c->d_first_idx, sizeof(uint32_t) * c->ns, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < c->ns; ++i) corr_idx[c->perm[i]] = (int)idx[i];
+    }
+    return FGOICP_OK;
+}
+
+int fgoicp_ctx_profile(fgoicp_ctx* c, double* kernel_ms, uint64_t* launches, uint64_t* subcubes, int reset) {
+    if (!c) return FGOICP_ERR_INVALID_ARG;
+    if (c->ev_used) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        int rc = ctx_flush_profile(c);
+        if (rc) return rc;
+    }
+    if (kernel_ms) *kernel_ms = c->prof_ms;
+    if (launches) *launches = c->prof_launches;
+    if (subcubes) *subcubes = c->prof_subcubes;
+    if (reset) { c->prof_ms = 0; c->prof_launches = 0; c->prof_subcubes = 0; }
+    return FGOICP_OK;
+}
+
+size_t fgoicp_ctx_ns(const fgoicp_ctx* c) { return c ? c->ns : 0; }
+size_t fgoicp_ctx_nt(const fgoicp_ctx* c) { return c ? c->nt : 0; }
+
+}  // extern "C"

@@ -1,0 +1,52 @@
+// Internal layout of the opaque fgoicp_ctx (include/fgoicp_amd.h).  Shared by the operator ABI
+// (ctx.hip) and the driver ABI (solver.cpp); not installed.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../host/math3.hpp"
+#include "kernels.hpp"
+
+struct fgoicp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    size_t ns = 0, nt = 0;
+    bool profile = false;
+
+    // HBM-resident state
+    float4* d_src = nullptr;     // ns  x {x,y,z,|p|^2}, Morton order (pristine source, registration.hpp:63)
+    float4* d_work = nullptr;    // ns  x {x,y,z,-}: ICP working copy (icp3d.hpp:24)
+    float4* d_tgt = nullptr;     // nt  x {x,y,z,0}, caller order (registration.hpp:61)
+    float* d_lut = nullptr;      // (dx+2)(dy+2)(dz+2) floats, x fastest, replicated border
+    fgoicp::LutGeom geom{};
+    std::vector<uint32_t> perm;  // device slot i holds caller point perm[i]
+
+    // bounds-operator scratch (persistent: the reference mallocs/frees per call, registration.cu:95-149)
+    int pts_per_thread = 1, nchunk = 0, max_subcubes = 0;
+    double2* d_partials = nullptr;           // [max_subcubes][nchunk] {sum_ub, sum_lb}
+    float *h_lb = nullptr, *h_ub = nullptr;  // pinned, device-visible result rows
+    float *hd_lb = nullptr, *hd_ub = nullptr;
+
+    // exact-NN / ICP scratch
+    uint32_t *d_min_bits = nullptr, *d_thr_bits = nullptr, *d_first_idx = nullptr;
+    double* d_bp = nullptr;      // per-block partial sums
+    double *h_sums = nullptr, *hd_sums = nullptr;  // pinned result of the last reduction (<= 16 doubles)
+
+    // HIP-event profile of the bounds kernel
+    std::vector<hipEvent_t> ev_start, ev_stop;
+    int ev_used = 0;
+    double prof_ms = 0.0;
+    uint64_t prof_launches = 0, prof_subcubes = 0;
+};
+
+namespace fgoicp {
+void set_error(const std::string& s);
+int ctx_bounds_multi(fgoicp_ctx* c, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets,
+                     const float* tn4, float* lb_out, float* ub_out);
+int ctx_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out);
+int ctx_icp(fgoicp_ctx* c, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3,
+            int* iters_out);
+}  // namespace fgoicp

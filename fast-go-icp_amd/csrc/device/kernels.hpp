@@ -1,0 +1,76 @@
+// Launch-side declarations of the gfx950 kernels (kernels.hip).  Host-callable wrappers only;
+// everything takes an explicit hipStream_t and never allocates or synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace fgoicp {
+
+constexpr int kMaxBatch = 32;          // translation nodes per bounds launch (kernarg-resident)
+constexpr int kBlock = 256;            // 4 wave64 per workgroup everywhere
+constexpr float kSqrt3 = 1.732050807568877f;   // fgoicp/common.hpp:19
+constexpr float kPi = 3.141592653589793f;      // fgoicp/common.hpp:17
+constexpr float kInf = 1E+10f;                 // fgoicp/common.hpp:18
+
+// Geometry of the nearest-squared-distance LUT (fgoicp/registration.cu:180-207).  The device
+// copy is stored with a one-voxel replicated border on every side, so that CUDA's clamp
+// addressing (registration.cu:226-228) needs no per-texel branch: padded[k] = T[clamp(k-1)].
+struct LutGeom {
+    float off_x, off_y, off_z;   // offset = -min_bound (registration.cu:202-204)
+    float scale;                 // 1/resolution (registration.cu:201)
+    float resolution;
+    int dx, dy, dz;              // reference dims (registration.cu:186-188)
+    int px, py, pz;              // padded dims = d + 2
+    int quantize;                // 1: interpolation weights in 1.8 fixed point (CUDA linear filtering)
+};
+
+// One bounds launch = one rotation node + up to kMaxBatch translation nodes, passed by value in
+// the kernarg segment (the reference passes RotNode/TransNode by value too, registration.cu:111).
+struct BoundsArgs {
+    float R[9];        // glm::mat3 order (column-major)
+    float sin_half;    // sin(rot_span * sqrt3 * pi / 2), registration.cu:42-43, hoisted to the host
+    int fix_rot;
+    int B;
+    int out_base;      // first row of `partials` this launch writes
+    int pad_;
+    float4 tn[kMaxBatch];   // t.x, t.y, t.z, span
+};
+
+// bounds: partials[(out_base + b) * nchunk + chunk] = {sum_ub, sum_lb} over the chunk's points
+void launch_bounds(const float4* src, int ns, const float* lut, const LutGeom& g, const BoundsArgs& a, double2* partials,
+                   int nchunk, int pts_per_thread, hipStream_t s);
+// out_lb[i], out_ub[i] = float(sum over chunks), fixed order → bit-reproducible
+void launch_bounds_finalize(const double2* partials, int nchunk, int total, float* out_lb, float* out_ub, hipStream_t s);
+
+void launch_lut_build(const float4* tgt_shifted, int nt, const LutGeom& g, float* lut_padded, hipStream_t s);
+void launch_lut_unpad(const float* lut_padded, const LutGeom& g, float* out, hipStream_t s);
+void launch_lut_search(const float* lut, const LutGeom& g, const float* q_xyz, size_t n, float* out, hipStream_t s);
+
+// Exact nearest neighbour (brute force, tiled through LDS).
+//   queries: if `apply` q_i = R*pts_i + t (fma convention) else q_i = pts_i.
+//   min_bits[i] = bit pattern of min_j |q_i - tgt_j|^2 (must be pre-filled with bits(1e10f)).
+void launch_fill_u32(uint32_t* p, uint32_t v, size_t n, hipStream_t s);
+void launch_nn_min(const float4* pts, int n, const float4* tgt, int nt, const float* R9, const float* t3, int apply,
+                   uint32_t* min_bits, hipStream_t s);
+// thr_bits[i] = largest float x with sqrtf(x) == sqrtf(min_i): every target within it ties under
+// glm::distance (icp3d.cu:20-25); first_idx must be pre-filled with 0x7fffffff.
+void launch_nn_tie_threshold(const uint32_t* min_bits, int n, uint32_t* thr_bits, hipStream_t s);
+void launch_nn_first_index(const float4* pts, int n, const float4* tgt, int nt, const uint32_t* thr_bits, uint32_t* first_idx,
+                           hipStream_t s);
+
+// deterministic double sums: out[k] = sum_i vals[i*stride + k]  (k < width <= 16)
+void launch_sum_f32_as_f64(const uint32_t* bits, int n, double* block_partials, int nblocks, hipStream_t s);
+void launch_sum_partials(const double* block_partials, int nblocks, int width, double* out, hipStream_t s);
+
+// ICP pieces (fgoicp/icp3d.cu:30-52)
+void launch_transform_inplace(float4* pts, int n, const float* R9, const float* t3, hipStream_t s);
+void launch_icp_sums(const float4* work, const float4* tgt, const uint32_t* idx, int n, double* block_partials, int nblocks,
+                     hipStream_t s);  // width 6: sum src xyz, sum corr xyz
+void launch_icp_cov(const float4* work, const float4* tgt, const uint32_t* idx, int n, const float* centroids6,
+                    double* block_partials, int nblocks, hipStream_t s);  // width 9: glm mat3 order
+
+int reduce_blocks_for(int n);
+
+}  // namespace fgoicp

@@ -1,0 +1,463 @@
+// Host side of the Go-ICP search: node types, pre-processing and the outer SO(3) / inner R^3
+// branch-and-bound of icp::FastGoICP (reference fgoicp/fgoicp.hpp:13-110, fgoicp/fgoicp.cpp:10-287,
+// fgoicp/common.hpp:30-128), written against an abstract operator backend `Ops`:
+//
+//     int    Ops::bounds_multi(G, R9, rot_span, fix_rot, offsets, tnodes4, lb, ub)   (fgoicp_bounds_multi)
+//     int    Ops::icp(R0, t0, max_iter, thr, &sse, R9, t3, &iters)                   (fgoicp_icp)
+//
+// The product instantiates it with the HIP context only (solver.cpp).  tests/ instantiate it with
+// the CPU oracle's operators to check the host logic without a GPU; no such instantiation is
+// compiled into libfgoicp_amd.so.
+//
+// Two schedules:
+//   SERIAL — the reference's exact exploration order: one rotation child at a time, UB inner BnB,
+//            optional ICP, LB inner BnB, `best_sse` updated between siblings (fgoicp.cpp:51-97).
+//   ROUND  — expansion rounds: pop K cubes, evaluate the UB and LB inner BnBs of all children
+//            concurrently (one fused operator submission per tick), children sharded over ranks,
+//            one min-all-reduce of the best error + one all-gather per round.  Bounds stay valid
+//            (a stale, larger `best_sse` only prunes less); the exploration order differs from the
+//            reference, the final optimum is asserted equal in tests.
+#pragma once
+#include <algorithm>
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <queue>
+#include <vector>
+
+#include "math3.hpp"
+
+namespace fgoicp {
+
+constexpr float kHostInf = 1E+10f;  // M_INF, common.hpp:18
+
+// ---- node types (common.hpp:30-128) ---------------------------------------------------------
+struct RotationQ {
+    float x, y, z, r;
+    Mat3f R;
+    RotationQ() : RotationQ(0.f, 0.f, 0.f) {}
+    RotationQ(float x_, float y_, float z_) : x(x_), y(y_), z(z_), r(x_ * x_ + y_ * y_ + z_ * z_), R(Mat3f::identity()) {
+        if (r > 1.0f) return;  // not a rotation: R stays identity, r stays the squared norm (common.hpp:42)
+        const float ww = 1.0f - r;
+        const float w = std::sqrt(ww);
+        const float wx = w * x, xx = x * x;
+        const float wy = w * y, xy = x * y, yy = y * y;
+        const float wz = w * z, xz = x * z, yz = y * z, zz = z * z;
+        const float cols[9] = {ww + xx - yy - zz, 2 * (xy - wz),     2 * (xz + wy),      // column 0
+                               2 * (xy + wz),     ww - xx + yy - zz, 2 * (yz - wx),      // column 1
+                               2 * (xz - wy),     2 * (yz + wx),     ww - xx - yy + zz}; // column 2
+        std::memcpy(R.m, cols, sizeof(cols));
+        r = std::sqrt(r);
+    }
+    bool in_SO3() const { return r <= 1.0f; }
+};
+
+struct RotCube {
+    RotationQ q;
+    float span, lb, ub;
+    RotCube(float x, float y, float z, float span_, float lb_, float ub_) : q(x, y, z), span(span_), lb(lb_), ub(ub_) {}
+    // std::priority_queue pops the smallest lb first, ties → larger span (common.hpp:85-92)
+    friend bool operator<(const RotCube& a, const RotCube& b) { return a.lb == b.lb ? a.span < b.span : a.lb > b.lb; }
+    bool overlaps_SO3() const {  // common.hpp:99-103
+        return q.r - 2 * span * (std::fabs(q.x) + std::fabs(q.y) + std::fabs(q.z)) + 3 * span * span <= 1;
+    }
+};
+
+struct TransCube {
+    Vec3f t;
+    float span, lb, ub;
+    TransCube(float x, float y, float z, float span_, float lb_, float ub_) : t{x, y, z}, span(span_), lb(lb_), ub(ub_) {}
+    friend bool operator<(const TransCube& a, const TransCube& b) { return a.lb == b.lb ? a.span < b.span : a.lb > b.lb; }
+};
+
+// ---- pre-processing (fgoicp.cpp:176-287; serial fp32, the omp pragmas there are inert) ----------
+inline Vec3f center_point_cloud(std::vector<Vec3f>& pc) {
+    Vec3f c{0.f, 0.f, 0.f};
+    for (const Vec3f& p : pc) c = c + p;
+    c = c / static_cast<float>(pc.size());
+    for (Vec3f& p : pc) p = p - c;
+    return -c;
+}
+inline float scale_point_clouds(std::vector<Vec3f>& pct, std::vector<Vec3f>& pcs) {
+    float max_abs = std::numeric_limits<float>::lowest();
+    for (const Vec3f& p : pcs) max_abs = std::max(max_abs, std::max(std::fabs(p.x), std::max(std::fabs(p.y), std::fabs(p.z))));
+    const float s = 1.0f / max_abs;
+    for (Vec3f& p : pcs) p = p * s;
+    for (Vec3f& p : pct) p = p * s;
+    return s;
+}
+inline void point_cloud_ranges(const std::vector<Vec3f>& pc, float bounds6[6]) {
+    for (int a = 0; a < 3; ++a) {
+        bounds6[2 * a] = std::numeric_limits<float>::max();
+        bounds6[2 * a + 1] = std::numeric_limits<float>::lowest();
+    }
+    for (const Vec3f& p : pc) {
+        const float v[3] = {p.x, p.y, p.z};
+        for (int a = 0; a < 3; ++a) {
+            bounds6[2 * a] = std::min(bounds6[2 * a], v[a]);
+            bounds6[2 * a + 1] = std::max(bounds6[2 * a + 1], v[a]);
+        }
+    }
+}
+
+// ---- exchange hook (mirrors fgoicp_exchange of the C ABI) --------------------------------------
+struct Exchange {
+    int rank = 0, world = 1;
+    int (*allreduce_min)(float*, size_t, void*) = nullptr;
+    int (*allgather)(const float*, float*, size_t, void*) = nullptr;
+    void* user = nullptr;
+};
+
+struct DriverStats {
+    uint64_t trans_cubes = 0, bounds_calls = 0, rot_cubes = 0, icp_runs = 0, icp_iters = 0, inner_bnb = 0, rounds = 0;
+    double seconds_total = 0, seconds_bnb = 0, seconds_icp = 0;
+};
+
+enum { kScheduleSerial = 0, kScheduleRound = 1 };
+enum { kDriverOk = 0, kDriverExchangeFailed = 6 };
+
+// ---- one inner (translation) BnB as a resumable task — fgoicp.cpp:102-174 -----------------------
+struct InnerTask {
+    bool fix_rot = true;
+    float best_error = 0.f;
+    Vec3f best_t{0.f, 0.f, 0.f};
+    float best_ub = kHostInf;
+    uint64_t count = 0;
+    std::priority_queue<TransCube> cand;
+    std::vector<TransCube> batch;
+
+    void start(bool fix, float best_sse, float rnode_ub) {
+        fix_rot = fix;
+        best_error = best_sse;  // :104
+        best_t = Vec3f{0.f, 0.f, 0.f};
+        best_ub = kHostInf;
+        count = 0;
+        cand = std::priority_queue<TransCube>();
+        cand.push(TransCube(0.f, 0.f, 0.f, 1.0f, 0.f, rnode_ub));  // :113
+        batch.clear();
+    }
+    // pops the next batch of <= 32 nodes; false when the search is over (:116-130)
+    bool next_batch(float sse_threshold) {
+        batch.clear();
+        while (batch.empty()) {
+            if (cand.empty()) return false;
+            if (best_error - cand.top().lb < sse_threshold) return false;  // :120
+            while (!cand.empty() && batch.size() < 32) {
+                TransCube tn = cand.top();
+                cand.pop();
+                if (tn.lb < best_error) batch.push_back(tn);
+            }
+        }
+        count += batch.size();  // :132
+        return true;
+    }
+    // consumes the operator's {lb, ub} of the current batch (:139-169)
+    void consume(const float* lb, const float* ub) {
+        const size_t n = batch.size();
+        size_t idx_min = 0;
+        for (size_t i = 1; i < n; ++i)
+            if (ub[i] < ub[idx_min]) idx_min = i;  // std::min_element: first minimum
+        best_ub = best_ub < ub[idx_min] ? best_ub : ub[idx_min];
+        if (ub[idx_min] < best_error) {
+            best_error = ub[idx_min];
+            best_t = batch[idx_min].t;
+        }
+        for (size_t i = 0; i < n; ++i) {
+            if (lb[i] >= best_error) continue;  // :151
+            const TransCube& tn = batch[i];
+            if (tn.span < 0.1f) continue;       // :155
+            const float span = tn.span / 2.0f;
+            for (char j = 0; j < 8; ++j)
+                cand.push(TransCube(tn.t.x - span + (j >> 0 & 1) * tn.span, tn.t.y - span + (j >> 1 & 1) * tn.span,
+                                    tn.t.z - span + (j >> 2 & 1) * tn.span, span, lb[i], ub[i]));
+        }
+    }
+};
+
+struct Task : InnerTask {
+    bool done = false;
+};
+
+template <class Ops>
+class GoIcpDriver {
+public:
+    GoIcpDriver(Ops& ops, size_t ns, float mse_threshold, int schedule, int round_width)
+        : ops_(ops), sse_threshold_(ns * mse_threshold), schedule_(schedule), round_width_(round_width < 1 ? 1 : round_width) {}
+
+    void set_exchange(const Exchange& ex) { ex_ = ex; }
+    const DriverStats& stats() const { return stats_; }
+
+    float best_sse() const { std::lock_guard<std::mutex> g(mu_); return best_sse_; }
+    void best_transform(Mat3f& R, Vec3f& t) const { std::lock_guard<std::mutex> g(mu_); R = best_R_; t = best_t_; }
+    void last_transform(Mat3f& R, Vec3f& t) const { std::lock_guard<std::mutex> g(mu_); R = last_R_; t = last_t_; }
+
+    // FastGoICP::run(), fgoicp.cpp:10-30 (without restore_translation: the caller owns the offsets)
+    int run() {
+        const auto t_start = clock::now();
+        stats_ = DriverStats{};
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            best_sse_ = kHostInf;
+            best_R_ = Mat3f::identity();
+            best_t_ = Vec3f{0.f, 0.f, 0.f};
+        }
+        float sse;
+        Mat3f R;
+        Vec3f t;
+        int rc = icp(Mat3f::identity(), Vec3f{0.f, 0.f, 0.f}, 0.05f, sse, R, t);  // :12-13
+        if (rc) return rc;
+        set_best_sse_only(sse);  // :14 — only the error is adopted
+        const auto t_bnb = clock::now();
+        rc = schedule_ == kScheduleSerial ? bnb_so3_serial() : bnb_so3_round();
+        stats_.seconds_bnb = seconds_since(t_bnb);
+        if (rc) return rc;
+        Mat3f bR;
+        Vec3f bt;
+        best_transform(bR, bt);
+        rc = icp(bR, bt, 0.0005f, sse, R, t);  // :22-23
+        if (rc) return rc;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            best_sse_ = sse;
+            best_R_ = R;
+            best_t_ = t;
+        }
+        stats_.seconds_total = seconds_since(t_start);
+        return kDriverOk;
+    }
+
+private:
+    using clock = std::chrono::steady_clock;
+    static double seconds_since(clock::time_point t0) { return std::chrono::duration<double>(clock::now() - t0).count(); }
+
+    int icp(const Mat3f& R0, const Vec3f& t0, float thr, float& sse, Mat3f& R, Vec3f& t) {
+        const auto t_icp = clock::now();
+        const float t03[3] = {t0.x, t0.y, t0.z};
+        float t3[3];
+        int iters = 0;
+        int rc = ops_.icp(R0.m, t03, 100, thr, &sse, R.m, t3, &iters);
+        t = Vec3f{t3[0], t3[1], t3[2]};
+        stats_.icp_runs++;
+        stats_.icp_iters += (uint64_t)iters;
+        stats_.seconds_icp += seconds_since(t_icp);
+        return rc;
+    }
+    void set_best_sse_only(float sse) { std::lock_guard<std::mutex> g(mu_); best_sse_ = sse; }
+    void set_last(const Mat3f& R, const Vec3f& t) { std::lock_guard<std::mutex> g(mu_); last_R_ = R; last_t_ = t; }
+
+    // branch_and_bound_R3 (fgoicp.cpp:102-174) for one rotation cube, run to completion
+    int bnb_r3(const RotCube& rnode, bool fix_rot, float best_sse_now, float& best_ub, Vec3f& best_t) {
+        Task task;
+        task.start(fix_rot, best_sse_now, rnode.ub);
+        stats_.inner_bnb++;
+        std::vector<Task*> v{&task};
+        std::vector<const RotCube*> c{&rnode};
+        int rc = run_task_list(v, c);
+        best_ub = task.best_ub;
+        best_t = task.best_t;
+        return rc;
+    }
+
+    // -------------------------------------------------------------------------------------------
+    // SERIAL: fgoicp.cpp:32-100 verbatim in behaviour
+    // -------------------------------------------------------------------------------------------
+    int bnb_so3_serial() {
+        std::priority_queue<RotCube> rcand;
+        rcand.push(RotCube(0.f, 0.f, 0.f, 1.0f, 0.f, best_sse()));
+        while (!rcand.empty()) {
+            const RotCube rnode = rcand.top();
+            rcand.pop();
+            stats_.rounds++;
+            if (best_sse() - rnode.lb <= sse_threshold_) break;  // :44
+            const float span = rnode.span / 2.0f;
+            for (char j = 0; j < 8; ++j) {
+                if (span < 0.05f) continue;  // :53
+                RotCube child(rnode.q.x - span + (j >> 0 & 1) * rnode.span, rnode.q.y - span + (j >> 1 & 1) * rnode.span,
+                              rnode.q.z - span + (j >> 2 & 1) * rnode.span, span, rnode.lb, rnode.ub);
+                if (!child.overlaps_SO3()) continue;
+                if (!child.q.in_SO3()) { rcand.push(child); continue; }
+                stats_.rot_cubes++;
+                float ub; Vec3f bt;
+                int rc = bnb_r3(child, true, best_sse(), ub, bt);  // :69
+                if (rc) return rc;
+                set_last(child.q.R, bt);  // :71-72
+                if (ub < best_sse() * 1.8) {  // :74, double compare
+                    float sse; Mat3f R; Vec3f t;
+                    rc = icp(child.q.R, bt, 0.005f, sse, R, t);
+                    if (rc) return rc;
+                    if (sse < best_sse()) { std::lock_guard<std::mutex> g(mu_); best_sse_ = sse; best_R_ = R; best_t_ = t; }
+                }
+                float lb; Vec3f unused;
+                rc = bnb_r3(child, false, best_sse(), lb, unused);  // :90
+                if (rc) return rc;
+                if (lb >= best_sse()) continue;  // :92
+                child.lb = lb;
+                child.ub = ub;
+                rcand.push(child);
+            }
+        }
+        return kDriverOk;
+    }
+
+    // -------------------------------------------------------------------------------------------
+    // ROUND: K parents per round, all children's UB+LB inner BnBs concurrently, children sharded
+    // over ranks, one all-reduce(min) + one all-gather per round.
+    // -------------------------------------------------------------------------------------------
+    int bnb_so3_round() {
+        std::priority_queue<RotCube> rcand;
+        rcand.push(RotCube(0.f, 0.f, 0.f, 1.0f, 0.f, best_sse()));
+        const int rank = ex_.rank, world = ex_.world < 1 ? 1 : ex_.world;
+        std::vector<RotCube> children;
+        while (!rcand.empty()) {
+            children.clear();
+            int popped = 0;
+            while (popped < round_width_ && !rcand.empty()) {
+                if (best_sse() - rcand.top().lb <= sse_threshold_) break;  // :44 (the top is the global min lb)
+                const RotCube rnode = rcand.top();
+                rcand.pop();
+                ++popped;
+                const float span = rnode.span / 2.0f;
+                for (char j = 0; j < 8; ++j) {
+                    if (span < 0.05f) continue;
+                    RotCube child(rnode.q.x - span + (j >> 0 & 1) * rnode.span, rnode.q.y - span + (j >> 1 & 1) * rnode.span,
+                                  rnode.q.z - span + (j >> 2 & 1) * rnode.span, span, rnode.lb, rnode.ub);
+                    if (!child.overlaps_SO3()) continue;
+                    if (!child.q.in_SO3()) { rcand.push(child); continue; }
+                    children.push_back(child);
+                }
+            }
+            if (popped == 0) break;
+            stats_.rounds++;
+            const size_t nchild = children.size();
+            const size_t slots = (nchild + world - 1) / world;  // per-rank child slots
+            const float snapshot = best_sse();
+
+            // my children: global index i with i % world == rank → slot i / world
+            std::vector<size_t> mine;
+            for (size_t i = rank; i < nchild; i += world) mine.push_back(i);
+            std::vector<Task> boxes(2 * mine.size());
+            std::vector<Task*> tasks;
+            std::vector<const RotCube*> cubes;
+            for (size_t k = 0; k < mine.size(); ++k) {
+                boxes[2 * k].start(true, snapshot, children[mine[k]].ub);
+                boxes[2 * k + 1].start(false, snapshot, children[mine[k]].ub);
+                tasks.push_back(&boxes[2 * k]); cubes.push_back(&children[mine[k]]);
+                tasks.push_back(&boxes[2 * k + 1]); cubes.push_back(&children[mine[k]]);
+                stats_.inner_bnb += 2;
+                stats_.rot_cubes++;
+            }
+            int rc = run_task_list(tasks, cubes);
+            if (rc) return rc;
+
+            // ICP triggers in child order against the running local best (fgoicp.cpp:74-88)
+            float loc_sse; Mat3f loc_R; Vec3f loc_t;
+            { std::lock_guard<std::mutex> g(mu_); loc_sse = best_sse_; loc_R = best_R_; loc_t = best_t_; }
+            for (size_t k = 0; k < mine.size(); ++k) {
+                const RotCube& ch = children[mine[k]];
+                const float ub = boxes[2 * k].best_ub;
+                const Vec3f bt = boxes[2 * k].best_t;
+                set_last(ch.q.R, bt);
+                if (ub < loc_sse * 1.8) {
+                    float sse; Mat3f R; Vec3f t;
+                    rc = icp(ch.q.R, bt, 0.005f, sse, R, t);
+                    if (rc) return rc;
+                    if (sse < loc_sse) { loc_sse = sse; loc_R = R; loc_t = t; }
+                }
+            }
+
+            // exchange: best error (min-all-reduce) + {candidate transform, child bounds} (all-gather)
+            std::vector<float> lbs(nchild), ubs(nchild);
+            if (world > 1) {
+                float gmin = loc_sse;
+                if (!ex_.allreduce_min || !ex_.allgather) return kDriverExchangeFailed;
+                if (ex_.allreduce_min(&gmin, 1, ex_.user)) return kDriverExchangeFailed;
+                const size_t per = 13 + 2 * slots;
+                std::vector<float> send(per, 0.f), recv(per * world, 0.f);
+                send[0] = loc_sse;
+                std::memcpy(&send[1], loc_R.m, sizeof(float) * 9);
+                send[10] = loc_t.x; send[11] = loc_t.y; send[12] = loc_t.z;
+                for (size_t k = 0; k < mine.size(); ++k) {
+                    send[13 + 2 * k] = boxes[2 * k + 1].best_ub;  // LB pass: its best_ub is the cube's lower bound (:90)
+                    send[13 + 2 * k + 1] = boxes[2 * k].best_ub;  // UB pass
+                }
+                if (ex_.allgather(send.data(), recv.data(), per, ex_.user)) return kDriverExchangeFailed;
+                for (int r = 0; r < world; ++r) {  // lowest rank holding the global minimum wins
+                    const float* p = &recv[per * r];
+                    if (p[0] == gmin && gmin < best_sse()) {
+                        std::lock_guard<std::mutex> g(mu_);
+                        best_sse_ = gmin;
+                        std::memcpy(best_R_.m, p + 1, sizeof(float) * 9);
+                        best_t_ = Vec3f{p[10], p[11], p[12]};
+                        break;
+                    }
+                }
+                for (size_t i = 0; i < nchild; ++i) {
+                    const float* p = &recv[per * (i % world)] + 13 + 2 * (i / world);
+                    lbs[i] = p[0];
+                    ubs[i] = p[1];
+                }
+            } else {
+                if (loc_sse < best_sse()) { std::lock_guard<std::mutex> g(mu_); best_sse_ = loc_sse; best_R_ = loc_R; best_t_ = loc_t; }
+                for (size_t k = 0; k < mine.size(); ++k) {
+                    lbs[mine[k]] = boxes[2 * k + 1].best_ub;
+                    ubs[mine[k]] = boxes[2 * k].best_ub;
+                }
+            }
+            const float now = best_sse();
+            for (size_t i = 0; i < nchild; ++i) {
+                if (lbs[i] >= now) continue;  // :92
+                children[i].lb = lbs[i];
+                children[i].ub = ubs[i];
+                rcand.push(children[i]);
+            }
+        }
+        return kDriverOk;
+    }
+
+    // Advance a set of inner tasks in lock-step: every tick submits the current batch of every live
+    // task in ONE operator call (G groups) and hands each task its slice of the results.
+    int run_task_list(std::vector<Task*>& tasks, const std::vector<const RotCube*>& cubes) {
+        std::vector<int> live;
+        std::vector<float> R9, spans, tn4, lb, ub;
+        std::vector<int> fix, offsets;
+        for (;;) {
+            live.clear();
+            R9.clear(); spans.clear(); fix.clear(); tn4.clear();
+            offsets.assign(1, 0);
+            for (size_t i = 0; i < tasks.size(); ++i) {
+                Task& tk = *tasks[i];
+                if (tk.done) continue;
+                if (!tk.next_batch(sse_threshold_)) { tk.done = true; continue; }
+                live.push_back((int)i);
+                R9.insert(R9.end(), cubes[i]->q.R.m, cubes[i]->q.R.m + 9);
+                spans.push_back(cubes[i]->span);
+                fix.push_back(tk.fix_rot ? 1 : 0);
+                for (const TransCube& c : tk.batch) {
+                    tn4.push_back(c.t.x); tn4.push_back(c.t.y); tn4.push_back(c.t.z); tn4.push_back(c.span);
+                }
+                offsets.push_back((int)(tn4.size() / 4));
+            }
+            if (live.empty()) return kDriverOk;
+            lb.resize(tn4.size() / 4);
+            ub.resize(tn4.size() / 4);
+            int rc = ops_.bounds_multi((int)live.size(), R9.data(), spans.data(), fix.data(), offsets.data(), tn4.data(), lb.data(), ub.data());
+            if (rc) return rc;
+            stats_.bounds_calls++;
+            stats_.trans_cubes += tn4.size() / 4;
+            for (size_t k = 0; k < live.size(); ++k) tasks[live[k]]->consume(lb.data() + offsets[k], ub.data() + offsets[k]);
+        }
+    }
+
+    Ops& ops_;
+    float sse_threshold_;
+    int schedule_, round_width_;
+    Exchange ex_;
+    DriverStats stats_;
+    mutable std::mutex mu_;
+    float best_sse_ = kHostInf;
+    Mat3f best_R_ = Mat3f::identity(), last_R_ = Mat3f::identity();
+    Vec3f best_t_{0.f, 0.f, 0.f}, last_t_{0.f, 0.f, 0.f};
+};
+
+}  // namespace fgoicp

@@ -1,0 +1,167 @@
+// Driver-level C ABI: icp::FastGoICP (reference fgoicp/fgoicp.hpp:13-43) over the HIP operator
+// context.  The driver template is instantiated with the HIP backend ONLY — there is no CPU
+// backend in this library.
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../../include/fgoicp_amd.h"
+#include "../device/ctx.hpp"
+#include "driver.hpp"
+
+namespace fgoicp {
+
+struct HipOps {
+    fgoicp_ctx* ctx;
+    int bounds_multi(int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets, const float* tn4, float* lb,
+                     float* ub) {
+        return ctx_bounds_multi(ctx, G, R9, rot_span, fix_rot, offsets, tn4, lb, ub);
+    }
+    int icp(const float* R0, const float* t0, size_t max_iter, float thr, float* sse, float* R9, float* t3, int* iters) {
+        return ctx_icp(ctx, R0, t0, max_iter, thr, sse, R9, t3, iters);
+    }
+};
+
+}  // namespace fgoicp
+
+using namespace fgoicp;
+
+struct fgoicp_solver {
+    // FastGoICP members in declaration order (fgoicp.hpp:47-58)
+    std::vector<Vec3f> pcs, pct;
+    size_t ns = 0, nt = 0;
+    Vec3f offset_pcs{0, 0, 0}, offset_pct{0, 0, 0};
+    float scaling_factor = 1.f;
+    float bounds6[6] = {0, 0, 0, 0, 0, 0};
+    fgoicp_ctx* ctx = nullptr;  // "registration"
+    HipOps ops{nullptr};
+    std::unique_ptr<GoIcpDriver<HipOps>> driver;
+    fgoicp_exchange ex{};
+    bool has_ex = false;
+};
+
+extern "C" {
+
+int fgoicp_solver_create(const float* tgt_xyz, size_t nt, const float* src_xyz, size_t ns, float lut_resolution, float mse_threshold,
+                         const fgoicp_solver_opts* opts, fgoicp_solver** out) {
+    if (!out) return FGOICP_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!tgt_xyz || !src_xyz || nt == 0 || ns == 0 || !(lut_resolution > 0) || !(mse_threshold >= 0)) {
+        set_error("fgoicp_solver_create: invalid argument");
+        return FGOICP_ERR_INVALID_ARG;
+    }
+    fgoicp_solver_opts o{FGOICP_SCHEDULE_SERIAL, 1, 0u, 0};
+    if (opts) o = *opts;
+    auto s = std::make_unique<fgoicp_solver>();
+    s->ns = ns;
+    s->nt = nt;
+    s->pcs.resize(ns);
+    s->pct.resize(nt);
+    std::memcpy(s->pcs.data(), src_xyz, sizeof(Vec3f) * ns);
+    std::memcpy(s->pct.data(), tgt_xyz, sizeof(Vec3f) * nt);
+    // member-initialiser order of the reference ctor (fgoicp.hpp:13-19)
+    s->offset_pcs = center_point_cloud(s->pcs);
+    s->offset_pct = center_point_cloud(s->pct);
+    s->scaling_factor = scale_point_clouds(s->pct, s->pcs);
+    point_cloud_ranges(s->pct, s->bounds6);
+    int rc = fgoicp_ctx_create(reinterpret_cast<const float*>(s->pct.data()), nt, reinterpret_cast<const float*>(s->pcs.data()), ns,
+                               s->bounds6, lut_resolution, o.device, o.ctx_flags, &s->ctx);
+    if (rc) return rc;
+    s->ops.ctx = s->ctx;
+    s->driver.reset(new GoIcpDriver<HipOps>(s->ops, ns, mse_threshold, o.schedule, o.round_width));
+    *out = s.release();
+    return FGOICP_OK;
+}
+
+void fgoicp_solver_destroy(fgoicp_solver* s) {
+    if (!s) return;
+    s->driver.reset();
+    fgoicp_ctx_destroy(s->ctx);
+    delete s;
+}
+
+int fgoicp_solver_set_exchange(fgoicp_solver* s, const fgoicp_exchange* ex) {
+    if (!s) return FGOICP_ERR_INVALID_ARG;
+    Exchange e;
+    if (ex) {
+        if (ex->world_size < 1 || ex->rank < 0 || ex->rank >= ex->world_size || (ex->world_size > 1 && (!ex->allreduce_min || !ex->allgather))) {
+            set_error("fgoicp_solver_set_exchange: invalid exchange");
+            return FGOICP_ERR_INVALID_ARG;
+        }
+        s->ex = *ex;
+        s->has_ex = true;
+        e.rank = ex->rank;
+        e.world = ex->world_size;
+        e.allreduce_min = ex->allreduce_min;
+        e.allgather = ex->allgather;
+        e.user = ex->user;
+    } else {
+        s->has_ex = false;
+    }
+    s->driver->set_exchange(e);
+    return FGOICP_OK;
+}
+
+int fgoicp_solver_run(fgoicp_solver* s, float* R_out9, float* t_out3) {
+    if (!s || !R_out9 || !t_out3) return FGOICP_ERR_INVALID_ARG;
+    int rc = s->driver->run();
+    if (rc == kDriverExchangeFailed) set_error("fgoicp_solver_run: exchange callback failed");
+    if (rc) return rc;
+    Mat3f R;
+    Vec3f t;
+    s->driver->best_transform(R, t);
+    // restore_translation, fgoicp.hpp:87-90
+    const Vec3f tr = t / s->scaling_factor + R * s->offset_pcs - s->offset_pct;
+    std::memcpy(R_out9, R.m, sizeof(R.m));
+    t_out3[0] = tr.x; t_out3[1] = tr.y; t_out3[2] = tr.z;
+    return FGOICP_OK;
+}
+
+int fgoicp_solver_best_error(const fgoicp_solver* s, float* sse_out) {
+    if (!s || !sse_out) return FGOICP_ERR_INVALID_ARG;
+    *sse_out = s->driver->best_sse();
+    return FGOICP_OK;
+}
+
+int fgoicp_solver_best_transform(const fgoicp_solver* s, float* R9, float* t3) {
+    if (!s || !R9 || !t3) return FGOICP_ERR_INVALID_ARG;
+    Mat3f R; Vec3f t;
+    s->driver->best_transform(R, t);
+    std::memcpy(R9, R.m, sizeof(R.m));
+    t3[0] = t.x; t3[1] = t.y; t3[2] = t.z;
+    return FGOICP_OK;
+}
+
+int fgoicp_solver_last_transform(const fgoicp_solver* s, float* R9, float* t3) {
+    if (!s || !R9 || !t3) return FGOICP_ERR_INVALID_ARG;
+    Mat3f R; Vec3f t;
+    s->driver->last_transform(R, t);
+    std::memcpy(R9, R.m, sizeof(R.m));
+    t3[0] = t.x; t3[1] = t.y; t3[2] = t.z;
+    return FGOICP_OK;
+}
+
+int fgoicp_solver_stats(const fgoicp_solver* s, fgoicp_run_stats* out) {
+    if (!s || !out) return FGOICP_ERR_INVALID_ARG;
+    const DriverStats& d = s->driver->stats();
+    out->trans_cubes = d.trans_cubes; out->bounds_calls = d.bounds_calls; out->rot_cubes = d.rot_cubes;
+    out->icp_runs = d.icp_runs; out->icp_iters = d.icp_iters; out->inner_bnb = d.inner_bnb; out->rounds = d.rounds;
+    out->seconds_total = d.seconds_total; out->seconds_bnb = d.seconds_bnb; out->seconds_icp = d.seconds_icp;
+    return FGOICP_OK;
+}
+
+int fgoicp_solver_preproc(const fgoicp_solver* s, float* offs6, float* scale, float* bounds6) {
+    if (!s) return FGOICP_ERR_INVALID_ARG;
+    if (offs6) {
+        offs6[0] = s->offset_pcs.x; offs6[1] = s->offset_pcs.y; offs6[2] = s->offset_pcs.z;
+        offs6[3] = s->offset_pct.x; offs6[4] = s->offset_pct.y; offs6[5] = s->offset_pct.z;
+    }
+    if (scale) *scale = s->scaling_factor;
+    if (bounds6) std::memcpy(bounds6, s->bounds6, sizeof(s->bounds6));
+    return FGOICP_OK;
+}
+
+fgoicp_ctx* fgoicp_solver_ctx(fgoicp_solver* s) { return s ? s->ctx : nullptr; }
+
+}  // extern "C"

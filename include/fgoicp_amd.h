@@ -1,0 +1,179 @@
+/*
+ * fgoicp_amd.h — C ABI of the MI355X-native Go-ICP hot path (libfgoicp_amd.so).
+ *
+ * The reference (solemnwind/fast-go-icp) has no FFI layer: its boundary is the C++ class
+ * interface in namespace icp.  Every entry point below names the reference
+ * interface it replaces (paths relative to the reference checkout).  Plain pointers and sizes
+ * only; every function returns an fgoicp_status (0 = OK) and never throws across the ABI.
+ *
+ * Conventions
+ *   - points:    float xyz triples, tightly packed (glm::vec3 / icp::Point3D, common.hpp:130).
+ *   - matrices:  9 floats in glm::mat3 memory order = COLUMN-major, m[col*3 + row]
+ *                (common.hpp:50-54).
+ *   - all pointers are HOST pointers unless a parameter says "device".
+ *   - a context is bound to one HIP device and one stream; it is not thread-safe.
+ *   - there is NO CPU fallback: without a usable HIP device every create call fails with
+ *     FGOICP_ERR_NO_DEVICE.
+ */
+#ifndef FGOICP_AMD_H
+#define FGOICP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum fgoicp_status {
+    FGOICP_OK = 0,
+    FGOICP_ERR_INVALID_ARG = 1,
+    FGOICP_ERR_NO_DEVICE = 2,   /* no HIP device / HIP runtime error at init            */
+    FGOICP_ERR_HIP = 3,         /* a HIP call failed (see fgoicp_last_error)             */
+    FGOICP_ERR_OOM = 4,
+    FGOICP_ERR_TOO_LARGE = 5,   /* batch larger than the context was sized for          */
+    FGOICP_ERR_EXCHANGE = 6     /* the multi-GPU exchange callback reported a failure   */
+} fgoicp_status;
+
+/* Thread-local description of the last failure on the calling thread ("" if none). */
+const char* fgoicp_last_error(void);
+const char* fgoicp_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Operator level: icp::Registration + icp::NearestNeighborLUT + icp::IterativeClosestPoint3D
+ * ------------------------------------------------------------------------------------------ */
+typedef struct fgoicp_ctx fgoicp_ctx;
+
+enum {
+    FGOICP_FLAG_NO_WEIGHT_QUANT = 1u << 0, /* trilinear weights in full fp32 instead of CUDA's 1.8 fixed point */
+    FGOICP_FLAG_NO_MORTON       = 1u << 1, /* keep the source cloud in caller order on the device             */
+    FGOICP_FLAG_PROFILE         = 1u << 2  /* bracket every bounds kernel with HIP events (fgoicp_ctx_profile) */
+};
+
+/*
+ * Replaces icp::Registration::Registration(pct, pcs, target_bounds, lut_resolution)
+ * (fgoicp/registration.hpp:68-80) together with icp::NearestNeighborLUT::NearestNeighborLUT /
+ * build (fgoicp/registration.cu:180-207, 258-318): uploads both clouds, builds the
+ * nearest-squared-distance LUT on the device.  bounds6 = {minx,maxx,miny,maxy,minz,maxz} of the
+ * target (std::array<std::pair<float,float>,3>).  Clouds are copied; the caller keeps ownership.
+ */
+int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, size_t ns, const float* bounds6,
+                      float lut_resolution, int device, unsigned flags, fgoicp_ctx** out);
+/* Replaces ~Registration / ~NearestNeighborLUT (registration.hpp:82-87, registration.cu:209-248). */
+void fgoicp_ctx_destroy(fgoicp_ctx* ctx);
+
+/* LUT geometry / contents in the reference's layout, index (z*dy + y)*dx + x
+ * (registration.cu:186-188, :276).  Used by tests and by INTEGRATION.md's façade. */
+int fgoicp_lut_dims(const fgoicp_ctx* ctx, int* dims3);
+int fgoicp_lut_read(fgoicp_ctx* ctx, float* out, size_t capacity_floats);
+/* Device evaluation of NearestNeighborLUT::search (registration.cu:320-328; CUDA tex3D linear
+ * filtering restated in software) at n query points. */
+int fgoicp_lut_search(fgoicp_ctx* ctx, const float* q_xyz, size_t n, float* out);
+
+/*
+ * Replaces Registration::compute_sse_error(RotNode&, std::vector<TransNode>&, bool, StreamPool&)
+ * (registration.hpp:97, registration.cu:88-152; kernel kernComputeBounds :27-60).
+ * tnodes4 = B x {t.x, t.y, t.z, span}.  Outputs: lb_out[B], ub_out[B] (the reference returns
+ * {lower, upper}, registration.cu:151).  B may exceed the reference's 32.
+ */
+int fgoicp_bounds_batch(fgoicp_ctx* ctx, const float* R9, float rot_span, const float* tnodes4, int B, int fix_rot,
+                        float* lb_out, float* ub_out);
+/*
+ * The same operator for G rotation nodes in one submission (one host<->device round trip):
+ * group g uses R9[g*9..], rot_span[g], fix_rot[g] and the translation nodes
+ * tnodes4[offsets[g]*4 .. offsets[g+1]*4).  lb_out/ub_out are indexed like tnodes.
+ */
+int fgoicp_bounds_multi(fgoicp_ctx* ctx, int G, const float* R9, const float* rot_span, const int* fix_rot,
+                        const int* offsets, const float* tnodes4, float* lb_out, float* ub_out);
+
+/* Replaces float Registration::compute_sse_error(glm::mat3 R, glm::vec3 t)
+ * (registration.hpp:96, registration.cu:62-86; kernels :14-25, :154-174): exact nearest
+ * neighbour SSE of R*src + t against the target. */
+int fgoicp_sse(fgoicp_ctx* ctx, const float* R9, const float* t3, float* sse_out);
+
+/* Replaces IterativeClosestPoint3D(reg, pct, pcs, max_iter, thr, R, t) + run()
+ * (fgoicp/icp3d.hpp:30-35, icp3d.cu:55-108).  Returns the reference's Result_t {sse, R, t}
+ * plus the number of loop iterations executed. */
+int fgoicp_icp(fgoicp_ctx* ctx, const float* R0_9, const float* t0_3, size_t max_iter, float conv_thr, float* sse_out,
+               float* R_out9, float* t_out3, int* iters_out);
+/* One IterativeClosestPoint3D::procrustes() step (icp3d.cu:140-172) on an explicit working cloud
+ * (ns x xyz, caller order).  Test hook: optional outputs may be NULL. */
+int fgoicp_procrustes(fgoicp_ctx* ctx, const float* working_xyz, float* R_out9, float* t_out3, float* centroids6,
+                      float* ABt9, int* corr_idx);
+
+/* Accumulated HIP-event timing of the bounds kernel since the last reset (FGOICP_FLAG_PROFILE):
+ * kernel_ms = sum of launch durations, launches = kernel launches, subcubes = (rot, trans) pairs. */
+int fgoicp_ctx_profile(fgoicp_ctx* ctx, double* kernel_ms, uint64_t* launches, uint64_t* subcubes, int reset);
+size_t fgoicp_ctx_ns(const fgoicp_ctx* ctx);
+size_t fgoicp_ctx_nt(const fgoicp_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------------
+ * Driver level: icp::FastGoICP (fgoicp/fgoicp.hpp:13-43, fgoicp/fgoicp.cpp:10-287)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct fgoicp_solver fgoicp_solver;
+
+typedef enum fgoicp_schedule {
+    FGOICP_SCHEDULE_SERIAL = 0, /* the reference's exact exploration order (fgoicp.cpp:32-174)       */
+    FGOICP_SCHEDULE_ROUND  = 1  /* expansion rounds: pop K cubes, evaluate all children concurrently  */
+} fgoicp_schedule;
+
+/*
+ * Exchange hook for the sharded outer BnB (one process per GPU).  Called once per expansion
+ * round on every rank, from the thread that called fgoicp_solver_run:
+ *   allreduce_min(buf, n, user)            — in-place element-wise MIN over ranks (RCCL all-reduce)
+ *   allgather(send, recv, n_per_rank, user)— recv[r*n .. (r+1)*n) = rank r's send[0..n)
+ * Both return 0 on success.
+ */
+typedef struct fgoicp_exchange {
+    int rank;
+    int world_size;
+    int (*allreduce_min)(float* buf, size_t n, void* user);
+    int (*allgather)(const float* send, float* recv, size_t n_per_rank, void* user);
+    void* user;
+} fgoicp_exchange;
+
+typedef struct fgoicp_solver_opts {
+    int schedule;        /* fgoicp_schedule                                            */
+    int round_width;     /* ROUND: rotation cubes popped per expansion round (K >= 1)  */
+    unsigned ctx_flags;  /* FGOICP_FLAG_*                                              */
+    int device;          /* HIP device ordinal                                         */
+} fgoicp_solver_opts;
+
+typedef struct fgoicp_run_stats {
+    uint64_t trans_cubes;   /* (rot, trans) subcubes evaluated = `count` of fgoicp.cpp:108,132 */
+    uint64_t bounds_calls;  /* bounds-operator submissions                                      */
+    uint64_t rot_cubes;     /* rotation cubes that went through branch_and_bound_R3             */
+    uint64_t icp_runs;
+    uint64_t icp_iters;
+    uint64_t inner_bnb;
+    uint64_t rounds;        /* expansion rounds (ROUND) / popped rotation nodes (SERIAL)        */
+    double   seconds_total; /* wall-clock of run()                                              */
+    double   seconds_bnb;   /* of which: outer BnB phase                                        */
+    double   seconds_icp;   /* of which: inside ICP                                             */
+} fgoicp_run_stats;
+
+/* Replaces FastGoICP::FastGoICP(pct, pcs, lut_resolution, mse_threshold) (fgoicp.hpp:13-25):
+ * centre, scale, bounds (fgoicp.cpp:176-287), then the Registration constructor. */
+int fgoicp_solver_create(const float* tgt_xyz, size_t nt, const float* src_xyz, size_t ns, float lut_resolution,
+                         float mse_threshold, const fgoicp_solver_opts* opts, fgoicp_solver** out);
+void fgoicp_solver_destroy(fgoicp_solver* s);
+/* Installs the multi-GPU exchange (NULL = single process). */
+int fgoicp_solver_set_exchange(fgoicp_solver* s, const fgoicp_exchange* ex);
+/* Replaces FastGoICP::run() (fgoicp.cpp:10-30): returns R and the restored translation
+ * (fgoicp.hpp:87-90). */
+int fgoicp_solver_run(fgoicp_solver* s, float* R_out9, float* t_out3);
+/* Replaces get_best_error / get_best_transform / get_last_transform (fgoicp.hpp:33-43);
+ * translations here are in the solver's scaled frame, as in the reference. */
+int fgoicp_solver_best_error(const fgoicp_solver* s, float* sse_out);
+int fgoicp_solver_best_transform(const fgoicp_solver* s, float* R9, float* t3);
+int fgoicp_solver_last_transform(const fgoicp_solver* s, float* R9, float* t3);
+int fgoicp_solver_stats(const fgoicp_solver* s, fgoicp_run_stats* out);
+/* Pre-processing results (tests): offs6 = {offset_pcs, offset_pct}, bounds6 as in ctx_create. */
+int fgoicp_solver_preproc(const fgoicp_solver* s, float* offs6, float* scale, float* bounds6);
+/* The operator context the solver drives (borrowed; valid until solver_destroy). */
+fgoicp_ctx* fgoicp_solver_ctx(fgoicp_solver* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FGOICP_AMD_H */

@@ -1,0 +1,567 @@
+// CPU restatement of the reference hot path — TEST INFRASTRUCTURE ONLY (see goicp_oracle.hpp).
+// PARITY UNPINNED (no reference outputs exist; see header).
+// Build with -ffp-contract=off: every fused multiply-add below is written explicitly.
+#include "goicp_oracle.hpp"
+
+#include <algorithm>
+#include <cfloat>
+#include <cstring>
+#include <limits>
+#include <queue>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace goicp_oracle {
+
+// ---------------------------------------------------------------------------------------------
+// small math (GLM semantics: column-major mat3)
+// ---------------------------------------------------------------------------------------------
+Mat3 mat3_identity() {
+    Mat3 m;
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) m.c[c][r] = (c == r) ? 1.0f : 0.0f;
+    return m;
+}
+
+// glm mat3*vec3: m[0][r]*v.x + m[1][r]*v.y + m[2][r]*v.z, device build → fma chain.
+Vec3 dev_mul(const Mat3& m, const Vec3& v) {
+    Vec3 o;
+    o.x = std::fmaf(m.c[2][0], v.z, std::fmaf(m.c[1][0], v.y, m.c[0][0] * v.x));
+    o.y = std::fmaf(m.c[2][1], v.z, std::fmaf(m.c[1][1], v.y, m.c[0][1] * v.x));
+    o.z = std::fmaf(m.c[2][2], v.z, std::fmaf(m.c[1][2], v.y, m.c[0][2] * v.x));
+    return o;
+}
+
+Vec3 host_mul(const Mat3& m, const Vec3& v) {
+    Vec3 o;
+    o.x = m.c[0][0] * v.x + m.c[1][0] * v.y + m.c[2][0] * v.z;
+    o.y = m.c[0][1] * v.x + m.c[1][1] * v.y + m.c[2][1] * v.z;
+    o.z = m.c[0][2] * v.x + m.c[1][2] * v.y + m.c[2][2] * v.z;
+    return o;
+}
+
+// glm mat3*mat3: Result[j][i] = A[0][i]*B[j][0] + A[1][i]*B[j][1] + A[2][i]*B[j][2]
+Mat3 host_mul(const Mat3& a, const Mat3& b) {
+    Mat3 o;
+    for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < 3; ++i)
+            o.c[j][i] = a.c[0][i] * b.c[j][0] + a.c[1][i] * b.c[j][1] + a.c[2][i] * b.c[j][2];
+    return o;
+}
+
+// device-side squared distance, registration.cu:154-160 / :250-256 (fma convention)
+static inline float dev_dist_sq(float ax, float ay, float az, float bx, float by, float bz) {
+    float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return std::fmaf(dz, dz, std::fmaf(dy, dy, dx * dx));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Rotation / RotNode — fgoicp/common.hpp:30-104 (host code: plain arithmetic)
+// ---------------------------------------------------------------------------------------------
+Rotation::Rotation(float x_, float y_, float z_) : x(x_), y(y_), z(z_), r(x_ * x_ + y_ * y_ + z_ * z_), R(mat3_identity()) {
+    if (r > 1.0f) return;  // common.hpp:42 — r keeps the *squared* norm, R stays identity
+    float ww = 1.0f - r;
+    float w = std::sqrt(ww);
+    float wx = w * x, xx = x * x;
+    float wy = w * y, xy = x * y, yy = y * y;
+    float wz = w * z, xz = x * z, yz = y * z, zz = z * z;
+    // glm::mat3(9 scalars) fills COLUMNS (common.hpp:50-54)
+    R.c[0][0] = ww + xx - yy - zz; R.c[0][1] = 2 * (xy - wz);     R.c[0][2] = 2 * (xz + wy);
+    R.c[1][0] = 2 * (xy + wz);     R.c[1][1] = ww - xx + yy - zz; R.c[1][2] = 2 * (yz - wx);
+    R.c[2][0] = 2 * (xz - wy);     R.c[2][1] = 2 * (yz + wx);     R.c[2][2] = ww - xx - yy + zz;
+    r = std::sqrt(r);
+}
+
+bool RotNode::overlaps_SO3() const {  // common.hpp:99-103
+    return q.r - 2 * span * (std::fabs(q.x) + std::fabs(q.y) + std::fabs(q.z)) + 3 * span * span <= 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// NearestNeighborLUT — registration.cu:180-207 (ctor), :258-318 (build), :320-328 (search)
+// ---------------------------------------------------------------------------------------------
+NearestNeighborLUT::NearestNeighborLUT(float res, const Bounds& b, const PointCloud& pc, bool build_now) : resolution(res) {
+    dims[0] = (int)std::ceil((b[0].second - b[0].first) / resolution);  // :186-188
+    dims[1] = (int)std::ceil((b[1].second - b[1].first) / resolution);
+    dims[2] = (int)std::ceil((b[2].second - b[2].first) / resolution);
+    scale = 1.0f / resolution;  // :201
+    offset = Vec3{-b[0].first, -b[1].first, -b[2].first};  // :202-204
+    if (build_now) build(pc);
+}
+
+void NearestNeighborLUT::build(const PointCloud& pc) {
+    const int np = (int)pc.size();
+    std::vector<Vec3> pts(np);
+    for (int i = 0; i < np; ++i)  // :289-296 (host)
+        pts[i] = Vec3{pc[i].x + offset.x, pc[i].y + offset.y, pc[i].z + offset.z};
+    data.assign(size(), 0.f);
+    const int dx = dims[0], dy = dims[1], dz = dims[2];
+#pragma omp parallel for collapse(2) schedule(dynamic, 4)
+    for (int z = 0; z < dz; ++z)
+        for (int y = 0; y < dy; ++y)
+            for (int x = 0; x < dx; ++x) {  // buildLUTKernel :258-278
+                float cx = x * resolution, cy = y * resolution, cz = z * resolution;
+                float minDist = FLT_MAX;
+                for (int i = 0; i < np; ++i) {
+                    float d = dev_dist_sq(cx, cy, cz, pts[i].x, pts[i].y, pts[i].z);
+                    minDist = minDist < d ? minDist : d;
+                }
+                data[((size_t)z * dy + y) * dx + x] = minDist;
+            }
+}
+
+// CUDA linear filtering, unnormalised coordinates, clamp addressing (CUDA C
+// Programming Guide "Texture Fetching / Linear Filtering"): xB = x - 0.5, i = floor(xB),
+// alpha = frac(xB) stored in 9-bit fixed point with 8 fractional bits.
+static inline void tex_axis(float u, int dim, bool quant, int& i0, int& i1, float& w) {
+    float ub = u - 0.5f;
+    float fl = std::floor(ub);
+    w = ub - fl;
+    if (quant) w = std::floor(w * 256.0f + 0.5f) * (1.0f / 256.0f);
+    // clamp in float first so that huge |u| cannot overflow the int conversion
+    float lo = fl < -1.0f ? -1.0f : (fl > (float)dim ? (float)dim : fl);
+    int i = (int)lo;
+    i0 = std::min(std::max(i, 0), dim - 1);
+    i1 = std::min(std::max(i + 1, 0), dim - 1);
+}
+
+float NearestNeighborLUT::search(const Vec3& q) const {
+    float x = (q.x + offset.x) * scale;  // :323-325
+    float y = (q.y + offset.y) * scale;
+    float z = (q.z + offset.z) * scale;
+    int x0, x1, y0, y1, z0, z1;
+    float a, b, c;
+    tex_axis(x, dims[0], quantize_weights, x0, x1, a);
+    tex_axis(y, dims[1], quantize_weights, y0, y1, b);
+    tex_axis(z, dims[2], quantize_weights, z0, z1, c);
+    const size_t dx = dims[0], dy = dims[1];
+    auto T = [&](int xi, int yi, int zi) { return data[((size_t)zi * dy + yi) * dx + xi]; };
+    auto lerp = [](float p, float q_, float w) { return std::fmaf(w, q_ - p, p); };
+    float c00 = lerp(T(x0, y0, z0), T(x1, y0, z0), a);
+    float c10 = lerp(T(x0, y1, z0), T(x1, y1, z0), a);
+    float c01 = lerp(T(x0, y0, z1), T(x1, y0, z1), a);
+    float c11 = lerp(T(x0, y1, z1), T(x1, y1, z1), a);
+    float c0 = lerp(c00, c10, b);
+    float c1 = lerp(c01, c11, b);
+    return lerp(c0, c1, c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Registration — registration.hpp:68-98, registration.cu:14-174
+// ---------------------------------------------------------------------------------------------
+Registration::Registration(const PointCloud& pct_, const PointCloud& pcs_, const Bounds& bounds, float lut_res, bool build_lut)
+    : pct(pct_), pcs(pcs_), nnlut(lut_res, bounds, pct_, build_lut) {}
+
+float brute_force_find_nearest_neighbor(const Vec3& q, const PointCloud& pct) {  // :162-174
+    float best = kInf;
+    const size_t nt = pct.size();
+    for (size_t i = 0; i < nt; ++i) {
+        float d = dev_dist_sq(q.x, q.y, q.z, pct[i].x, pct[i].y, pct[i].z);
+        if (d < best) best = d;
+    }
+    return best;
+}
+
+float Registration::compute_sse_error(const Mat3& R, const Vec3& t) const {  // :62-86 + kernel :14-25
+    const long ns = (long)pcs.size();
+    double sum = 0.0;  // thrust::reduce(float, plus) restated as a double sum (header, conventions)
+#pragma omp parallel for reduction(+ : sum) schedule(static)
+    for (long i = 0; i < ns; ++i) {
+        Vec3 rp = dev_mul(R, pcs[i]);
+        Vec3 q{rp.x + t.x, rp.y + t.y, rp.z + t.z};
+        sum += (double)brute_force_find_nearest_neighbor(q, pct);
+    }
+    return (float)sum;
+}
+
+std::tuple<std::vector<float>, std::vector<float>>
+Registration::compute_sse_error(const RotNode& rnode, const std::vector<TransNode>& tnodes, bool fix_rot) const {
+    const size_t B = tnodes.size();
+    const long ns = (long)pcs.size();
+    std::vector<float> upper(B), lower(B);
+    // kernComputeBounds :27-60; the per-kernel constants are hoisted (they do not depend on the point)
+    float half_angle = rnode.span * kSqrt3 * kPi / 2.0f;  // :42
+    float sin_half = std::sin(half_angle);                // float overload, as device sin(float)
+    for (size_t b = 0; b < B; ++b) {
+        const TransNode& tn = tnodes[b];
+        float trans_uncertain_radius = kSqrt3 * tn.span;  // :33
+        double sum_ub = 0.0, sum_lb = 0.0;
+#pragma omp parallel for reduction(+ : sum_ub, sum_lb) schedule(static)
+        for (long i = 0; i < ns; ++i) {
+            const Vec3 p = pcs[i];
+            Vec3 rp = dev_mul(rnode.q.R, p);
+            Vec3 q{rp.x + tn.t.x, rp.y + tn.t.y, rp.z + tn.t.z};  // :34
+            float rot_uncertain_radius = 0.f;
+            if (!fix_rot) {
+                float radius = std::fmaf(p.z, p.z, std::fmaf(p.y, p.y, p.x * p.x));  // :39-41 (squared norm: reference quirk)
+                rot_uncertain_radius = 2.0f * radius * sin_half;                         // :43
+            }
+            float dsq = nnlut.search(q);  // :46
+            float d = std::sqrt(dsq);     // :48
+            if (!fix_rot) d -= rot_uncertain_radius;
+            float ubv = d > 0.0f ? d * d : 0.0f;  // :54
+            float l = d - trans_uncertain_radius;  // :57
+            float lbv = l > 0.0f ? l * l : 0.0f;
+            sum_ub += (double)ubv;
+            sum_lb += (double)lbv;
+        }
+        upper[b] = (float)sum_ub;
+        lower[b] = (float)sum_lb;
+    }
+    return {lower, upper};  // :151 — lower first
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 SVD in double (stands in for Eigen::JacobiSVD<Matrix3d>, icp3d.cu:118-121):
+// two-sided Jacobi — each (p,q) 2x2 block is first symmetrised by a left rotation, then
+// diagonalised by a symmetric Jacobi rotation.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct M3d { double a[3][3]; };  // row-major math matrix a[row][col]
+
+M3d m3d_identity() { M3d m{}; for (int i = 0; i < 3; ++i) m.a[i][i] = 1.0; return m; }
+M3d m3d_mul(const M3d& x, const M3d& y) {
+    M3d o{};
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += x.a[i][k] * y.a[k][j]; o.a[i][j] = s; }
+    return o;
+}
+M3d m3d_T(const M3d& x) { M3d o{}; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) o.a[i][j] = x.a[j][i]; return o; }
+double m3d_det(const M3d& m) {
+    return m.a[0][0] * (m.a[1][1] * m.a[2][2] - m.a[1][2] * m.a[2][1]) - m.a[0][1] * (m.a[1][0] * m.a[2][2] - m.a[1][2] * m.a[2][0]) +
+           m.a[0][2] * (m.a[1][0] * m.a[2][1] - m.a[1][1] * m.a[2][0]);
+}
+
+// A = U * diag(S) * V^T, S sorted descending, S >= 0.
+void svd3(const M3d& Ain, M3d& U, double S[3], M3d& V) {
+    M3d A = Ain;
+    U = m3d_identity();
+    V = m3d_identity();
+    double scale = 0;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) scale = std::max(scale, std::fabs(A.a[i][j]));
+    if (scale == 0) { S[0] = S[1] = S[2] = 0; return; }
+    const double eps = std::numeric_limits<double>::epsilon();
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool done = true;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double thr = std::max(std::fabs(A.a[p][p]), std::fabs(A.a[q][q])) * 2 * eps;
+                thr = std::max(thr, std::numeric_limits<double>::min());
+                if (std::fabs(A.a[p][q]) <= thr && std::fabs(A.a[q][p]) <= thr) continue;
+                done = false;
+                // 2x2 block
+                double a = A.a[p][p], b = A.a[p][q], c = A.a[q][p], d = A.a[q][q];
+                // left rotation G=[[cg,sg],[-sg,cg]] with G*M symmetric: cg*b + sg*d = -sg*a + cg*c
+                double cg = 1, sg = 0;
+                double tt = a + d, dd = c - b;
+                if (std::fabs(dd) > std::numeric_limits<double>::min()) {
+                    double u = tt / dd;
+                    double h = std::sqrt(1.0 + u * u);
+                    sg = 1.0 / h;
+                    cg = u / h;
+                }
+                // S = G*M
+                double s00 = cg * a + sg * c, s01 = cg * b + sg * d, s11 = -sg * b + cg * d;
+                // Jacobi rotation J=[[cj,sj],[-sj,cj]] diagonalising symmetric [[s00,s01],[s01,s11]]
+                double cj = 1, sj = 0;
+                if (std::fabs(s01) > std::numeric_limits<double>::min()) {
+                    double tau = (s11 - s00) / (2.0 * s01);
+                    double tj = (tau >= 0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1.0 + tau * tau));
+                    cj = 1.0 / std::sqrt(1.0 + tj * tj);
+                    sj = tj * cj;
+                }
+                // M = G^T S, S = J D J^T  =>  A <- (J^T G) A J,  U <- U (J^T G)^T,  V <- V J
+                double G[2][2] = {{cg, sg}, {-sg, cg}};
+                double J[2][2] = {{cj, sj}, {-sj, cj}};
+                double L[2][2];  // L = J^T * G
+                for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) L[i][j] = J[0][i] * G[0][j] + J[1][i] * G[1][j];
+                // A <- L * A (rows p,q)
+                for (int col = 0; col < 3; ++col) {
+                    double r0 = A.a[p][col], r1 = A.a[q][col];
+                    A.a[p][col] = L[0][0] * r0 + L[0][1] * r1;
+                    A.a[q][col] = L[1][0] * r0 + L[1][1] * r1;
+                }
+                // A <- A * J (cols p,q)
+                for (int row = 0; row < 3; ++row) {
+                    double c0 = A.a[row][p], c1 = A.a[row][q];
+                    A.a[row][p] = c0 * J[0][0] + c1 * J[1][0];
+                    A.a[row][q] = c0 * J[0][1] + c1 * J[1][1];
+                }
+                // U <- U * L^T, V <- V * J
+                for (int row = 0; row < 3; ++row) {
+                    double u0 = U.a[row][p], u1 = U.a[row][q];
+                    U.a[row][p] = u0 * L[0][0] + u1 * L[0][1];
+                    U.a[row][q] = u0 * L[1][0] + u1 * L[1][1];
+                    double v0 = V.a[row][p], v1 = V.a[row][q];
+                    V.a[row][p] = v0 * J[0][0] + v1 * J[1][0];
+                    V.a[row][q] = v0 * J[0][1] + v1 * J[1][1];
+                }
+            }
+        if (done) break;
+    }
+    for (int i = 0; i < 3; ++i) {
+        S[i] = A.a[i][i];
+        if (S[i] < 0) { S[i] = -S[i]; for (int r = 0; r < 3; ++r) U.a[r][i] = -U.a[r][i]; }
+    }
+    // sort descending (selection, swapping columns of U and V)
+    for (int i = 0; i < 2; ++i) {
+        int m = i;
+        for (int j = i + 1; j < 3; ++j) if (S[j] > S[m]) m = j;
+        if (m != i) {
+            std::swap(S[i], S[m]);
+            for (int r = 0; r < 3; ++r) { std::swap(U.a[r][i], U.a[r][m]); std::swap(V.a[r][i], V.a[r][m]); }
+        }
+    }
+}
+}  // namespace
+
+// icp3d.cu:110-138
+Mat3 closest_orthogonal_approximation(const Mat3& ABt) {
+    M3d H;  // matrix(r,c) = ABt[c][r]  (:113-116)
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H.a[r][c] = (double)ABt.c[c][r];
+    M3d U, V;
+    double S[3];
+    svd3(H, U, S, V);
+    M3d VUt = m3d_mul(V, m3d_T(U));
+    double det = m3d_det(VUt);
+    M3d D = m3d_identity();
+    D.a[2][2] = det;
+    M3d R = m3d_mul(m3d_mul(V, D), m3d_T(U));
+    Mat3 out;  // glm::mat3{R(0,0),R(1,0),R(2,0), ...}: out[c][r] = R(r,c)  (:135-137)
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) out.c[c][r] = (float)R.a[r][c];
+    return out;
+}
+
+// exposed for tests through the C API
+void svd3_rowmajor(const double* A9, double* U9, double* S3, double* V9) {
+    M3d A, U, V;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) A.a[i][j] = A9[i * 3 + j];
+    svd3(A, U, S3, V);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { U9[i * 3 + j] = U.a[i][j]; V9[i * 3 + j] = V.a[i][j]; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// IterativeClosestPoint3D — icp3d.cu:11-172
+// ---------------------------------------------------------------------------------------------
+IterativeClosestPoint3D::IterativeClosestPoint3D(const Registration& reg, const PointCloud& pct, const PointCloud& pcs, size_t max_iter,
+                                                 float conv_thr, const Mat3& R, const Vec3& t)
+    : reg_(reg), pct_(pct), pcs_buf_(pcs), R_(R), t_(t), max_iter_(max_iter), thr_(conv_thr) {}
+
+static void rotate_translate_inplace(PointCloud& pc, const Mat3& R, const Vec3& t) {  // kernRotateTranslateInplace :30-36
+    const long n = (long)pc.size();
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; ++i) {
+        Vec3 rp = dev_mul(R, pc[i]);
+        pc[i] = Vec3{rp.x + t.x, rp.y + t.y, rp.z + t.z};
+    }
+}
+
+std::tuple<Mat3, Vec3> IterativeClosestPoint3D::procrustes(ProcrustesDebug* dbg) {  // :140-172
+    const long ns = (long)pcs_buf_.size();
+    const long nt = (long)pct_.size();
+    PointCloud corrs(ns);
+    corr_idx_.assign(ns, -1);
+    // kernFindNearestNeighbor :11-28 — sqrt distance, strict '>' so the first minimum wins
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < ns; ++i) {
+        float dist_min = kInf;
+        Vec3 corr{0.f, 0.f, 0.f};
+        int best = -1;
+        const Vec3 s = pcs_buf_[i];
+        for (long j = 0; j < nt; ++j) {
+            float dist = std::sqrt(dev_dist_sq(pct_[j].x, pct_[j].y, pct_[j].z, s.x, s.y, s.z));
+            if (dist_min > dist) { dist_min = dist; corr = pct_[j]; best = (int)j; }
+        }
+        corrs[i] = corr;
+        corr_idx_[i] = best;
+    }
+    // thrust::reduce of Point3D x2 (:152-153) → double sums rounded to fp32
+    double sx = 0, sy = 0, sz = 0, cx = 0, cy = 0, cz = 0;
+    for (long i = 0; i < ns; ++i) {
+        sx += pcs_buf_[i].x; sy += pcs_buf_[i].y; sz += pcs_buf_[i].z;
+        cx += corrs[i].x; cy += corrs[i].y; cz += corrs[i].z;
+    }
+    Vec3 src_centroid{(float)sx, (float)sy, (float)sz};
+    Vec3 cor_centroid{(float)cx, (float)cy, (float)cz};
+    float fn = static_cast<float>(ns);
+    src_centroid = Vec3{src_centroid.x / fn, src_centroid.y / fn, src_centroid.z / fn};  // :155-156
+    cor_centroid = Vec3{cor_centroid.x / fn, cor_centroid.y / fn, cor_centroid.z / fn};
+    // kernCentralize x2 (:38-44), kernOuterProduct (:46-52), reduce mat3 (:165-166)
+    double acc[3][3] = {{0}};
+    for (long i = 0; i < ns; ++i) {
+        float a[3] = {pcs_buf_[i].x - src_centroid.x, pcs_buf_[i].y - src_centroid.y, pcs_buf_[i].z - src_centroid.z};
+        float b[3] = {corrs[i].x - cor_centroid.x, corrs[i].y - cor_centroid.y, corrs[i].z - cor_centroid.z};
+        // glm::outerProduct(c=a, r=b): m[col i][row k] = a[k]*b[i]
+        for (int col = 0; col < 3; ++col)
+            for (int row = 0; row < 3; ++row) acc[col][row] += (double)(a[row] * b[col]);
+    }
+    Mat3 ABt;
+    for (int col = 0; col < 3; ++col) for (int row = 0; row < 3; ++row) ABt.c[col][row] = (float)acc[col][row];
+    Mat3 Rn = closest_orthogonal_approximation(ABt);  // :168
+    Vec3 rs = host_mul(Rn, src_centroid);
+    Vec3 tn{cor_centroid.x - rs.x, cor_centroid.y - rs.y, cor_centroid.z - rs.z};  // :169
+    if (dbg) { dbg->src_centroid = src_centroid; dbg->cor_centroid = cor_centroid; dbg->ABt = ABt; }
+    return {Rn, tn};
+}
+
+std::tuple<float, Mat3, Vec3> IterativeClosestPoint3D::run() {  // :80-108
+    rotate_translate_inplace(pcs_buf_, R_, t_);  // :85
+    size_t iter = 0;
+    float sse = kInf;
+    float last_sse = 2.0f * kInf;
+    Mat3 last_R = mat3_identity();
+    Vec3 last_t{0, 0, 0};
+    iters_ = 0;
+    while (iter++ < max_iter_ && (last_sse - sse) > thr_ * last_sse) {
+        last_sse = sse;
+        last_R = R_;
+        last_t = t_;
+        auto [Rn, tn] = procrustes();
+        rotate_translate_inplace(pcs_buf_, Rn, tn);  // :100
+        R_ = host_mul(Rn, R_);                        // :101
+        Vec3 rt = host_mul(Rn, t_);
+        t_ = Vec3{rt.x + tn.x, rt.y + tn.y, rt.z + tn.z};  // :102
+        sse = reg_.compute_sse_error(R_, t_);         // :103
+        ++iters_;
+    }
+    if (sse < last_sse) return {sse, R_, t_};
+    return {last_sse, last_R, last_t};
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pre-processing — fgoicp.cpp:176-287 (the omp pragmas there are inert; serial fp32 sums)
+// ---------------------------------------------------------------------------------------------
+Vec3 center_point_cloud(PointCloud& pc) {
+    Vec3 c{0, 0, 0};
+    for (size_t i = 0; i < pc.size(); ++i) { c.x += pc[i].x; c.y += pc[i].y; c.z += pc[i].z; }
+    float fn = static_cast<float>(pc.size());
+    c = Vec3{c.x / fn, c.y / fn, c.z / fn};
+    for (size_t i = 0; i < pc.size(); ++i) { pc[i].x -= c.x; pc[i].y -= c.y; pc[i].z -= c.z; }
+    return Vec3{-c.x, -c.y, -c.z};
+}
+
+float get_scaling_factor(const PointCloud& pc) {
+    float max_abs = std::numeric_limits<float>::lowest();
+    for (const auto& p : pc) max_abs = std::max(max_abs, std::max(std::fabs(p.x), std::max(std::fabs(p.y), std::fabs(p.z))));
+    return 1.0f / max_abs;
+}
+
+float scale_point_clouds(PointCloud& pct, PointCloud& pcs) {
+    float s = get_scaling_factor(pcs);
+    for (auto& p : pcs) { p.x *= s; p.y *= s; p.z *= s; }
+    for (auto& p : pct) { p.x *= s; p.y *= s; p.z *= s; }
+    return s;
+}
+
+Bounds get_point_cloud_ranges(const PointCloud& pc) {
+    Bounds r = {std::make_pair(std::numeric_limits<float>::max(), std::numeric_limits<float>::lowest()),
+                std::make_pair(std::numeric_limits<float>::max(), std::numeric_limits<float>::lowest()),
+                std::make_pair(std::numeric_limits<float>::max(), std::numeric_limits<float>::lowest())};
+    for (const auto& p : pc) {
+        r[0].first = std::min(r[0].first, p.x); r[0].second = std::max(r[0].second, p.x);
+        r[1].first = std::min(r[1].first, p.y); r[1].second = std::max(r[1].second, p.y);
+        r[2].first = std::min(r[2].first, p.z); r[2].second = std::max(r[2].second, p.z);
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FastGoICP — fgoicp.hpp:13-25 (member init order :47-58), fgoicp.cpp:10-174
+// ---------------------------------------------------------------------------------------------
+FastGoICP::FastGoICP(PointCloud pct_, PointCloud pcs_, float lut_resolution, float mse_thr)
+    : pcs(std::move(pcs_)), pct(std::move(pct_)), ns(pcs.size()), nt(pct.size()),
+      offset_pcs(center_point_cloud(pcs)), offset_pct(center_point_cloud(pct)),
+      scaling_factor(scale_point_clouds(pct, pcs)), target_bounds(get_point_cloud_ranges(pct)),
+      registration(pct, pcs, target_bounds, lut_resolution),
+      best_sse(kInf), best_rotation(mat3_identity()), best_translation{0, 0, 0},
+      mse_threshold(mse_thr), sse_threshold(ns * mse_thr) {}
+
+Vec3 FastGoICP::restore_translation(const Mat3& R, const Vec3& t) const {  // fgoicp.hpp:87-90
+    Vec3 ro = host_mul(R, offset_pcs);
+    return Vec3{t.x / scaling_factor + ro.x - offset_pct.x, t.y / scaling_factor + ro.y - offset_pct.y,
+                t.z / scaling_factor + ro.z - offset_pct.z};
+}
+
+std::tuple<Mat3, Vec3> FastGoICP::run() {  // fgoicp.cpp:10-30
+    {
+        IterativeClosestPoint3D icp3d(registration, pct, pcs, 100, 0.05f, mat3_identity(), Vec3{0, 0, 0});
+        auto [icp_sse, icp_R, icp_t] = icp3d.run();
+        (void)icp_R; (void)icp_t;
+        best_sse = icp_sse;  // :14 — only the error is adopted, not (R,t)
+        stats_.icp_runs++; stats_.icp_iters += icp3d.iterations();
+    }
+    branch_and_bound_SO3();
+    IterativeClosestPoint3D icp3d_best(registration, pct, pcs, 100, 0.0005f, best_rotation, best_translation);
+    std::tie(best_sse, best_rotation, best_translation) = icp3d_best.run();
+    stats_.icp_runs++; stats_.icp_iters += icp3d_best.iterations();
+    return {best_rotation, restore_translation(best_rotation, best_translation)};
+}
+
+float FastGoICP::branch_and_bound_SO3() {  // fgoicp.cpp:32-100
+    std::priority_queue<RotNode> rcandidates;
+    rcandidates.push(RotNode(0.0f, 0.0f, 0.0f, 1.0f, 0.0f, best_sse));
+    while (!rcandidates.empty()) {
+        RotNode rnode = rcandidates.top();
+        rcandidates.pop();
+        if (best_sse - rnode.lb <= sse_threshold) break;  // :44
+        float span = rnode.span / 2.0f;
+        for (char j = 0; j < 8; ++j) {
+            if (span < 0.05f) continue;  // :53
+            RotNode child(rnode.q.x - span + (j >> 0 & 1) * rnode.span, rnode.q.y - span + (j >> 1 & 1) * rnode.span,
+                          rnode.q.z - span + (j >> 2 & 1) * rnode.span, span, rnode.lb, rnode.ub);
+            if (!child.overlaps_SO3()) continue;
+            if (!child.q.in_SO3()) { rcandidates.push(child); continue; }
+            stats_.rot_cubes++;
+            auto [ub, best_t] = branch_and_bound_R3(child, true);  // :69
+            if (ub < best_sse * 1.8) {                              // :74 (double compare)
+                IterativeClosestPoint3D icp3d(registration, pct, pcs, 100, 0.005f, child.q.R, best_t);
+                auto [icp_sse, icp_R, icp_t] = icp3d.run();
+                stats_.icp_runs++; stats_.icp_iters += icp3d.iterations();
+                if (icp_sse < best_sse) { best_sse = icp_sse; best_rotation = icp_R; best_translation = icp_t; }
+            }
+            auto [lb, unused_t] = branch_and_bound_R3(child, false);  // :90
+            (void)unused_t;
+            if (lb >= best_sse) continue;
+            child.lb = lb;
+            child.ub = ub;
+            rcandidates.push(child);
+        }
+    }
+    return best_sse;
+}
+
+std::tuple<float, Vec3> FastGoICP::branch_and_bound_R3(RotNode& rnode, bool fix_rot) {  // fgoicp.cpp:102-174
+    float best_error = best_sse;
+    Vec3 best_t{0, 0, 0};
+    float best_ub = kInf;
+    stats_.inner_bnb++;
+    std::priority_queue<TransNode> tcandidates;
+    tcandidates.push(TransNode(0.0f, 0.0f, 0.0f, 1.0f, 0.0f, rnode.ub));
+    while (!tcandidates.empty()) {
+        std::vector<TransNode> tnodes;
+        if (best_error - tcandidates.top().lb < sse_threshold) break;  // :120
+        while (!tcandidates.empty() && tnodes.size() < 32) {
+            TransNode tn = tcandidates.top();
+            tcandidates.pop();
+            if (tn.lb < best_error) tnodes.push_back(tn);
+        }
+        stats_.trans_cubes += tnodes.size();
+        stats_.bounds_calls++;
+        auto [lb, ub] = registration.compute_sse_error(rnode, tnodes, fix_rot);
+        size_t idx_min = std::distance(ub.begin(), std::min_element(ub.begin(), ub.end()));
+        best_ub = best_ub < ub[idx_min] ? best_ub : ub[idx_min];
+        if (ub[idx_min] < best_error) { best_error = ub[idx_min]; best_t = tnodes[idx_min].t; }
+        for (size_t i = 0; i < tnodes.size(); ++i) {
+            if (lb[i] >= best_error) continue;
+            TransNode& tn = tnodes[i];
+            if (tn.span < 0.1f) continue;  // :155
+            float span = tn.span / 2.0f;
+            for (char j = 0; j < 8; ++j)
+                tcandidates.push(TransNode(tn.t.x - span + (j >> 0 & 1) * tn.span, tn.t.y - span + (j >> 1 & 1) * tn.span,
+                                           tn.t.z - span + (j >> 2 & 1) * tn.span, span, lb[i], ub[i]));
+        }
+    }
+    return {best_ub, best_t};
+}
+
+}  // namespace goicp_oracle

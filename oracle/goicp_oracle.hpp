@@ -1,0 +1,188 @@
+// ============================================================================
+// goicp_oracle — CPU restatement of solemnwind/fast-go-icp's hot path.
+//
+// THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, bench.py's
+// `cpu_baseline` leg and __graft_entry__.smoke() may build, load or call it.
+// The product (fast-go-icp_amd/) never includes, links or dlopens anything
+// under oracle/.
+//
+// PARITY UNPINNED: the reference (CUDA + Thrust + GLM + Eigen + CUDA texture
+// unit) cannot be built in this image, and it ships no unit tests, golden
+// vectors or published outputs.  This file restates the
+// reference's arithmetic line by line (each function cites the file:line it
+// follows, paths relative to the reference checkout) and is pinned only by
+// analytic known-answer tests and by an independent numpy restatement
+// (oracle/np_restatement.py), not by reference outputs.
+//
+// Conventions that the reference inherits from CUDA/GLM/Thrust and that are
+// therefore *chosen* here (documented in DESIGN.md §Oracle):
+//   * device code (nvcc -fmad=true): a*x + b*y + c*z is evaluated as
+//     fma(c, z, fma(b, y, a*x)); host code (fgoicp.cpp, the host half of
+//     icp3d.cu) uses plain mul/add, left to right;
+//   * Thrust reductions (unspecified fp32 tree order) are restated as a
+//     double-precision serial sum rounded once to fp32;
+//   * CUDA linear texture filtering: sample at x-0.5, i=floor, weight held in
+//     1.8 fixed point (round-to-nearest), clamp addressing, lerp x→y→z.
+// ============================================================================
+#pragma once
+#include <array>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+namespace goicp_oracle {
+
+// fgoicp/common.hpp:17-19
+constexpr float kPi = 3.141592653589793f;
+constexpr float kInf = 1E+10f;
+constexpr float kSqrt3 = 1.732050807568877f;
+
+struct Vec3 { float x, y, z; };
+// glm::mat3 layout: c[col][row], 36 B, column-major.
+struct Mat3 { float c[3][3]; };
+
+Mat3 mat3_identity();
+Vec3 dev_mul(const Mat3& m, const Vec3& v);   // device R*p   (fma convention)
+Vec3 host_mul(const Mat3& m, const Vec3& v);  // host   R*p   (plain)
+Mat3 host_mul(const Mat3& a, const Mat3& b);  // host   A*B   (plain)
+
+// fgoicp/common.hpp:30-69
+struct Rotation {
+    float x, y, z, r;
+    Mat3 R;
+    Rotation() : Rotation(0.f, 0.f, 0.f) {}
+    Rotation(float x, float y, float z);
+    bool in_SO3() const { return r <= 1.0f; }
+};
+
+// fgoicp/common.hpp:75-104
+struct RotNode {
+    Rotation q;
+    float span, lb, ub;
+    RotNode(float x, float y, float z, float span, float lb, float ub)
+        : q(x, y, z), span(span), lb(lb), ub(ub) {}
+    friend bool operator<(const RotNode& a, const RotNode& b) {
+        if (a.lb == b.lb) return a.span < b.span;
+        return a.lb > b.lb;
+    }
+    bool overlaps_SO3() const;
+};
+
+// fgoicp/common.hpp:110-128
+struct TransNode {
+    Vec3 t;
+    float span, lb, ub;
+    TransNode(float x, float y, float z, float span, float lb, float ub)
+        : t{x, y, z}, span(span), lb(lb), ub(ub) {}
+    friend bool operator<(const TransNode& a, const TransNode& b) {
+        if (a.lb == b.lb) return a.span < b.span;
+        return a.lb > b.lb;
+    }
+};
+
+using PointCloud = std::vector<Vec3>;
+using Bounds = std::array<std::pair<float, float>, 3>;
+
+// fgoicp/registration.cu:180-207, 258-328 (+ CUDA texture semantics)
+struct NearestNeighborLUT {
+    float resolution = 0.f;
+    int dims[3] = {0, 0, 0};
+    float scale = 0.f;
+    Vec3 offset{0, 0, 0};
+    std::vector<float> data;  // x fastest: (z*dy + y)*dx + x
+    bool quantize_weights = true;  // 1.8 fixed-point interpolation weights
+
+    NearestNeighborLUT() = default;
+    NearestNeighborLUT(float resolution, const Bounds& target_bounds, const PointCloud& pc, bool build_now = true);
+    void build(const PointCloud& pc);
+    float search(const Vec3& q) const;
+    size_t size() const { return (size_t)dims[0] * dims[1] * dims[2]; }
+};
+
+// fgoicp/registration.hpp:49-98, registration.cu:14-174
+class Registration {
+public:
+    Registration(const PointCloud& pct, const PointCloud& pcs, const Bounds& bounds, float lut_resolution,
+                 bool build_lut = true);
+    float compute_sse_error(const Mat3& R, const Vec3& t) const;
+    // returns {lower, upper} — lower first, registration.cu:151
+    std::tuple<std::vector<float>, std::vector<float>>
+    compute_sse_error(const RotNode& rnode, const std::vector<TransNode>& tnodes, bool fix_rot) const;
+
+    const PointCloud& pct;
+    const PointCloud& pcs;
+    NearestNeighborLUT nnlut;
+};
+
+float brute_force_find_nearest_neighbor(const Vec3& q, const PointCloud& pct);  // registration.cu:162-174
+
+// fgoicp/icp3d.hpp / icp3d.cu
+Mat3 closest_orthogonal_approximation(const Mat3& ABt);  // icp3d.cu:110-138
+struct ProcrustesDebug { Vec3 src_centroid, cor_centroid; Mat3 ABt; };
+class IterativeClosestPoint3D {
+public:
+    IterativeClosestPoint3D(const Registration& reg, const PointCloud& pct, const PointCloud& pcs,
+                            size_t max_iter, float conv_thr, const Mat3& R, const Vec3& t);
+    std::tuple<float, Mat3, Vec3> run();
+    std::tuple<Mat3, Vec3> procrustes(ProcrustesDebug* dbg = nullptr);
+    size_t iterations() const { return iters_; }
+    PointCloud& working() { return pcs_buf_; }
+    std::vector<int>& last_corr_index() { return corr_idx_; }
+private:
+    const Registration& reg_;
+    const PointCloud& pct_;
+    PointCloud pcs_buf_;
+    Mat3 R_;
+    Vec3 t_;
+    size_t max_iter_;
+    float thr_;
+    size_t iters_ = 0;
+    std::vector<int> corr_idx_;
+};
+
+// fgoicp/fgoicp.hpp, fgoicp.cpp
+struct RunStats {
+    uint64_t trans_cubes = 0;     // `count` of fgoicp.cpp:108,132 summed over all inner BnBs
+    uint64_t bounds_calls = 0;    // Registration::compute_sse_error(batch) calls
+    uint64_t rot_cubes = 0;       // rotation children that went through branch_and_bound_R3
+    uint64_t icp_runs = 0;
+    uint64_t icp_iters = 0;
+    uint64_t inner_bnb = 0;
+};
+
+class FastGoICP {
+public:
+    FastGoICP(PointCloud pct, PointCloud pcs, float lut_resolution, float mse_threshold);
+    std::tuple<Mat3, Vec3> run();
+    float get_best_error() const { return best_sse; }
+    std::tuple<Mat3, Vec3> get_best_transform() const { return {best_rotation, best_translation}; }
+    const RunStats& stats() const { return stats_; }
+
+    // pre-processing results exposed for tests (fgoicp.cpp:176-287)
+    PointCloud pcs, pct;
+    size_t ns, nt;
+    Vec3 offset_pcs, offset_pct;
+    float scaling_factor;
+    Bounds target_bounds;
+    Registration registration;
+    float best_sse;
+    Mat3 best_rotation;
+    Vec3 best_translation;
+    float mse_threshold, sse_threshold;
+
+    Vec3 restore_translation(const Mat3& R, const Vec3& t) const;  // fgoicp.hpp:87-90
+    std::tuple<float, Vec3> branch_and_bound_R3(RotNode& rnode, bool fix_rot);
+    float branch_and_bound_SO3();
+private:
+    RunStats stats_;
+};
+
+Vec3 center_point_cloud(PointCloud& pc);                  // fgoicp.cpp:176-195
+float get_scaling_factor(const PointCloud& pc);            // fgoicp.cpp:197-220
+float scale_point_clouds(PointCloud& pct, PointCloud& pcs);  // fgoicp.cpp:271-287
+Bounds get_point_cloud_ranges(const PointCloud& pc);       // fgoicp.cpp:222-268
+
+}  // namespace goicp_oracle

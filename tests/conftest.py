@@ -1,0 +1,51 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU restatement (checker only)."""
+    from oracle import pyoracle
+    pyoracle.build()
+    pyoracle.lib()
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def fg():
+    import fgoicp_amd
+    return fgoicp_amd
+
+
+@pytest.fixture(scope="session")
+def tiny_case(fg):
+    """Pre-processed (centred, scaled) tiny cloud pair + LUT bounds, shared by operator tests."""
+    tgt, src, R_gt, t_gt = fg.synth.workload("tiny", angle_deg=25.0)
+    t_c, s_c, off_t, off_s, scale, bounds = fg.synth.preprocess(tgt, src)
+    return dict(pct=t_c, pcs=s_c, bounds=bounds, res=0.05, R_gt=R_gt, t_gt=t_gt, raw=(tgt, src))
+
+
+@pytest.fixture(scope="session")
+def gpu_required():
+    if not _has_gpu():
+        pytest.fail("this test is marked gpu but no GPU is visible (run it with -m gpu on the GPU box)")
+    return True

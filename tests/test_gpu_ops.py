@@ -1,0 +1,182 @@
+"""GPU parity tests of the operator level (through the C ABI) against the CPU oracle.
+
+Bars: LUT nodes, LUT lookups, nearest-neighbour indices — bit-exact.  Sums over points
+(bounds, SSE, centroids, covariance) — the per-point fp32 values are identical, both sides
+accumulate in fp64 and round once, in different orders: tolerance 1e-6 relative
+(north_star allows 1e-5 on the final result)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-6
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def regs(fg, oracle, tiny_case, gpu_required):
+    c = tiny_case
+    hip = fg.Registration(c["pct"], c["pcs"], c["bounds"], c["res"])
+    orc = oracle.Registration(c["pct"], c["pcs"], c["bounds"], c["res"])
+    yield hip, orc
+    hip.close()
+
+
+def _tnodes(rng, B, span):
+    t = rng.uniform(-0.6, 0.6, size=(B, 3)).astype(np.float32)
+    return np.concatenate([t, np.full((B, 1), span, np.float32)], axis=1)
+
+
+def test_lut_nodes_bit_exact(regs):
+    hip, orc = regs
+    assert hip.lut_dims() == orc.lut_dims()
+    a, b = hip.lut_read(), orc.lut_get()
+    assert a.shape == b.shape
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_lut_search_bit_exact(regs, tiny_case):
+    hip, orc = regs
+    rng = np.random.default_rng(5)
+    lo, hi = tiny_case["bounds"][:, 0], tiny_case["bounds"][:, 1]
+    inside = rng.uniform(lo, hi, size=(20000, 3))
+    outside = rng.uniform(lo - 1.5, hi + 1.5, size=(20000, 3))  # exercises clamp addressing
+    edge = np.concatenate([lo[None, :] + rng.uniform(-0.06, 0.06, (2000, 3)), hi[None, :] + rng.uniform(-0.06, 0.06, (2000, 3))])
+    far = np.array([[1e6, -1e6, 0.0], [-3e38, 3e38, 1.0]], np.float32)
+    q = np.concatenate([inside, outside, edge, far]).astype(np.float32)
+    a, b = hip.lut_search(q), orc.lut_search(q)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_lut_search_no_quant_flag(fg, oracle, tiny_case, gpu_required):
+    c = tiny_case
+    hip = fg.Registration(c["pct"], c["pcs"], c["bounds"], c["res"], flags=fg.FLAG_NO_WEIGHT_QUANT)
+    orc = oracle.Registration(c["pct"], c["pcs"], c["bounds"], c["res"], quantize=False)
+    q = np.random.default_rng(6).uniform(-1.2, 1.2, size=(5000, 3)).astype(np.float32)
+    assert np.array_equal(hip.lut_search(q).view(np.uint32), orc.lut_search(q).view(np.uint32))
+    hip.close()
+
+
+@pytest.mark.parametrize("fix_rot", [True, False])
+@pytest.mark.parametrize("B,span", [(32, 0.25), (1, 1.0), (7, 0.0625), (33, 0.5), (100, 0.125)])
+def test_bounds_batch_parity(regs, fg, fix_rot, B, span):
+    hip, orc = regs
+    rng = np.random.default_rng(100 + B)
+    rn = fg.RotNode(0.25, -0.125, 0.375, 0.125)
+    tn = _tnodes(rng, B, span)
+    lb, ub = hip.compute_sse_error(rn, tn, fix_rot)
+    lb_o, ub_o = orc.compute_bounds(rn.q.R, rn.span, tn, fix_rot)
+    assert lb.shape == (B,) and ub.shape == (B,)
+    assert rel(ub, ub_o) <= REL, (ub, ub_o)
+    # lower bounds can be exactly 0 for large spans: compare absolutely against the ub scale
+    assert np.max(np.abs(lb.astype(np.float64) - lb_o)) <= REL * np.max(ub_o)
+    assert np.all(lb <= ub * (1 + 1e-6))
+
+
+def test_bounds_multi_equals_batches(regs, fg):
+    hip, _ = regs
+    rng = np.random.default_rng(9)
+    nodes = [fg.RotNode(0.5, 0.5, -0.5, 0.5), fg.RotNode(0.0, 0.125, 0.0, 0.25), fg.RotNode(-0.25, 0.25, 0.25, 0.0625)]
+    groups = [_tnodes(rng, 32, 0.5), _tnodes(rng, 5, 0.25), _tnodes(rng, 40, 0.125)]
+    fixes = [True, False, False]
+    multi = hip.compute_bounds_multi([n.q.R for n in nodes], [n.span for n in nodes], fixes, groups)
+    for n, g, f, (lb, ub) in zip(nodes, groups, fixes, multi):
+        lb1, ub1 = hip.compute_sse_error(n, g, f)
+        assert np.array_equal(lb, lb1) and np.array_equal(ub, ub1)  # same launches → bit-identical
+
+
+def test_bounds_run_to_run_deterministic(regs, fg):
+    hip, _ = regs
+    tn = _tnodes(np.random.default_rng(3), 32, 0.25)
+    rn = fg.RotNode(0.1, 0.2, 0.3, 0.25)
+    a = hip.compute_sse_error(rn, tn, False)
+    b = hip.compute_sse_error(rn, tn, False)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_bounds_empty_batch(regs, fg):
+    hip, _ = regs
+    lb, ub = hip.compute_sse_error(fg.RotNode(0, 0, 0, 1.0), np.zeros((0, 4), np.float32), True)
+    assert lb.size == 0 and ub.size == 0
+
+
+def test_morton_order_is_transparent(fg, tiny_case, regs, gpu_required):
+    c = tiny_case
+    plain = fg.Registration(c["pct"], c["pcs"], c["bounds"], c["res"], flags=fg.FLAG_NO_MORTON)
+    hip, _ = regs
+    tn = _tnodes(np.random.default_rng(4), 16, 0.25)
+    rn = fg.RotNode(-0.3, 0.1, 0.2, 0.125)
+    a = plain.compute_sse_error(rn, tn, False)
+    b = hip.compute_sse_error(rn, tn, False)
+    assert rel(a[1], b[1]) <= REL
+    plain.close()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_exact_sse_parity(regs, fg, seed):
+    hip, orc = regs
+    rng = np.random.default_rng(seed)
+    R = fg.synth.random_rotation(rng, 60.0).astype(np.float32)
+    t = rng.uniform(-0.3, 0.3, 3).astype(np.float32)
+    a, b = hip.compute_sse_error(R, t), orc.compute_sse_error(R, t)
+    assert abs(float(a) - float(b)) <= REL * float(b)
+
+
+def test_procrustes_step_parity(regs, fg, tiny_case):
+    hip, orc = regs
+    rng = np.random.default_rng(12)
+    R0 = fg.synth.random_rotation(rng, 15.0).astype(np.float32)
+    w = (tiny_case["pcs"] @ R0.T + rng.uniform(-0.05, 0.05, 3)).astype(np.float32)
+    R, t, cen, ABt, idx = hip.procrustes(w)
+    Ro, to, ceno, ABto, idxo = orc.procrustes(w)
+    assert np.array_equal(idx, idxo)                       # nearest neighbours incl. the sqrt tie rule
+    assert np.allclose(cen, ceno, rtol=1e-6, atol=1e-7)
+    assert np.allclose(ABt, ABto, rtol=1e-5, atol=1e-5)
+    assert np.allclose(R, Ro, atol=2e-6) and np.allclose(t, to, atol=2e-6)
+
+
+def test_nn_tie_rule_lowest_index(fg, oracle, gpu_required):
+    """Duplicate target points and exact distance ties: the first index must win (icp3d.cu:20-25)."""
+    rng = np.random.default_rng(1)
+    base = rng.uniform(-1, 1, size=(300, 3)).astype(np.float32)
+    tgt = np.concatenate([base, base[::-1], base])          # every point three times
+    src = (base[:200] + rng.normal(scale=1e-3, size=(200, 3))).astype(np.float32)
+    bounds = np.array([[-1, 1]] * 3, np.float32)
+    hip = fg.Registration(tgt, src, bounds, 0.1)
+    orc = oracle.Registration(tgt, src, bounds, 0.1, build_lut=False)
+    *_, idx = hip.procrustes(src)
+    *_, idxo = orc.procrustes(src)
+    assert np.array_equal(idx, idxo)
+    assert np.all(idx < 300)
+    hip.close()
+
+
+@pytest.mark.parametrize("thr,angle", [(0.05, 10.0), (0.005, 25.0), (0.0005, 5.0)])
+def test_icp_parity(regs, fg, thr, angle):
+    hip, orc = regs
+    rng = np.random.default_rng(int(angle))
+    R0 = fg.synth.random_rotation(rng, angle).astype(np.float32)
+    t0 = rng.uniform(-0.05, 0.05, 3).astype(np.float32)
+    icp = fg.IterativeClosestPoint3D(hip, None, None, 100, thr, R0, t0)
+    sse, R, t = icp.run()
+    sse_o, R_o, t_o, it_o = orc.icp(R0, t0, 100, thr)
+    assert icp.iterations == it_o
+    assert abs(float(sse) - float(sse_o)) <= 1e-5 * float(sse_o)
+    assert np.allclose(R, R_o, atol=1e-5) and np.allclose(t, t_o, atol=1e-5)
+
+
+def test_icp_zero_iterations(regs, fg):
+    hip, _ = regs
+    icp = fg.IterativeClosestPoint3D(hip, None, None, 0, 0.05, np.eye(3), np.zeros(3))
+    sse, R, t = icp.run()
+    # max_iter = 0: loop body never runs, sse(1e10) < last_sse(2e10) → returns (1e10, R0, t0)  (icp3d.cu:94,106)
+    assert float(sse) == pytest.approx(1e10) and np.array_equal(R, np.eye(3, dtype=np.float32))
+
+
+def test_invalid_arguments_fail_loudly(fg, gpu_required):
+    with pytest.raises(fg.FgoicpError):
+        fg.Registration(np.zeros((4, 3), np.float32), np.zeros((4, 3), np.float32), np.array([[0, 1]] * 3, np.float32), -1.0)
