@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -324,6 +325,10 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
     {
         int P = 8;
         while (P > 1 && ((ns + (size_t)kBlock * P - 1) / ((size_t)kBlock * P)) * kMaxBatch < 2048) P >>= 1;
+        if (const char* e = std::getenv("FGOICP_PTS_PER_THREAD")) {  // tuning knob: 1, 2, 4 or 8
+            const int v = std::atoi(e);
+            if (v == 1 || v == 2 || v == 4 || v == 8) P = v;
+        }
         c->pts_per_thread = P;
         c->nchunk = (int)((ns + (size_t)kBlock * P - 1) / ((size_t)kBlock * P));
         c->max_subcubes = 4096;

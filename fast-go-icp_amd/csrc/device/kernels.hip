@@ -76,62 +76,101 @@ __device__ __forceinline__ void tex_axis(float u, int d, int quant, int& i, floa
 
 __device__ __forceinline__ float lerp(float p, float q, float w) { return fma_(w, q - p, p); }
 
-__device__ __forceinline__ float lut_search(const float* __restrict__ lut, const LutGeom& g, float qx, float qy, float qz) {
-    float x = (qx + g.off_x) * g.scale;
-    float y = (qy + g.off_y) * g.scale;
-    float z = (qz + g.off_z) * g.scale;
-    int ix, iy, iz;
-    float a, b, c;
-    tex_axis(x, g.dx, g.quantize, ix, a);
-    tex_axis(y, g.dy, g.quantize, iy, b);
-    tex_axis(z, g.dz, g.quantize, iz, c);
-    const size_t sy = (size_t)g.px, sz = (size_t)g.px * g.py;
-    const float* p = lut + ((size_t)iz * g.py + iy) * sy + ix;
-    float2u v00 = *(const float2u*)(p);
-    float2u v10 = *(const float2u*)(p + sy);
-    float2u v01 = *(const float2u*)(p + sz);
-    float2u v11 = *(const float2u*)(p + sz + sy);
-    float c00 = lerp(v00.x, v00.y, a);
-    float c10 = lerp(v10.x, v10.y, a);
-    float c01 = lerp(v01.x, v01.y, a);
-    float c11 = lerp(v11.x, v11.y, a);
-    float c0 = lerp(c00, c10, b);
-    float c1 = lerp(c01, c11, b);
-    return lerp(c0, c1, c);
-}
-
 // ---------------------------------------------------------------------------------------------
 // kernComputeBounds (+ the two thrust::reduce calls) — fgoicp/registration.cu:27-60, :126-140.
-// grid = (chunks of 256*P points, translation nodes of the batch); one block owns one
-// (chunk, subcube) pair and emits one {sum_ub, sum_lb} partial.  The source cloud is float4
+// grid = chunks of 256*P points x translation nodes of the batch (XCD-aware order); one block
+// owns one (chunk, subcube) pair and emits one {sum_ub, sum_lb} partial.  The source cloud is float4
 // {x, y, z, x*x+y*y+z*z}: one coalesced 16-byte load per point (TODO.md:14 of the reference).
 // ---------------------------------------------------------------------------------------------
+// lut_search split in two so that a thread can put the gathers of several points in flight before
+// it consumes any of them (memory-level parallelism is what bounds this kernel, not arithmetic).
+struct TexAddr {
+    const float* p;   // first texel (x0, y0, z0) in the padded LUT
+    float a, b, c;    // interpolation weights
+};
+__device__ __forceinline__ TexAddr lut_address(const float* __restrict__ lut, const LutGeom& g, float qx, float qy, float qz) {
+    const float x = (qx + g.off_x) * g.scale;
+    const float y = (qy + g.off_y) * g.scale;
+    const float z = (qz + g.off_z) * g.scale;
+    int ix, iy, iz;
+    TexAddr t;
+    tex_axis(x, g.dx, g.quantize, ix, t.a);
+    tex_axis(y, g.dy, g.quantize, iy, t.b);
+    tex_axis(z, g.dz, g.quantize, iz, t.c);
+    t.p = lut + ((size_t)iz * g.py + iy) * (size_t)g.px + ix;
+    return t;
+}
+__device__ __forceinline__ float lut_blend(const TexAddr& t, float2u v00, float2u v10, float2u v01, float2u v11) {
+    const float c00 = lerp(v00.x, v00.y, t.a);
+    const float c10 = lerp(v10.x, v10.y, t.a);
+    const float c01 = lerp(v01.x, v01.y, t.a);
+    const float c11 = lerp(v11.x, v11.y, t.a);
+    return lerp(lerp(c00, c10, t.b), lerp(c01, c11, t.b), t.c);
+}
+
+__device__ __forceinline__ float lut_search(const float* __restrict__ lut, const LutGeom& g, float qx, float qy, float qz) {
+    const TexAddr t = lut_address(lut, g, qx, qy, qz);
+    const size_t sy = (size_t)g.px, sz = (size_t)g.px * g.py;
+    return lut_blend(t, *(const float2u*)(t.p), *(const float2u*)(t.p + sy), *(const float2u*)(t.p + sz), *(const float2u*)(t.p + sz + sy));
+}
+
+// XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (each with a private
+// 4 MiB L2), so linear ids congruent mod 8 share an L2.  Map them to CONSECUTIVE virtual ids: an
+// XCD then walks whole subcubes chunk by chunk, and Morton-adjacent chunks — which share the LUT
+// lines along their common border — hit in the same L2.  Bijective for any grid size.
+__device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned total) {
+    const unsigned q = total >> 3, r = total & 7u, xcd = id & 7u, k = id >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 template <int P>
 __global__ __launch_bounds__(kBlock) void bounds_kernel(const float4* __restrict__ src, int ns, const float* __restrict__ lut,
                                                         LutGeom g, BoundsArgs a, double2* __restrict__ partials, int nchunk) {
     __shared__ double red[8];
-    const int b = blockIdx.y;
-    const int chunk = blockIdx.x;
+    const unsigned v = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = (int)(v / (unsigned)nchunk);
+    const int chunk = (int)(v - (unsigned)b * (unsigned)nchunk);
     const float4 tn = a.tn[b];
     const float trans_uncertain_radius = kSqrt3 * tn.w;  // :33
-    double acc[2] = {0.0, 0.0};
     const int base = chunk * (kBlock * P) + threadIdx.x;
+    const size_t sy = (size_t)g.px, sz = (size_t)g.px * g.py;
+
+    // phase 1: the points (coalesced 16-byte loads; out-of-range lanes re-read the last point)
+    float4 p[P];
 #pragma unroll
     for (int k = 0; k < P; ++k) {
         const int i = base + k * kBlock;
-        if (i < ns) {
-            const float4 p = src[i];
-            float rx, ry, rz;
-            rotate(a.R, p.x, p.y, p.z, rx, ry, rz);
-            const float dsq = lut_search(lut, g, rx + tn.x, ry + tn.y, rz + tn.z);  // :34, :46
-            float d = sqrtf(dsq);                                                    // :48
-            if (!a.fix_rot) d -= 2.0f * p.w * a.sin_half;                            // :39-43, :49-52
-            const float ubv = d > 0.0f ? d * d : 0.0f;                               // :54
-            const float l = d - trans_uncertain_radius;                              // :57
-            const float lbv = l > 0.0f ? l * l : 0.0f;                               // :58
-            acc[0] += (double)ubv;
-            acc[1] += (double)lbv;
-        }
+        p[k] = src[i < ns ? i : ns - 1];
+    }
+    // phase 2: all 4*P gathers in flight
+    TexAddr ta[P];
+    float2u v00[P], v10[P], v01[P], v11[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        float rx, ry, rz;
+        rotate(a.R, p[k].x, p[k].y, p[k].z, rx, ry, rz);
+        ta[k] = lut_address(lut, g, rx + tn.x, ry + tn.y, rz + tn.z);  // :34, :323-325
+    }
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        v00[k] = *(const float2u*)(ta[k].p);
+        v10[k] = *(const float2u*)(ta[k].p + sy);
+        v01[k] = *(const float2u*)(ta[k].p + sz);
+        v11[k] = *(const float2u*)(ta[k].p + sz + sy);
+    }
+    // phase 3: blend, bounds, fp64 accumulation
+    double acc[2] = {0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        const float dsq = lut_blend(ta[k], v00[k], v10[k], v01[k], v11[k]);  // :46
+        float d = sqrtf(dsq);                                                 // :48
+        if (!a.fix_rot) d -= 2.0f * p[k].w * a.sin_half;                      // :39-43, :49-52
+        const float ubv = d > 0.0f ? d * d : 0.0f;                            // :54
+        const float l = d - trans_uncertain_radius;                           // :57
+        const float lbv = l > 0.0f ? l * l : 0.0f;                            // :58
+        const bool valid = base + k * kBlock < ns;
+        acc[0] += valid ? (double)ubv : 0.0;
+        acc[1] += valid ? (double)lbv : 0.0;
     }
     const double r = block_sum<2>(acc, red);
     // threads 0 and 1 hold sum_ub and sum_lb
@@ -432,7 +471,7 @@ int nn_slices(int nq, int nt) {
 // ---------------------------------------------------------------------------------------------
 void launch_bounds(const float4* src, int ns, const float* lut, const LutGeom& g, const BoundsArgs& a, double2* partials, int nchunk,
                    int P, hipStream_t s) {
-    dim3 grid(nchunk, a.B), block(kBlock);
+    dim3 grid((unsigned)nchunk * (unsigned)a.B), block(kBlock);
     switch (P) {
         case 1: hipLaunchKernelGGL(bounds_kernel<1>, grid, block, 0, s, src, ns, lut, g, a, partials, nchunk); break;
         case 2: hipLaunchKernelGGL(bounds_kernel<2>, grid, block, 0, s, src, ns, lut, g, a, partials, nchunk); break;

@@ -1,0 +1,109 @@
+"""Independent numpy restatement of the per-point arithmetic of the hot path, used ONLY to
+cross-check the C++ oracle (tests/test_oracle_kat.py).  TEST INFRASTRUCTURE.  PARITY UNPINNED.
+
+Written from the reference source and SURVEY.md Appendix A, not from oracle/goicp_oracle.cpp:
+fgoicp/registration.cu:27-60 (bounds), :258-278 (LUT nodes), :320-328 + CUDA linear filtering (lookup),
+fgoicp/common.hpp:37-57 (rotation).  fp32 throughout; fma(a,b,c) is emulated as
+float32(float64(a)*float64(b) + float64(c)) (exact product, one extra rounding in rare cases)."""
+import numpy as np
+
+f32 = np.float32
+SQRT3 = f32(1.732050807568877)
+PI = f32(3.141592653589793)
+
+
+def fma(a, b, c):
+    return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(np.float32)
+
+
+def rot_apply(R, p):
+    """device R*p for math-convention R (3,3) and points (n,3): fma(R[r,2], z, fma(R[r,1], y, R[r,0]*x))"""
+    R = np.asarray(R, f32); p = np.asarray(p, f32)
+    out = np.empty_like(p)
+    for r in range(3):
+        out[:, r] = fma(R[r, 2], p[:, 2], fma(R[r, 1], p[:, 1], (R[r, 0] * p[:, 0]).astype(f32)))
+    return out
+
+
+def dist_sq(a, b):
+    d = (np.asarray(a, f32) - np.asarray(b, f32)).astype(f32)
+    return fma(d[..., 2], d[..., 2], fma(d[..., 1], d[..., 1], (d[..., 0] * d[..., 0]).astype(f32)))
+
+
+def lut_dims(bounds, res):
+    b = np.asarray(bounds, f32).reshape(3, 2)
+    return tuple(int(np.ceil(f32(f32(b[a, 1] - b[a, 0]) / f32(res)))) for a in range(3))
+
+
+def lut_build(tgt, bounds, res):
+    b = np.asarray(bounds, f32).reshape(3, 2)
+    dx, dy, dz = lut_dims(bounds, res)
+    pts = (np.asarray(tgt, f32) + (-b[:, 0])[None, :]).astype(f32)
+    zz, yy, xx = np.meshgrid(np.arange(dz), np.arange(dy), np.arange(dx), indexing="ij")
+    nodes = np.stack([xx, yy, zz], -1).astype(f32) * f32(res)
+    out = np.full((dz, dy, dx), np.finfo(f32).max, f32)
+    for p in pts:  # O(nodes * nt): small inputs only
+        out = np.minimum(out, dist_sq(nodes, p[None, None, None, :]))
+    return out
+
+
+def _axis(u, dim, quant):
+    ub = (u - f32(0.5)).astype(f32)
+    fl = np.floor(ub)
+    w = (ub - fl).astype(f32)
+    if quant:
+        w = (np.floor(w * f32(256) + f32(0.5)) / f32(256)).astype(f32)
+    i = np.clip(fl, -1, dim).astype(np.int64)
+    return np.clip(i, 0, dim - 1), np.clip(i + 1, 0, dim - 1), w
+
+
+def lut_search(lut, bounds, res, q, quant=True):
+    b = np.asarray(bounds, f32).reshape(3, 2)
+    dz, dy, dx = lut.shape
+    q = np.asarray(q, f32)
+    scale = f32(1.0) / f32(res)
+    u = [((q[:, a] + (-b[a, 0])).astype(f32) * scale).astype(f32) for a in range(3)]
+    x0, x1, a = _axis(u[0], dx, quant)
+    y0, y1, bb = _axis(u[1], dy, quant)
+    z0, z1, c = _axis(u[2], dz, quant)
+    lerp = lambda p, q_, w: fma(w, (q_ - p).astype(f32), p)
+    c00 = lerp(lut[z0, y0, x0], lut[z0, y0, x1], a)
+    c10 = lerp(lut[z0, y1, x0], lut[z0, y1, x1], a)
+    c01 = lerp(lut[z1, y0, x0], lut[z1, y0, x1], a)
+    c11 = lerp(lut[z1, y1, x0], lut[z1, y1, x1], a)
+    return lerp(lerp(c00, c10, bb), lerp(c01, c11, bb), c)
+
+
+def bounds(lut, lut_bounds, res, src, R, rot_span, tnodes4, fix_rot, quant=True):
+    src = np.asarray(src, f32)
+    rp = rot_apply(R, src)
+    half_angle = f32(f32(f32(f32(rot_span) * SQRT3) * PI) / f32(2.0))
+    sin_half = f32(np.sin(half_angle, dtype=np.float32))
+    radius = fma(src[:, 2], src[:, 2], fma(src[:, 1], src[:, 1], (src[:, 0] * src[:, 0]).astype(f32)))
+    lbs, ubs = [], []
+    for tx, ty, tz, span in np.asarray(tnodes4, f32):
+        q = (rp + np.array([tx, ty, tz], f32)[None, :]).astype(f32)
+        d = np.sqrt(lut_search(lut, lut_bounds, res, q, quant)).astype(f32)
+        if not fix_rot:
+            d = (d - ((f32(2.0) * radius).astype(f32) * sin_half).astype(f32)).astype(f32)
+        ub = np.where(d > 0, (d * d).astype(f32), f32(0))
+        l = (d - f32(SQRT3 * f32(span))).astype(f32)
+        lb = np.where(l > 0, (l * l).astype(f32), f32(0))
+        ubs.append(f32(ub.astype(np.float64).sum()))
+        lbs.append(f32(lb.astype(np.float64).sum()))
+    return np.array(lbs, f32), np.array(ubs, f32)
+
+
+def rotation(x, y, z):
+    """common.hpp:37-57 → (math-convention R, r, in_SO3)"""
+    x, y, z = f32(x), f32(y), f32(z)
+    r = f32(f32(f32(x * x) + f32(y * y)) + f32(z * z))
+    if r > 1:
+        return np.eye(3, dtype=f32), r, False
+    ww = f32(1) - r
+    w = np.sqrt(ww, dtype=f32)
+    # standard unit-quaternion (w, x, y, z) rotation matrix, TRANSPOSED (glm fills columns)
+    Rq = np.array([[ww + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                   [2 * (x * y + w * z), ww - x * x + y * y - z * z, 2 * (y * z - w * x)],
+                   [2 * (x * z - w * y), 2 * (y * z + w * x), ww - x * x - y * y + z * z]], np.float64)
+    return Rq.T.astype(f32), np.sqrt(r, dtype=f32), True

@@ -1,0 +1,106 @@
+"""Builds and binds tests/host_harness/harness.cpp (driver template x oracle operators). Test-only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_REPO = os.path.dirname(os.path.dirname(_DIR))
+_SO = os.path.join(_DIR, "libhost_harness.so")
+_fp = C.POINTER(C.c_float)
+_dp = C.POINTER(C.c_double)
+AR = C.CFUNCTYPE(C.c_int, _fp, C.c_size_t, C.c_void_p)
+AG = C.CFUNCTYPE(C.c_int, _fp, _fp, C.c_size_t, C.c_void_p)
+
+
+def build():
+    from oracle import pyoracle
+    pyoracle.build()
+    deps = [os.path.join(_DIR, "harness.cpp"), os.path.join(_REPO, "fast-go-icp_amd/csrc/host/driver.hpp"),
+            os.path.join(_REPO, "fast-go-icp_amd/csrc/host/math3.hpp"), os.path.join(_REPO, "oracle/libgoicp_oracle.so")]
+    if not os.path.exists(_SO) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fopenmp", "-shared", "-o", _SO,
+                        os.path.join(_DIR, "harness.cpp"), "-L" + os.path.join(_REPO, "oracle"), "-lgoicp_oracle",
+                        "-Wl,-rpath," + os.path.join(_REPO, "oracle")], check=True)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        L.harness_create.argtypes = [_fp, C.c_size_t, _fp, C.c_size_t, C.c_float, C.c_float, C.c_int, C.c_int]
+        L.harness_create.restype = C.c_void_p
+        L.harness_destroy.argtypes = [C.c_void_p]
+        L.harness_set_exchange.argtypes = [C.c_void_p, C.c_int, C.c_int, AR, AG]
+        L.harness_preproc.argtypes = [C.c_void_p, _fp, _fp, _fp]
+        L.harness_run.argtypes = [C.c_void_p, _fp, _fp, _fp, _fp, C.POINTER(C.c_ulonglong)]
+        L.harness_rotation.argtypes = [C.c_float, C.c_float, C.c_float, _fp, _fp, C.POINTER(C.c_int)]
+        L.harness_overlaps.argtypes = [C.c_float] * 4
+        L.harness_closest_orthogonal.argtypes = [_fp, _fp]
+        L.harness_svd3.argtypes = [_dp, _dp, _dp, _dp]
+        _lib = L
+    return _lib
+
+
+def _f(a):
+    return a.ctypes.data_as(_fp)
+
+
+class HostDriver:
+    """Product driver template over oracle operators."""
+
+    def __init__(self, pct, pcs, lut_res, mse_thr, schedule=0, round_width=1):
+        pct = np.ascontiguousarray(pct, np.float32); pcs = np.ascontiguousarray(pcs, np.float32)
+        self._h = C.c_void_p(lib().harness_create(_f(pct), len(pct), _f(pcs), len(pcs), lut_res, mse_thr, schedule, round_width))
+        self._cbs = None
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().harness_destroy(self._h)
+            self._h = None
+
+    def set_exchange(self, rank, world, allreduce_min, allgather):
+        self._cbs = (AR(allreduce_min), AG(allgather))
+        lib().harness_set_exchange(self._h, rank, world, *self._cbs)
+
+    def preproc(self):
+        offs = np.empty(6, np.float32); scale = C.c_float(); b = np.empty(6, np.float32)
+        lib().harness_preproc(self._h, _f(offs), C.byref(scale), _f(b))
+        return dict(offset_pcs=offs[:3].copy(), offset_pct=offs[3:].copy(), scale=np.float32(scale.value), bounds=b.reshape(3, 2))
+
+    def run(self):
+        R = np.empty(9, np.float32); t = np.empty(3, np.float32); ts = np.empty(3, np.float32); sse = C.c_float()
+        st = (C.c_ulonglong * 7)()
+        rc = lib().harness_run(self._h, _f(R), _f(t), _f(ts), C.byref(sse), st)
+        if rc:
+            raise RuntimeError(f"driver failed with status {rc}")
+        names = ["trans_cubes", "bounds_calls", "rot_cubes", "icp_runs", "icp_iters", "inner_bnb", "rounds"]
+        return dict(R=R.reshape(3, 3).T.copy(), t=t, t_scaled=ts, best_sse=np.float32(sse.value), stats={n: int(st[i]) for i, n in enumerate(names)})
+
+
+def rotation(x, y, z):
+    R = np.empty(9, np.float32); r = C.c_float(); ok = C.c_int()
+    lib().harness_rotation(x, y, z, _f(R), C.byref(r), C.byref(ok))
+    return R.reshape(3, 3).T.copy(), np.float32(r.value), bool(ok.value)
+
+
+def overlaps(x, y, z, span):
+    return bool(lib().harness_overlaps(x, y, z, span))
+
+
+def closest_orthogonal(ABt9):
+    a = np.ascontiguousarray(ABt9, np.float32).reshape(9); out = np.empty(9, np.float32)
+    lib().harness_closest_orthogonal(_f(a), _f(out))
+    return out
+
+
+def svd3(A):
+    A = np.ascontiguousarray(A, np.float64).reshape(9)
+    U = np.empty(9); S = np.empty(3); V = np.empty(9)
+    lib().harness_svd3(A.ctypes.data_as(_dp), U.ctypes.data_as(_dp), S.ctypes.data_as(_dp), V.ctypes.data_as(_dp))
+    return U.reshape(3, 3), S, V.reshape(3, 3)

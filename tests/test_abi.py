@@ -1,0 +1,68 @@
+"""The C-ABI shared library loads, exports every symbol include/fgoicp_amd.h declares, and fails
+loudly (no CPU fallback) when no GPU is present."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(REPO, "include", "fgoicp_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(fgoicp_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_builds_and_exports_every_declared_symbol(fg):
+    path = fg.build.build()
+    assert os.path.exists(path)
+    out = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+    exported = set(re.findall(r"\b(fgoicp_[a-z_0-9]+)\b", out))
+    declared = header_symbols()
+    assert len(declared) >= 25
+    missing = [s for s in declared if s not in exported]
+    assert not missing, missing
+    assert sorted(fg._lib.exported_symbols()) == declared  # the ctypes table covers the whole header
+    lib = fg._lib.load()
+    assert b"gfx950" in lib.fgoicp_version()
+
+
+def test_library_contains_gfx950_code_object(fg):
+    path = fg.build.build()
+    data = open(path, "rb").read()
+    assert b"gfx950" in data and b"bounds_kernel" in data
+
+
+def test_product_does_not_reference_the_oracle(fg):
+    """The product must not link, load or import anything under oracle/."""
+    path = fg.build.build()
+    ldd = subprocess.run(["ldd", path], capture_output=True, text=True).stdout
+    assert "oracle" not in ldd
+    pkg = os.path.join(REPO, "fast-go-icp_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                src = open(os.path.join(root, f), errors="replace").read()
+                assert "pyoracle" not in src and "goicp_oracle" not in src, os.path.join(root, f)
+
+
+def test_no_gpu_means_loud_failure_not_cpu_fallback(fg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    pts = np.random.default_rng(0).uniform(-1, 1, (16, 3)).astype(np.float32)
+    with pytest.raises(fg.FgoicpError) as e:
+        fg.Registration(pts, pts, np.array([[-1, 1]] * 3, np.float32), 0.1)
+    assert e.value.status == 2 and "no CPU path" in str(e.value)
+    with pytest.raises(fg.FgoicpError):
+        fg.FastGoICP(pts, pts, 0.1, 1e-3)
+
+
+def test_missing_library_is_a_loud_error(fg, monkeypatch, tmp_path):
+    monkeypatch.setattr(fg._lib, "_lib", None)
+    monkeypatch.setattr(fg._lib, "lib_path", lambda: str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        fg._lib.load()
