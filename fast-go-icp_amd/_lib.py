@@ -52,6 +52,7 @@ _SIGS = {
     "fgoicp_icp": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_size_t, C.c_float, c_float_p, c_float_p, c_float_p, c_int_p]),
     "fgoicp_procrustes": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_int_p]),
     "fgoicp_ctx_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
+    "fgoicp_ctx_set_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "fgoicp_ctx_ns": (C.c_size_t, [C.c_void_p]),
     "fgoicp_ctx_nt": (C.c_size_t, [C.c_void_p]),
     "fgoicp_solver_create": (C.c_int, [c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_float, C.c_float,

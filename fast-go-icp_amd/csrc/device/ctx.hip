@@ -345,15 +345,12 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
     CHK(hipMalloc(&c->d_bp, sizeof(double) * 1024 * 16));
     CHK(hipHostMalloc((void**)&c->h_sums, sizeof(double) * 16, hipHostMallocMapped));
     CHK(hipHostGetDevicePointer((void**)&c->hd_sums, c->h_sums, 0));
-    if (c->profile) {
-        c->ev_start.resize(1024);
-        c->ev_stop.resize(1024);
-        for (size_t i = 0; i < c->ev_start.size(); ++i) {
-            CHK(hipEventCreate(&c->ev_start[i]));
-            CHK(hipEventCreate(&c->ev_stop[i]));
-        }
-    }
 #undef CHK
+    if (c->profile) {
+        c->profile = false;
+        int rc = fgoicp_ctx_set_profile(c, 1);
+        if (rc) { fgoicp_ctx_destroy(c); return rc; }
+    }
     *out = c;
     return FGOICP_OK;
 }
@@ -473,6 +470,26 @@ int fgoicp_ctx_profile(fgoicp_ctx* c, double* kernel_ms, uint64_t* launches, uin
     if (launches) *launches = c->prof_launches;
     if (subcubes) *subcubes = c->prof_subcubes;
     if (reset) { c->prof_ms = 0; c->prof_launches = 0; c->prof_subcubes = 0; }
+    return FGOICP_OK;
+}
+
+int fgoicp_ctx_set_profile(fgoicp_ctx* c, int enabled) {
+    if (!c) return FGOICP_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    if (enabled && c->ev_start.empty()) {
+        c->ev_start.assign(1024, nullptr);
+        c->ev_stop.assign(1024, nullptr);
+        for (size_t i = 0; i < c->ev_start.size(); ++i) {
+            HIPCHK(hipEventCreate(&c->ev_start[i]));
+            HIPCHK(hipEventCreate(&c->ev_stop[i]));
+        }
+    }
+    if (!enabled && c->ev_used) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        int rc = ctx_flush_profile(c);
+        if (rc) return rc;
+    }
+    c->profile = enabled != 0;
     return FGOICP_OK;
 }
 

@@ -131,6 +131,9 @@ class Registration:
                    "fgoicp_procrustes")
         return from_glm(R), t, cen, ABt, idx
 
+    def set_profile(self, enabled):
+        _lib.check(self._lib.fgoicp_ctx_set_profile(self._h, int(bool(enabled))), "fgoicp_ctx_set_profile")
+
     def profile(self, reset=False):
         ms = C.c_double(); launches = C.c_uint64(); sub = C.c_uint64()
         _lib.check(self._lib.fgoicp_ctx_profile(self._h, C.byref(ms), C.byref(launches), C.byref(sub), int(reset)), "fgoicp_ctx_profile")

@@ -1,0 +1,42 @@
+// icp::FastGoICP for C++ callers — reference fgoicp/fgoicp.hpp:8-110.  The branch-and-bound runs in
+// host C++ inside libfgoicp_amd.so (fast-go-icp_amd/csrc/host/driver.hpp) and calls the HIP operators.
+#pragma once
+#include <tuple>
+#include <vector>
+
+#include "common.hpp"
+
+namespace icp {
+
+class FastGoICP {
+public:
+    // fgoicp.hpp:13 (+ optional schedule: FGOICP_SCHEDULE_SERIAL reproduces the reference's order)
+    FastGoICP(std::vector<vec3> pct, std::vector<vec3> pcs, float lut_resolution, float mse_threshold,
+              int schedule = FGOICP_SCHEDULE_SERIAL, int round_width = 1, int device = 0) {
+        fgoicp_solver_opts o{schedule, round_width, 0u, device};
+        check_status(fgoicp_solver_create(&pct.data()->x, pct.size(), &pcs.data()->x, pcs.size(), lut_resolution, mse_threshold, &o, &s_),
+                     "fgoicp_solver_create");
+    }
+    ~FastGoICP() { fgoicp_solver_destroy(s_); }
+    FastGoICP(const FastGoICP&) = delete;
+    FastGoICP& operator=(const FastGoICP&) = delete;
+
+    using Result_t = std::tuple<mat3, vec3>;
+    Result_t run() {  // fgoicp.hpp:28
+        mat3 R;
+        vec3 t;
+        check_status(fgoicp_solver_run(s_, R.data(), &t.x), "fgoicp_solver_run");
+        return {R, t};
+    }
+    // interfaces for visualisation, fgoicp.hpp:31-43 (safe to poll from another thread)
+    float get_best_error() const { float v = 0; check_status(fgoicp_solver_best_error(s_, &v), "fgoicp_solver_best_error"); return v; }
+    Result_t get_best_transform() const { mat3 R; vec3 t; check_status(fgoicp_solver_best_transform(s_, R.data(), &t.x), "fgoicp_solver_best_transform"); return {R, t}; }
+    Result_t get_last_transform() const { mat3 R; vec3 t; check_status(fgoicp_solver_last_transform(s_, R.data(), &t.x), "fgoicp_solver_last_transform"); return {R, t}; }
+
+    fgoicp_run_stats stats() const { fgoicp_run_stats st{}; check_status(fgoicp_solver_stats(s_, &st), "fgoicp_solver_stats"); return st; }
+    fgoicp_solver* handle() const { return s_; }
+private:
+    fgoicp_solver* s_ = nullptr;
+};
+
+}  // namespace icp

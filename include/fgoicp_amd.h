@@ -104,6 +104,8 @@ int fgoicp_procrustes(fgoicp_ctx* ctx, const float* working_xyz, float* R_out9, 
 /* Accumulated HIP-event timing of the bounds kernel since the last reset (FGOICP_FLAG_PROFILE):
  * kernel_ms = sum of launch durations, launches = kernel launches, subcubes = (rot, trans) pairs. */
 int fgoicp_ctx_profile(fgoicp_ctx* ctx, double* kernel_ms, uint64_t* launches, uint64_t* subcubes, int reset);
+/* Turns the HIP-event bracketing on or off at run time (events are created on first use). */
+int fgoicp_ctx_set_profile(fgoicp_ctx* ctx, int enabled);
 size_t fgoicp_ctx_ns(const fgoicp_ctx* ctx);
 size_t fgoicp_ctx_nt(const fgoicp_ctx* ctx);
 

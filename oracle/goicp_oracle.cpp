@@ -163,51 +163,71 @@ float brute_force_find_nearest_neighbor(const Vec3& q, const PointCloud& pct) { 
     return best;
 }
 
+// Sums over points: fixed 1024-point chunks, one fp64 partial per chunk, chunks combined in index
+// order — independent of the OpenMP thread count, so fixtures reproduce on any host.
+static constexpr long kChunk = 1024;
+
 float Registration::compute_sse_error(const Mat3& R, const Vec3& t) const {  // :62-86 + kernel :14-25
     const long ns = (long)pcs.size();
-    double sum = 0.0;  // thrust::reduce(float, plus) restated as a double sum (header, conventions)
-#pragma omp parallel for reduction(+ : sum) schedule(static)
-    for (long i = 0; i < ns; ++i) {
-        Vec3 rp = dev_mul(R, pcs[i]);
-        Vec3 q{rp.x + t.x, rp.y + t.y, rp.z + t.z};
-        sum += (double)brute_force_find_nearest_neighbor(q, pct);
+    const long nchunk = (ns + kChunk - 1) / kChunk;
+    std::vector<double> part(nchunk, 0.0);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (long c = 0; c < nchunk; ++c) {
+        double s = 0.0;
+        for (long i = c * kChunk; i < std::min(ns, (c + 1) * kChunk); ++i) {
+            Vec3 rp = dev_mul(R, pcs[i]);
+            Vec3 q{rp.x + t.x, rp.y + t.y, rp.z + t.z};
+            s += (double)brute_force_find_nearest_neighbor(q, pct);
+        }
+        part[c] = s;
     }
+    double sum = 0.0;  // thrust::reduce(float, plus) restated as a double sum (header, conventions)
+    for (long c = 0; c < nchunk; ++c) sum += part[c];
     return (float)sum;
 }
 
 std::tuple<std::vector<float>, std::vector<float>>
 Registration::compute_sse_error(const RotNode& rnode, const std::vector<TransNode>& tnodes, bool fix_rot) const {
-    const size_t B = tnodes.size();
+    const long B = (long)tnodes.size();
     const long ns = (long)pcs.size();
     std::vector<float> upper(B), lower(B);
     // kernComputeBounds :27-60; the per-kernel constants are hoisted (they do not depend on the point)
     float half_angle = rnode.span * kSqrt3 * kPi / 2.0f;  // :42
     float sin_half = std::sin(half_angle);                // float overload, as device sin(float)
-    for (size_t b = 0; b < B; ++b) {
-        const TransNode& tn = tnodes[b];
-        float trans_uncertain_radius = kSqrt3 * tn.span;  // :33
-        double sum_ub = 0.0, sum_lb = 0.0;
-#pragma omp parallel for reduction(+ : sum_ub, sum_lb) schedule(static)
-        for (long i = 0; i < ns; ++i) {
-            const Vec3 p = pcs[i];
-            Vec3 rp = dev_mul(rnode.q.R, p);
-            Vec3 q{rp.x + tn.t.x, rp.y + tn.t.y, rp.z + tn.t.z};  // :34
-            float rot_uncertain_radius = 0.f;
-            if (!fix_rot) {
-                float radius = std::fmaf(p.z, p.z, std::fmaf(p.y, p.y, p.x * p.x));  // :39-41 (squared norm: reference quirk)
-                rot_uncertain_radius = 2.0f * radius * sin_half;                         // :43
+    const long nchunk = (ns + kChunk - 1) / kChunk;
+    std::vector<double> part_ub(B * nchunk, 0.0), part_lb(B * nchunk, 0.0);
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+    for (long b = 0; b < B; ++b)
+        for (long c = 0; c < nchunk; ++c) {
+            const TransNode& tn = tnodes[b];
+            float trans_uncertain_radius = kSqrt3 * tn.span;  // :33
+            double sum_ub = 0.0, sum_lb = 0.0;
+            for (long i = c * kChunk; i < std::min(ns, (c + 1) * kChunk); ++i) {
+                const Vec3 p = pcs[i];
+                Vec3 rp = dev_mul(rnode.q.R, p);
+                Vec3 q{rp.x + tn.t.x, rp.y + tn.t.y, rp.z + tn.t.z};  // :34
+                float rot_uncertain_radius = 0.f;
+                if (!fix_rot) {
+                    float radius = std::fmaf(p.z, p.z, std::fmaf(p.y, p.y, p.x * p.x));  // :39-41 (squared norm: reference quirk)
+                    rot_uncertain_radius = 2.0f * radius * sin_half;                         // :43
+                }
+                float dsq = nnlut.search(q);  // :46
+                float d = std::sqrt(dsq);     // :48
+                if (!fix_rot) d -= rot_uncertain_radius;
+                float ubv = d > 0.0f ? d * d : 0.0f;  // :54
+                float l = d - trans_uncertain_radius;  // :57
+                float lbv = l > 0.0f ? l * l : 0.0f;
+                sum_ub += (double)ubv;
+                sum_lb += (double)lbv;
             }
-            float dsq = nnlut.search(q);  // :46
-            float d = std::sqrt(dsq);     // :48
-            if (!fix_rot) d -= rot_uncertain_radius;
-            float ubv = d > 0.0f ? d * d : 0.0f;  // :54
-            float l = d - trans_uncertain_radius;  // :57
-            float lbv = l > 0.0f ? l * l : 0.0f;
-            sum_ub += (double)ubv;
-            sum_lb += (double)lbv;
+            part_ub[b * nchunk + c] = sum_ub;
+            part_lb[b * nchunk + c] = sum_lb;
         }
-        upper[b] = (float)sum_ub;
-        lower[b] = (float)sum_lb;
+    for (long b = 0; b < B; ++b) {
+        double su = 0.0, sl = 0.0;
+        for (long c = 0; c < nchunk; ++c) { su += part_ub[b * nchunk + c]; sl += part_lb[b * nchunk + c]; }
+        upper[b] = (float)su;
+        lower[b] = (float)sl;
     }
     return {lower, upper};  // :151 — lower first
 }
