@@ -6,7 +6,7 @@
 There is no CPU implementation in this package: every operator raises if the HIP library is
 missing or no MI355X is visible."""
 from . import _lib, build, nodes, synth  # noqa: F401
-from ._lib import (FLAG_NO_MORTON, FLAG_NO_WEIGHT_QUANT, FLAG_PROFILE, SCHEDULE_ROUND, SCHEDULE_SERIAL, FgoicpError)  # noqa: F401
+from ._lib import (FLAG_BRUTE_FORCE_NN, FLAG_NO_MORTON, FLAG_NO_WEIGHT_QUANT, FLAG_PROFILE, SCHEDULE_ROUND, SCHEDULE_SERIAL, FgoicpError)  # noqa: F401
 from .registration import IterativeClosestPoint3D, Registration, StreamPool  # noqa: F401
 from .nodes import Rotation, RotNode, TransNode, from_glm, to_glm  # noqa: F401
 

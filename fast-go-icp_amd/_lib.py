@@ -24,7 +24,7 @@ class RunStats(C.Structure):
     _fields_ = [("trans_cubes", C.c_uint64), ("bounds_calls", C.c_uint64), ("rot_cubes", C.c_uint64),
                 ("icp_runs", C.c_uint64), ("icp_iters", C.c_uint64), ("inner_bnb", C.c_uint64),
                 ("rounds", C.c_uint64), ("seconds_total", C.c_double), ("seconds_bnb", C.c_double),
-                ("seconds_icp", C.c_double)]
+                ("seconds_icp", C.c_double), ("initial_icp_sse", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -33,6 +33,7 @@ class RunStats(C.Structure):
 FLAG_NO_WEIGHT_QUANT = 1 << 0
 FLAG_NO_MORTON = 1 << 1
 FLAG_PROFILE = 1 << 2
+FLAG_BRUTE_FORCE_NN = 1 << 3
 SCHEDULE_SERIAL = 0
 SCHEDULE_ROUND = 1
 

@@ -18,6 +18,7 @@ CLI_PATH = os.path.join(LIB_DIR, "fast-go-icp")
 SOURCES = [
     os.path.join(CSRC, "device", "kernels.hip"),
     os.path.join(CSRC, "device", "ctx.hip"),
+    os.path.join(CSRC, "device", "bvh.hip"),
     os.path.join(CSRC, "host", "solver.cpp"),
 ]
 CLI_SOURCES = [os.path.join(CSRC, "cli", "main.cpp")]

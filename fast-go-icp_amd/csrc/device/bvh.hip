@@ -1,0 +1,77 @@
+// Host-side construction and upload of the implicit bounding-volume tree (bvh.hpp).
+#include "bvh.hpp"
+
+#include <cfloat>
+#include <cstring>
+
+#include "morton.hpp"
+
+namespace fgoicp {
+
+BvhHost bvh_build_host(const float4* p, size_t n) {
+    BvhHost h;
+    const size_t nleaf_needed = (n + kBvhLeaf - 1) / kBvhLeaf;
+    int depth = 0;
+    while (((size_t)1 << depth) < nleaf_needed) ++depth;
+    const size_t nleaf = (size_t)1 << depth;
+    h.depth = depth;
+    h.first_leaf = (int)(nleaf - 1);
+    const size_t nnodes = 2 * nleaf - 1;
+    const std::vector<uint32_t> perm = morton_order(reinterpret_cast<const float*>(p), n, 4);
+    h.pts.assign(nleaf * kBvhLeaf, make_float4(FLT_MAX, FLT_MAX, FLT_MAX, 0.f));
+    for (size_t i = 0; i < nleaf * kBvhLeaf; ++i) {
+        uint32_t idx = 0x7fffffffu;
+        if (i < n) {
+            idx = perm[i];
+            h.pts[i].x = p[idx].x; h.pts[i].y = p[idx].y; h.pts[i].z = p[idx].z;
+        }
+        std::memcpy(&h.pts[i].w, &idx, sizeof(idx));
+    }
+    h.box.assign(2 * nnodes, make_float4(0, 0, 0, 0));
+    auto set_empty = [&](size_t node) {
+        h.box[2 * node] = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, 0.f);
+        h.box[2 * node + 1] = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, 0.f);
+    };
+    for (size_t l = 0; l < nleaf; ++l) {
+        const size_t node = h.first_leaf + l;
+        set_empty(node);
+        for (size_t k = 0; k < (size_t)kBvhLeaf; ++k) {
+            const size_t i = l * kBvhLeaf + k;
+            if (i >= n) break;
+            float4& lo = h.box[2 * node];
+            float4& hi = h.box[2 * node + 1];
+            lo.x = std::min(lo.x, h.pts[i].x); lo.y = std::min(lo.y, h.pts[i].y); lo.z = std::min(lo.z, h.pts[i].z);
+            hi.x = std::max(hi.x, h.pts[i].x); hi.y = std::max(hi.y, h.pts[i].y); hi.z = std::max(hi.z, h.pts[i].z);
+        }
+    }
+    for (long node = (long)h.first_leaf - 1; node >= 0; --node) {
+        const size_t l = 2 * (size_t)node + 1, r = l + 1;
+        float4& lo = h.box[2 * node];
+        float4& hi = h.box[2 * node + 1];
+        lo = make_float4(std::min(h.box[2 * l].x, h.box[2 * r].x), std::min(h.box[2 * l].y, h.box[2 * r].y), std::min(h.box[2 * l].z, h.box[2 * r].z), 0.f);
+        hi = make_float4(std::max(h.box[2 * l + 1].x, h.box[2 * r + 1].x), std::max(h.box[2 * l + 1].y, h.box[2 * r + 1].y),
+                         std::max(h.box[2 * l + 1].z, h.box[2 * r + 1].z), 0.f);
+    }
+    return h;
+}
+
+hipError_t bvh_upload(const BvhHost& h, BvhDevice* d) {
+    d->depth = h.depth;
+    d->first_leaf = h.first_leaf;
+    hipError_t e = hipMalloc(&d->box, h.box.size() * sizeof(float4));
+    if (e != hipSuccess) return e;
+    e = hipMalloc(&d->pts, h.pts.size() * sizeof(float4));
+    if (e != hipSuccess) return e;
+    e = hipMemcpy(d->box, h.box.data(), h.box.size() * sizeof(float4), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(d->pts, h.pts.data(), h.pts.size() * sizeof(float4), hipMemcpyHostToDevice);
+}
+
+void bvh_free(BvhDevice* d) {
+    if (d->box) (void)hipFree(d->box);
+    if (d->pts) (void)hipFree(d->pts);
+    d->box = nullptr;
+    d->pts = nullptr;
+}
+
+}  // namespace fgoicp

@@ -1,0 +1,49 @@
+// Exact nearest-neighbour search over a point set: an implicit, heap-ordered bounding-volume tree
+// over the Morton-sorted points (leaves of 8 points), traversed without a stack.
+//
+// It replaces the reference's brute-force loops (fgoicp/registration.cu:162-174, :258-278,
+// fgoicp/icp3d.cu:11-28) with a search that returns BIT-IDENTICAL results: every candidate distance
+// is evaluated with the same fp32 expression as the brute force (dist_sq, kernels.hip), and a
+// subtree is skipped only when its box is provably farther than the incumbent — the fp32 box
+// distance is shrunk by 1e-6 relative, which covers the <=4e-7 relative rounding of both the box
+// distance and the point distances.  min is order-independent, so pruning cannot change the value.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+namespace fgoicp {
+
+constexpr int kBvhLeaf = 8;
+
+// Device view.  Node i (heap order: children 2i+1, 2i+2) has box[2i] = {lo.xyz, -}, box[2i+1] = {hi.xyz, -}.
+// Leaves are the last level: leaf l = node first_leaf + l holds pts[8l .. 8l+8) = {x, y, z, bits(original index)};
+// padding points sit at +FLT_MAX (distance +inf), empty leaves have an inverted box (distance +inf).
+struct BvhView {
+    const float4* box;
+    const float4* pts;
+    int depth;       // leaves live at this depth (root = 0)
+    int first_leaf;  // (1 << depth) - 1
+};
+
+struct BvhHost {
+    std::vector<float4> box;
+    std::vector<float4> pts;
+    int depth = 0;
+    int first_leaf = 0;
+};
+
+// Builds the tree over n points (xyz float4, w ignored); original indices are the positions in `p`.
+BvhHost bvh_build_host(const float4* p, size_t n);
+
+struct BvhDevice {
+    float4* box = nullptr;
+    float4* pts = nullptr;
+    int depth = 0, first_leaf = 0;
+    BvhView view() const { return BvhView{box, pts, depth, first_leaf}; }
+};
+hipError_t bvh_upload(const BvhHost& h, BvhDevice* d);
+void bvh_free(BvhDevice* d);
+
+}  // namespace fgoicp

@@ -16,6 +16,7 @@
 #include "../host/math3.hpp"
 #include "ctx.hpp"
 #include "kernels.hpp"
+#include "morton.hpp"
 
 namespace fgoicp {
 
@@ -32,42 +33,6 @@ void set_error(const std::string& s) { g_last_error = s; }
     } while (0)
 
 namespace {
-
-// 30-bit Morton code of a point inside [lo, hi]^3 — neighbouring lanes then stay in neighbouring
-// LUT voxels under any rigid motion (the LUT gathers of one wave share cache lines).
-uint32_t expand10(uint32_t v) {
-    v &= 0x3ff;
-    v = (v | (v << 16)) & 0x030000FF;
-    v = (v | (v << 8)) & 0x0300F00F;
-    v = (v | (v << 4)) & 0x030C30C3;
-    v = (v | (v << 2)) & 0x09249249;
-    return v;
-}
-
-std::vector<uint32_t> morton_order(const float* xyz, size_t n) {
-    std::vector<uint32_t> perm(n);
-    std::iota(perm.begin(), perm.end(), 0u);
-    if (n == 0) return perm;
-    float lo[3] = {xyz[0], xyz[1], xyz[2]}, hi[3] = {xyz[0], xyz[1], xyz[2]};
-    for (size_t i = 0; i < n; ++i)
-        for (int a = 0; a < 3; ++a) {
-            lo[a] = std::min(lo[a], xyz[3 * i + a]);
-            hi[a] = std::max(hi[a], xyz[3 * i + a]);
-        }
-    float ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
-    if (!(ext > 0)) return perm;
-    std::vector<uint32_t> code(n);
-    for (size_t i = 0; i < n; ++i) {
-        uint32_t c[3];
-        for (int a = 0; a < 3; ++a) {
-            float f = (xyz[3 * i + a] - lo[a]) / ext * 1023.0f;
-            c[a] = (uint32_t)std::min(1023.0f, std::max(0.0f, f));
-        }
-        code[i] = expand10(c[0]) | (expand10(c[1]) << 1) | (expand10(c[2]) << 2);
-    }
-    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return code[a] < code[b]; });
-    return perm;
-}
 
 }  // namespace
 
@@ -143,8 +108,12 @@ int ctx_bounds_multi(fgoicp_ctx* c, int G, const float* R9, const float* rot_spa
 int ctx_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out) {
     HIPCHK(hipSetDevice(c->device));
     const int ns = (int)c->ns;
-    launch_fill_u32(c->d_min_bits, 0x501502F9u /* bits(1e10f) */, c->ns, c->stream);
-    launch_nn_min(c->d_src, ns, c->d_tgt, (int)c->nt, R9, t3, 1, c->d_min_bits, c->stream);
+    if (c->brute_force_nn) {
+        launch_fill_u32(c->d_min_bits, 0x501502F9u /* bits(1e10f) */, c->ns, c->stream);
+        launch_nn_min(c->d_src, ns, c->d_tgt, (int)c->nt, R9, t3, 1, c->d_min_bits, c->stream);
+    } else {
+        launch_nn_bvh_min(c->d_src, ns, c->bvh_tgt.view(), c->d_tgt, (int)c->nt, c->d_lut, c->geom, R9, t3, 1, c->d_min_bits, c->d_hard, c->stream);
+    }
     const int nb = reduce_blocks_for(ns);
     launch_sum_f32_as_f64(c->d_min_bits, ns, c->d_bp, nb, c->stream);
     launch_sum_partials(c->d_bp, nb, 1, c->hd_sums, c->stream);
@@ -158,23 +127,24 @@ int ctx_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out) {
 int ctx_procrustes_device(fgoicp_ctx* c, Mat3f* R_out, Vec3f* t_out, float* centroids6_out, Mat3f* ABt_out) {
     const int ns = (int)c->ns, nt = (int)c->nt;
     // kernFindNearestNeighbor (icp3d.cu:11-28): min distance, tie set, lowest index
-    launch_fill_u32(c->d_min_bits, 0x501502F9u, c->ns, c->stream);
-    launch_fill_u32(c->d_first_idx, 0x7fffffffu, c->ns, c->stream);
-    launch_nn_min(c->d_work, ns, c->d_tgt, nt, nullptr, nullptr, 0, c->d_min_bits, c->stream);
-    launch_nn_tie_threshold(c->d_min_bits, ns, c->d_thr_bits, c->stream);
-    launch_nn_first_index(c->d_work, ns, c->d_tgt, nt, c->d_thr_bits, c->d_first_idx, c->stream);
+    if (c->brute_force_nn) {
+        launch_fill_u32(c->d_min_bits, 0x501502F9u, c->ns, c->stream);
+        launch_fill_u32(c->d_first_idx, 0x7fffffffu, c->ns, c->stream);
+        launch_nn_min(c->d_work, ns, c->d_tgt, nt, nullptr, nullptr, 0, c->d_min_bits, c->stream);
+        launch_nn_tie_threshold(c->d_min_bits, ns, c->d_thr_bits, c->stream);
+        launch_nn_first_index(c->d_work, ns, c->d_tgt, nt, c->d_thr_bits, c->d_first_idx, c->stream);
+    } else {
+        launch_nn_bvh_corr(c->d_work, ns, c->bvh_tgt.view(), c->d_tgt, nt, c->d_lut, c->geom, c->d_first_idx, c->d_hard, c->stream);
+    }
     const int nb = reduce_blocks_for(ns);
-    launch_icp_sums(c->d_work, c->d_tgt, c->d_first_idx, ns, c->d_bp, nb, c->stream);
-    launch_sum_partials(c->d_bp, nb, 6, c->hd_sums, c->stream);
+    launch_icp_sums(c->d_work, c->d_tgt, c->d_first_idx, ns, nt, c->d_bp, nb, c->stream);
+    launch_icp_centroids(c->d_bp, nb, ns, c->d_cen, c->hd_cen, c->stream);  // icp3d.cu:152-156, no host round trip
+    launch_icp_cov(c->d_work, c->d_tgt, c->d_first_idx, ns, nt, c->d_cen, c->d_bp2, nb, c->stream);
+    launch_sum_partials(c->d_bp2, nb, 9, c->hd_sums, c->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
-    const float fn = static_cast<float>(c->ns);
     float cen[6];
-    for (int k = 0; k < 6; ++k) cen[k] = (float)c->h_sums[k] / fn;  // icp3d.cu:155-156
-    launch_icp_cov(c->d_work, c->d_tgt, c->d_first_idx, ns, cen, c->d_bp, nb, c->stream);
-    launch_sum_partials(c->d_bp, nb, 9, c->hd_sums, c->stream);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(c->stream));
+    std::memcpy(cen, c->h_cen, sizeof(cen));
     Mat3f ABt;
     for (int k = 0; k < 9; ++k) ABt.m[k] = (float)c->h_sums[k];
     const Mat3f Rn = closest_orthogonal_approximation(ABt);  // icp3d.cu:168
@@ -261,6 +231,7 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
     c->ns = ns;
     c->nt = nt;
     c->profile = (flags & FGOICP_FLAG_PROFILE) != 0;
+    c->brute_force_nn = (flags & FGOICP_FLAG_BRUTE_FORCE_NN) != 0;
     auto fail = [&](int rc) { fgoicp_ctx_destroy(c); return rc; };
 #define CHK(expr) do { hipError_t e2_ = (expr); if (e2_ != hipSuccess) { set_error(std::string(#expr) + " failed: " + hipGetErrorString(e2_)); return fail(e2_ == hipErrorOutOfMemory ? FGOICP_ERR_OOM : FGOICP_ERR_HIP); } } while (0)
     CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -284,7 +255,7 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
     // contraction order (registration.cu:39-41).  Target: caller order (index tie rule), w = 0.
     c->perm.resize(ns);
     if (flags & FGOICP_FLAG_NO_MORTON) std::iota(c->perm.begin(), c->perm.end(), 0u);
-    else c->perm = morton_order(src_xyz, ns);
+    else c->perm = morton_order(src_xyz, ns, 3);
     {
         std::vector<float4> h(ns);
         for (size_t i = 0; i < ns; ++i) {
@@ -295,7 +266,7 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
         CHK(hipMemcpy(c->d_src, h.data(), sizeof(float4) * ns, hipMemcpyHostToDevice));
         CHK(hipMalloc(&c->d_work, sizeof(float4) * ns));
     }
-    float4* d_tgt_shift = nullptr;
+    // target on the device (caller order) + exact-NN tree; LUT build — buildLUTKernel, registration.cu:258-318
     {
         std::vector<float4> h(nt), hs(nt);
         for (size_t i = 0; i < nt; ++i) {
@@ -305,20 +276,33 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
         }
         CHK(hipMalloc(&c->d_tgt, sizeof(float4) * nt));
         CHK(hipMemcpy(c->d_tgt, h.data(), sizeof(float4) * nt, hipMemcpyHostToDevice));
-        CHK(hipMalloc(&d_tgt_shift, sizeof(float4) * nt));
-        hipError_t e3 = hipMemcpy(d_tgt_shift, hs.data(), sizeof(float4) * nt, hipMemcpyHostToDevice);
-        if (e3 != hipSuccess) { (void)hipFree(d_tgt_shift); set_error("upload of shifted target failed"); return fail(FGOICP_ERR_HIP); }
-    }
-    // LUT build — buildLUTKernel, registration.cu:258-318
-    {
         const size_t total = (size_t)g.px * g.py * g.pz;
-        hipError_t e3 = hipMalloc(&c->d_lut, total * sizeof(float));
-        if (e3 == hipSuccess) {
-            launch_lut_build(d_tgt_shift, (int)nt, g, c->d_lut, c->stream);
-            e3 = hipGetLastError();
-            if (e3 == hipSuccess) e3 = hipStreamSynchronize(c->stream);
+        CHK(hipMalloc(&c->d_lut, total * sizeof(float)));
+        hipError_t e3 = hipSuccess;
+        if (c->brute_force_nn) {
+            float4* d_tgt_shift = nullptr;
+            e3 = hipMalloc(&d_tgt_shift, sizeof(float4) * nt);
+            if (e3 == hipSuccess) e3 = hipMemcpy(d_tgt_shift, hs.data(), sizeof(float4) * nt, hipMemcpyHostToDevice);
+            if (e3 == hipSuccess) {
+                launch_lut_build(d_tgt_shift, (int)nt, g, c->d_lut, c->stream);
+                e3 = hipGetLastError();
+                if (e3 == hipSuccess) e3 = hipStreamSynchronize(c->stream);
+            }
+            (void)hipFree(d_tgt_shift);
+        } else {
+            CHK(bvh_upload(bvh_build_host(h.data(), nt), &c->bvh_tgt));
+            BvhDevice shifted;  // the LUT is built from the SHIFTED targets (pc + offset in fp32), its own tree
+            e3 = bvh_upload(bvh_build_host(hs.data(), nt), &shifted);
+            float* scratch = nullptr;
+            if (e3 == hipSuccess) e3 = hipMalloc(&scratch, total * sizeof(float));
+            if (e3 == hipSuccess) {
+                launch_lut_build_bvh(shifted.view(), g, scratch, c->d_lut, c->stream);
+                e3 = hipGetLastError();
+                if (e3 == hipSuccess) e3 = hipStreamSynchronize(c->stream);
+            }
+            (void)hipFree(scratch);
+            bvh_free(&shifted);
         }
-        (void)hipFree(d_tgt_shift);
         if (e3 != hipSuccess) { set_error(std::string("LUT build failed: ") + hipGetErrorString(e3)); return fail(e3 == hipErrorOutOfMemory ? FGOICP_ERR_OOM : FGOICP_ERR_HIP); }
     }
     // bounds scratch: P points per thread so that one 32-subcube launch has >= ~2048 blocks
@@ -342,7 +326,12 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
     CHK(hipMalloc(&c->d_min_bits, sizeof(uint32_t) * ns));
     CHK(hipMalloc(&c->d_thr_bits, sizeof(uint32_t) * ns));
     CHK(hipMalloc(&c->d_first_idx, sizeof(uint32_t) * ns));
+    CHK(hipMalloc(&c->d_hard, sizeof(uint32_t) * (ns + 1)));
     CHK(hipMalloc(&c->d_bp, sizeof(double) * 1024 * 16));
+    CHK(hipMalloc(&c->d_bp2, sizeof(double) * 1024 * 16));
+    CHK(hipMalloc(&c->d_cen, sizeof(float) * 8));
+    CHK(hipHostMalloc((void**)&c->h_cen, sizeof(float) * 8, hipHostMallocMapped));
+    CHK(hipHostGetDevicePointer((void**)&c->hd_cen, c->h_cen, 0));
     CHK(hipHostMalloc((void**)&c->h_sums, sizeof(double) * 16, hipHostMallocMapped));
     CHK(hipHostGetDevicePointer((void**)&c->hd_sums, c->h_sums, 0));
 #undef CHK
@@ -362,8 +351,10 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
     for (auto& e : c->ev_start) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_stop) if (e) (void)hipEventDestroy(e);
     (void)hipFree(c->d_src); (void)hipFree(c->d_work); (void)hipFree(c->d_tgt); (void)hipFree(c->d_lut);
-    (void)hipFree(c->d_partials); (void)hipFree(c->d_min_bits); (void)hipFree(c->d_thr_bits); (void)hipFree(c->d_first_idx);
-    (void)hipFree(c->d_bp);
+    (void)hipFree(c->d_partials); (void)hipFree(c->d_min_bits); (void)hipFree(c->d_thr_bits); (void)hipFree(c->d_first_idx); (void)hipFree(c->d_hard);
+    (void)hipFree(c->d_bp); (void)hipFree(c->d_bp2); (void)hipFree(c->d_cen);
+    if (c->h_cen) (void)hipHostFree(c->h_cen);
+    bvh_free(&c->bvh_tgt);
     if (c->h_lb) (void)hipHostFree(c->h_lb);
     if (c->h_ub) (void)hipHostFree(c->h_ub);
     if (c->h_sums) (void)hipHostFree(c->h_sums);

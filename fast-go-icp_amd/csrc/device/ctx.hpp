@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../host/math3.hpp"
+#include "bvh.hpp"
 #include "kernels.hpp"
 
 struct fgoicp_ctx {
@@ -22,6 +23,8 @@ struct fgoicp_ctx {
     float4* d_tgt = nullptr;     // nt  x {x,y,z,0}, caller order (registration.hpp:61)
     float* d_lut = nullptr;      // (dx+2)(dy+2)(dz+2) floats, x fastest, replicated border
     fgoicp::LutGeom geom{};
+    fgoicp::BvhDevice bvh_tgt;   // exact-NN tree over the target (caller indices in pts[].w)
+    bool brute_force_nn = false; // FGOICP_FLAG_BRUTE_FORCE_NN: O(ns*nt) kernels instead of the tree
     std::vector<uint32_t> perm;  // device slot i holds caller point perm[i]
 
     // bounds-operator scratch (persistent: the reference mallocs/frees per call, registration.cu:95-149)
@@ -32,8 +35,12 @@ struct fgoicp_ctx {
 
     // exact-NN / ICP scratch
     uint32_t *d_min_bits = nullptr, *d_thr_bits = nullptr, *d_first_idx = nullptr;
+    uint32_t* d_hard = nullptr;  // [0] = count, [1..] = queries the budgeted tree search deferred to the wave-per-query fallback
     double* d_bp = nullptr;      // per-block partial sums
     double *h_sums = nullptr, *hd_sums = nullptr;  // pinned result of the last reduction (<= 16 doubles)
+    double* d_bp2 = nullptr;     // second partial buffer (covariance), so both reductions of a Procrustes step queue back to back
+    float* d_cen = nullptr;      // centroids {src, corr} on the device
+    float *h_cen = nullptr, *hd_cen = nullptr;  // ... and their pinned host copy
 
     // HIP-event profile of the bounds kernel
     std::vector<hipEvent_t> ev_start, ev_stop;

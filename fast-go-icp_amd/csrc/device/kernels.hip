@@ -10,6 +10,8 @@
 // approximate in an unspecified order (fgoicp/registration.cu:126-140).
 #include "kernels.hpp"
 
+#include "bvh.hpp"
+
 namespace fgoicp {
 namespace {
 
@@ -373,6 +375,260 @@ __global__ __launch_bounds__(kBlock) void nn_first_index_kernel(const float4* __
         if (qi[k] < n && idx[k] != 0x7fffffffu) atomicMin(&first_idx[qi[k]], idx[k]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Exact nearest neighbour through the implicit BVH (bvh.hpp): same candidate arithmetic as the brute
+// force above, conservative pruning, no stack (a per-level "sibling pending" bit mask + heap-index
+// arithmetic find the next node), one thread per query.  Queries arrive in Morton order, so the
+// lanes of a wave walk almost the same path.
+// ---------------------------------------------------------------------------------------------
+constexpr float kBoxShrink = 0.999999f;  // see bvh.hpp: covers fp32 rounding of box and point distances
+
+__device__ __forceinline__ float box_d2(const float4 lo, const float4 hi, float qx, float qy, float qz) {
+    const float dx = fmaxf(fmaxf(lo.x - qx, qx - hi.x), 0.0f);
+    const float dy = fmaxf(fmaxf(lo.y - qy, qy - hi.y), 0.0f);
+    const float dz = fmaxf(fmaxf(lo.z - qz, qz - hi.z), 0.0f);
+    return fma_(dz, dz, fma_(dy, dy, dx * dx));
+}
+
+// Visits every leaf point whose subtree is not provably farther than bound(); bound() may shrink
+// while the traversal runs (pass 1) or stay fixed (pass 2).  Returns false if more than `budget`
+// nodes were touched: queries near the medial axis of the target are (almost) equidistant from
+// large parts of it, nothing can be pruned for them, and one such lane would hold up its whole wave —
+// the caller then hands the query to the wave-per-query exact fallback (nn_hard_*_kernel).
+template <class LeafFn, class BoundFn>
+__device__ __forceinline__ bool bvh_traverse(const BvhView t, float qx, float qy, float qz, int budget, LeafFn leaf, BoundFn bound) {
+    unsigned pending = 0;  // bit d set: the sibling of the current path's node at depth d is still to be visited
+    int node = 0, depth = 0;
+    for (;;) {
+        bool pop = false;
+        if (--budget < 0) return false;
+        if (depth == t.depth) {
+            const float4* p = t.pts + (size_t)(node - t.first_leaf) * kBvhLeaf;
+#pragma unroll
+            for (int k = 0; k < kBvhLeaf; ++k) leaf(p[k]);
+            pop = true;
+        } else {
+            const int l = 2 * node + 1;
+            const float dl = box_d2(t.box[2 * l], t.box[2 * l + 1], qx, qy, qz);
+            const float dr = box_d2(t.box[2 * l + 2], t.box[2 * l + 3], qx, qy, qz);
+            const float b = bound();
+            const bool vl = !(dl * kBoxShrink > b), vr = !(dr * kBoxShrink > b);
+            if (vl && vr) {
+                node = dl <= dr ? l : l + 1;  // nearer child first, the other one stays pending
+                ++depth;
+                pending |= 1u << depth;
+            } else if (vl || vr) {
+                node = vl ? l : l + 1;
+                ++depth;
+            } else {
+                pop = true;
+            }
+        }
+        if (pop) {
+            for (;;) {
+                if (!pending) return true;
+                const int lvl = 31 - __clz(pending);
+                pending &= ~(1u << lvl);
+                const int anc = ((node + 1) >> (depth - lvl)) - 1;  // ancestor of the current node at depth lvl
+                node = ((anc + 1) ^ 1) - 1;                          // its sibling
+                depth = lvl;
+                if (!(box_d2(t.box[2 * node], t.box[2 * node + 1], qx, qy, qz) * kBoxShrink > bound())) break;
+                if (--budget < 0) return false;
+            }
+        }
+    }
+}
+
+// Minimum squared distance.  `ub` is any value >= the true minimum (or +huge): it only seeds the
+// pruning bound; the result is the minimum over VISITED points, and the true nearest point is never
+// pruned while the bound stays >= its distance.  If fp32 rounding made the seed a hair too small and
+// nothing was found, the search is repeated unseeded — the result is exact either way.
+// ok = false: the step budget ran out, the returned value is meaningless.
+__device__ __forceinline__ float bvh_min_d2(const BvhView t, float qx, float qy, float qz, float ub, float init, int budget, bool& ok) {
+    float best = ub < init ? ub : init;
+    float found = init;
+    ok = bvh_traverse(t, qx, qy, qz, budget,
+                      [&](const float4 p) {
+                          const float d = dist_sq(qx, qy, qz, p.x, p.y, p.z);
+                          found = d < found ? d : found;
+                          best = d < best ? d : best;
+                      },
+                      [&]() { return best; });
+    if (ok && found > best) {  // seed below every visited distance: cannot happen with a valid seed; stay exact anyway
+        found = init;
+        ok = bvh_traverse(t, qx, qy, qz, budget,
+                          [&](const float4 p) {
+                              const float d = dist_sq(qx, qy, qz, p.x, p.y, p.z);
+                              found = d < found ? d : found;
+                          },
+                          [&]() { return found; });
+    }
+    return found;
+}
+
+// Upper bound on the nearest-target squared distance of q from the LUT: for ANY LUT node c,
+// min_j |q - tgt_j| <= |q - c| + min_j |c - tgt_j| = |q - c| + sqrt(T[c])  (triangle inequality).  With the
+// node nearest to q (clamped into the grid, so it also works outside the target's box) the slack is
+// at most half a voxel diagonal.  Inflated by 1e-4 relative + 1e-6 absolute: T was computed from
+// the shifted targets in fp32.
+__device__ __forceinline__ float lut_upper_bound_d2(const float* __restrict__ lut, const LutGeom& g, float qx, float qy, float qz) {
+    const float sx = qx + g.off_x, sy = qy + g.off_y, sz = qz + g.off_z;
+    const float fx = fminf(fmaxf(rintf(sx * g.scale), 0.0f), (float)(g.dx - 1));
+    const float fy = fminf(fmaxf(rintf(sy * g.scale), 0.0f), (float)(g.dy - 1));
+    const float fz = fminf(fmaxf(rintf(sz * g.scale), 0.0f), (float)(g.dz - 1));
+    const float T = lut[((size_t)((int)fz + 1) * g.py + ((int)fy + 1)) * (size_t)g.px + ((int)fx + 1)];
+    const float dx = sx - fx * g.resolution, dy = sy - fy * g.resolution, dz = sz - fz * g.resolution;
+    const float u = sqrtf(T) + sqrtf(dx * dx + dy * dy + dz * dz);
+    return u * u * 1.0001f + 1e-6f;
+}
+
+constexpr int kNnBudget = 192;          // nodes a query may touch before it is declared hard
+constexpr int kLutBudget = 1 << 30;     // LUT nodes are never deferred (one-off build, no fallback list)
+
+__device__ __forceinline__ float tie_threshold(float best) {  // see nn_tie_threshold_kernel
+    uint32_t b = __float_as_uint(best);
+    const float s = sqrtf(best);
+    for (int it = 0; it < 8; ++it) {
+        const uint32_t nb = b + 1;
+        if (sqrtf(__uint_as_float(nb)) == s) b = nb; else break;
+    }
+    return __uint_as_float(b);
+}
+
+__device__ __forceinline__ void load_query(const float4* __restrict__ pts, int i, const Rt& rt, int apply, float& qx, float& qy, float& qz) {
+    const float4 p = pts[i];
+    qx = p.x; qy = p.y; qz = p.z;
+    if (apply) {
+        rotate(rt.R, p.x, p.y, p.z, qx, qy, qz);
+        qx += rt.t[0]; qy += rt.t[1]; qz += rt.t[2];
+    }
+}
+
+// hard[0] = number of deferred queries, hard[1 + k] = their indices (zeroed by the caller per call)
+__global__ __launch_bounds__(kBlock) void nn_bvh_min_kernel(const float4* __restrict__ pts, int n, BvhView t, const float* __restrict__ lut,
+                                                            LutGeom g, Rt rt, int apply, uint32_t* __restrict__ min_bits,
+                                                            uint32_t* __restrict__ hard) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float qx, qy, qz;
+    load_query(pts, i, rt, apply, qx, qy, qz);
+    bool ok;
+    const float best = bvh_min_d2(t, qx, qy, qz, lut_upper_bound_d2(lut, g, qx, qy, qz), kInf, kNnBudget, ok);
+    if (ok) min_bits[i] = __float_as_uint(best);
+    else hard[1 + atomicAdd(&hard[0], 1u)] = (uint32_t)i;
+}
+
+// kernFindNearestNeighbor (icp3d.cu:11-28) in one kernel: minimum, sqrt-tie threshold, lowest index.
+__global__ __launch_bounds__(kBlock) void nn_bvh_corr_kernel(const float4* __restrict__ pts, int n, BvhView t, const float* __restrict__ lut,
+                                                             LutGeom g, uint32_t* __restrict__ first_idx, uint32_t* __restrict__ hard) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 q = pts[i];
+    bool ok;
+    const float best = bvh_min_d2(t, q.x, q.y, q.z, lut_upper_bound_d2(lut, g, q.x, q.y, q.z), kInf, kNnBudget, ok);
+    uint32_t idx = 0x7fffffffu;
+    if (ok) {
+        const float thr = tie_threshold(best);
+        ok = bvh_traverse(t, q.x, q.y, q.z, kNnBudget,
+                          [&](const float4 p) {
+                              const float d = dist_sq(q.x, q.y, q.z, p.x, p.y, p.z);
+                              const uint32_t cand = d <= thr ? __float_as_uint(p.w) : 0x7fffffffu;
+                              idx = min(idx, cand);
+                          },
+                          [&]() { return thr; });
+    }
+    if (ok) first_idx[i] = idx;
+    else hard[1 + atomicAdd(&hard[0], 1u)] = (uint32_t)i;
+}
+
+// Exact fallback for the deferred queries: ONE WAVE PER QUERY sweeps all targets (coalesced 16-byte
+// loads, lane-strided), wave-reduces the minimum (and for correspondences the lowest index inside the
+// sqrt-tie threshold).  Same candidate arithmetic, min is order-independent -> same bits as any other path.
+__device__ __forceinline__ float wave_min_f(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_min_u(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, off, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(kBlock) void nn_hard_kernel(const float4* __restrict__ pts, const float4* __restrict__ tgt, int nt, Rt rt, int apply,
+                                                         int want_index, const uint32_t* __restrict__ hard, uint32_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * kBlock) >> 6;
+    const uint32_t count = hard[0];
+    for (uint32_t h = wave; h < count; h += nwaves) {
+        const int i = (int)hard[1 + h];
+        float qx, qy, qz;
+        load_query(pts, i, rt, apply, qx, qy, qz);
+        float best = kInf;
+        for (int j = lane; j < nt; j += 64) {
+            const float4 p = tgt[j];
+            const float d = dist_sq(qx, qy, qz, p.x, p.y, p.z);
+            best = d < best ? d : best;
+        }
+        best = wave_min_f(best);
+        if (!want_index) {
+            if (lane == 0) out[i] = __float_as_uint(best);
+            continue;
+        }
+        const float thr = tie_threshold(best);
+        uint32_t idx = 0x7fffffffu;
+        for (int j = lane; j < nt; j += 64) {
+            const float4 p = tgt[j];
+            const float d = dist_sq(qx, qy, qz, p.x, p.y, p.z);
+            idx = min(idx, d <= thr ? (uint32_t)j : 0x7fffffffu);
+        }
+        idx = wave_min_u(idx);
+        if (lane == 0) out[i] = idx;
+    }
+}
+
+// buildLUTKernel (registration.cu:258-278) through the BVH of the shifted targets, coarse to fine:
+// pass 0 evaluates the nodes whose (clamped) coordinates are multiples of kLutCoarse unseeded, pass 1
+// evaluates every node seeded with the triangle-inequality bound from its coarse neighbour.  Both
+// passes return exact minima (bvh_min_d2), pass 1 recomputes the coarse nodes identically.
+constexpr int kLutCoarse = 4;
+
+__device__ __forceinline__ void lut_node_coords(const LutGeom& g, size_t n, int& cx, int& cy, int& cz) {
+    const int x = (int)(n % g.px);
+    const size_t r = n / g.px;
+    const int y = (int)(r % g.py);
+    const int z = (int)(r / g.py);
+    cx = min(max(x - 1, 0), g.dx - 1);  // padded index -> clamped reference node index
+    cy = min(max(y - 1, 0), g.dy - 1);
+    cz = min(max(z - 1, 0), g.dz - 1);
+}
+
+__global__ __launch_bounds__(kBlock) void lut_build_bvh_coarse_kernel(BvhView t, LutGeom g, float* __restrict__ lut) {
+    const int ncx = (g.dx + kLutCoarse - 1) / kLutCoarse, ncy = (g.dy + kLutCoarse - 1) / kLutCoarse, ncz = (g.dz + kLutCoarse - 1) / kLutCoarse;
+    const size_t total = (size_t)ncx * ncy * ncz;
+    const size_t n = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (n >= total) return;
+    const int ix = (int)(n % ncx) * kLutCoarse, iy = (int)((n / ncx) % ncy) * kLutCoarse, iz = (int)(n / ((size_t)ncx * ncy)) * kLutCoarse;
+    const float cx = (float)ix * g.resolution, cy = (float)iy * g.resolution, cz = (float)iz * g.resolution;  // :265
+    lut[((size_t)(iz + 1) * g.py + (iy + 1)) * (size_t)g.px + (ix + 1)] = [&] { bool ok; return bvh_min_d2(t, cx, cy, cz, 3.402823466e+38f, 3.402823466e+38f, kLutBudget, ok); }();
+}
+
+__global__ __launch_bounds__(kBlock) void lut_build_bvh_kernel(BvhView t, LutGeom g, const float* __restrict__ coarse, float* __restrict__ lut) {
+    const size_t total = (size_t)g.px * g.py * g.pz;
+    const size_t n = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (n >= total) return;
+    int ix, iy, iz;
+    lut_node_coords(g, n, ix, iy, iz);
+    const float cx = (float)ix * g.resolution, cy = (float)iy * g.resolution, cz = (float)iz * g.resolution;  // :265
+    const int kx = ix / kLutCoarse * kLutCoarse, ky = iy / kLutCoarse * kLutCoarse, kz = iz / kLutCoarse * kLutCoarse;
+    const float T = coarse[((size_t)(kz + 1) * g.py + (ky + 1)) * (size_t)g.px + (kx + 1)];
+    const float ddx = (float)(ix - kx) * g.resolution, ddy = (float)(iy - ky) * g.resolution, ddz = (float)(iz - kz) * g.resolution;
+    const float u = sqrtf(T) + sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+    bool ok;
+    lut[n] = bvh_min_d2(t, cx, cy, cz, u * u * 1.0001f + 1e-6f, 3.402823466e+38f, kLutBudget, ok);  // FLT_MAX, :266
+}
+
 __global__ __launch_bounds__(kBlock) void fill_u32_kernel(uint32_t* p, uint32_t v, size_t n) {
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) p[i] = v;
 }
@@ -388,13 +644,15 @@ __global__ __launch_bounds__(kBlock) void sum_f32_kernel(const uint32_t* __restr
     if (threadIdx.x == 0) bp[blockIdx.x] = r;
 }
 
-// single block: out[k] = sum over blocks (in order) of bp[b*width + k]
-__global__ __launch_bounds__(64) void sum_partials_kernel(const double* __restrict__ bp, int nblocks, int width, double* __restrict__ out) {
-    const int k = threadIdx.x;
+// single block, one wave per component: out[k] = sum over blocks of bp[b*width + k]
+// (lane-strided partial sums + shuffle tree: a fixed order, hence reproducible)
+__global__ __launch_bounds__(1024) void sum_partials_kernel(const double* __restrict__ bp, int nblocks, int width, double* __restrict__ out) {
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (k >= width) return;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += bp[(size_t)b * width + k];
-    out[k] = s;
+    for (int b = lane; b < nblocks; b += 64) s += bp[(size_t)b * width + k];
+    s = wave_sum(s);
+    if (lane == 0) out[k] = s;
 }
 
 // kernRotateTranslateInplace — fgoicp/icp3d.cu:30-36
@@ -412,12 +670,12 @@ __global__ __launch_bounds__(kBlock) void transform_inplace_kernel(float4* __res
 
 // Sum of the working cloud and of its correspondences (icp3d.cu:152-153).
 __global__ __launch_bounds__(kBlock) void icp_sums_kernel(const float4* __restrict__ work, const float4* __restrict__ tgt,
-                                                          const uint32_t* __restrict__ idx, int n, double* __restrict__ bp) {
+                                                          const uint32_t* __restrict__ idx, int n, int nt, double* __restrict__ bp) {
     __shared__ double red[24];
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const float4 a = work[i];
-        const float4 c = tgt[idx[i]];
+        const float4 c = tgt[min(idx[i], (uint32_t)(nt - 1))];  // an index is always found for finite clouds; never read out of bounds
         acc[0] += (double)a.x; acc[1] += (double)a.y; acc[2] += (double)a.z;
         acc[3] += (double)c.x; acc[4] += (double)c.y; acc[5] += (double)c.z;
     }
@@ -428,17 +686,16 @@ __global__ __launch_bounds__(kBlock) void icp_sums_kernel(const float4* __restri
 // kernCentralize x2 + kernOuterProduct + reduce (icp3d.cu:38-52, :158-166), fused: per-point fp32
 // centring and products exactly as the reference, fp64 accumulation.  Output in glm::mat3 order:
 // ABt[col][row] = sum a[row]*b[col]  (glm::outerProduct(c, r): m[i] = c * r[i]).
-struct Centroids { float s[3]; float c[3]; };
 __global__ __launch_bounds__(kBlock) void icp_cov_kernel(const float4* __restrict__ work, const float4* __restrict__ tgt,
-                                                         const uint32_t* __restrict__ idx, int n, Centroids cen,
+                                                         const uint32_t* __restrict__ idx, int n, int nt, const float* __restrict__ cen,
                                                          double* __restrict__ bp) {
     __shared__ double red[36];
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const float4 p = work[i];
-        const float4 q = tgt[idx[i]];
-        const float a[3] = {p.x - cen.s[0], p.y - cen.s[1], p.z - cen.s[2]};
-        const float b[3] = {q.x - cen.c[0], q.y - cen.c[1], q.z - cen.c[2]};
+        const float4 q = tgt[min(idx[i], (uint32_t)(nt - 1))];
+        const float a[3] = {p.x - cen[0], p.y - cen[1], p.z - cen[2]};
+        const float b[3] = {q.x - cen[3], q.y - cen[4], q.z - cen[5]};
 #pragma unroll
         for (int col = 0; col < 3; ++col)
 #pragma unroll
@@ -446,6 +703,22 @@ __global__ __launch_bounds__(kBlock) void icp_cov_kernel(const float4* __restric
     }
     const double r = block_sum<9>(acc, red);
     if (threadIdx.x < 9) bp[(size_t)blockIdx.x * 9 + threadIdx.x] = r;
+}
+
+// Centroids on the device (icp3d.cu:152-156): ordered fp64 sum of the block partials, rounded to fp32,
+// divided by float(ns) in fp32 (correctly rounded division, as on the host).  Written both to device
+// memory (for icp_cov_kernel) and to pinned host memory (for t_ = c_corr - R_ * c_src).
+__global__ __launch_bounds__(384) void icp_centroids_kernel(const double* __restrict__ bp, int nblocks, int ns, float* __restrict__ cen_dev,
+                                                            float* __restrict__ cen_host) {
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;  // one wave per component
+    double s = 0.0;
+    for (int b = lane; b < nblocks; b += 64) s += bp[(size_t)b * 6 + k];
+    s = wave_sum(s);
+    if (lane == 0) {
+        const float c = (float)s / (float)ns;
+        cen_dev[k] = c;
+        cen_host[k] = c;
+    }
 }
 
 Rt make_rt(const float* R9, const float* t3) {
@@ -527,6 +800,31 @@ void launch_nn_first_index(const float4* pts, int n, const float4* tgt, int nt, 
     hipLaunchKernelGGL(nn_first_index_kernel, dim3(qtiles, nsl), dim3(kBlock), 0, s, pts, n, tgt, nt, slice_len, thr_bits, first_idx);
 }
 
+// `hard` = 1 + n uint32 on the device; hard[0] is zeroed here, the deferred queries are finished by
+// the wave-per-query fallback queued right behind (no host round trip).
+void launch_nn_bvh_min(const float4* pts, int n, const BvhView& t, const float4* tgt, int nt, const float* lut, const LutGeom& g,
+                       const float* R9, const float* t3, int apply, uint32_t* min_bits, uint32_t* hard, hipStream_t s) {
+    (void)hipMemsetAsync(hard, 0, sizeof(uint32_t), s);
+    const Rt rt = make_rt(R9, t3);
+    hipLaunchKernelGGL(nn_bvh_min_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, n, t, lut, g, rt, apply, min_bits, hard);
+    hipLaunchKernelGGL(nn_hard_kernel, dim3(1024), dim3(kBlock), 0, s, pts, tgt, nt, rt, apply, 0, hard, min_bits);
+}
+
+void launch_nn_bvh_corr(const float4* pts, int n, const BvhView& t, const float4* tgt, int nt, const float* lut, const LutGeom& g,
+                        uint32_t* first_idx, uint32_t* hard, hipStream_t s) {
+    (void)hipMemsetAsync(hard, 0, sizeof(uint32_t), s);
+    hipLaunchKernelGGL(nn_bvh_corr_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, n, t, lut, g, first_idx, hard);
+    hipLaunchKernelGGL(nn_hard_kernel, dim3(1024), dim3(kBlock), 0, s, pts, tgt, nt, make_rt(nullptr, nullptr), 0, 1, hard, first_idx);
+}
+
+// `scratch` must hold as many floats as the padded LUT; it receives the coarse pass.
+void launch_lut_build_bvh(const BvhView& t, const LutGeom& g, float* scratch, float* lut_padded, hipStream_t s) {
+    const size_t ncoarse = (size_t)((g.dx + kLutCoarse - 1) / kLutCoarse) * ((g.dy + kLutCoarse - 1) / kLutCoarse) * ((g.dz + kLutCoarse - 1) / kLutCoarse);
+    hipLaunchKernelGGL(lut_build_bvh_coarse_kernel, dim3((unsigned)((ncoarse + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, t, g, scratch);
+    const size_t total = (size_t)g.px * g.py * g.pz;
+    hipLaunchKernelGGL(lut_build_bvh_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, t, g, scratch, lut_padded);
+}
+
 int reduce_blocks_for(int n) {
     int b = (n + kBlock - 1) / kBlock;
     if (b < 1) b = 1;
@@ -538,22 +836,24 @@ void launch_sum_f32_as_f64(const uint32_t* bits, int n, double* bp, int nblocks,
 }
 
 void launch_sum_partials(const double* bp, int nblocks, int width, double* out, hipStream_t s) {
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, s, bp, nblocks, width, out);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64 * width), 0, s, bp, nblocks, width, out);
 }
 
 void launch_transform_inplace(float4* pts, int n, const float* R9, const float* t3, hipStream_t s) {
     hipLaunchKernelGGL(transform_inplace_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, n, make_rt(R9, t3));
 }
 
-void launch_icp_sums(const float4* work, const float4* tgt, const uint32_t* idx, int n, double* bp, int nblocks, hipStream_t s) {
-    hipLaunchKernelGGL(icp_sums_kernel, dim3(nblocks), dim3(kBlock), 0, s, work, tgt, idx, n, bp);
+void launch_icp_sums(const float4* work, const float4* tgt, const uint32_t* idx, int n, int nt, double* bp, int nblocks, hipStream_t s) {
+    hipLaunchKernelGGL(icp_sums_kernel, dim3(nblocks), dim3(kBlock), 0, s, work, tgt, idx, n, nt, bp);
 }
 
-void launch_icp_cov(const float4* work, const float4* tgt, const uint32_t* idx, int n, const float* centroids6, double* bp,
-                    int nblocks, hipStream_t s) {
-    Centroids cen;
-    for (int i = 0; i < 3; ++i) { cen.s[i] = centroids6[i]; cen.c[i] = centroids6[3 + i]; }
-    hipLaunchKernelGGL(icp_cov_kernel, dim3(nblocks), dim3(kBlock), 0, s, work, tgt, idx, n, cen, bp);
+void launch_icp_centroids(const double* bp, int nblocks, int ns, float* cen_dev, float* cen_host, hipStream_t s) {
+    hipLaunchKernelGGL(icp_centroids_kernel, dim3(1), dim3(384), 0, s, bp, nblocks, ns, cen_dev, cen_host);
+}
+
+void launch_icp_cov(const float4* work, const float4* tgt, const uint32_t* idx, int n, int nt, const float* cen_dev, double* bp, int nblocks,
+                    hipStream_t s) {
+    hipLaunchKernelGGL(icp_cov_kernel, dim3(nblocks), dim3(kBlock), 0, s, work, tgt, idx, n, nt, cen_dev, bp);
 }
 
 }  // namespace fgoicp

@@ -8,6 +8,8 @@
 
 namespace fgoicp {
 
+struct BvhView;
+
 constexpr int kMaxBatch = 32;          // translation nodes per bounds launch (kernarg-resident)
 constexpr int kBlock = 256;            // 4 wave64 per workgroup everywhere
 constexpr float kSqrt3 = 1.732050807568877f;   // fgoicp/common.hpp:19
@@ -60,16 +62,24 @@ void launch_nn_tie_threshold(const uint32_t* min_bits, int n, uint32_t* thr_bits
 void launch_nn_first_index(const float4* pts, int n, const float4* tgt, int nt, const uint32_t* thr_bits, uint32_t* first_idx,
                            hipStream_t s);
 
+// Exact NN through the implicit BVH (bvh.hpp) — bit-identical to the brute-force kernels above.
+void launch_nn_bvh_min(const float4* pts, int n, const BvhView& t, const float4* tgt, int nt, const float* lut, const LutGeom& g,
+                       const float* R9, const float* t3, int apply, uint32_t* min_bits, uint32_t* hard, hipStream_t s);
+void launch_nn_bvh_corr(const float4* pts, int n, const BvhView& t, const float4* tgt, int nt, const float* lut, const LutGeom& g,
+                        uint32_t* first_idx, uint32_t* hard, hipStream_t s);
+void launch_lut_build_bvh(const BvhView& shifted_targets, const LutGeom& g, float* scratch_padded, float* lut_padded, hipStream_t s);
+
 // deterministic double sums: out[k] = sum_i vals[i*stride + k]  (k < width <= 16)
 void launch_sum_f32_as_f64(const uint32_t* bits, int n, double* block_partials, int nblocks, hipStream_t s);
 void launch_sum_partials(const double* block_partials, int nblocks, int width, double* out, hipStream_t s);
 
 // ICP pieces (fgoicp/icp3d.cu:30-52)
 void launch_transform_inplace(float4* pts, int n, const float* R9, const float* t3, hipStream_t s);
-void launch_icp_sums(const float4* work, const float4* tgt, const uint32_t* idx, int n, double* block_partials, int nblocks,
+void launch_icp_sums(const float4* work, const float4* tgt, const uint32_t* idx, int n, int nt, double* block_partials, int nblocks,
                      hipStream_t s);  // width 6: sum src xyz, sum corr xyz
-void launch_icp_cov(const float4* work, const float4* tgt, const uint32_t* idx, int n, const float* centroids6,
-                    double* block_partials, int nblocks, hipStream_t s);  // width 9: glm mat3 order
+void launch_icp_centroids(const double* block_partials, int nblocks, int ns, float* cen_dev, float* cen_host, hipStream_t s);
+void launch_icp_cov(const float4* work, const float4* tgt, const uint32_t* idx, int n, int nt, const float* cen_dev, double* block_partials,
+                    int nblocks, hipStream_t s);  // width 9: glm mat3 order
 
 int reduce_blocks_for(int n);
 

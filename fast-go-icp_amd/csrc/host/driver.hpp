@@ -111,7 +111,7 @@ struct Exchange {
 
 struct DriverStats {
     uint64_t trans_cubes = 0, bounds_calls = 0, rot_cubes = 0, icp_runs = 0, icp_iters = 0, inner_bnb = 0, rounds = 0;
-    double seconds_total = 0, seconds_bnb = 0, seconds_icp = 0;
+    double seconds_total = 0, seconds_bnb = 0, seconds_icp = 0, initial_icp_sse = 0;
 };
 
 enum { kScheduleSerial = 0, kScheduleRound = 1 };
@@ -208,6 +208,7 @@ public:
         int rc = icp(Mat3f::identity(), Vec3f{0.f, 0.f, 0.f}, 0.05f, sse, R, t);  // :12-13
         if (rc) return rc;
         set_best_sse_only(sse);  // :14 — only the error is adopted
+        stats_.initial_icp_sse = sse;
         const auto t_bnb = clock::now();
         rc = schedule_ == kScheduleSerial ? bnb_so3_serial() : bnb_so3_round();
         stats_.seconds_bnb = seconds_since(t_bnb);

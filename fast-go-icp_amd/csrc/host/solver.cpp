@@ -147,7 +147,7 @@ int fgoicp_solver_stats(const fgoicp_solver* s, fgoicp_run_stats* out) {
     const DriverStats& d = s->driver->stats();
     out->trans_cubes = d.trans_cubes; out->bounds_calls = d.bounds_calls; out->rot_cubes = d.rot_cubes;
     out->icp_runs = d.icp_runs; out->icp_iters = d.icp_iters; out->inner_bnb = d.inner_bnb; out->rounds = d.rounds;
-    out->seconds_total = d.seconds_total; out->seconds_bnb = d.seconds_bnb; out->seconds_icp = d.seconds_icp;
+    out->seconds_total = d.seconds_total; out->seconds_bnb = d.seconds_bnb; out->seconds_icp = d.seconds_icp; out->initial_icp_sse = d.initial_icp_sse;
     return FGOICP_OK;
 }
 

@@ -47,7 +47,8 @@ typedef struct fgoicp_ctx fgoicp_ctx;
 enum {
     FGOICP_FLAG_NO_WEIGHT_QUANT = 1u << 0, /* trilinear weights in full fp32 instead of CUDA's 1.8 fixed point */
     FGOICP_FLAG_NO_MORTON       = 1u << 1, /* keep the source cloud in caller order on the device             */
-    FGOICP_FLAG_PROFILE         = 1u << 2  /* bracket every bounds kernel with HIP events (fgoicp_ctx_profile) */
+    FGOICP_FLAG_PROFILE         = 1u << 2, /* bracket every bounds kernel with HIP events (fgoicp_ctx_profile) */
+    FGOICP_FLAG_BRUTE_FORCE_NN  = 1u << 3  /* O(n*m) brute-force kernels for LUT build / SSE / ICP instead of the exact BVH */
 };
 
 /*
@@ -152,6 +153,7 @@ typedef struct fgoicp_run_stats {
     double   seconds_total; /* wall-clock of run()                                              */
     double   seconds_bnb;   /* of which: outer BnB phase                                        */
     double   seconds_icp;   /* of which: inside ICP                                             */
+    double   initial_icp_sse; /* error of the initial ICP from identity (fgoicp.cpp:12-17)        */
 } fgoicp_run_stats;
 
 /* Replaces FastGoICP::FastGoICP(pct, pcs, lut_resolution, mse_threshold) (fgoicp.hpp:13-25):

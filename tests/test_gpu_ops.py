@@ -180,3 +180,39 @@ def test_icp_zero_iterations(regs, fg):
 def test_invalid_arguments_fail_loudly(fg, gpu_required):
     with pytest.raises(fg.FgoicpError):
         fg.Registration(np.zeros((4, 3), np.float32), np.zeros((4, 3), np.float32), np.array([[0, 1]] * 3, np.float32), -1.0)
+
+
+# ---- exact BVH nearest neighbour vs the brute-force kernels (both HIP), at sizes the CPU oracle cannot reach ----
+@pytest.mark.parametrize("name,res", [("small", 0.02), ("bunny", 0.02)])
+def test_bvh_nn_equals_brute_force_at_scale(fg, gpu_required, name, res):
+    tgt, src, _, _ = fg.synth.workload(name, angle_deg=60.0)
+    pct, pcs, *_, bounds = fg.synth.preprocess(tgt, src)
+    tree = fg.Registration(pct, pcs, bounds, res)
+    brute = fg.Registration(pct, pcs, bounds, res, flags=fg.FLAG_BRUTE_FORCE_NN)
+    # LUT nodes: bit-exact
+    a, b = tree.lut_read(), brute.lut_read()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    rng = np.random.default_rng(0)
+    for k, shift in enumerate([0.0, 0.3, 3.0]):  # near, off, and far outside the target's box
+        R = fg.synth.random_rotation(rng, 90.0).astype(np.float32)
+        t = (rng.uniform(-0.1, 0.1, 3) + shift).astype(np.float32)
+        # exact SSE: same per-point minima, same summation order -> identical bits
+        assert tree.compute_sse_error(R, t).view(np.uint32) == brute.compute_sse_error(R, t).view(np.uint32)
+        w = (pcs @ R.T + t).astype(np.float32)
+        Ra, ta, cena, ABta, idxa = tree.procrustes(w)
+        Rb, tb, cenb, ABtb, idxb = brute.procrustes(w)
+        assert np.array_equal(idxa, idxb)
+        assert np.array_equal(Ra, Rb) and np.array_equal(ta, tb)
+    tree.close(); brute.close()
+
+
+def test_brute_force_flag_matches_oracle(fg, oracle, tiny_case, gpu_required):
+    c = tiny_case
+    hip = fg.Registration(c["pct"], c["pcs"], c["bounds"], c["res"], flags=fg.FLAG_BRUTE_FORCE_NN)
+    orc = oracle.Registration(c["pct"], c["pcs"], c["bounds"], c["res"])
+    assert np.array_equal(hip.lut_read().view(np.uint32), orc.lut_get().view(np.uint32))
+    w = (c["pcs"] + np.float32(0.03)).astype(np.float32)
+    *_, idx = hip.procrustes(w)
+    *_, idxo = orc.procrustes(w)
+    assert np.array_equal(idx, idxo)
+    hip.close()
