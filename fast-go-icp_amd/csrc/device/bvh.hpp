@@ -1,5 +1,6 @@
 // Exact nearest-neighbour search over a point set: an implicit, heap-ordered bounding-volume tree
-// over the Morton-sorted points (leaves of 8 points), traversed without a stack.
+// over the Morton-sorted points (leaves of kBvhLeaf points).  The device code (kernels.hip, box_scan)
+// uses two of its levels — the leaves and the "super-leaves" 5 levels up — as a flat two-level scan.
 //
 // It replaces the reference's brute-force loops (fgoicp/registration.cu:162-174, :258-278,
 // fgoicp/icp3d.cu:11-28) with a search that returns BIT-IDENTICAL results: every candidate distance
@@ -15,10 +16,10 @@
 
 namespace fgoicp {
 
-constexpr int kBvhLeaf = 8;
+constexpr int kBvhLeaf = 32;  // big leaves: leaf points are throughput work, tree levels are latency
 
 // Device view.  Node i (heap order: children 2i+1, 2i+2) has box[2i] = {lo.xyz, -}, box[2i+1] = {hi.xyz, -}.
-// Leaves are the last level: leaf l = node first_leaf + l holds pts[8l .. 8l+8) = {x, y, z, bits(original index)};
+// Leaves are the last level: leaf l = node first_leaf + l holds pts[kBvhLeaf*l .. kBvhLeaf*(l+1)) = {x, y, z, bits(original index)};
 // padding points sit at +FLT_MAX (distance +inf), empty leaves have an inverted box (distance +inf).
 struct BvhView {
     const float4* box;

@@ -112,7 +112,7 @@ int ctx_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out) {
         launch_fill_u32(c->d_min_bits, 0x501502F9u /* bits(1e10f) */, c->ns, c->stream);
         launch_nn_min(c->d_src, ns, c->d_tgt, (int)c->nt, R9, t3, 1, c->d_min_bits, c->stream);
     } else {
-        launch_nn_bvh_min(c->d_src, ns, c->bvh_tgt.view(), c->d_tgt, (int)c->nt, c->d_lut, c->geom, R9, t3, 1, c->d_min_bits, c->d_hard, c->stream);
+        launch_nn_scan(c->d_src, ns, c->bvh_tgt.view(), c->d_lut, c->geom, R9, t3, 1, 0, c->d_min_bits, c->stream);
     }
     const int nb = reduce_blocks_for(ns);
     launch_sum_f32_as_f64(c->d_min_bits, ns, c->d_bp, nb, c->stream);
@@ -134,7 +134,7 @@ int ctx_procrustes_device(fgoicp_ctx* c, Mat3f* R_out, Vec3f* t_out, float* cent
         launch_nn_tie_threshold(c->d_min_bits, ns, c->d_thr_bits, c->stream);
         launch_nn_first_index(c->d_work, ns, c->d_tgt, nt, c->d_thr_bits, c->d_first_idx, c->stream);
     } else {
-        launch_nn_bvh_corr(c->d_work, ns, c->bvh_tgt.view(), c->d_tgt, nt, c->d_lut, c->geom, c->d_first_idx, c->d_hard, c->stream);
+        launch_nn_scan(c->d_work, ns, c->bvh_tgt.view(), c->d_lut, c->geom, nullptr, nullptr, 0, 1, c->d_first_idx, c->stream);
     }
     const int nb = reduce_blocks_for(ns);
     launch_icp_sums(c->d_work, c->d_tgt, c->d_first_idx, ns, nt, c->d_bp, nb, c->stream);
@@ -296,7 +296,7 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
             float* scratch = nullptr;
             if (e3 == hipSuccess) e3 = hipMalloc(&scratch, total * sizeof(float));
             if (e3 == hipSuccess) {
-                launch_lut_build_bvh(shifted.view(), g, scratch, c->d_lut, c->stream);
+                launch_lut_build_scan(shifted.view(), g, scratch, c->d_lut, c->stream);
                 e3 = hipGetLastError();
                 if (e3 == hipSuccess) e3 = hipStreamSynchronize(c->stream);
             }
@@ -326,7 +326,6 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
     CHK(hipMalloc(&c->d_min_bits, sizeof(uint32_t) * ns));
     CHK(hipMalloc(&c->d_thr_bits, sizeof(uint32_t) * ns));
     CHK(hipMalloc(&c->d_first_idx, sizeof(uint32_t) * ns));
-    CHK(hipMalloc(&c->d_hard, sizeof(uint32_t) * (ns + 1)));
     CHK(hipMalloc(&c->d_bp, sizeof(double) * 1024 * 16));
     CHK(hipMalloc(&c->d_bp2, sizeof(double) * 1024 * 16));
     CHK(hipMalloc(&c->d_cen, sizeof(float) * 8));
@@ -351,7 +350,7 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
     for (auto& e : c->ev_start) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_stop) if (e) (void)hipEventDestroy(e);
     (void)hipFree(c->d_src); (void)hipFree(c->d_work); (void)hipFree(c->d_tgt); (void)hipFree(c->d_lut);
-    (void)hipFree(c->d_partials); (void)hipFree(c->d_min_bits); (void)hipFree(c->d_thr_bits); (void)hipFree(c->d_first_idx); (void)hipFree(c->d_hard);
+    (void)hipFree(c->d_partials); (void)hipFree(c->d_min_bits); (void)hipFree(c->d_thr_bits); (void)hipFree(c->d_first_idx);
     (void)hipFree(c->d_bp); (void)hipFree(c->d_bp2); (void)hipFree(c->d_cen);
     if (c->h_cen) (void)hipHostFree(c->h_cen);
     bvh_free(&c->bvh_tgt);

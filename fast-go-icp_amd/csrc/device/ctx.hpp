@@ -35,7 +35,6 @@ struct fgoicp_ctx {
 
     // exact-NN / ICP scratch
     uint32_t *d_min_bits = nullptr, *d_thr_bits = nullptr, *d_first_idx = nullptr;
-    uint32_t* d_hard = nullptr;  // [0] = count, [1..] = queries the budgeted tree search deferred to the wave-per-query fallback
     double* d_bp = nullptr;      // per-block partial sums
     double *h_sums = nullptr, *hd_sums = nullptr;  // pinned result of the last reduction (<= 16 doubles)
     double* d_bp2 = nullptr;     // second partial buffer (covariance), so both reductions of a Procrustes step queue back to back

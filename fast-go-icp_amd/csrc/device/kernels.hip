@@ -376,12 +376,21 @@ __global__ __launch_bounds__(kBlock) void nn_first_index_kernel(const float4* __
 }
 
 // ---------------------------------------------------------------------------------------------
-// Exact nearest neighbour through the implicit BVH (bvh.hpp): same candidate arithmetic as the brute
-// force above, conservative pruning, no stack (a per-level "sibling pending" bit mask + heap-index
-// arithmetic find the next node), one thread per query.  Queries arrive in Morton order, so the
-// lanes of a wave walk almost the same path.
+// Exact nearest neighbour by a two-level box scan over the Morton-sorted targets (bvh.hpp):
+// "leaves" of kBvhLeaf = 32 consecutive points and "super-leaves" of 32 leaves (1024 points), each
+// with its bounding box (two levels of the implicit tree).  Every query walks the SAME sequence
+//     for each super-leaf:  box test  ->  for each of its leaves:  box test  ->  its 32 points
+// so control flow is wave-uniform (a branch is taken when ANY lane needs it) and every box and point
+// load has a wave-uniform address (one broadcast transaction, scalar-cacheable) — no dependent-load
+// chains, no stack, no divergence beyond the exec mask.  The queries of a wave are Morton neighbours
+// and each starts with a provable upper bound of its nearest distance from the distance LUT
+// (lut_upper_bound_d2), so a wave touches a handful of leaves; the worst case (queries equidistant
+// from the whole target) degrades to the cost of the brute-force sweep, never beyond.
+// Candidate distances use the brute force's fp32 expression and min is order-independent: results
+// are bit-identical to kernComputeClosestError / kernFindNearestNeighbor / buildLUTKernel.
 // ---------------------------------------------------------------------------------------------
 constexpr float kBoxShrink = 0.999999f;  // see bvh.hpp: covers fp32 rounding of box and point distances
+constexpr int kSuperShift = 5;           // 32 leaves per super-leaf
 
 __device__ __forceinline__ float box_d2(const float4 lo, const float4 hi, float qx, float qy, float qz) {
     const float dx = fmaxf(fmaxf(lo.x - qx, qx - hi.x), 0.0f);
@@ -390,50 +399,81 @@ __device__ __forceinline__ float box_d2(const float4 lo, const float4 hi, float 
     return fma_(dz, dz, fma_(dy, dy, dx * dx));
 }
 
-// Visits every leaf point whose subtree is not provably farther than bound(); bound() may shrink
-// while the traversal runs (pass 1) or stay fixed (pass 2).  Returns false if more than `budget`
-// nodes were touched: queries near the medial axis of the target are (almost) equidistant from
-// large parts of it, nothing can be pruned for them, and one such lane would hold up its whole wave —
-// the caller then hands the query to the wave-per-query exact fallback (nn_hard_*_kernel).
-template <class LeafFn, class BoundFn>
-__device__ __forceinline__ bool bvh_traverse(const BvhView t, float qx, float qy, float qz, int budget, LeafFn leaf, BoundFn bound) {
-    unsigned pending = 0;  // bit d set: the sibling of the current path's node at depth d is still to be visited
-    int node = 0, depth = 0;
-    for (;;) {
-        bool pop = false;
-        if (--budget < 0) return false;
-        if (depth == t.depth) {
-            const float4* p = t.pts + (size_t)(node - t.first_leaf) * kBvhLeaf;
+__device__ __forceinline__ float wave_min_f(float v) {
 #pragma unroll
-            for (int k = 0; k < kBvhLeaf; ++k) leaf(p[k]);
-            pop = true;
-        } else {
-            const int l = 2 * node + 1;
-            const float dl = box_d2(t.box[2 * l], t.box[2 * l + 1], qx, qy, qz);
-            const float dr = box_d2(t.box[2 * l + 2], t.box[2 * l + 3], qx, qy, qz);
-            const float b = bound();
-            const bool vl = !(dl * kBoxShrink > b), vr = !(dr * kBoxShrink > b);
-            if (vl && vr) {
-                node = dl <= dr ? l : l + 1;  // nearer child first, the other one stays pending
-                ++depth;
-                pending |= 1u << depth;
-            } else if (vl || vr) {
-                node = vl ? l : l + 1;
-                ++depth;
-            } else {
-                pop = true;
-            }
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float bcast(float v, int lane) {  // lane is wave-uniform -> v_readlane_b32
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+// squared distance between a box and the wave's query region [wl, wh] — a lower bound of box_d2 for every lane
+__device__ __forceinline__ float boxbox_d2(const float4 lo, const float4 hi, const float (&wl)[3], const float (&wh)[3]) {
+    const float dx = fmaxf(fmaxf(lo.x - wh[0], wl[0] - hi.x), 0.0f);
+    const float dy = fmaxf(fmaxf(lo.y - wh[1], wl[1] - hi.y), 0.0f);
+    const float dz = fmaxf(fmaxf(lo.z - wh[2], wl[2] - hi.z), 0.0f);
+    return fma_(dz, dz, fma_(dy, dy, dx * dx));
+}
+
+// Calls leaf(p) for every target point p whose leaf box is not provably farther than bound() (which
+// may shrink as points are consumed).  `active` = false lanes only tag along.  Wave-cooperative:
+//   1. lanes test 64 super-leaf boxes at a time against the wave's query region inflated by the
+//      largest bound in the wave (one coalesced load per 64 boxes) -> ballot of candidate super-leaves;
+//   2. per candidate, lanes 0..31 test its 32 leaf boxes the same way -> ballot of candidate leaves;
+//   3. per candidate leaf, its box is broadcast from the lane that loaded it (readlane), every query
+//      tests it against its OWN bound, and if any query needs it lanes 0..31 load its 32 points once
+//      and broadcast them one by one.
+// Steps 1-2 are supersets of what each query needs (box-to-region distance <= box-to-query distance,
+// wave radius >= own bound), step 3 applies the exact per-query rule, so no needed point is skipped.
+template <class LeafFn, class BoundFn>
+__device__ __forceinline__ void box_scan(const BvhView t, float qx, float qy, float qz, bool active, LeafFn leaf, BoundFn bound) {
+    const int lane = threadIdx.x & 63;
+    const float big = 3.0e38f;
+    const float wl[3] = {wave_min_f(active ? qx : big), wave_min_f(active ? qy : big), wave_min_f(active ? qz : big)};
+    const float wh[3] = {wave_max_f(active ? qx : -big), wave_max_f(active ? qy : -big), wave_max_f(active ? qz : -big)};
+    float r2 = wave_max_f(active ? bound() : 0.0f);
+    const int sdepth = t.depth > kSuperShift ? t.depth - kSuperShift : 0;
+    const int nsuper = 1 << sdepth;
+    const int lps = 1 << (t.depth - sdepth);  // leaves per super-leaf (<= 32)
+    const int first_super = nsuper - 1;
+    for (int sb = 0; sb < nsuper; sb += 64) {
+        bool sc = false;
+        if (sb + lane < nsuper) {
+            const int sn = first_super + sb + lane;
+            sc = !(boxbox_d2(t.box[2 * sn], t.box[2 * sn + 1], wl, wh) * kBoxShrink > r2);
         }
-        if (pop) {
-            for (;;) {
-                if (!pending) return true;
-                const int lvl = 31 - __clz(pending);
-                pending &= ~(1u << lvl);
-                const int anc = ((node + 1) >> (depth - lvl)) - 1;  // ancestor of the current node at depth lvl
-                node = ((anc + 1) ^ 1) - 1;                          // its sibling
-                depth = lvl;
-                if (!(box_d2(t.box[2 * node], t.box[2 * node + 1], qx, qy, qz) * kBoxShrink > bound())) break;
-                if (--budget < 0) return false;
+        unsigned long long smask = __ballot(sc);
+        while (smask) {
+            const int s = sb + __ffsll((long long)smask) - 1;
+            smask &= smask - 1;
+            float4 llo = make_float4(big, big, big, 0.f), lhi = make_float4(-big, -big, -big, 0.f);
+            bool lc = false;
+            if (lane < lps) {
+                const int ln = t.first_leaf + s * lps + lane;
+                llo = t.box[2 * ln];
+                lhi = t.box[2 * ln + 1];
+                lc = !(boxbox_d2(llo, lhi, wl, wh) * kBoxShrink > r2);
+            }
+            unsigned long long lmask = __ballot(lc);
+            while (lmask) {
+                const int l = __ffsll((long long)lmask) - 1;
+                lmask &= lmask - 1;
+                const float4 lo = make_float4(bcast(llo.x, l), bcast(llo.y, l), bcast(llo.z, l), 0.f);
+                const float4 hi = make_float4(bcast(lhi.x, l), bcast(lhi.y, l), bcast(lhi.z, l), 0.f);
+                const bool pl = active && !(box_d2(lo, hi, qx, qy, qz) * kBoxShrink > bound());
+                if (!__any(pl)) continue;
+                const float4 pp = t.pts[(size_t)(s * lps + l) * kBvhLeaf + (lane & (kBvhLeaf - 1))];
+#pragma unroll
+                for (int k = 0; k < kBvhLeaf; ++k) {
+                    const float4 c = make_float4(bcast(pp.x, k), bcast(pp.y, k), bcast(pp.z, k), bcast(pp.w, k));
+                    if (pl) leaf(c);
+                }
+                r2 = wave_max_f(active ? bound() : 0.0f);  // the wave radius only shrinks
             }
         }
     }
@@ -441,27 +481,27 @@ __device__ __forceinline__ bool bvh_traverse(const BvhView t, float qx, float qy
 
 // Minimum squared distance.  `ub` is any value >= the true minimum (or +huge): it only seeds the
 // pruning bound; the result is the minimum over VISITED points, and the true nearest point is never
-// pruned while the bound stays >= its distance.  If fp32 rounding made the seed a hair too small and
-// nothing was found, the search is repeated unseeded — the result is exact either way.
-// ok = false: the step budget ran out, the returned value is meaningless.
-__device__ __forceinline__ float bvh_min_d2(const BvhView t, float qx, float qy, float qz, float ub, float init, int budget, bool& ok) {
+// pruned while the bound stays >= its distance.  If fp32 rounding made a seed a hair too small and
+// some lane found nothing, the wave repeats the scan unseeded — the result is exact either way.
+__device__ __forceinline__ float scan_min_d2(const BvhView t, float qx, float qy, float qz, float ub, float init, bool active) {
     float best = ub < init ? ub : init;
     float found = init;
-    ok = bvh_traverse(t, qx, qy, qz, budget,
-                      [&](const float4 p) {
-                          const float d = dist_sq(qx, qy, qz, p.x, p.y, p.z);
-                          found = d < found ? d : found;
-                          best = d < best ? d : best;
-                      },
-                      [&]() { return best; });
-    if (ok && found > best) {  // seed below every visited distance: cannot happen with a valid seed; stay exact anyway
-        found = init;
-        ok = bvh_traverse(t, qx, qy, qz, budget,
-                          [&](const float4 p) {
-                              const float d = dist_sq(qx, qy, qz, p.x, p.y, p.z);
-                              found = d < found ? d : found;
-                          },
-                          [&]() { return found; });
+    box_scan(t, qx, qy, qz, active,
+             [&](const float4 p) {
+                 const float d = dist_sq(qx, qy, qz, p.x, p.y, p.z);
+                 found = d < found ? d : found;
+                 best = d < best ? d : best;
+             },
+             [&]() { return best; });
+    const bool redo = active && found > best;  // cannot happen with a valid seed
+    if (__any(redo)) {
+        if (redo) found = init;
+        box_scan(t, qx, qy, qz, redo,
+                 [&](const float4 p) {
+                     const float d = dist_sq(qx, qy, qz, p.x, p.y, p.z);
+                     found = d < found ? d : found;
+                 },
+                 [&]() { return found; });
     }
     return found;
 }
@@ -482,9 +522,6 @@ __device__ __forceinline__ float lut_upper_bound_d2(const float* __restrict__ lu
     return u * u * 1.0001f + 1e-6f;
 }
 
-constexpr int kNnBudget = 192;          // nodes a query may touch before it is declared hard
-constexpr int kLutBudget = 1 << 30;     // LUT nodes are never deferred (one-off build, no fallback list)
-
 __device__ __forceinline__ float tie_threshold(float best) {  // see nn_tie_threshold_kernel
     uint32_t b = __float_as_uint(best);
     const float s = sqrtf(best);
@@ -495,138 +532,73 @@ __device__ __forceinline__ float tie_threshold(float best) {  // see nn_tie_thre
     return __uint_as_float(b);
 }
 
-__device__ __forceinline__ void load_query(const float4* __restrict__ pts, int i, const Rt& rt, int apply, float& qx, float& qy, float& qz) {
-    const float4 p = pts[i];
-    qx = p.x; qy = p.y; qz = p.z;
+//   want_index = 0: out[i] = bits(min_j |q_i - tgt_j|^2)                       (registration.cu:162-174)
+//   want_index = 1: out[i] = lowest j inside the sqrt-tie set of the minimum      (icp3d.cu:11-28)
+__global__ __launch_bounds__(kBlock) void nn_scan_kernel(const float4* __restrict__ pts, int n, BvhView t, const float* __restrict__ lut,
+                                                         LutGeom g, Rt rt, int apply, int want_index, uint32_t* __restrict__ out) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const bool active = i < n;
+    const float4 p = pts[active ? i : n - 1];
+    float qx = p.x, qy = p.y, qz = p.z;
     if (apply) {
         rotate(rt.R, p.x, p.y, p.z, qx, qy, qz);
         qx += rt.t[0]; qy += rt.t[1]; qz += rt.t[2];
     }
-}
-
-// hard[0] = number of deferred queries, hard[1 + k] = their indices (zeroed by the caller per call)
-__global__ __launch_bounds__(kBlock) void nn_bvh_min_kernel(const float4* __restrict__ pts, int n, BvhView t, const float* __restrict__ lut,
-                                                            LutGeom g, Rt rt, int apply, uint32_t* __restrict__ min_bits,
-                                                            uint32_t* __restrict__ hard) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    float qx, qy, qz;
-    load_query(pts, i, rt, apply, qx, qy, qz);
-    bool ok;
-    const float best = bvh_min_d2(t, qx, qy, qz, lut_upper_bound_d2(lut, g, qx, qy, qz), kInf, kNnBudget, ok);
-    if (ok) min_bits[i] = __float_as_uint(best);
-    else hard[1 + atomicAdd(&hard[0], 1u)] = (uint32_t)i;
-}
-
-// kernFindNearestNeighbor (icp3d.cu:11-28) in one kernel: minimum, sqrt-tie threshold, lowest index.
-__global__ __launch_bounds__(kBlock) void nn_bvh_corr_kernel(const float4* __restrict__ pts, int n, BvhView t, const float* __restrict__ lut,
-                                                             LutGeom g, uint32_t* __restrict__ first_idx, uint32_t* __restrict__ hard) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const float4 q = pts[i];
-    bool ok;
-    const float best = bvh_min_d2(t, q.x, q.y, q.z, lut_upper_bound_d2(lut, g, q.x, q.y, q.z), kInf, kNnBudget, ok);
-    uint32_t idx = 0x7fffffffu;
-    if (ok) {
-        const float thr = tie_threshold(best);
-        ok = bvh_traverse(t, q.x, q.y, q.z, kNnBudget,
-                          [&](const float4 p) {
-                              const float d = dist_sq(q.x, q.y, q.z, p.x, p.y, p.z);
-                              const uint32_t cand = d <= thr ? __float_as_uint(p.w) : 0x7fffffffu;
-                              idx = min(idx, cand);
-                          },
-                          [&]() { return thr; });
-    }
-    if (ok) first_idx[i] = idx;
-    else hard[1 + atomicAdd(&hard[0], 1u)] = (uint32_t)i;
-}
-
-// Exact fallback for the deferred queries: ONE WAVE PER QUERY sweeps all targets (coalesced 16-byte
-// loads, lane-strided), wave-reduces the minimum (and for correspondences the lowest index inside the
-// sqrt-tie threshold).  Same candidate arithmetic, min is order-independent -> same bits as any other path.
-__device__ __forceinline__ float wave_min_f(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_min_u(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, off, 64));
-    return v;
-}
-
-__global__ __launch_bounds__(kBlock) void nn_hard_kernel(const float4* __restrict__ pts, const float4* __restrict__ tgt, int nt, Rt rt, int apply,
-                                                         int want_index, const uint32_t* __restrict__ hard, uint32_t* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * kBlock) >> 6;
-    const uint32_t count = hard[0];
-    for (uint32_t h = wave; h < count; h += nwaves) {
-        const int i = (int)hard[1 + h];
-        float qx, qy, qz;
-        load_query(pts, i, rt, apply, qx, qy, qz);
-        float best = kInf;
-        for (int j = lane; j < nt; j += 64) {
-            const float4 p = tgt[j];
-            const float d = dist_sq(qx, qy, qz, p.x, p.y, p.z);
-            best = d < best ? d : best;
-        }
-        best = wave_min_f(best);
-        if (!want_index) {
-            if (lane == 0) out[i] = __float_as_uint(best);
-            continue;
-        }
+    const float best = scan_min_d2(t, qx, qy, qz, lut_upper_bound_d2(lut, g, qx, qy, qz), kInf, active);
+    uint32_t result = __float_as_uint(best);
+    if (want_index) {
         const float thr = tie_threshold(best);
         uint32_t idx = 0x7fffffffu;
-        for (int j = lane; j < nt; j += 64) {
-            const float4 p = tgt[j];
-            const float d = dist_sq(qx, qy, qz, p.x, p.y, p.z);
-            idx = min(idx, d <= thr ? (uint32_t)j : 0x7fffffffu);
-        }
-        idx = wave_min_u(idx);
-        if (lane == 0) out[i] = idx;
+        box_scan(t, qx, qy, qz, active,
+                 [&](const float4 c) {
+                     const float d = dist_sq(qx, qy, qz, c.x, c.y, c.z);
+                     idx = min(idx, d <= thr ? __float_as_uint(c.w) : 0x7fffffffu);
+                 },
+                 [&]() { return thr; });
+        result = idx;
     }
+    if (active) out[i] = result;
 }
 
-// buildLUTKernel (registration.cu:258-278) through the BVH of the shifted targets, coarse to fine:
+// buildLUTKernel (registration.cu:258-278) through the box scan of the shifted targets, coarse to fine:
 // pass 0 evaluates the nodes whose (clamped) coordinates are multiples of kLutCoarse unseeded, pass 1
 // evaluates every node seeded with the triangle-inequality bound from its coarse neighbour.  Both
-// passes return exact minima (bvh_min_d2), pass 1 recomputes the coarse nodes identically.
+// passes return exact minima, pass 1 recomputes the coarse nodes identically.  Threads are mapped to
+// 4x4x4 node bricks so that a wave's 64 queries are spatially compact.
 constexpr int kLutCoarse = 4;
 
-__device__ __forceinline__ void lut_node_coords(const LutGeom& g, size_t n, int& cx, int& cy, int& cz) {
-    const int x = (int)(n % g.px);
-    const size_t r = n / g.px;
-    const int y = (int)(r % g.py);
-    const int z = (int)(r / g.py);
-    cx = min(max(x - 1, 0), g.dx - 1);  // padded index -> clamped reference node index
-    cy = min(max(y - 1, 0), g.dy - 1);
-    cz = min(max(z - 1, 0), g.dz - 1);
-}
-
-__global__ __launch_bounds__(kBlock) void lut_build_bvh_coarse_kernel(BvhView t, LutGeom g, float* __restrict__ lut) {
+__global__ __launch_bounds__(kBlock) void lut_build_scan_coarse_kernel(BvhView t, LutGeom g, float* __restrict__ lut) {
     const int ncx = (g.dx + kLutCoarse - 1) / kLutCoarse, ncy = (g.dy + kLutCoarse - 1) / kLutCoarse, ncz = (g.dz + kLutCoarse - 1) / kLutCoarse;
-    const size_t total = (size_t)ncx * ncy * ncz;
-    const size_t n = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (n >= total) return;
-    const int ix = (int)(n % ncx) * kLutCoarse, iy = (int)((n / ncx) % ncy) * kLutCoarse, iz = (int)(n / ((size_t)ncx * ncy)) * kLutCoarse;
+    // 4x4x4 bricks of coarse nodes per wave
+    const int bx = (ncx + 3) / 4, by = (ncy + 3) / 4, bz = (ncz + 3) / 4;
+    const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= (size_t)bx * by * bz) return;
+    const int wx = (int)(wave % bx), wy = (int)((wave / bx) % by), wz = (int)(wave / ((size_t)bx * by));
+    const int jx = wx * 4 + (lane & 3), jy = wy * 4 + ((lane >> 2) & 3), jz = wz * 4 + (lane >> 4);
+    const bool active = jx < ncx && jy < ncy && jz < ncz;
+    const int ix = min(jx, ncx - 1) * kLutCoarse, iy = min(jy, ncy - 1) * kLutCoarse, iz = min(jz, ncz - 1) * kLutCoarse;
     const float cx = (float)ix * g.resolution, cy = (float)iy * g.resolution, cz = (float)iz * g.resolution;  // :265
-    lut[((size_t)(iz + 1) * g.py + (iy + 1)) * (size_t)g.px + (ix + 1)] = [&] { bool ok; return bvh_min_d2(t, cx, cy, cz, 3.402823466e+38f, 3.402823466e+38f, kLutBudget, ok); }();
+    const float v = scan_min_d2(t, cx, cy, cz, 3.402823466e+38f, 3.402823466e+38f, active);
+    if (active) lut[((size_t)(iz + 1) * g.py + (iy + 1)) * (size_t)g.px + (ix + 1)] = v;
 }
 
-__global__ __launch_bounds__(kBlock) void lut_build_bvh_kernel(BvhView t, LutGeom g, const float* __restrict__ coarse, float* __restrict__ lut) {
-    const size_t total = (size_t)g.px * g.py * g.pz;
-    const size_t n = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (n >= total) return;
-    int ix, iy, iz;
-    lut_node_coords(g, n, ix, iy, iz);
+__global__ __launch_bounds__(kBlock) void lut_build_scan_kernel(BvhView t, LutGeom g, const float* __restrict__ coarse, float* __restrict__ lut) {
+    const int bx = (g.px + 3) / 4, by = (g.py + 3) / 4, bz = (g.pz + 3) / 4;
+    const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= (size_t)bx * by * bz) return;
+    const int wx = (int)(wave % bx), wy = (int)((wave / bx) % by), wz = (int)(wave / ((size_t)bx * by));
+    const int x = wx * 4 + (lane & 3), y = wy * 4 + ((lane >> 2) & 3), z = wz * 4 + (lane >> 4);  // padded node index
+    const bool active = x < g.px && y < g.py && z < g.pz;
+    const int ix = min(max(x - 1, 0), g.dx - 1), iy = min(max(y - 1, 0), g.dy - 1), iz = min(max(z - 1, 0), g.dz - 1);
     const float cx = (float)ix * g.resolution, cy = (float)iy * g.resolution, cz = (float)iz * g.resolution;  // :265
     const int kx = ix / kLutCoarse * kLutCoarse, ky = iy / kLutCoarse * kLutCoarse, kz = iz / kLutCoarse * kLutCoarse;
     const float T = coarse[((size_t)(kz + 1) * g.py + (ky + 1)) * (size_t)g.px + (kx + 1)];
     const float ddx = (float)(ix - kx) * g.resolution, ddy = (float)(iy - ky) * g.resolution, ddz = (float)(iz - kz) * g.resolution;
     const float u = sqrtf(T) + sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
-    bool ok;
-    lut[n] = bvh_min_d2(t, cx, cy, cz, u * u * 1.0001f + 1e-6f, 3.402823466e+38f, kLutBudget, ok);  // FLT_MAX, :266
+    const float v = scan_min_d2(t, cx, cy, cz, u * u * 1.0001f + 1e-6f, 3.402823466e+38f, active);  // FLT_MAX, :266
+    if (active) lut[((size_t)z * g.py + y) * (size_t)g.px + x] = v;
 }
 
 __global__ __launch_bounds__(kBlock) void fill_u32_kernel(uint32_t* p, uint32_t v, size_t n) {
@@ -800,29 +772,19 @@ void launch_nn_first_index(const float4* pts, int n, const float4* tgt, int nt, 
     hipLaunchKernelGGL(nn_first_index_kernel, dim3(qtiles, nsl), dim3(kBlock), 0, s, pts, n, tgt, nt, slice_len, thr_bits, first_idx);
 }
 
-// `hard` = 1 + n uint32 on the device; hard[0] is zeroed here, the deferred queries are finished by
-// the wave-per-query fallback queued right behind (no host round trip).
-void launch_nn_bvh_min(const float4* pts, int n, const BvhView& t, const float4* tgt, int nt, const float* lut, const LutGeom& g,
-                       const float* R9, const float* t3, int apply, uint32_t* min_bits, uint32_t* hard, hipStream_t s) {
-    (void)hipMemsetAsync(hard, 0, sizeof(uint32_t), s);
-    const Rt rt = make_rt(R9, t3);
-    hipLaunchKernelGGL(nn_bvh_min_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, n, t, lut, g, rt, apply, min_bits, hard);
-    hipLaunchKernelGGL(nn_hard_kernel, dim3(1024), dim3(kBlock), 0, s, pts, tgt, nt, rt, apply, 0, hard, min_bits);
-}
-
-void launch_nn_bvh_corr(const float4* pts, int n, const BvhView& t, const float4* tgt, int nt, const float* lut, const LutGeom& g,
-                        uint32_t* first_idx, uint32_t* hard, hipStream_t s) {
-    (void)hipMemsetAsync(hard, 0, sizeof(uint32_t), s);
-    hipLaunchKernelGGL(nn_bvh_corr_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, n, t, lut, g, first_idx, hard);
-    hipLaunchKernelGGL(nn_hard_kernel, dim3(1024), dim3(kBlock), 0, s, pts, tgt, nt, make_rt(nullptr, nullptr), 0, 1, hard, first_idx);
+void launch_nn_scan(const float4* pts, int n, const BvhView& t, const float* lut, const LutGeom& g, const float* R9, const float* t3, int apply,
+                    int want_index, uint32_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(nn_scan_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, want_index, out);
 }
 
 // `scratch` must hold as many floats as the padded LUT; it receives the coarse pass.
-void launch_lut_build_bvh(const BvhView& t, const LutGeom& g, float* scratch, float* lut_padded, hipStream_t s) {
-    const size_t ncoarse = (size_t)((g.dx + kLutCoarse - 1) / kLutCoarse) * ((g.dy + kLutCoarse - 1) / kLutCoarse) * ((g.dz + kLutCoarse - 1) / kLutCoarse);
-    hipLaunchKernelGGL(lut_build_bvh_coarse_kernel, dim3((unsigned)((ncoarse + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, t, g, scratch);
-    const size_t total = (size_t)g.px * g.py * g.pz;
-    hipLaunchKernelGGL(lut_build_bvh_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, t, g, scratch, lut_padded);
+void launch_lut_build_scan(const BvhView& t, const LutGeom& g, float* scratch, float* lut_padded, hipStream_t s) {
+    auto cdiv = [](size_t a, size_t b) { return (a + b - 1) / b; };
+    const size_t ncx = cdiv(g.dx, kLutCoarse), ncy = cdiv(g.dy, kLutCoarse), ncz = cdiv(g.dz, kLutCoarse);
+    const size_t cwaves = cdiv(ncx, 4) * cdiv(ncy, 4) * cdiv(ncz, 4);
+    hipLaunchKernelGGL(lut_build_scan_coarse_kernel, dim3((unsigned)cdiv(cwaves, kBlock / 64)), dim3(kBlock), 0, s, t, g, scratch);
+    const size_t waves = cdiv(g.px, 4) * cdiv(g.py, 4) * cdiv(g.pz, 4);
+    hipLaunchKernelGGL(lut_build_scan_kernel, dim3((unsigned)cdiv(waves, kBlock / 64)), dim3(kBlock), 0, s, t, g, scratch, lut_padded);
 }
 
 int reduce_blocks_for(int n) {

@@ -62,12 +62,11 @@ void launch_nn_tie_threshold(const uint32_t* min_bits, int n, uint32_t* thr_bits
 void launch_nn_first_index(const float4* pts, int n, const float4* tgt, int nt, const uint32_t* thr_bits, uint32_t* first_idx,
                            hipStream_t s);
 
-// Exact NN through the implicit BVH (bvh.hpp) — bit-identical to the brute-force kernels above.
-void launch_nn_bvh_min(const float4* pts, int n, const BvhView& t, const float4* tgt, int nt, const float* lut, const LutGeom& g,
-                       const float* R9, const float* t3, int apply, uint32_t* min_bits, uint32_t* hard, hipStream_t s);
-void launch_nn_bvh_corr(const float4* pts, int n, const BvhView& t, const float4* tgt, int nt, const float* lut, const LutGeom& g,
-                        uint32_t* first_idx, uint32_t* hard, hipStream_t s);
-void launch_lut_build_bvh(const BvhView& shifted_targets, const LutGeom& g, float* scratch_padded, float* lut_padded, hipStream_t s);
+// Exact NN through the two-level box scan (bvh.hpp) — bit-identical to the brute-force kernels above.
+//   want_index = 0: out[i] = bits(min squared distance);  1: out[i] = lowest index in the sqrt-tie set
+void launch_nn_scan(const float4* pts, int n, const BvhView& t, const float* lut, const LutGeom& g, const float* R9, const float* t3, int apply,
+                    int want_index, uint32_t* out, hipStream_t s);
+void launch_lut_build_scan(const BvhView& shifted_targets, const LutGeom& g, float* scratch_padded, float* lut_padded, hipStream_t s);
 
 // deterministic double sums: out[k] = sum_i vals[i*stride + k]  (k < width <= 16)
 void launch_sum_f32_as_f64(const uint32_t* bits, int n, double* block_partials, int nblocks, hipStream_t s);
