@@ -47,11 +47,78 @@ int ctx_flush_profile(fgoicp_ctx* c) {
 }
 
 // -------------------------------------------------------------------------------------------
+// Registration::compute_sse_error(RotNode&, vector<TransNode>&, bool, StreamPool&) for G groups,
+// locality-sorted whole-tick path: descriptors -> device, sort the (subcube, chunk) items by LUT
+// cell, one bounds launch, one finalize, one host sync per window of <= max_subcubes subcubes.
+// -------------------------------------------------------------------------------------------
+static int ctx_bounds_multi_sorted(fgoicp_ctx* c, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets,
+                                   const float* tn4, float* lb_out, float* ub_out) {
+    int g = 0;
+    const int total = offsets[G];
+    int pos = 0;
+    while (pos < total) {
+        // window: subcubes [pos, end) using at most max_groups rotation nodes
+        while (g < G && offsets[g + 1] <= pos) ++g;
+        const int g0 = g;
+        int end = pos, ng = 0;
+        for (int gg = g0; gg < G && ng < c->max_groups && end - pos < c->max_subcubes; ++gg, ++ng) {
+            TickGroup& tg = c->h_groups[ng];
+            std::memcpy(tg.R, R9 + 9 * gg, sizeof(tg.R));
+            const float half_angle = rot_span[gg] * kSqrt3 * kPi / 2.0f;  // registration.cu:42
+            tg.sin_half = std::sin(half_angle);
+            tg.fix_rot = fix_rot[gg] ? 1 : 0;
+            tg.pad_ = 0;
+            const int first = std::max(offsets[gg], pos);
+            const int last = std::min(offsets[gg + 1], pos + c->max_subcubes);
+            for (int i = first; i < last; ++i) {
+                TickSub& ts = c->h_subs[i - pos];
+                ts.tx = tn4[4 * (size_t)i]; ts.ty = tn4[4 * (size_t)i + 1]; ts.tz = tn4[4 * (size_t)i + 2]; ts.span = tn4[4 * (size_t)i + 3];
+                ts.group = ng;
+                ts.pad_[0] = ts.pad_[1] = ts.pad_[2] = 0;
+            }
+            end = std::max(end, last);
+            if (last < offsets[gg + 1]) { ++ng; break; }  // window full in the middle of a group
+        }
+        const int rows = end - pos;
+        if (rows <= 0) break;
+        HIPCHK(hipMemcpyAsync(c->d_groups, c->h_groups, sizeof(TickGroup) * ng, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_subs, c->h_subs, sizeof(TickSub) * rows, hipMemcpyHostToDevice, c->stream));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (c->profile) {
+            if (c->ev_used == (int)c->ev_start.size()) {
+                HIPCHK(hipStreamSynchronize(c->stream));
+                int rc = ctx_flush_profile(c);
+                if (rc) return rc;
+            }
+            e0 = c->ev_start[c->ev_used];
+            e1 = c->ev_stop[c->ev_used];
+            c->ev_used++;
+            c->prof_launches++;
+            c->prof_subcubes += rows;
+        }
+        launch_bounds_sorted(c->d_src, (int)c->ns, c->d_lut, c->geom, c->d_chunk_cen, c->nchunk1, c->d_groups, c->d_subs, rows, c->cell_shift,
+                             c->d_keys, c->d_hist, c->d_cursor, c->d_sorted, c->d_partials1, e0, e1, c->stream);
+        launch_bounds_finalize(c->d_partials1, c->nchunk1, rows, c->hd_lb, c->hd_ub, c->stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));
+        std::memcpy(lb_out + pos, c->h_lb, sizeof(float) * rows);
+        std::memcpy(ub_out + pos, c->h_ub, sizeof(float) * rows);
+        if (c->profile) {
+            int rc = ctx_flush_profile(c);
+            if (rc) return rc;
+        }
+        pos = end;
+    }
+    return FGOICP_OK;
+}
+
+// -------------------------------------------------------------------------------------------
 // Registration::compute_sse_error(RotNode&, vector<TransNode>&, bool, StreamPool&) for G groups.
 // -------------------------------------------------------------------------------------------
 int ctx_bounds_multi(fgoicp_ctx* c, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets,
                      const float* tn4, float* lb_out, float* ub_out) {
     HIPCHK(hipSetDevice(c->device));
+    if (c->sorted_bounds) return ctx_bounds_multi_sorted(c, G, R9, rot_span, fix_rot, offsets, tn4, lb_out, ub_out);
     struct Piece { int g, pos, B; };
     std::vector<Piece> pieces;
     for (int g = 0; g < G; ++g)
@@ -322,6 +389,38 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
         CHK(hipHostGetDevicePointer((void**)&c->hd_lb, c->h_lb, 0));
         CHK(hipHostGetDevicePointer((void**)&c->hd_ub, c->h_ub, 0));
     }
+    // locality-sorted whole-tick path
+    {
+        if (const char* e = std::getenv("FGOICP_BOUNDS_SORTED")) c->sorted_bounds = std::atoi(e) != 0;
+        c->nchunk1 = (int)((ns + kBlock - 1) / kBlock);
+        c->max_groups = 512;
+        int maxd = std::max(g.dx, std::max(g.dy, g.dz));
+        c->cell_shift = 0;
+        while ((maxd >> c->cell_shift) > 32) ++c->cell_shift;  // 5 bits per axis
+        std::vector<float4> cen(c->nchunk1);
+        for (int k = 0; k < c->nchunk1; ++k) {
+            double sx = 0, sy = 0, sz = 0;
+            const size_t a = (size_t)k * kBlock, b = std::min(ns, a + kBlock);
+            for (size_t i = a; i < b; ++i) {
+                const float* p = src_xyz + 3 * (size_t)c->perm[i];
+                sx += p[0]; sy += p[1]; sz += p[2];
+            }
+            const double inv = 1.0 / (double)(b - a);
+            cen[k] = make_float4((float)(sx * inv), (float)(sy * inv), (float)(sz * inv), 0.f);
+        }
+        CHK(hipMalloc(&c->d_chunk_cen, sizeof(float4) * c->nchunk1));
+        CHK(hipMemcpy(c->d_chunk_cen, cen.data(), sizeof(float4) * c->nchunk1, hipMemcpyHostToDevice));
+        const size_t max_items = (size_t)c->max_subcubes * c->nchunk1;
+        CHK(hipMalloc(&c->d_groups, sizeof(TickGroup) * c->max_groups));
+        CHK(hipMalloc(&c->d_subs, sizeof(TickSub) * c->max_subcubes));
+        CHK(hipHostMalloc((void**)&c->h_groups, sizeof(TickGroup) * c->max_groups, hipHostMallocDefault));
+        CHK(hipHostMalloc((void**)&c->h_subs, sizeof(TickSub) * c->max_subcubes, hipHostMallocDefault));
+        CHK(hipMalloc(&c->d_keys, sizeof(unsigned short) * max_items));
+        CHK(hipMalloc(&c->d_hist, sizeof(unsigned) * kTickNumKeys));
+        CHK(hipMalloc(&c->d_cursor, sizeof(unsigned) * kTickNumKeys));
+        CHK(hipMalloc(&c->d_sorted, sizeof(unsigned) * max_items));
+        CHK(hipMalloc(&c->d_partials1, sizeof(double2) * max_items));
+    }
     // exact-NN / ICP scratch
     CHK(hipMalloc(&c->d_min_bits, sizeof(uint32_t) * ns));
     CHK(hipMalloc(&c->d_thr_bits, sizeof(uint32_t) * ns));
@@ -354,6 +453,10 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
     (void)hipFree(c->d_bp); (void)hipFree(c->d_bp2); (void)hipFree(c->d_cen);
     if (c->h_cen) (void)hipHostFree(c->h_cen);
     bvh_free(&c->bvh_tgt);
+    (void)hipFree(c->d_chunk_cen); (void)hipFree(c->d_groups); (void)hipFree(c->d_subs); (void)hipFree(c->d_keys);
+    (void)hipFree(c->d_hist); (void)hipFree(c->d_cursor); (void)hipFree(c->d_sorted); (void)hipFree(c->d_partials1);
+    if (c->h_groups) (void)hipHostFree(c->h_groups);
+    if (c->h_subs) (void)hipHostFree(c->h_subs);
     if (c->h_lb) (void)hipHostFree(c->h_lb);
     if (c->h_ub) (void)hipHostFree(c->h_ub);
     if (c->h_sums) (void)hipHostFree(c->h_sums);

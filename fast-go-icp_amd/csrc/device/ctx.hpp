@@ -33,6 +33,16 @@ struct fgoicp_ctx {
     float *h_lb = nullptr, *h_ub = nullptr;  // pinned, device-visible result rows
     float *hd_lb = nullptr, *hd_ub = nullptr;
 
+    // locality-sorted whole-tick path (kernels.hip, bounds_sorted_kernel): 256-point chunks
+    bool sorted_bounds = true;
+    int nchunk1 = 0, max_groups = 0, cell_shift = 4;
+    float4* d_chunk_cen = nullptr;           // centroid of every chunk (source frame)
+    fgoicp::TickGroup *d_groups = nullptr, *h_groups = nullptr;   // device / pinned staging
+    fgoicp::TickSub *d_subs = nullptr, *h_subs = nullptr;
+    unsigned short* d_keys = nullptr;
+    unsigned *d_hist = nullptr, *d_cursor = nullptr, *d_sorted = nullptr;
+    double2* d_partials1 = nullptr;          // [max_subcubes][nchunk1]
+
     // exact-NN / ICP scratch
     uint32_t *d_min_bits = nullptr, *d_thr_bits = nullptr, *d_first_idx = nullptr;
     double* d_bp = nullptr;      // per-block partial sums

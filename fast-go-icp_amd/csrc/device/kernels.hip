@@ -10,6 +10,8 @@
 // approximate in an unspecified order (fgoicp/registration.cu:126-140).
 #include "kernels.hpp"
 
+#include <algorithm>
+
 #include "bvh.hpp"
 
 namespace fgoicp {
@@ -177,6 +179,105 @@ __global__ __launch_bounds__(kBlock) void bounds_kernel(const float4* __restrict
     const double r = block_sum<2>(acc, red);
     // threads 0 and 1 hold sum_ub and sum_lb
     double* out = reinterpret_cast<double*>(partials + ((size_t)(a.out_base + b) * nchunk + chunk));
+    if (threadIdx.x < 2) out[threadIdx.x] = r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Locality-sorted variant for a whole tick (many rotation nodes, hundreds of subcubes).
+// A work item is (subcube s, chunk c of 256 Morton-consecutive points): a compact surface patch that
+// reads a compact region of the LUT.  One tick's items together want every LUT line ~25 times, but
+// in submission order two users of a line run far apart in time, the 203 MB LUT streams through the
+// 4 MiB L2s over and over, and the kernel runs at the fabric rate instead of the L2 rate.  So the
+// items are ordered by the Morton code of the LUT cell their patch centre lands in (counting sort on
+// the device, 15-bit keys), and the XCD-aware remap hands each XCD one contiguous run of that order:
+// blocks resident together on an XCD read the same neighbourhood of the LUT.  Every item writes the
+// same partial it would write in any order, and the finalize sum is ordered by (s, c) — results
+// are bit-identical to the plain kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr int kKeyBits = 15;
+constexpr int kNumKeys = 1 << kKeyBits;
+
+__device__ __forceinline__ unsigned part1by2_5(unsigned v) {  // spread 5 bits to every third position
+    v &= 31u;
+    v = (v | (v << 8)) & 0x100fu;
+    v = (v | (v << 4)) & 0x10c3u;
+    v = (v | (v << 2)) & 0x1249u;
+    return v;
+}
+
+__global__ __launch_bounds__(kBlock) void tick_keys_kernel(const float4* __restrict__ chunk_cen, int nchunk, const TickGroup* __restrict__ groups,
+                                                           const TickSub* __restrict__ subs, int nsub, LutGeom g, int cell_shift,
+                                                           unsigned short* __restrict__ keys, unsigned* __restrict__ hist) {
+    const size_t nitems = (size_t)nsub * nchunk;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nitems; i += (size_t)gridDim.x * kBlock) {
+        const int s = (int)(i / nchunk), c = (int)(i - (size_t)s * nchunk);
+        const TickSub sb = subs[s];
+        const TickGroup& gr = groups[sb.group];
+        const float4 cc = chunk_cen[c];
+        float rx, ry, rz;
+        rotate(gr.R, cc.x, cc.y, cc.z, rx, ry, rz);
+        const int vx = (int)fminf(fmaxf((rx + sb.tx + g.off_x) * g.scale, 0.0f), (float)(g.dx - 1)) >> cell_shift;
+        const int vy = (int)fminf(fmaxf((ry + sb.ty + g.off_y) * g.scale, 0.0f), (float)(g.dy - 1)) >> cell_shift;
+        const int vz = (int)fminf(fmaxf((rz + sb.tz + g.off_z) * g.scale, 0.0f), (float)(g.dz - 1)) >> cell_shift;
+        const unsigned key = part1by2_5((unsigned)vx) | (part1by2_5((unsigned)vy) << 1) | (part1by2_5((unsigned)vz) << 2);
+        keys[i] = (unsigned short)key;
+        atomicAdd(&hist[key], 1u);
+    }
+}
+
+// exclusive scan of the 32768-bin histogram, one block of 1024 threads (32 bins each)
+__global__ __launch_bounds__(1024) void tick_scan_kernel(const unsigned* __restrict__ hist, unsigned* __restrict__ cursor) {
+    __shared__ unsigned wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned loc[32];
+    unsigned sum = 0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { loc[k] = sum; sum += hist[tid * 32 + k]; }
+    unsigned incl = sum;  // inclusive scan of `sum` across the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    unsigned base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    base += incl - sum;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) cursor[tid * 32 + k] = base + loc[k];
+}
+
+__global__ __launch_bounds__(kBlock) void tick_scatter_kernel(const unsigned short* __restrict__ keys, size_t nitems, unsigned* __restrict__ cursor,
+                                                              unsigned* __restrict__ sorted) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nitems; i += (size_t)gridDim.x * kBlock)
+        sorted[atomicAdd(&cursor[keys[i]], 1u)] = (unsigned)i;  // order inside a bin is irrelevant (scheduling only)
+}
+
+__global__ __launch_bounds__(kBlock) void bounds_sorted_kernel(const float4* __restrict__ src, int ns, const float* __restrict__ lut, LutGeom g,
+                                                               const TickGroup* __restrict__ groups, const TickSub* __restrict__ subs,
+                                                               const unsigned* __restrict__ sorted, int nchunk, double2* __restrict__ partials) {
+    __shared__ double red[8];
+    const unsigned item = sorted[xcd_remap(blockIdx.x, gridDim.x)];
+    const int s = (int)(item / (unsigned)nchunk);
+    const int chunk = (int)(item - (unsigned)s * (unsigned)nchunk);
+    const TickSub sb = subs[s];
+    const TickGroup& gr = groups[sb.group];
+    const float trans_uncertain_radius = kSqrt3 * sb.span;  // registration.cu:33
+    const int i = chunk * kBlock + threadIdx.x;
+    const float4 p = src[i < ns ? i : ns - 1];
+    float rx, ry, rz;
+    rotate(gr.R, p.x, p.y, p.z, rx, ry, rz);
+    const float dsq = lut_search(lut, g, rx + sb.tx, ry + sb.ty, rz + sb.tz);  // :34, :46
+    float d = sqrtf(dsq);                                                        // :48
+    if (!gr.fix_rot) d -= 2.0f * p.w * gr.sin_half;                              // :39-43, :49-52
+    const float ubv = d > 0.0f ? d * d : 0.0f;                                   // :54
+    const float l = d - trans_uncertain_radius;                                  // :57
+    const float lbv = l > 0.0f ? l * l : 0.0f;                                   // :58
+    const bool valid = i < ns;
+    const double acc[2] = {valid ? (double)ubv : 0.0, valid ? (double)lbv : 0.0};
+    const double r = block_sum<2>(acc, red);
+    double* out = reinterpret_cast<double*>(partials + ((size_t)s * nchunk + chunk));
     if (threadIdx.x < 2) out[threadIdx.x] = r;
 }
 
@@ -723,6 +824,22 @@ void launch_bounds(const float4* src, int ns, const float* lut, const LutGeom& g
         case 4: hipLaunchKernelGGL(bounds_kernel<4>, grid, block, 0, s, src, ns, lut, g, a, partials, nchunk); break;
         default: hipLaunchKernelGGL(bounds_kernel<8>, grid, block, 0, s, src, ns, lut, g, a, partials, nchunk); break;
     }
+}
+
+void launch_bounds_sorted(const float4* src, int ns, const float* lut, const LutGeom& g, const float4* chunk_cen, int nchunk, const TickGroup* groups,
+                          const TickSub* subs, int nsub, int cell_shift, unsigned short* keys, unsigned* hist, unsigned* cursor, unsigned* sorted,
+                          double2* partials, hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s) {
+    const size_t nitems = (size_t)nsub * nchunk;
+    const TickGroup* gp = groups;
+    const TickSub* sp = subs;
+    (void)hipMemsetAsync(hist, 0, sizeof(unsigned) * kNumKeys, s);
+    const unsigned kb = (unsigned)std::min<size_t>((nitems + kBlock - 1) / kBlock, 2048);
+    hipLaunchKernelGGL(tick_keys_kernel, dim3(kb), dim3(kBlock), 0, s, chunk_cen, nchunk, gp, sp, nsub, g, cell_shift, keys, hist);
+    hipLaunchKernelGGL(tick_scan_kernel, dim3(1), dim3(1024), 0, s, hist, cursor);
+    hipLaunchKernelGGL(tick_scatter_kernel, dim3(kb), dim3(kBlock), 0, s, keys, nitems, cursor, sorted);
+    if (ev_start) (void)hipEventRecord(ev_start, s);
+    hipLaunchKernelGGL(bounds_sorted_kernel, dim3((unsigned)nitems), dim3(kBlock), 0, s, src, ns, lut, g, gp, sp, sorted, nchunk, partials);
+    if (ev_stop) (void)hipEventRecord(ev_stop, s);
 }
 
 void launch_bounds_finalize(const double2* partials, int nchunk, int total, float* out_lb, float* out_ub, hipStream_t s) {

@@ -43,6 +43,24 @@ struct BoundsArgs {
 // bounds: partials[(out_base + b) * nchunk + chunk] = {sum_ub, sum_lb} over the chunk's points
 void launch_bounds(const float4* src, int ns, const float* lut, const LutGeom& g, const BoundsArgs& a, double2* partials,
                    int nchunk, int pts_per_thread, hipStream_t s);
+// Whole-tick variant: all subcubes of all rotation nodes in ONE launch, work items ordered by LUT locality
+// (kernels.hip).  groups/subs are device arrays of TickGroup (48 B) / TickSub (32 B); partials is indexed
+// [s * nchunk + chunk] with 256-point chunks; events (optional) bracket the bounds kernel only.
+struct TickGroup {   // one rotation node
+    float R[9];
+    float sin_half;
+    int fix_rot;
+    int pad_;
+};
+struct TickSub {     // one translation node + its rotation node
+    float tx, ty, tz, span;
+    int group;
+    int pad_[3];
+};
+constexpr int kTickNumKeys = 1 << 15;
+void launch_bounds_sorted(const float4* src, int ns, const float* lut, const LutGeom& g, const float4* chunk_cen, int nchunk, const TickGroup* groups,
+                          const TickSub* subs, int nsub, int cell_shift, unsigned short* keys, unsigned* hist, unsigned* cursor, unsigned* sorted,
+                          double2* partials, hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s);
 // out_lb[i], out_ub[i] = float(sum over chunks), fixed order → bit-reproducible
 void launch_bounds_finalize(const double2* partials, int nchunk, int total, float* out_lb, float* out_ub, hipStream_t s);
 

@@ -216,3 +216,41 @@ def test_brute_force_flag_matches_oracle(fg, oracle, tiny_case, gpu_required):
     *_, idxo = orc.procrustes(w)
     assert np.array_equal(idx, idxo)
     hip.close()
+
+
+def test_sorted_and_plain_bounds_paths_agree(fg, tiny_case, gpu_required, monkeypatch):
+    """The locality-sorted whole-tick kernel and the plain per-rotation-node kernel compute the same
+    per-point values; only the fp64 chunking differs (256- vs 256*P-point chunks)."""
+    c = tiny_case
+    rng = np.random.default_rng(8)
+    nodes = [fg.RotNode(0.5, 0.5, -0.5, 0.5), fg.RotNode(0.0, 0.125, 0.0, 0.25), fg.RotNode(-0.25, 0.25, 0.25, 0.0625)]
+    groups = [_tnodes(rng, 32, 0.5), _tnodes(rng, 5, 0.25), _tnodes(rng, 70, 0.125)]
+    fixes = [True, False, False]
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FGOICP_BOUNDS_SORTED", mode)
+        reg = fg.Registration(c["pct"], c["pcs"], c["bounds"], c["res"])
+        out[mode] = reg.compute_bounds_multi([n.q.R for n in nodes], [n.span for n in nodes], fixes, groups)
+        again = reg.compute_bounds_multi([n.q.R for n in nodes], [n.span for n in nodes], fixes, groups)
+        for (a, b), (a2, b2) in zip(out[mode], again):
+            assert np.array_equal(a, a2) and np.array_equal(b, b2)  # run-to-run bit-reproducible in either mode
+        reg.close()
+    for (lb1, ub1), (lb0, ub0) in zip(out["1"], out["0"]):
+        assert rel(ub1, ub0) <= REL
+        assert np.max(np.abs(lb1.astype(np.float64) - lb0)) <= REL * max(float(np.max(ub0)), 1e-30)
+
+
+def test_bounds_multi_many_groups_and_windows(fg, tiny_case, gpu_required):
+    """More subcubes than one window (4096) and many rotation nodes: windows split mid-group."""
+    c = tiny_case
+    reg = fg.Registration(c["pct"], c["pcs"], c["bounds"], c["res"])
+    rng = np.random.default_rng(10)
+    nodes = [fg.RotNode(*rng.uniform(-0.4, 0.4, 3), 0.125) for _ in range(40)]
+    groups = [_tnodes(rng, int(rng.integers(1, 260)), 0.25) for _ in nodes]
+    assert sum(len(g) for g in groups) > 4096
+    fixes = [bool(i % 2) for i in range(len(nodes))]
+    multi = reg.compute_bounds_multi([n.q.R for n in nodes], [n.span for n in nodes], fixes, groups)
+    for k in (0, 7, 23, 39):
+        lb1, ub1 = reg.compute_sse_error(nodes[k], groups[k], fixes[k])
+        assert np.array_equal(multi[k][0], lb1) and np.array_equal(multi[k][1], ub1)
+    reg.close()
