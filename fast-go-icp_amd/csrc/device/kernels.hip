@@ -529,11 +529,15 @@ __device__ __forceinline__ float boxbox_d2(const float4 lo, const float4 hi, con
 //   3. per candidate leaf, its box is broadcast from the lane that loaded it (readlane), every query
 //      tests it against its OWN bound, and if any query needs it lanes 0..31 load its 32 points once
 //      and broadcast them one by one.
+// When `nparts` waves share the same 64 queries (small clouds: more waves in flight), every wave runs
+// steps 1-2 identically (the wave radius r2 is NOT tightened then, so all see the same candidate list)
+// and takes every nparts-th candidate leaf; the caller min-combines their results.
 // Steps 1-2 are supersets of what each query needs (box-to-region distance <= box-to-query distance,
 // wave radius >= own bound), step 3 applies the exact per-query rule, so no needed point is skipped.
 template <class LeafFn, class BoundFn>
-__device__ __forceinline__ void box_scan(const BvhView t, float qx, float qy, float qz, bool active, LeafFn leaf, BoundFn bound) {
+__device__ __forceinline__ void box_scan(const BvhView t, float qx, float qy, float qz, bool active, int part, int nparts, LeafFn leaf, BoundFn bound) {
     const int lane = threadIdx.x & 63;
+    int turn = 0;  // candidate leaves are dealt round-robin to the `nparts` waves that share these 64 queries
     const float big = 3.0e38f;
     const float wl[3] = {wave_min_f(active ? qx : big), wave_min_f(active ? qy : big), wave_min_f(active ? qz : big)};
     const float wh[3] = {wave_max_f(active ? qx : -big), wave_max_f(active ? qy : -big), wave_max_f(active ? qz : -big)};
@@ -564,6 +568,11 @@ __device__ __forceinline__ void box_scan(const BvhView t, float qx, float qy, fl
             while (lmask) {
                 const int l = __ffsll((long long)lmask) - 1;
                 lmask &= lmask - 1;
+                if (nparts > 1) {
+                    const bool mine = turn == part;
+                    turn = turn + 1 == nparts ? 0 : turn + 1;
+                    if (!mine) continue;
+                }
                 const float4 lo = make_float4(bcast(llo.x, l), bcast(llo.y, l), bcast(llo.z, l), 0.f);
                 const float4 hi = make_float4(bcast(lhi.x, l), bcast(lhi.y, l), bcast(lhi.z, l), 0.f);
                 const bool pl = active && !(box_d2(lo, hi, qx, qy, qz) * kBoxShrink > bound());
@@ -574,7 +583,7 @@ __device__ __forceinline__ void box_scan(const BvhView t, float qx, float qy, fl
                     const float4 c = make_float4(bcast(pp.x, k), bcast(pp.y, k), bcast(pp.z, k), bcast(pp.w, k));
                     if (pl) leaf(c);
                 }
-                r2 = wave_max_f(active ? bound() : 0.0f);  // the wave radius only shrinks
+                if (nparts == 1) r2 = wave_max_f(active ? bound() : 0.0f);  // the wave radius only shrinks
             }
         }
     }
@@ -587,7 +596,7 @@ __device__ __forceinline__ void box_scan(const BvhView t, float qx, float qy, fl
 __device__ __forceinline__ float scan_min_d2(const BvhView t, float qx, float qy, float qz, float ub, float init, bool active) {
     float best = ub < init ? ub : init;
     float found = init;
-    box_scan(t, qx, qy, qz, active,
+    box_scan(t, qx, qy, qz, active, 0, 1,
              [&](const float4 p) {
                  const float d = dist_sq(qx, qy, qz, p.x, p.y, p.z);
                  found = d < found ? d : found;
@@ -597,7 +606,7 @@ __device__ __forceinline__ float scan_min_d2(const BvhView t, float qx, float qy
     const bool redo = active && found > best;  // cannot happen with a valid seed
     if (__any(redo)) {
         if (redo) found = init;
-        box_scan(t, qx, qy, qz, redo,
+        box_scan(t, qx, qy, qz, redo, 0, 1,
                  [&](const float4 p) {
                      const float d = dist_sq(qx, qy, qz, p.x, p.y, p.z);
                      found = d < found ? d : found;
@@ -635,9 +644,15 @@ __device__ __forceinline__ float tie_threshold(float best) {  // see nn_tie_thre
 
 //   want_index = 0: out[i] = bits(min_j |q_i - tgt_j|^2)                       (registration.cu:162-174)
 //   want_index = 1: out[i] = lowest j inside the sqrt-tie set of the minimum      (icp3d.cu:11-28)
-__global__ __launch_bounds__(kBlock) void nn_scan_kernel(const float4* __restrict__ pts, int n, BvhView t, const float* __restrict__ lut,
-                                                         LutGeom g, Rt rt, int apply, int want_index, uint32_t* __restrict__ out) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
+// One block = 64 queries x `nparts` waves (blockDim = 64 * nparts): each wave scans its share of the
+// candidate leaves, the shares are min-combined through LDS.
+constexpr int kMaxParts = 16;
+
+__global__ __launch_bounds__(64 * kMaxParts) void nn_scan_kernel(const float4* __restrict__ pts, int n, BvhView t, const float* __restrict__ lut,
+                                                                 LutGeom g, Rt rt, int apply, int want_index, uint32_t* __restrict__ out) {
+    __shared__ uint32_t comb[kMaxParts][64];
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6, nparts = blockDim.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
     const bool active = i < n;
     const float4 p = pts[active ? i : n - 1];
     float qx = p.x, qy = p.y, qz = p.z;
@@ -645,20 +660,61 @@ __global__ __launch_bounds__(kBlock) void nn_scan_kernel(const float4* __restric
         rotate(rt.R, p.x, p.y, p.z, qx, qy, qz);
         qx += rt.t[0]; qy += rt.t[1]; qz += rt.t[2];
     }
-    const float best = scan_min_d2(t, qx, qy, qz, lut_upper_bound_d2(lut, g, qx, qy, qz), kInf, active);
-    uint32_t result = __float_as_uint(best);
+    // pass 1: minimum.  `found` = min over the points this wave visited, `best` additionally seeded.
+    const float ub = lut_upper_bound_d2(lut, g, qx, qy, qz);
+    float best = ub < kInf ? ub : kInf, found = kInf;
+    box_scan(t, qx, qy, qz, active, part, nparts,
+             [&](const float4 c) {
+                 const float d = dist_sq(qx, qy, qz, c.x, c.y, c.z);
+                 found = d < found ? d : found;
+                 best = d < best ? d : best;
+             },
+             [&]() { return best; });
+    if (nparts > 1) {
+        comb[part][lane] = __float_as_uint(found);  // non-negative floats order like their bit patterns
+        __syncthreads();
+        uint32_t m = comb[0][lane];
+        for (int k = 1; k < nparts; ++k) m = min(m, comb[k][lane]);
+        found = __uint_as_float(m);
+        __syncthreads();
+    }
+    const bool redo = active && found > (ub < kInf ? ub : kInf);  // seed too small by rounding: cannot happen, stay exact
+    if (__syncthreads_or(redo)) {
+        float f2 = kInf;
+        box_scan(t, qx, qy, qz, redo, part, nparts,
+                 [&](const float4 c) {
+                     const float d = dist_sq(qx, qy, qz, c.x, c.y, c.z);
+                     f2 = d < f2 ? d : f2;
+                 },
+                 [&]() { return f2; });
+        if (nparts > 1) {
+            comb[part][lane] = __float_as_uint(f2);
+            __syncthreads();
+            uint32_t m = comb[0][lane];
+            for (int k = 1; k < nparts; ++k) m = min(m, comb[k][lane]);
+            f2 = __uint_as_float(m);
+            __syncthreads();
+        }
+        if (redo) found = f2;
+    }
+    uint32_t result = __float_as_uint(found);
     if (want_index) {
-        const float thr = tie_threshold(best);
+        const float thr = tie_threshold(found);
         uint32_t idx = 0x7fffffffu;
-        box_scan(t, qx, qy, qz, active,
+        box_scan(t, qx, qy, qz, active, part, nparts,
                  [&](const float4 c) {
                      const float d = dist_sq(qx, qy, qz, c.x, c.y, c.z);
                      idx = min(idx, d <= thr ? __float_as_uint(c.w) : 0x7fffffffu);
                  },
                  [&]() { return thr; });
+        if (nparts > 1) {
+            comb[part][lane] = idx;
+            __syncthreads();
+            for (int k = 0; k < nparts; ++k) idx = min(idx, comb[k][lane]);
+        }
         result = idx;
     }
-    if (active) out[i] = result;
+    if (active && part == 0) out[i] = result;
 }
 
 // buildLUTKernel (registration.cu:258-278) through the box scan of the shifted targets, coarse to fine:
@@ -891,7 +947,10 @@ void launch_nn_first_index(const float4* pts, int n, const float4* tgt, int nt, 
 
 void launch_nn_scan(const float4* pts, int n, const BvhView& t, const float* lut, const LutGeom& g, const float* R9, const float* t3, int apply,
                     int want_index, uint32_t* out, hipStream_t s) {
-    hipLaunchKernelGGL(nn_scan_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, want_index, out);
+    const int groups = (n + 63) / 64;
+    int nparts = 1;  // enough waves to occupy the chip: >= ~8 per CU
+    while (nparts < kMaxParts && groups * nparts < 2048) nparts <<= 1;
+    hipLaunchKernelGGL(nn_scan_kernel, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, want_index, out);
 }
 
 // `scratch` must hold as many floats as the padded LUT; it receives the coarse pass.
