@@ -111,7 +111,7 @@ def main():
 
     # synthetic pair: rotation far outside the ICP basin, so the search has real work to do
     tgt, src, R_gt, t_gt = fg.synth.workload(a.workload, angle_deg=150.0, min_angle_deg=110.0)
-    K = a.round_width if a.round_width > 0 else 4 * world  # rotation cubes per round: 32 children per rank
+    K = a.round_width if a.round_width > 0 else 32 * world  # rotation cubes popped per round (<= 256 children per rank)
     sched = fg.SCHEDULE_ROUND if a.schedule == "round" else fg.SCHEDULE_SERIAL
     t0 = time.perf_counter()
     solver = fg.FastGoICP(tgt, src, a.lut_resolution, a.mse_threshold, schedule=sched, round_width=K, device=local_rank)

@@ -19,9 +19,15 @@
 //            reference, the final optimum is asserted equal in tests.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <cstdlib>
+#include <functional>
+#include <thread>
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <queue>
 #include <vector>
@@ -177,13 +183,93 @@ struct InnerTask {
 
 struct Task : InnerTask {
     bool done = false;
+    bool has_batch = false;
+};
+
+// A few host threads for the per-task queue work of a tick (the inner BnBs of a round are independent:
+// popping the next batch and pushing the children of the evaluated one touch only the task's own
+// priority queue).  The calling thread takes part; results do not depend on the thread count.
+class WorkerPool {
+public:
+    explicit WorkerPool(int nthreads) {
+        for (int i = 1; i < nthreads; ++i) threads_.emplace_back([this] { worker(); });
+    }
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+            ++generation_;
+        }
+        cv_start_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    size_t size() const { return threads_.size() + 1; }
+    void parallel_for(size_t n, const std::function<void(size_t)>& f) {
+        if (threads_.empty() || n < 2) {
+            for (size_t i = 0; i < n; ++i) f(i);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> g(m_);
+            fn_ = &f;
+            n_ = n;
+            next_.store(0, std::memory_order_relaxed);
+            active_ = threads_.size();
+            ++generation_;
+        }
+        cv_start_.notify_all();
+        drain();
+        std::unique_lock<std::mutex> lk(m_);
+        cv_done_.wait(lk, [this] { return active_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    void drain() {
+        for (;;) {
+            const size_t i = next_.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n_) break;
+            (*fn_)(i);
+        }
+    }
+    void worker() {
+        int seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_start_.wait(lk, [&] { return generation_ != seen; });
+                seen = generation_;
+                if (stop_) return;
+            }
+            drain();
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (--active_ == 0) cv_done_.notify_one();
+            }
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable cv_start_, cv_done_;
+    const std::function<void(size_t)>* fn_ = nullptr;
+    size_t n_ = 0, active_ = 0;
+    std::atomic<size_t> next_{0};
+    int generation_ = 0;
+    bool stop_ = false;
 };
 
 template <class Ops>
 class GoIcpDriver {
 public:
     GoIcpDriver(Ops& ops, size_t ns, float mse_threshold, int schedule, int round_width)
-        : ops_(ops), sse_threshold_(ns * mse_threshold), schedule_(schedule), round_width_(round_width < 1 ? 1 : round_width) {}
+        : ops_(ops), sse_threshold_(ns * mse_threshold), schedule_(schedule), round_width_(round_width < 1 ? 1 : round_width) {
+        int nthreads = 4;
+        if (const char* e = std::getenv("FGOICP_HOST_THREADS")) nthreads = std::atoi(e);
+        const int hw = (int)std::thread::hardware_concurrency();
+        if (hw > 0 && nthreads > hw) nthreads = hw;
+        if (nthreads < 1) nthreads = 1;
+        pool_.reset(new WorkerPool(schedule == kScheduleRound ? nthreads : 1));
+    }
 
     void set_exchange(const Exchange& ex) { ex_ = ex; }
     const DriverStats& stats() const { return stats_; }
@@ -422,14 +508,24 @@ private:
         std::vector<int> live;
         std::vector<float> R9, spans, tn4, lb, ub;
         std::vector<int> fix, offsets;
+        const bool par = tasks.size() >= 8 && pool_->size() > 1;
+        const std::function<void(size_t)> pop_fn = [&](size_t i) {
+            Task& tk = *tasks[i];
+            tk.has_batch = false;
+            if (tk.done) return;
+            if (!tk.next_batch(sse_threshold_)) { tk.done = true; return; }
+            tk.has_batch = true;
+        };
+        const std::function<void(size_t)> push_fn = [&](size_t k) { tasks[live[k]]->consume(lb.data() + offsets[k], ub.data() + offsets[k]); };
         for (;;) {
+            if (par) pool_->parallel_for(tasks.size(), pop_fn);
+            else for (size_t i = 0; i < tasks.size(); ++i) pop_fn(i);
             live.clear();
             R9.clear(); spans.clear(); fix.clear(); tn4.clear();
             offsets.assign(1, 0);
             for (size_t i = 0; i < tasks.size(); ++i) {
                 Task& tk = *tasks[i];
-                if (tk.done) continue;
-                if (!tk.next_batch(sse_threshold_)) { tk.done = true; continue; }
+                if (!tk.has_batch) continue;
                 live.push_back((int)i);
                 R9.insert(R9.end(), cubes[i]->q.R.m, cubes[i]->q.R.m + 9);
                 spans.push_back(cubes[i]->span);
@@ -446,11 +542,13 @@ private:
             if (rc) return rc;
             stats_.bounds_calls++;
             stats_.trans_cubes += tn4.size() / 4;
-            for (size_t k = 0; k < live.size(); ++k) tasks[live[k]]->consume(lb.data() + offsets[k], ub.data() + offsets[k]);
+            if (par) pool_->parallel_for(live.size(), push_fn);
+            else for (size_t k = 0; k < live.size(); ++k) push_fn(k);
         }
     }
 
     Ops& ops_;
+    std::unique_ptr<WorkerPool> pool_;
     float sse_threshold_;
     int schedule_, round_width_;
     Exchange ex_;
