@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -51,6 +52,16 @@ int ctx_flush_profile(fgoicp_ctx* c) {
 // locality-sorted whole-tick path: descriptors -> device, sort the (subcube, chunk) items by LUT
 // cell, one bounds launch, one finalize, one host sync per window of <= max_subcubes subcubes.
 // -------------------------------------------------------------------------------------------
+namespace {
+struct TickTiming {  // FGOICP_TIMING=1: where a tick's wall time goes (host side), printed at context destruction
+    bool on = std::getenv("FGOICP_TIMING") != nullptr;
+    double pack = 0, enqueue = 0, wait = 0, copyout = 0;
+    uint64_t ticks = 0;
+};
+TickTiming g_tt;
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
 static int ctx_bounds_multi_sorted(fgoicp_ctx* c, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets,
                                    const float* tn4, float* lb_out, float* ub_out) {
     int g = 0;
@@ -58,6 +69,7 @@ static int ctx_bounds_multi_sorted(fgoicp_ctx* c, int G, const float* R9, const 
     int pos = 0;
     while (pos < total) {
         // window: subcubes [pos, end) using at most max_groups rotation nodes
+        const double t0 = g_tt.on ? now_s() : 0;
         while (g < G && offsets[g + 1] <= pos) ++g;
         const int g0 = g;
         int end = pos, ng = 0;
@@ -81,6 +93,7 @@ static int ctx_bounds_multi_sorted(fgoicp_ctx* c, int G, const float* R9, const 
         }
         const int rows = end - pos;
         if (rows <= 0) break;
+        const double t1 = g_tt.on ? now_s() : 0;
         HIPCHK(hipMemcpyAsync(c->d_groups, c->h_groups, sizeof(TickGroup) * ng, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->d_subs, c->h_subs, sizeof(TickSub) * rows, hipMemcpyHostToDevice, c->stream));
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -100,9 +113,12 @@ static int ctx_bounds_multi_sorted(fgoicp_ctx* c, int G, const float* R9, const 
                              c->d_keys, c->d_hist, c->d_cursor, c->d_sorted, c->d_partials1, e0, e1, c->stream);
         launch_bounds_finalize(c->d_partials1, c->nchunk1, rows, c->hd_lb, c->hd_ub, c->stream);
         HIPCHK(hipGetLastError());
+        const double t2 = g_tt.on ? now_s() : 0;
         HIPCHK(hipStreamSynchronize(c->stream));
+        const double t3 = g_tt.on ? now_s() : 0;
         std::memcpy(lb_out + pos, c->h_lb, sizeof(float) * rows);
         std::memcpy(ub_out + pos, c->h_ub, sizeof(float) * rows);
+        if (g_tt.on) { g_tt.pack += t1 - t0; g_tt.enqueue += t2 - t1; g_tt.wait += t3 - t2; g_tt.copyout += now_s() - t3; g_tt.ticks++; }
         if (c->profile) {
             int rc = ctx_flush_profile(c);
             if (rc) return rc;
@@ -444,6 +460,11 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
 
 void fgoicp_ctx_destroy(fgoicp_ctx* c) {
     if (!c) return;
+    if (g_tt.on && g_tt.ticks) {
+        std::fprintf(stderr, "[fgoicp timing] ticks %llu: pack %.1f us, enqueue %.1f us, wait %.1f us, copyout %.1f us per tick\n", (unsigned long long)g_tt.ticks,
+                     1e6 * g_tt.pack / g_tt.ticks, 1e6 * g_tt.enqueue / g_tt.ticks, 1e6 * g_tt.wait / g_tt.ticks, 1e6 * g_tt.copyout / g_tt.ticks);
+        g_tt = TickTiming{};
+    }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& e : c->ev_start) if (e) (void)hipEventDestroy(e);

@@ -11,6 +11,7 @@
 #include "kernels.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "bvh.hpp"
 
@@ -47,8 +48,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // Sum K doubles per thread over the 256-thread block; the result is valid in threads 0..K-1
 // (thread k holds component k).  Fixed order: shuffle tree inside a wave, then waves 0..3.
-template <int K>
-__device__ __forceinline__ double block_sum(const double (&v)[K], double* lds /* [4*K] */) {
+template <int K, int NW = 4>
+__device__ __forceinline__ double block_sum(const double (&v)[K], double* lds /* [NW*K] */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -57,7 +58,11 @@ __device__ __forceinline__ double block_sum(const double (&v)[K], double* lds /*
     }
     __syncthreads();
     double out = 0.0;
-    if (threadIdx.x < K) out = ((lds[threadIdx.x] + lds[K + threadIdx.x]) + lds[2 * K + threadIdx.x]) + lds[3 * K + threadIdx.x];
+    if (threadIdx.x < K) {
+        out = lds[threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) out += lds[w * K + threadIdx.x];
+    }
     __syncthreads();
     return out;
 }
@@ -254,29 +259,54 @@ __global__ __launch_bounds__(kBlock) void tick_scatter_kernel(const unsigned sho
         sorted[atomicAdd(&cursor[keys[i]], 1u)] = (unsigned)i;  // order inside a bin is irrelevant (scheduling only)
 }
 
-__global__ __launch_bounds__(kBlock) void bounds_sorted_kernel(const float4* __restrict__ src, int ns, const float* __restrict__ lut, LutGeom g,
-                                                               const TickGroup* __restrict__ groups, const TickSub* __restrict__ subs,
-                                                               const unsigned* __restrict__ sorted, int nchunk, double2* __restrict__ partials) {
-    __shared__ double red[8];
+// THREADS x P = 256 points per item.  Measured on MI355X (2048 subcubes per launch): 256x1 2.35 / 6.4 TB/s
+// algorithmic (bunny / dragon shape), 128x2 2.45 / 7.6 TB/s (default), 64x4 2.32 TB/s; fewer resident
+// blocks per CU (LDS padding) only hurts — the kernel wants every wave slot and many gathers in flight.
+template <int THREADS, int P>
+__global__ __launch_bounds__(THREADS) void bounds_sorted_kernel(const float4* __restrict__ src, int ns, const float* __restrict__ lut, LutGeom g,
+                                                                const TickGroup* __restrict__ groups, const TickSub* __restrict__ subs,
+                                                                const unsigned* __restrict__ sorted, int nchunk, double2* __restrict__ partials) {
+    static_assert(THREADS * P == kBlock, "an item is 256 points");
+    __shared__ double red[2 * (THREADS / 64)];
     const unsigned item = sorted[xcd_remap(blockIdx.x, gridDim.x)];
     const int s = (int)(item / (unsigned)nchunk);
     const int chunk = (int)(item - (unsigned)s * (unsigned)nchunk);
     const TickSub sb = subs[s];
     const TickGroup& gr = groups[sb.group];
     const float trans_uncertain_radius = kSqrt3 * sb.span;  // registration.cu:33
-    const int i = chunk * kBlock + threadIdx.x;
-    const float4 p = src[i < ns ? i : ns - 1];
-    float rx, ry, rz;
-    rotate(gr.R, p.x, p.y, p.z, rx, ry, rz);
-    const float dsq = lut_search(lut, g, rx + sb.tx, ry + sb.ty, rz + sb.tz);  // :34, :46
-    float d = sqrtf(dsq);                                                        // :48
-    if (!gr.fix_rot) d -= 2.0f * p.w * gr.sin_half;                              // :39-43, :49-52
-    const float ubv = d > 0.0f ? d * d : 0.0f;                                   // :54
-    const float l = d - trans_uncertain_radius;                                  // :57
-    const float lbv = l > 0.0f ? l * l : 0.0f;                                   // :58
-    const bool valid = i < ns;
-    const double acc[2] = {valid ? (double)ubv : 0.0, valid ? (double)lbv : 0.0};
-    const double r = block_sum<2>(acc, red);
+    const size_t sy = (size_t)g.px, sz = (size_t)g.px * g.py;
+    float4 p[P];
+    TexAddr ta[P];
+    float2u v00[P], v10[P], v01[P], v11[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        const int i = chunk * kBlock + k * THREADS + threadIdx.x;
+        p[k] = src[i < ns ? i : ns - 1];
+        float rx, ry, rz;
+        rotate(gr.R, p[k].x, p[k].y, p[k].z, rx, ry, rz);
+        ta[k] = lut_address(lut, g, rx + sb.tx, ry + sb.ty, rz + sb.tz);  // :34, :323-325
+    }
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        v00[k] = *(const float2u*)(ta[k].p);  // default cache policy: non-temporal loads measured 2x slower here
+        v10[k] = *(const float2u*)(ta[k].p + sy);
+        v01[k] = *(const float2u*)(ta[k].p + sz);
+        v11[k] = *(const float2u*)(ta[k].p + sz + sy);
+    }
+    double acc[2] = {0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        const float dsq = lut_blend(ta[k], v00[k], v10[k], v01[k], v11[k]);  // :46
+        float d = sqrtf(dsq);                                                 // :48
+        if (!gr.fix_rot) d -= 2.0f * p[k].w * gr.sin_half;                    // :39-43, :49-52
+        const float ubv = d > 0.0f ? d * d : 0.0f;                            // :54
+        const float l = d - trans_uncertain_radius;                           // :57
+        const float lbv = l > 0.0f ? l * l : 0.0f;                            // :58
+        const bool valid = chunk * kBlock + k * THREADS + (int)threadIdx.x < ns;
+        acc[0] += valid ? (double)ubv : 0.0;
+        acc[1] += valid ? (double)lbv : 0.0;
+    }
+    const double r = block_sum<2, THREADS / 64>(acc, red);
     double* out = reinterpret_cast<double*>(partials + ((size_t)s * nchunk + chunk));
     if (threadIdx.x < 2) out[threadIdx.x] = r;
 }
@@ -894,7 +924,14 @@ void launch_bounds_sorted(const float4* src, int ns, const float* lut, const Lut
     hipLaunchKernelGGL(tick_scan_kernel, dim3(1), dim3(1024), 0, s, hist, cursor);
     hipLaunchKernelGGL(tick_scatter_kernel, dim3(kb), dim3(kBlock), 0, s, keys, nitems, cursor, sorted);
     if (ev_start) (void)hipEventRecord(ev_start, s);
-    hipLaunchKernelGGL(bounds_sorted_kernel, dim3((unsigned)nitems), dim3(kBlock), 0, s, src, ns, lut, g, gp, sp, sorted, nchunk, partials);
+    static const int lds_pad = [] { const char* e = std::getenv("FGOICP_BOUNDS_LDS_PAD_KB"); return e ? std::atoi(e) * 1024 : 0; }();  // tuning knob
+    static const int variant = [] { const char* e = std::getenv("FGOICP_BOUNDS_VARIANT"); return e ? std::atoi(e) : 1; }();  // tuning knob (1 = default)
+    if (variant == 1)
+        hipLaunchKernelGGL((bounds_sorted_kernel<128, 2>), dim3((unsigned)nitems), dim3(128), lds_pad, s, src, ns, lut, g, gp, sp, sorted, nchunk, partials);
+    else if (variant == 2)
+        hipLaunchKernelGGL((bounds_sorted_kernel<64, 4>), dim3((unsigned)nitems), dim3(64), lds_pad, s, src, ns, lut, g, gp, sp, sorted, nchunk, partials);
+    else
+        hipLaunchKernelGGL((bounds_sorted_kernel<256, 1>), dim3((unsigned)nitems), dim3(kBlock), lds_pad, s, src, ns, lut, g, gp, sp, sorted, nchunk, partials);
     if (ev_stop) (void)hipEventRecord(ev_stop, s);
 }
 

@@ -26,6 +26,7 @@
 #include <functional>
 #include <thread>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -311,6 +312,10 @@ public:
             best_t_ = t;
         }
         stats_.seconds_total = seconds_since(t_start);
+        if (std::getenv("FGOICP_TIMING"))
+            std::fprintf(stderr, "[fgoicp timing] run %.3f s: pop+pack %.3f s, operator %.3f s, push %.3f s, icp %.3f s, calls %llu\n", stats_.seconds_total, t_pop_, t_ops_,
+                         t_push_, stats_.seconds_icp, (unsigned long long)stats_.bounds_calls);
+        t_pop_ = t_ops_ = t_push_ = 0;
         return kDriverOk;
     }
 
@@ -517,7 +522,9 @@ private:
             tk.has_batch = true;
         };
         const std::function<void(size_t)> push_fn = [&](size_t k) { tasks[live[k]]->consume(lb.data() + offsets[k], ub.data() + offsets[k]); };
+        const bool timing = std::getenv("FGOICP_TIMING") != nullptr;
         for (;;) {
+            const auto ta = clock::now();
             if (par) pool_->parallel_for(tasks.size(), pop_fn);
             else for (size_t i = 0; i < tasks.size(); ++i) pop_fn(i);
             live.clear();
@@ -538,16 +545,24 @@ private:
             if (live.empty()) return kDriverOk;
             lb.resize(tn4.size() / 4);
             ub.resize(tn4.size() / 4);
+            const auto tb = clock::now();
             int rc = ops_.bounds_multi((int)live.size(), R9.data(), spans.data(), fix.data(), offsets.data(), tn4.data(), lb.data(), ub.data());
             if (rc) return rc;
             stats_.bounds_calls++;
             stats_.trans_cubes += tn4.size() / 4;
+            const auto tc = clock::now();
             if (par) pool_->parallel_for(live.size(), push_fn);
             else for (size_t k = 0; k < live.size(); ++k) push_fn(k);
+            if (timing) {
+                t_pop_ += std::chrono::duration<double>(tb - ta).count();
+                t_ops_ += std::chrono::duration<double>(tc - tb).count();
+                t_push_ += std::chrono::duration<double>(clock::now() - tc).count();
+            }
         }
     }
 
     Ops& ops_;
+    double t_pop_ = 0, t_ops_ = 0, t_push_ = 0;
     std::unique_ptr<WorkerPool> pool_;
     float sse_threshold_;
     int schedule_, round_width_;

@@ -254,3 +254,86 @@ def test_bounds_multi_many_groups_and_windows(fg, tiny_case, gpu_required):
         lb1, ub1 = reg.compute_sse_error(nodes[k], groups[k], fixes[k])
         assert np.array_equal(multi[k][0], lb1) and np.array_equal(multi[k][1], ub1)
     reg.close()
+
+
+# ---- size-independent properties at the benchmark's full size (the CPU oracle cannot reach it) ----
+@pytest.fixture(scope="module")
+def bunny_full(fg, gpu_required):
+    tgt, src, R_gt, t_gt = fg.synth.workload("bunny", angle_deg=150.0, min_angle_deg=110.0)
+    pct, pcs, off_t, off_s, scale, bounds = fg.synth.preprocess(tgt, src)
+    reg = fg.Registration(pct, pcs, bounds, 0.005)
+    yield dict(reg=reg, pct=pct, pcs=pcs, bounds=bounds, R_gt=R_gt, t_gt=t_gt, off_t=off_t, off_s=off_s, scale=scale)
+    reg.close()
+
+
+def test_full_size_bounds_are_additive_over_the_source(fg, bunny_full):
+    """Bounds are sums over source points: bounds(A u B) = bounds(A) + bounds(B) for a split of the cloud."""
+    c = bunny_full
+    rng = np.random.default_rng(0)
+    mask = rng.random(len(c["pcs"])) < 0.37
+    ra = fg.Registration(c["pct"], c["pcs"][mask], c["bounds"], 0.005)
+    rb = fg.Registration(c["pct"], c["pcs"][~mask], c["bounds"], 0.005)
+    rn = fg.RotNode(-0.375, 0.125, 0.25, 0.125)
+    tn = _tnodes(rng, 64, 0.125)
+    for fix in (True, False):
+        lb, ub = c["reg"].compute_sse_error(rn, tn, fix)
+        la, ua = ra.compute_sse_error(rn, tn, fix)
+        lbb, ubb = rb.compute_sse_error(rn, tn, fix)
+        assert np.allclose(ub, ua.astype(np.float64) + ubb, rtol=2e-6)
+        assert np.allclose(lb, la.astype(np.float64) + lbb, rtol=2e-6, atol=2e-6 * float(ub.max()))
+    ra.close(); rb.close()
+
+
+def test_full_size_bound_orderings(fg, bunny_full):
+    """lb <= ub; widening the translation cube can only lower lb; the rotation slack can only lower both."""
+    reg = bunny_full["reg"]
+    rng = np.random.default_rng(1)
+    rn = fg.RotNode(0.125, 0.375, -0.125, 0.25)
+    t = rng.uniform(-0.5, 0.5, (32, 3)).astype(np.float32)
+    prev_lb = None
+    for span in (0.0625, 0.125, 0.25, 0.5):
+        tn = np.concatenate([t, np.full((32, 1), span, np.float32)], axis=1)
+        lb0, ub0 = reg.compute_sse_error(rn, tn, True)
+        lb1, ub1 = reg.compute_sse_error(rn, tn, False)
+        assert np.all(lb0 <= ub0) and np.all(lb1 <= ub1)
+        assert np.all(ub1 <= ub0 * (1 + 1e-6)) and np.all(lb1 <= lb0 * (1 + 1e-6) + 1e-6)
+        if prev_lb is not None:
+            assert np.all(lb0 <= prev_lb * (1 + 1e-6) + 1e-6)
+        prev_lb = lb0
+
+
+def test_full_size_sse_and_icp_properties(fg, bunny_full):
+    c = bunny_full
+    reg = c["reg"]
+    # ground truth in the scaled frame: R_gt, t' = (t_gt + R_gt c_s - c_t) * scale  (inverse of restore_translation)
+    R = c["R_gt"].astype(np.float32)
+    t = ((c["t_gt"] + c["R_gt"] @ (-c["off_s"].astype(np.float64)) + c["off_t"].astype(np.float64)) * float(c["scale"])).astype(np.float32)
+    sse_gt = float(reg.compute_sse_error(R, t))
+    assert sse_gt / len(c["pcs"]) < 2e-4                     # aligned: only sampling + noise residual
+    assert float(reg.compute_sse_error(np.eye(3), np.zeros(3))) > 50 * sse_gt
+    # the exact-NN scan equals the brute-force kernels at full size (bits of the fp32 result)
+    brute = fg.Registration(c["pct"], c["pcs"], c["bounds"], 0.02, flags=fg.FLAG_BRUTE_FORCE_NN)
+    assert reg.compute_sse_error(R, t).view(np.uint32) == brute.compute_sse_error(R, t).view(np.uint32)
+    brute.close()
+    # ICP from the ground truth converges in a few iterations, does not get worse, and is a fixed point
+    icp = fg.IterativeClosestPoint3D(reg, None, None, 100, 0.0005, R, t)
+    sse1, R1, t1 = icp.run()
+    assert float(sse1) <= sse_gt * (1 + 1e-6) and icp.iterations <= 10
+    icp2 = fg.IterativeClosestPoint3D(reg, None, None, 100, 0.0005, R1, t1)
+    sse2, R2, t2 = icp2.run()
+    assert float(sse2) <= float(sse1) * (1 + 1e-6) and np.allclose(R2, R1, atol=1e-4) and icp2.iterations <= 3
+
+
+def test_full_size_run_schedules_agree(fg, gpu_required):
+    """SERIAL (reference order) and ROUND reach the same optimum on the 40k benchmark pair, default threshold."""
+    tgt, src, R_gt, t_gt = fg.synth.workload("bunny", angle_deg=150.0, min_angle_deg=110.0)
+    res = {}
+    for name, (sched, K) in {"serial": (fg.SCHEDULE_SERIAL, 1), "round": (fg.SCHEDULE_ROUND, 32)}.items():
+        s = fg.FastGoICP(tgt, src, 0.005, 1e-3, schedule=sched, round_width=K)
+        R, t = s.run()
+        res[name] = (R, t, float(s.get_best_error()), s.stats())
+        s.close()
+    (Rs, ts, es, _), (Rr, tr, er, _) = res["serial"], res["round"]
+    assert er == pytest.approx(es, rel=1e-5) and np.allclose(Rs, Rr, atol=1e-5) and np.allclose(ts, tr, atol=1e-5 * max(1.0, float(np.abs(ts).max())))
+    ang = np.degrees(np.arccos(np.clip((np.trace(Rs.astype(np.float64).T @ R_gt) - 1) / 2, -1, 1)))
+    assert ang < 0.5 and np.linalg.norm(ts - t_gt) < 1e-3
