@@ -109,7 +109,7 @@ static int ctx_bounds_multi_sorted(fgoicp_ctx* c, int G, const float* R9, const 
             c->prof_launches++;
             c->prof_subcubes += rows;
         }
-        launch_bounds_sorted(c->d_src, (int)c->ns, c->d_lut, c->geom, c->d_chunk_cen, c->nchunk1, c->d_groups, c->d_subs, rows, c->cell_shift,
+        launch_bounds_sorted(c->d_src, (int)c->ns, c->d_lut, c->d_lut_zp, c->geom, c->d_chunk_cen, c->nchunk1, c->d_groups, c->d_subs, rows, c->cell_shift,
                              c->d_keys, c->d_hist, c->d_cursor, c->d_sorted, c->d_partials1, e0, e1, c->stream);
         launch_bounds_finalize(c->d_partials1, c->nchunk1, rows, c->hd_lb, c->hd_ub, c->stream);
         HIPCHK(hipGetLastError());
@@ -387,6 +387,14 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
             bvh_free(&shifted);
         }
         if (e3 != hipSuccess) { set_error(std::string("LUT build failed: ") + hipGetErrorString(e3)); return fail(e3 == hipErrorOutOfMemory ? FGOICP_ERR_OOM : FGOICP_ERR_HIP); }
+        bool zpair = true;
+        if (const char* e = std::getenv("FGOICP_LUT_ZPAIR")) zpair = std::atoi(e) != 0;
+        if (zpair) {
+            CHK(hipMalloc(&c->d_lut_zp, total * sizeof(float2)));
+            launch_lut_zpair(c->d_lut, g, c->d_lut_zp, c->stream);
+            CHK(hipGetLastError());
+            CHK(hipStreamSynchronize(c->stream));
+        }
     }
     // bounds scratch: P points per thread so that one 32-subcube launch has >= ~2048 blocks
     {
@@ -469,7 +477,7 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& e : c->ev_start) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_stop) if (e) (void)hipEventDestroy(e);
-    (void)hipFree(c->d_src); (void)hipFree(c->d_work); (void)hipFree(c->d_tgt); (void)hipFree(c->d_lut);
+    (void)hipFree(c->d_src); (void)hipFree(c->d_work); (void)hipFree(c->d_tgt); (void)hipFree(c->d_lut); (void)hipFree(c->d_lut_zp);
     (void)hipFree(c->d_partials); (void)hipFree(c->d_min_bits); (void)hipFree(c->d_thr_bits); (void)hipFree(c->d_first_idx);
     (void)hipFree(c->d_bp); (void)hipFree(c->d_bp2); (void)hipFree(c->d_cen);
     if (c->h_cen) (void)hipHostFree(c->h_cen);

@@ -94,10 +94,10 @@ __device__ __forceinline__ float lerp(float p, float q, float w) { return fma_(w
 // lut_search split in two so that a thread can put the gathers of several points in flight before
 // it consumes any of them (memory-level parallelism is what bounds this kernel, not arithmetic).
 struct TexAddr {
-    const float* p;   // first texel (x0, y0, z0) in the padded LUT
+    size_t o;         // element offset of the first texel (x0, y0, z0) in the padded LUT
     float a, b, c;    // interpolation weights
 };
-__device__ __forceinline__ TexAddr lut_address(const float* __restrict__ lut, const LutGeom& g, float qx, float qy, float qz) {
+__device__ __forceinline__ TexAddr lut_address(const LutGeom& g, float qx, float qy, float qz) {
     const float x = (qx + g.off_x) * g.scale;
     const float y = (qy + g.off_y) * g.scale;
     const float z = (qz + g.off_z) * g.scale;
@@ -106,7 +106,7 @@ __device__ __forceinline__ TexAddr lut_address(const float* __restrict__ lut, co
     tex_axis(x, g.dx, g.quantize, ix, t.a);
     tex_axis(y, g.dy, g.quantize, iy, t.b);
     tex_axis(z, g.dz, g.quantize, iz, t.c);
-    t.p = lut + ((size_t)iz * g.py + iy) * (size_t)g.px + ix;
+    t.o = ((size_t)iz * g.py + iy) * (size_t)g.px + ix;
     return t;
 }
 __device__ __forceinline__ float lut_blend(const TexAddr& t, float2u v00, float2u v10, float2u v01, float2u v11) {
@@ -118,9 +118,32 @@ __device__ __forceinline__ float lut_blend(const TexAddr& t, float2u v00, float2
 }
 
 __device__ __forceinline__ float lut_search(const float* __restrict__ lut, const LutGeom& g, float qx, float qy, float qz) {
-    const TexAddr t = lut_address(lut, g, qx, qy, qz);
+    const TexAddr t = lut_address(g, qx, qy, qz);
     const size_t sy = (size_t)g.px, sz = (size_t)g.px * g.py;
-    return lut_blend(t, *(const float2u*)(t.p), *(const float2u*)(t.p + sy), *(const float2u*)(t.p + sz), *(const float2u*)(t.p + sz + sy));
+    const float* p = lut + t.o;
+    return lut_blend(t, *(const float2u*)(p), *(const float2u*)(p + sy), *(const float2u*)(p + sz), *(const float2u*)(p + sz + sy));
+}
+
+// Z-paired copy of the LUT: zp[o] = {T[o], T[o + one z-slice]} as float2, same (padded, x-fastest) indexing.
+// The 2x2x2 footprint of a lookup is then TWO 16-byte gathers — {T[x0,y,z0], T[x0,y,z1], T[x1,y,z0], T[x1,y,z1]}
+// for y = y0 and y0+1 — instead of four 8-byte ones: the bounds kernel is bound by per-lane address
+// processing of divergent gathers, not by bytes (measured 1.6x on the sparse 40k cloud).  Same texels,
+// same blend order -> bit-identical values.
+typedef float float4u __attribute__((ext_vector_type(4), aligned(8)));
+__device__ __forceinline__ void zpair_gather(const float2* __restrict__ zp, const LutGeom& g, const TexAddr& t, float2u& v00, float2u& v10,
+                                             float2u& v01, float2u& v11) {
+    const float4u a = *(const float4u*)(zp + t.o);
+    const float4u b = *(const float4u*)(zp + t.o + (size_t)g.px);
+    v00 = float2u{a.x, a.z};  // (x0, x1) at (y0, z0)
+    v01 = float2u{a.y, a.w};  // (x0, x1) at (y0, z1)
+    v10 = float2u{b.x, b.z};  // (x0, x1) at (y1, z0)
+    v11 = float2u{b.y, b.w};  // (x0, x1) at (y1, z1)
+}
+
+__global__ __launch_bounds__(kBlock) void lut_zpair_kernel(const float* __restrict__ lut, LutGeom g, float2* __restrict__ zp) {
+    const size_t total = (size_t)g.px * g.py * g.pz, sz = (size_t)g.px * g.py;
+    for (size_t n = (size_t)blockIdx.x * kBlock + threadIdx.x; n < total; n += (size_t)gridDim.x * kBlock)
+        zp[n] = make_float2(lut[n], n + sz < total ? lut[n + sz] : lut[n]);  // the last padded slice is never a z0
 }
 
 // XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (each with a private
@@ -158,14 +181,15 @@ __global__ __launch_bounds__(kBlock) void bounds_kernel(const float4* __restrict
     for (int k = 0; k < P; ++k) {
         float rx, ry, rz;
         rotate(a.R, p[k].x, p[k].y, p[k].z, rx, ry, rz);
-        ta[k] = lut_address(lut, g, rx + tn.x, ry + tn.y, rz + tn.z);  // :34, :323-325
+        ta[k] = lut_address(g, rx + tn.x, ry + tn.y, rz + tn.z);  // :34, :323-325
     }
 #pragma unroll
     for (int k = 0; k < P; ++k) {
-        v00[k] = *(const float2u*)(ta[k].p);
-        v10[k] = *(const float2u*)(ta[k].p + sy);
-        v01[k] = *(const float2u*)(ta[k].p + sz);
-        v11[k] = *(const float2u*)(ta[k].p + sz + sy);
+        const float* q = lut + ta[k].o;
+        v00[k] = *(const float2u*)(q);
+        v10[k] = *(const float2u*)(q + sy);
+        v01[k] = *(const float2u*)(q + sz);
+        v11[k] = *(const float2u*)(q + sz + sy);
     }
     // phase 3: blend, bounds, fp64 accumulation
     double acc[2] = {0.0, 0.0};
@@ -262,8 +286,9 @@ __global__ __launch_bounds__(kBlock) void tick_scatter_kernel(const unsigned sho
 // THREADS x P = 256 points per item.  Measured on MI355X (2048 subcubes per launch): 256x1 2.35 / 6.4 TB/s
 // algorithmic (bunny / dragon shape), 128x2 2.45 / 7.6 TB/s (default), 64x4 2.32 TB/s; fewer resident
 // blocks per CU (LDS padding) only hurts — the kernel wants every wave slot and many gathers in flight.
-template <int THREADS, int P>
-__global__ __launch_bounds__(THREADS) void bounds_sorted_kernel(const float4* __restrict__ src, int ns, const float* __restrict__ lut, LutGeom g,
+template <int THREADS, int P, int ZPAIR>
+__global__ __launch_bounds__(THREADS) void bounds_sorted_kernel(const float4* __restrict__ src, int ns, const float* __restrict__ lut,
+                                                                const float2* __restrict__ zp, LutGeom g,
                                                                 const TickGroup* __restrict__ groups, const TickSub* __restrict__ subs,
                                                                 const unsigned* __restrict__ sorted, int nchunk, double2* __restrict__ partials) {
     static_assert(THREADS * P == kBlock, "an item is 256 points");
@@ -284,14 +309,19 @@ __global__ __launch_bounds__(THREADS) void bounds_sorted_kernel(const float4* __
         p[k] = src[i < ns ? i : ns - 1];
         float rx, ry, rz;
         rotate(gr.R, p[k].x, p[k].y, p[k].z, rx, ry, rz);
-        ta[k] = lut_address(lut, g, rx + sb.tx, ry + sb.ty, rz + sb.tz);  // :34, :323-325
+        ta[k] = lut_address(g, rx + sb.tx, ry + sb.ty, rz + sb.tz);  // :34, :323-325
     }
 #pragma unroll
     for (int k = 0; k < P; ++k) {
-        v00[k] = *(const float2u*)(ta[k].p);  // default cache policy: non-temporal loads measured 2x slower here
-        v10[k] = *(const float2u*)(ta[k].p + sy);
-        v01[k] = *(const float2u*)(ta[k].p + sz);
-        v11[k] = *(const float2u*)(ta[k].p + sz + sy);
+        if (ZPAIR) {
+            zpair_gather(zp, g, ta[k], v00[k], v10[k], v01[k], v11[k]);
+        } else {
+            const float* q = lut + ta[k].o;
+            v00[k] = *(const float2u*)(q);  // default cache policy: non-temporal loads measured 2x slower here
+            v10[k] = *(const float2u*)(q + sy);
+            v01[k] = *(const float2u*)(q + sz);
+            v11[k] = *(const float2u*)(q + sz + sy);
+        }
     }
     double acc[2] = {0.0, 0.0};
 #pragma unroll
@@ -912,7 +942,7 @@ void launch_bounds(const float4* src, int ns, const float* lut, const LutGeom& g
     }
 }
 
-void launch_bounds_sorted(const float4* src, int ns, const float* lut, const LutGeom& g, const float4* chunk_cen, int nchunk, const TickGroup* groups,
+void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* zp, const LutGeom& g, const float4* chunk_cen, int nchunk, const TickGroup* groups,
                           const TickSub* subs, int nsub, int cell_shift, unsigned short* keys, unsigned* hist, unsigned* cursor, unsigned* sorted,
                           double2* partials, hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s) {
     const size_t nitems = (size_t)nsub * nchunk;
@@ -924,14 +954,17 @@ void launch_bounds_sorted(const float4* src, int ns, const float* lut, const Lut
     hipLaunchKernelGGL(tick_scan_kernel, dim3(1), dim3(1024), 0, s, hist, cursor);
     hipLaunchKernelGGL(tick_scatter_kernel, dim3(kb), dim3(kBlock), 0, s, keys, nitems, cursor, sorted);
     if (ev_start) (void)hipEventRecord(ev_start, s);
-    static const int lds_pad = [] { const char* e = std::getenv("FGOICP_BOUNDS_LDS_PAD_KB"); return e ? std::atoi(e) * 1024 : 0; }();  // tuning knob
     static const int variant = [] { const char* e = std::getenv("FGOICP_BOUNDS_VARIANT"); return e ? std::atoi(e) : 1; }();  // tuning knob (1 = default)
-    if (variant == 1)
-        hipLaunchKernelGGL((bounds_sorted_kernel<128, 2>), dim3((unsigned)nitems), dim3(128), lds_pad, s, src, ns, lut, g, gp, sp, sorted, nchunk, partials);
-    else if (variant == 2)
-        hipLaunchKernelGGL((bounds_sorted_kernel<64, 4>), dim3((unsigned)nitems), dim3(64), lds_pad, s, src, ns, lut, g, gp, sp, sorted, nchunk, partials);
-    else
-        hipLaunchKernelGGL((bounds_sorted_kernel<256, 1>), dim3((unsigned)nitems), dim3(kBlock), lds_pad, s, src, ns, lut, g, gp, sp, sorted, nchunk, partials);
+    const dim3 grid((unsigned)nitems);
+    if (zp) {
+        if (variant == 0) hipLaunchKernelGGL((bounds_sorted_kernel<256, 1, 1>), grid, dim3(256), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, partials);
+        else if (variant == 2) hipLaunchKernelGGL((bounds_sorted_kernel<64, 4, 1>), grid, dim3(64), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, partials);
+        else hipLaunchKernelGGL((bounds_sorted_kernel<128, 2, 1>), grid, dim3(128), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, partials);
+    } else {
+        if (variant == 0) hipLaunchKernelGGL((bounds_sorted_kernel<256, 1, 0>), grid, dim3(256), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, partials);
+        else if (variant == 2) hipLaunchKernelGGL((bounds_sorted_kernel<64, 4, 0>), grid, dim3(64), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, partials);
+        else hipLaunchKernelGGL((bounds_sorted_kernel<128, 2, 0>), grid, dim3(128), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, partials);
+    }
     if (ev_stop) (void)hipEventRecord(ev_stop, s);
 }
 
@@ -944,6 +977,10 @@ void launch_lut_build(const float4* tgt_shifted, int nt, const LutGeom& g, float
     const size_t per_block = (size_t)kBlock * kLutNodes;
     const unsigned blocks = (unsigned)((total + per_block - 1) / per_block);
     hipLaunchKernelGGL(lut_build_kernel, dim3(blocks), dim3(kBlock), 0, s, tgt_shifted, nt, g, lut_padded);
+}
+
+void launch_lut_zpair(const float* lut_padded, const LutGeom& g, float2* zp, hipStream_t s) {
+    hipLaunchKernelGGL(lut_zpair_kernel, dim3(8192), dim3(kBlock), 0, s, lut_padded, g, zp);
 }
 
 void launch_lut_unpad(const float* lut_padded, const LutGeom& g, float* out, hipStream_t s) {

@@ -58,13 +58,15 @@ struct TickSub {     // one translation node + its rotation node
     int pad_[3];
 };
 constexpr int kTickNumKeys = 1 << 15;
-void launch_bounds_sorted(const float4* src, int ns, const float* lut, const LutGeom& g, const float4* chunk_cen, int nchunk, const TickGroup* groups,
+void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* zpair_or_null, const LutGeom& g, const float4* chunk_cen, int nchunk, const TickGroup* groups,
                           const TickSub* subs, int nsub, int cell_shift, unsigned short* keys, unsigned* hist, unsigned* cursor, unsigned* sorted,
                           double2* partials, hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s);
 // out_lb[i], out_ub[i] = float(sum over chunks), fixed order → bit-reproducible
 void launch_bounds_finalize(const double2* partials, int nchunk, int total, float* out_lb, float* out_ub, hipStream_t s);
 
 void launch_lut_build(const float4* tgt_shifted, int nt, const LutGeom& g, float* lut_padded, hipStream_t s);
+// zp[o] = {lut[o], lut[o + one z-slice]}: the z-paired copy the sorted bounds kernel gathers from (kernels.hip)
+void launch_lut_zpair(const float* lut_padded, const LutGeom& g, float2* zp, hipStream_t s);
 void launch_lut_unpad(const float* lut_padded, const LutGeom& g, float* out, hipStream_t s);
 void launch_lut_search(const float* lut, const LutGeom& g, const float* q_xyz, size_t n, float* out, hipStream_t s);
 
