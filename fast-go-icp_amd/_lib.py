@@ -49,6 +49,8 @@ _SIGS = {
     "fgoicp_bounds_batch": (C.c_int, [C.c_void_p, c_float_p, C.c_float, c_float_p, C.c_int, C.c_int, c_float_p, c_float_p]),
     "fgoicp_bounds_multi": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_int_p, c_int_p, c_float_p, c_float_p,
                                       c_float_p]),
+    "fgoicp_bounds_submit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_float_p, c_float_p, c_int_p, c_int_p, c_float_p]),
+    "fgoicp_bounds_collect": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p]),
     "fgoicp_sse": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_float_p]),
     "fgoicp_icp": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_size_t, C.c_float, c_float_p, c_float_p, c_float_p, c_int_p]),
     "fgoicp_procrustes": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_int_p]),

@@ -62,70 +62,123 @@ TickTiming g_tt;
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }  // namespace
 
-static int ctx_bounds_multi_sorted(fgoicp_ctx* c, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets,
-                                   const float* tn4, float* lb_out, float* ub_out) {
+// Enqueues the window [pos, pos+rows) of a submission on its slot: descriptors -> device, sort the
+// (subcube, chunk) items by LUT cell, one bounds launch, one finalize.  Returns the window end.
+static int tick_enqueue_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl, int G, const float* R9, const float* rot_span, const int* fix_rot,
+                               const int* offsets, const float* tn4, int pos, int* end_out) {
+    const double t0 = g_tt.on ? now_s() : 0;
     int g = 0;
-    const int total = offsets[G];
-    int pos = 0;
-    while (pos < total) {
-        // window: subcubes [pos, end) using at most max_groups rotation nodes
-        const double t0 = g_tt.on ? now_s() : 0;
-        while (g < G && offsets[g + 1] <= pos) ++g;
-        const int g0 = g;
-        int end = pos, ng = 0;
-        for (int gg = g0; gg < G && ng < c->max_groups && end - pos < c->max_subcubes; ++gg, ++ng) {
-            TickGroup& tg = c->h_groups[ng];
-            std::memcpy(tg.R, R9 + 9 * gg, sizeof(tg.R));
-            const float half_angle = rot_span[gg] * kSqrt3 * kPi / 2.0f;  // registration.cu:42
-            tg.sin_half = std::sin(half_angle);
-            tg.fix_rot = fix_rot[gg] ? 1 : 0;
-            tg.pad_ = 0;
-            const int first = std::max(offsets[gg], pos);
-            const int last = std::min(offsets[gg + 1], pos + c->max_subcubes);
-            for (int i = first; i < last; ++i) {
-                TickSub& ts = c->h_subs[i - pos];
-                ts.tx = tn4[4 * (size_t)i]; ts.ty = tn4[4 * (size_t)i + 1]; ts.tz = tn4[4 * (size_t)i + 2]; ts.span = tn4[4 * (size_t)i + 3];
-                ts.group = ng;
-                ts.pad_[0] = ts.pad_[1] = ts.pad_[2] = 0;
-            }
-            end = std::max(end, last);
-            if (last < offsets[gg + 1]) { ++ng; break; }  // window full in the middle of a group
+    while (g < G && offsets[g + 1] <= pos) ++g;
+    int end = pos, ng = 0;
+    for (int gg = g; gg < G && ng < c->max_groups && end - pos < c->max_subcubes; ++gg) {
+        TickGroup& tg = sl.h_groups[ng];
+        std::memcpy(tg.R, R9 + 9 * gg, sizeof(tg.R));
+        const float half_angle = rot_span[gg] * kSqrt3 * kPi / 2.0f;  // registration.cu:42
+        tg.sin_half = std::sin(half_angle);
+        tg.fix_rot = fix_rot[gg] ? 1 : 0;
+        tg.pad_ = 0;
+        const int first = std::max(offsets[gg], pos);
+        const int last = std::min(offsets[gg + 1], pos + c->max_subcubes);
+        for (int i = first; i < last; ++i) {
+            TickSub& ts = sl.h_subs[i - pos];
+            ts.tx = tn4[4 * (size_t)i]; ts.ty = tn4[4 * (size_t)i + 1]; ts.tz = tn4[4 * (size_t)i + 2]; ts.span = tn4[4 * (size_t)i + 3];
+            ts.group = ng;
+            ts.pad_[0] = ts.pad_[1] = ts.pad_[2] = 0;
         }
-        const int rows = end - pos;
-        if (rows <= 0) break;
-        const double t1 = g_tt.on ? now_s() : 0;
-        HIPCHK(hipMemcpyAsync(c->d_groups, c->h_groups, sizeof(TickGroup) * ng, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(c->d_subs, c->h_subs, sizeof(TickSub) * rows, hipMemcpyHostToDevice, c->stream));
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (c->profile) {
-            if (c->ev_used == (int)c->ev_start.size()) {
-                HIPCHK(hipStreamSynchronize(c->stream));
-                int rc = ctx_flush_profile(c);
-                if (rc) return rc;
-            }
-            e0 = c->ev_start[c->ev_used];
-            e1 = c->ev_stop[c->ev_used];
-            c->ev_used++;
-            c->prof_launches++;
-            c->prof_subcubes += rows;
-        }
-        launch_bounds_sorted(c->d_src, (int)c->ns, c->d_lut, c->d_lut_zp, c->geom, c->d_chunk_cen, c->nchunk1, c->d_groups, c->d_subs, rows, c->cell_shift,
-                             c->d_keys, c->d_hist, c->d_cursor, c->d_sorted, c->d_partials1, e0, e1, c->stream);
-        launch_bounds_finalize(c->d_partials1, c->nchunk1, rows, c->hd_lb, c->hd_ub, c->stream);
-        HIPCHK(hipGetLastError());
-        const double t2 = g_tt.on ? now_s() : 0;
-        HIPCHK(hipStreamSynchronize(c->stream));
-        const double t3 = g_tt.on ? now_s() : 0;
-        std::memcpy(lb_out + pos, c->h_lb, sizeof(float) * rows);
-        std::memcpy(ub_out + pos, c->h_ub, sizeof(float) * rows);
-        if (g_tt.on) { g_tt.pack += t1 - t0; g_tt.enqueue += t2 - t1; g_tt.wait += t3 - t2; g_tt.copyout += now_s() - t3; g_tt.ticks++; }
-        if (c->profile) {
+        end = std::max(end, last);
+        ++ng;
+        if (last < offsets[gg + 1]) break;  // window full in the middle of a group
+    }
+    const int rows = end - pos;
+    *end_out = end;
+    if (rows <= 0) return FGOICP_OK;
+    const double t1 = g_tt.on ? now_s() : 0;
+    HIPCHK(hipMemcpyAsync(sl.d_groups, sl.h_groups, sizeof(TickGroup) * ng, hipMemcpyHostToDevice, sl.stream));
+    HIPCHK(hipMemcpyAsync(sl.d_subs, sl.h_subs, sizeof(TickSub) * rows, hipMemcpyHostToDevice, sl.stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profile) {
+        if (c->ev_used == (int)c->ev_start.size()) {  // drain both slots before recycling events
+            HIPCHK(hipStreamSynchronize(c->stream));
             int rc = ctx_flush_profile(c);
             if (rc) return rc;
         }
+        e0 = c->ev_start[c->ev_used];
+        e1 = c->ev_stop[c->ev_used];
+        c->ev_used++;
+        c->prof_launches++;
+        c->prof_subcubes += rows;
+    }
+    launch_bounds_sorted(c->d_src, (int)c->ns, c->d_lut, c->d_lut_zp, c->geom, c->d_chunk_cen, c->nchunk1, sl.d_groups, sl.d_subs, rows, c->cell_shift,
+                         sl.d_keys, sl.d_hist, sl.d_cursor, sl.d_sorted, sl.d_partials, e0, e1, sl.stream);
+    launch_bounds_finalize(sl.d_partials, c->nchunk1, rows, sl.hd_lb, sl.hd_ub, sl.stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(sl.done, sl.stream));
+    sl.win_pos = pos;
+    sl.win_rows = rows;
+    if (g_tt.on) { g_tt.pack += t1 - t0; g_tt.enqueue += now_s() - t1; g_tt.ticks++; }
+    return FGOICP_OK;
+}
+
+static int tick_wait_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
+    const double t2 = g_tt.on ? now_s() : 0;
+    HIPCHK(hipEventSynchronize(sl.done));
+    const double t3 = g_tt.on ? now_s() : 0;
+    std::memcpy(sl.lb.data() + sl.win_pos, sl.h_lb, sizeof(float) * sl.win_rows);
+    std::memcpy(sl.ub.data() + sl.win_pos, sl.h_ub, sizeof(float) * sl.win_rows);
+    if (g_tt.on) { g_tt.wait += t3 - t2; g_tt.copyout += now_s() - t3; }
+    return FGOICP_OK;
+}
+
+// fgoicp_bounds_submit: all windows but the last are completed here, the last one stays in flight.
+int ctx_bounds_submit(fgoicp_ctx* c, int slot, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets,
+                      const float* tn4) {
+    HIPCHK(hipSetDevice(c->device));
+    fgoicp_ctx::TickSlot& sl = c->slots[slot];
+    if (sl.inflight) { set_error("fgoicp_bounds_submit: slot still in flight (collect it first)"); return FGOICP_ERR_INVALID_ARG; }
+    sl.total = offsets[G];
+    sl.lb.resize(sl.total);
+    sl.ub.resize(sl.total);
+    sl.win_rows = 0;
+    int pos = 0;
+    while (pos < sl.total) {
+        int end = pos;
+        int rc = tick_enqueue_window(c, sl, G, R9, rot_span, fix_rot, offsets, tn4, pos, &end);
+        if (rc) return rc;
+        if (end <= pos) break;
         pos = end;
+        if (pos < sl.total) {  // more windows follow: this one has to be drained first (its buffers are reused)
+            rc = tick_wait_window(c, sl);
+            if (rc) return rc;
+            sl.win_rows = 0;
+        }
+    }
+    sl.inflight = true;
+    return FGOICP_OK;
+}
+
+int ctx_bounds_collect(fgoicp_ctx* c, int slot, float* lb_out, float* ub_out) {
+    HIPCHK(hipSetDevice(c->device));
+    fgoicp_ctx::TickSlot& sl = c->slots[slot];
+    if (!sl.inflight) { set_error("fgoicp_bounds_collect: nothing submitted on this slot"); return FGOICP_ERR_INVALID_ARG; }
+    if (sl.win_rows > 0) {
+        int rc = tick_wait_window(c, sl);
+        if (rc) return rc;
+    }
+    sl.inflight = false;
+    std::memcpy(lb_out, sl.lb.data(), sizeof(float) * sl.total);
+    std::memcpy(ub_out, sl.ub.data(), sizeof(float) * sl.total);
+    if (c->profile && !c->slots[0].inflight && !c->slots[1].inflight) {
+        int rc = ctx_flush_profile(c);
+        if (rc) return rc;
     }
     return FGOICP_OK;
+}
+
+static int ctx_bounds_multi_sorted(fgoicp_ctx* c, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets,
+                                   const float* tn4, float* lb_out, float* ub_out) {
+    int rc = ctx_bounds_submit(c, 0, G, R9, rot_span, fix_rot, offsets, tn4);
+    if (rc) return rc;
+    return ctx_bounds_collect(c, 0, lb_out, ub_out);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -435,15 +488,27 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
         CHK(hipMalloc(&c->d_chunk_cen, sizeof(float4) * c->nchunk1));
         CHK(hipMemcpy(c->d_chunk_cen, cen.data(), sizeof(float4) * c->nchunk1, hipMemcpyHostToDevice));
         const size_t max_items = (size_t)c->max_subcubes * c->nchunk1;
-        CHK(hipMalloc(&c->d_groups, sizeof(TickGroup) * c->max_groups));
-        CHK(hipMalloc(&c->d_subs, sizeof(TickSub) * c->max_subcubes));
-        CHK(hipHostMalloc((void**)&c->h_groups, sizeof(TickGroup) * c->max_groups, hipHostMallocDefault));
-        CHK(hipHostMalloc((void**)&c->h_subs, sizeof(TickSub) * c->max_subcubes, hipHostMallocDefault));
-        CHK(hipMalloc(&c->d_keys, sizeof(unsigned short) * max_items));
-        CHK(hipMalloc(&c->d_hist, sizeof(unsigned) * kTickNumKeys));
-        CHK(hipMalloc(&c->d_cursor, sizeof(unsigned) * kTickNumKeys));
-        CHK(hipMalloc(&c->d_sorted, sizeof(unsigned) * max_items));
-        CHK(hipMalloc(&c->d_partials1, sizeof(double2) * max_items));
+        for (int k = 0; k < 2; ++k) {
+            fgoicp_ctx::TickSlot& sl = c->slots[k];
+            sl.stream = c->stream;
+            CHK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+            CHK(hipMalloc(&sl.d_groups, sizeof(TickGroup) * c->max_groups));
+            CHK(hipMalloc(&sl.d_subs, sizeof(TickSub) * c->max_subcubes));
+            CHK(hipHostMalloc((void**)&sl.h_groups, sizeof(TickGroup) * c->max_groups, hipHostMallocDefault));
+            CHK(hipHostMalloc((void**)&sl.h_subs, sizeof(TickSub) * c->max_subcubes, hipHostMallocDefault));
+            CHK(hipMalloc(&sl.d_keys, sizeof(unsigned short) * max_items));
+            CHK(hipMalloc(&sl.d_hist, sizeof(unsigned) * kTickNumKeys));
+            CHK(hipMalloc(&sl.d_cursor, sizeof(unsigned) * kTickNumKeys));
+            CHK(hipMalloc(&sl.d_sorted, sizeof(unsigned) * max_items));
+            CHK(hipMalloc(&sl.d_partials, sizeof(double2) * max_items));
+            if (k == 0) { sl.h_lb = c->h_lb; sl.h_ub = c->h_ub; sl.hd_lb = c->hd_lb; sl.hd_ub = c->hd_ub; }
+            else {
+                CHK(hipHostMalloc((void**)&sl.h_lb, sizeof(float) * c->max_subcubes, hipHostMallocMapped));
+                CHK(hipHostMalloc((void**)&sl.h_ub, sizeof(float) * c->max_subcubes, hipHostMallocMapped));
+                CHK(hipHostGetDevicePointer((void**)&sl.hd_lb, sl.h_lb, 0));
+                CHK(hipHostGetDevicePointer((void**)&sl.hd_ub, sl.h_ub, 0));
+            }
+        }
     }
     // exact-NN / ICP scratch
     CHK(hipMalloc(&c->d_min_bits, sizeof(uint32_t) * ns));
@@ -482,10 +547,17 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
     (void)hipFree(c->d_bp); (void)hipFree(c->d_bp2); (void)hipFree(c->d_cen);
     if (c->h_cen) (void)hipHostFree(c->h_cen);
     bvh_free(&c->bvh_tgt);
-    (void)hipFree(c->d_chunk_cen); (void)hipFree(c->d_groups); (void)hipFree(c->d_subs); (void)hipFree(c->d_keys);
-    (void)hipFree(c->d_hist); (void)hipFree(c->d_cursor); (void)hipFree(c->d_sorted); (void)hipFree(c->d_partials1);
-    if (c->h_groups) (void)hipHostFree(c->h_groups);
-    if (c->h_subs) (void)hipHostFree(c->h_subs);
+    (void)hipFree(c->d_chunk_cen);
+    for (int k = 0; k < 2; ++k) {
+        fgoicp_ctx::TickSlot& sl = c->slots[k];
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        (void)hipFree(sl.d_groups); (void)hipFree(sl.d_subs); (void)hipFree(sl.d_keys); (void)hipFree(sl.d_hist);
+        (void)hipFree(sl.d_cursor); (void)hipFree(sl.d_sorted); (void)hipFree(sl.d_partials);
+        if (sl.h_groups) (void)hipHostFree(sl.h_groups);
+        if (sl.h_subs) (void)hipHostFree(sl.h_subs);
+        if (k == 1 && sl.h_lb) (void)hipHostFree(sl.h_lb);
+        if (k == 1 && sl.h_ub) (void)hipHostFree(sl.h_ub);
+    }
     if (c->h_lb) (void)hipHostFree(c->h_lb);
     if (c->h_ub) (void)hipHostFree(c->h_ub);
     if (c->h_sums) (void)hipHostFree(c->h_sums);
@@ -538,6 +610,22 @@ int fgoicp_bounds_multi(fgoicp_ctx* c, int G, const float* R9, const float* rot_
         if (offsets[g + 1] < offsets[g] || offsets[0] != 0) { set_error("fgoicp_bounds_multi: offsets must start at 0 and be non-decreasing"); return FGOICP_ERR_INVALID_ARG; }
     if (offsets[G] == 0) return FGOICP_OK;
     return ctx_bounds_multi(c, G, R9, rot_span, fix_rot, offsets, tn4, lb_out, ub_out);
+}
+
+int fgoicp_bounds_submit(fgoicp_ctx* c, int slot, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets,
+                         const float* tn4) {
+    if (!c || slot < 0 || slot > 1 || G < 0 || (G > 0 && (!R9 || !rot_span || !fix_rot || !offsets || !tn4))) return FGOICP_ERR_INVALID_ARG;
+    if (!c->sorted_bounds) { set_error("fgoicp_bounds_submit needs the sorted bounds path (FGOICP_BOUNDS_SORTED=0 is set)"); return FGOICP_ERR_INVALID_ARG; }
+    static const int zero[1] = {0};
+    if (G == 0) offsets = zero;
+    for (int g = 0; g < G; ++g)
+        if (offsets[g + 1] < offsets[g] || offsets[0] != 0) { set_error("fgoicp_bounds_submit: offsets must start at 0 and be non-decreasing"); return FGOICP_ERR_INVALID_ARG; }
+    return ctx_bounds_submit(c, slot, G, R9, rot_span, fix_rot, offsets, tn4);
+}
+
+int fgoicp_bounds_collect(fgoicp_ctx* c, int slot, float* lb_out, float* ub_out) {
+    if (!c || slot < 0 || slot > 1) return FGOICP_ERR_INVALID_ARG;
+    return ctx_bounds_collect(c, slot, lb_out, ub_out);
 }
 
 int fgoicp_bounds_batch(fgoicp_ctx* c, const float* R9, float rot_span, const float* tn4, int B, int fix_rot, float* lb_out, float* ub_out) {

@@ -34,15 +34,27 @@ struct fgoicp_ctx {
     float *h_lb = nullptr, *h_ub = nullptr;  // pinned, device-visible result rows
     float *hd_lb = nullptr, *hd_ub = nullptr;
 
-    // locality-sorted whole-tick path (kernels.hip, bounds_sorted_kernel): 256-point chunks
+    // locality-sorted whole-tick path (kernels.hip, bounds_sorted_kernel): 256-point chunks.
+    // Two tick slots: the host prepares / consumes one half of a round's inner BnBs while the device
+    // evaluates the other (fgoicp_bounds_submit / _collect).
+    struct TickSlot {
+        hipStream_t stream = nullptr;            // both slots queue on the context stream: their kernels run back to back, never
+                                                 // concurrently (two sorted kernels at once would thrash each other's L2 neighbourhoods)
+        hipEvent_t done = nullptr;               // recorded behind the slot's last kernel; collect waits on it, not on the stream
+        fgoicp::TickGroup *d_groups = nullptr, *h_groups = nullptr;   // device / pinned staging
+        fgoicp::TickSub *d_subs = nullptr, *h_subs = nullptr;
+        unsigned short* d_keys = nullptr;
+        unsigned *d_hist = nullptr, *d_cursor = nullptr, *d_sorted = nullptr;
+        double2* d_partials = nullptr;           // [max_subcubes][nchunk1]
+        float *h_lb = nullptr, *h_ub = nullptr, *hd_lb = nullptr, *hd_ub = nullptr;  // pinned results of the window in flight
+        std::vector<float> lb, ub;               // results of the whole submission
+        int total = 0, win_pos = 0, win_rows = 0;
+        bool inflight = false;
+    };
     bool sorted_bounds = true;
     int nchunk1 = 0, max_groups = 0, cell_shift = 4;
     float4* d_chunk_cen = nullptr;           // centroid of every chunk (source frame)
-    fgoicp::TickGroup *d_groups = nullptr, *h_groups = nullptr;   // device / pinned staging
-    fgoicp::TickSub *d_subs = nullptr, *h_subs = nullptr;
-    unsigned short* d_keys = nullptr;
-    unsigned *d_hist = nullptr, *d_cursor = nullptr, *d_sorted = nullptr;
-    double2* d_partials1 = nullptr;          // [max_subcubes][nchunk1]
+    TickSlot slots[2];
 
     // exact-NN / ICP scratch
     uint32_t *d_min_bits = nullptr, *d_thr_bits = nullptr, *d_first_idx = nullptr;
@@ -63,6 +75,8 @@ namespace fgoicp {
 void set_error(const std::string& s);
 int ctx_bounds_multi(fgoicp_ctx* c, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets,
                      const float* tn4, float* lb_out, float* ub_out);
+int ctx_bounds_submit(fgoicp_ctx* c, int slot, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets, const float* tn4);
+int ctx_bounds_collect(fgoicp_ctx* c, int slot, float* lb_out, float* ub_out);
 int ctx_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out);
 int ctx_icp(fgoicp_ctx* c, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3,
             int* iters_out);

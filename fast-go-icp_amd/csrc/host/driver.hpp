@@ -3,6 +3,8 @@
 // fgoicp/common.hpp:30-128), written against an abstract operator backend `Ops`:
 //
 //     int    Ops::bounds_multi(G, R9, rot_span, fix_rot, offsets, tnodes4, lb, ub)   (fgoicp_bounds_multi)
+//     int    Ops::bounds_submit(slot, G, ...tnodes4) / bounds_collect(slot, lb, ub)  (fgoicp_bounds_submit / _collect)
+//     bool   Ops::async()                                                            two slots available?
 //     int    Ops::icp(R0, t0, max_iter, thr, &sse, R9, t3, &iters)                   (fgoicp_icp)
 //
 // The product instantiates it with the HIP context only (solver.cpp).  tests/ instantiate it with
@@ -509,50 +511,103 @@ private:
 
     // Advance a set of inner tasks in lock-step: every tick submits the current batch of every live
     // task in ONE operator call (G groups) and hands each task its slice of the results.
-    int run_task_list(std::vector<Task*>& tasks, const std::vector<const RotCube*>& cubes) {
-        std::vector<int> live;
+    // One half of a round's tasks: its current batches packed for one operator submission.
+    struct Half {
+        std::vector<size_t> members;   // indices into tasks
+        std::vector<int> live;         // members with a batch in this submission
         std::vector<float> R9, spans, tn4, lb, ub;
         std::vector<int> fix, offsets;
-        const bool par = tasks.size() >= 8 && pool_->size() > 1;
-        const std::function<void(size_t)> pop_fn = [&](size_t i) {
-            Task& tk = *tasks[i];
+        bool inflight = false;
+    };
+
+    // pops the next batch of every task of the half and packs them; false if none is left
+    bool prepare_half(Half& h, std::vector<Task*>& tasks, const std::vector<const RotCube*>& cubes, bool par) {
+        const std::function<void(size_t)> pop_fn = [&](size_t k) {
+            Task& tk = *tasks[h.members[k]];
             tk.has_batch = false;
             if (tk.done) return;
             if (!tk.next_batch(sse_threshold_)) { tk.done = true; return; }
             tk.has_batch = true;
         };
-        const std::function<void(size_t)> push_fn = [&](size_t k) { tasks[live[k]]->consume(lb.data() + offsets[k], ub.data() + offsets[k]); };
+        if (par) pool_->parallel_for(h.members.size(), pop_fn);
+        else for (size_t k = 0; k < h.members.size(); ++k) pop_fn(k);
+        h.live.clear();
+        h.R9.clear(); h.spans.clear(); h.fix.clear(); h.tn4.clear();
+        h.offsets.assign(1, 0);
+        for (size_t i : h.members) {
+            Task& tk = *tasks[i];
+            if (!tk.has_batch) continue;
+            h.live.push_back((int)i);
+            h.R9.insert(h.R9.end(), cubes[i]->q.R.m, cubes[i]->q.R.m + 9);
+            h.spans.push_back(cubes[i]->span);
+            h.fix.push_back(tk.fix_rot ? 1 : 0);
+            for (const TransCube& c : tk.batch) {
+                h.tn4.push_back(c.t.x); h.tn4.push_back(c.t.y); h.tn4.push_back(c.t.z); h.tn4.push_back(c.span);
+            }
+            h.offsets.push_back((int)(h.tn4.size() / 4));
+        }
+        h.lb.resize(h.tn4.size() / 4);
+        h.ub.resize(h.tn4.size() / 4);
+        return !h.live.empty();
+    }
+    void consume_half(Half& h, std::vector<Task*>& tasks, bool par) {
+        const std::function<void(size_t)> push_fn = [&](size_t k) { tasks[h.live[k]]->consume(h.lb.data() + h.offsets[k], h.ub.data() + h.offsets[k]); };
+        if (par) pool_->parallel_for(h.live.size(), push_fn);
+        else for (size_t k = 0; k < h.live.size(); ++k) push_fn(k);
+        stats_.bounds_calls++;
+        stats_.trans_cubes += h.tn4.size() / 4;
+    }
+
+    // Advance a set of inner tasks to completion.  Every submission carries the current batch of every
+    // live task of a half in ONE operator call (G groups).  With an asynchronous backend the tasks are
+    // split into two halves on two slots: while the device evaluates one half, the host consumes the
+    // results of the other and pops its next batches.  A task's own sequence of batches is the same
+    // either way, so results do not depend on the mode.
+    int run_task_list(std::vector<Task*>& tasks, const std::vector<const RotCube*>& cubes) {
+        const bool par = tasks.size() >= 8 && pool_->size() > 1;
         const bool timing = std::getenv("FGOICP_TIMING") != nullptr;
+        if (tasks.size() >= 4 && ops_.async()) {
+            Half h[2];
+            for (size_t i = 0; i < tasks.size(); ++i) h[i & 1].members.push_back(i);
+            for (int k = 0; k < 2; ++k)
+                if (prepare_half(h[k], tasks, cubes, par)) {
+                    int rc = ops_.bounds_submit(k, (int)h[k].live.size(), h[k].R9.data(), h[k].spans.data(), h[k].fix.data(), h[k].offsets.data(), h[k].tn4.data());
+                    if (rc) return rc;
+                    h[k].inflight = true;
+                }
+            while (h[0].inflight || h[1].inflight)
+                for (int k = 0; k < 2; ++k) {
+                    if (!h[k].inflight) continue;
+                    const auto ta = clock::now();
+                    int rc = ops_.bounds_collect(k, h[k].lb.data(), h[k].ub.data());
+                    if (rc) return rc;
+                    h[k].inflight = false;
+                    const auto tb = clock::now();
+                    consume_half(h[k], tasks, par);
+                    const auto tc = clock::now();
+                    if (prepare_half(h[k], tasks, cubes, par)) {
+                        rc = ops_.bounds_submit(k, (int)h[k].live.size(), h[k].R9.data(), h[k].spans.data(), h[k].fix.data(), h[k].offsets.data(), h[k].tn4.data());
+                        if (rc) return rc;
+                        h[k].inflight = true;
+                    }
+                    if (timing) {
+                        t_ops_ += std::chrono::duration<double>(tb - ta).count();
+                        t_push_ += std::chrono::duration<double>(tc - tb).count();
+                        t_pop_ += std::chrono::duration<double>(clock::now() - tc).count();
+                    }
+                }
+            return kDriverOk;
+        }
+        Half h;
+        for (size_t i = 0; i < tasks.size(); ++i) h.members.push_back(i);
         for (;;) {
             const auto ta = clock::now();
-            if (par) pool_->parallel_for(tasks.size(), pop_fn);
-            else for (size_t i = 0; i < tasks.size(); ++i) pop_fn(i);
-            live.clear();
-            R9.clear(); spans.clear(); fix.clear(); tn4.clear();
-            offsets.assign(1, 0);
-            for (size_t i = 0; i < tasks.size(); ++i) {
-                Task& tk = *tasks[i];
-                if (!tk.has_batch) continue;
-                live.push_back((int)i);
-                R9.insert(R9.end(), cubes[i]->q.R.m, cubes[i]->q.R.m + 9);
-                spans.push_back(cubes[i]->span);
-                fix.push_back(tk.fix_rot ? 1 : 0);
-                for (const TransCube& c : tk.batch) {
-                    tn4.push_back(c.t.x); tn4.push_back(c.t.y); tn4.push_back(c.t.z); tn4.push_back(c.span);
-                }
-                offsets.push_back((int)(tn4.size() / 4));
-            }
-            if (live.empty()) return kDriverOk;
-            lb.resize(tn4.size() / 4);
-            ub.resize(tn4.size() / 4);
+            if (!prepare_half(h, tasks, cubes, par)) return kDriverOk;
             const auto tb = clock::now();
-            int rc = ops_.bounds_multi((int)live.size(), R9.data(), spans.data(), fix.data(), offsets.data(), tn4.data(), lb.data(), ub.data());
+            int rc = ops_.bounds_multi((int)h.live.size(), h.R9.data(), h.spans.data(), h.fix.data(), h.offsets.data(), h.tn4.data(), h.lb.data(), h.ub.data());
             if (rc) return rc;
-            stats_.bounds_calls++;
-            stats_.trans_cubes += tn4.size() / 4;
             const auto tc = clock::now();
-            if (par) pool_->parallel_for(live.size(), push_fn);
-            else for (size_t k = 0; k < live.size(); ++k) push_fn(k);
+            consume_half(h, tasks, par);
             if (timing) {
                 t_pop_ += std::chrono::duration<double>(tb - ta).count();
                 t_ops_ += std::chrono::duration<double>(tc - tb).count();

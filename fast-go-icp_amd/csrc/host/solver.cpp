@@ -1,6 +1,7 @@
 // Driver-level C ABI: icp::FastGoICP (reference fgoicp/fgoicp.hpp:13-43) over the HIP operator
 // context.  The driver template is instantiated with the HIP backend ONLY — there is no CPU
 // backend in this library.
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -13,14 +14,20 @@
 namespace fgoicp {
 
 struct HipOps {
-    fgoicp_ctx* ctx;
+    fgoicp_ctx* ctx = nullptr;
     int bounds_multi(int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets, const float* tn4, float* lb,
                      float* ub) {
         return ctx_bounds_multi(ctx, G, R9, rot_span, fix_rot, offsets, tn4, lb, ub);
     }
+    int bounds_submit(int slot, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets, const float* tn4) {
+        return ctx_bounds_submit(ctx, slot, G, R9, rot_span, fix_rot, offsets, tn4);
+    }
+    int bounds_collect(int slot, float* lb, float* ub) { return ctx_bounds_collect(ctx, slot, lb, ub); }
+    bool async() const { return ctx->sorted_bounds && pipeline; }
     int icp(const float* R0, const float* t0, size_t max_iter, float thr, float* sse, float* R9, float* t3, int* iters) {
         return ctx_icp(ctx, R0, t0, max_iter, thr, sse, R9, t3, iters);
     }
+    bool pipeline = std::getenv("FGOICP_PIPELINE") ? std::atoi(std::getenv("FGOICP_PIPELINE")) != 0 : true;  // tuning knob
 };
 
 }  // namespace fgoicp
@@ -35,7 +42,7 @@ struct fgoicp_solver {
     float scaling_factor = 1.f;
     float bounds6[6] = {0, 0, 0, 0, 0, 0};
     fgoicp_ctx* ctx = nullptr;  // "registration"
-    HipOps ops{nullptr};
+    HipOps ops;
     std::unique_ptr<GoIcpDriver<HipOps>> driver;
     fgoicp_exchange ex{};
     bool has_ex = false;

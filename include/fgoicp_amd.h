@@ -87,6 +87,16 @@ int fgoicp_bounds_batch(fgoicp_ctx* ctx, const float* R9, float rot_span, const 
 int fgoicp_bounds_multi(fgoicp_ctx* ctx, int G, const float* R9, const float* rot_span, const int* fix_rot,
                         const int* offsets, const float* tnodes4, float* lb_out, float* ub_out);
 
+/*
+ * Asynchronous form of fgoicp_bounds_multi on one of two slots (0, 1), each with its own buffers (the
+ * kernels of both queue on the context's stream and run back to back): submit returns once the work is queued, collect waits for it and returns the bounds in
+ * submission order.  Lets the host prepare the next submission of one slot while the device works on
+ * the other.  A slot must be collected before it is submitted again.
+ */
+int fgoicp_bounds_submit(fgoicp_ctx* ctx, int slot, int G, const float* R9, const float* rot_span, const int* fix_rot,
+                         const int* offsets, const float* tnodes4);
+int fgoicp_bounds_collect(fgoicp_ctx* ctx, int slot, float* lb_out, float* ub_out);
+
 /* Replaces float Registration::compute_sse_error(glm::mat3 R, glm::vec3 t)
  * (registration.hpp:96, registration.cu:62-86; kernels :14-25, :154-174): exact nearest
  * neighbour SSE of R*src + t against the target. */

@@ -14,9 +14,9 @@ using namespace fgoicp;
 
 namespace {
 struct OracleOps {
-    const orc::Registration* reg;
-    const orc::PointCloud* pct;
-    const orc::PointCloud* pcs;
+    const orc::Registration* reg = nullptr;
+    const orc::PointCloud* pct = nullptr;
+    const orc::PointCloud* pcs = nullptr;
     int bounds_multi(int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets, const float* tn4, float* lb,
                      float* ub) {
         for (int g = 0; g < G; ++g) {
@@ -27,6 +27,20 @@ struct OracleOps {
             auto [l, u] = reg->compute_sse_error(rn, tns, fix_rot[g] != 0);
             for (size_t k = 0; k < tns.size(); ++k) { lb[offsets[g] + k] = l[k]; ub[offsets[g] + k] = u[k]; }
         }
+        return 0;
+    }
+    // "asynchronous" slots for the pipelined driver path: evaluated at submit, handed out at collect
+    std::vector<float> slot_lb[2], slot_ub[2];
+    bool use_async = false;
+    bool async() const { return use_async; }
+    int bounds_submit(int slot, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets, const float* tn4) {
+        slot_lb[slot].assign(offsets[G], 0.f);
+        slot_ub[slot].assign(offsets[G], 0.f);
+        return bounds_multi(G, R9, rot_span, fix_rot, offsets, tn4, slot_lb[slot].data(), slot_ub[slot].data());
+    }
+    int bounds_collect(int slot, float* lb, float* ub) {
+        std::memcpy(lb, slot_lb[slot].data(), slot_lb[slot].size() * sizeof(float));
+        std::memcpy(ub, slot_ub[slot].data(), slot_ub[slot].size() * sizeof(float));
         return 0;
     }
     int icp(const float* R0, const float* t0, size_t max_iter, float thr, float* sse, float* R9, float* t3, int* iters) {
@@ -73,7 +87,9 @@ void* harness_create(const float* tgt, size_t nt, const float* src, size_t ns, f
     std::memcpy(h->opcs.data(), h->pcs.data(), sizeof(Vec3f) * ns);
     orc::Bounds b{std::make_pair(h->bounds6[0], h->bounds6[1]), std::make_pair(h->bounds6[2], h->bounds6[3]), std::make_pair(h->bounds6[4], h->bounds6[5])};
     h->reg.reset(new orc::Registration(h->opct, h->opcs, b, lut_res));
-    h->ops = OracleOps{h->reg.get(), &h->opct, &h->opcs};
+    h->ops.reg = h->reg.get(); h->ops.pct = &h->opct; h->ops.pcs = &h->opcs;
+    h->ops.use_async = schedule >= 2;  // schedule 2 = ROUND with the two-slot pipelined task loop
+    if (schedule >= 2) schedule = 1;
     h->drv.reset(new GoIcpDriver<OracleOps>(h->ops, ns, mse_thr, schedule, round_width));
     return h;
 }

@@ -337,3 +337,42 @@ def test_full_size_run_schedules_agree(fg, gpu_required):
     assert er == pytest.approx(es, rel=1e-5) and np.allclose(Rs, Rr, atol=1e-5) and np.allclose(ts, tr, atol=1e-5 * max(1.0, float(np.abs(ts).max())))
     ang = np.degrees(np.arccos(np.clip((np.trace(Rs.astype(np.float64).T @ R_gt) - 1) / 2, -1, 1)))
     assert ang < 0.5 and np.linalg.norm(ts - t_gt) < 1e-3
+
+
+def test_submit_collect_two_slots_equal_synchronous_call(fg, tiny_case, gpu_required):
+    """fgoicp_bounds_submit / _collect on both slots at once give the bounds of the synchronous call."""
+    import ctypes as C
+    from fgoicp_amd import _lib
+    from fgoicp_amd.registration import _fp
+    c = tiny_case
+    reg = fg.Registration(c["pct"], c["pcs"], c["bounds"], c["res"])
+    rng = np.random.default_rng(11)
+    lib = reg._lib
+    subs = []
+    for slot in (0, 1):
+        nodes = [fg.RotNode(*rng.uniform(-0.4, 0.4, 3), 0.125) for _ in range(6 + slot)]
+        groups = [_tnodes(rng, int(rng.integers(1, 900)), 0.25) for _ in nodes]  # slot 1 exceeds one window (4096)
+        fixes = [bool(i % 2) for i in range(len(nodes))]
+        Rg = np.concatenate([fg.to_glm(n.q.R) for n in nodes]).astype(np.float32)
+        spans = np.array([n.span for n in nodes], np.float32)
+        fr = np.array([int(f) for f in fixes], np.int32)
+        offs = np.zeros(len(nodes) + 1, np.int32); offs[1:] = np.cumsum([len(g) for g in groups])
+        tn = np.ascontiguousarray(np.concatenate(groups))
+        subs.append((nodes, groups, fixes, Rg, spans, fr, offs, tn))
+        _lib.check(lib.fgoicp_bounds_submit(reg._h, slot, len(nodes), _fp(Rg), _fp(spans), fr.ctypes.data_as(_lib.c_int_p),
+                                            offs.ctypes.data_as(_lib.c_int_p), _fp(tn)), "fgoicp_bounds_submit")
+    # a busy slot refuses a second submission
+    assert lib.fgoicp_bounds_submit(reg._h, 0, 0, None, None, None, None, None) != 0
+    outs = []
+    for slot in (1, 0):
+        n = int(subs[slot][6][-1])
+        lb = np.empty(n, np.float32); ub = np.empty(n, np.float32)
+        _lib.check(lib.fgoicp_bounds_collect(reg._h, slot, _fp(lb), _fp(ub)), "fgoicp_bounds_collect")
+        outs.append((slot, lb, ub))
+    assert lib.fgoicp_bounds_collect(reg._h, 0, _fp(lb), _fp(ub)) != 0  # nothing in flight any more
+    for slot, lb, ub in outs:
+        nodes, groups, fixes, *_ , offs, tn = subs[slot]
+        ref = reg.compute_bounds_multi([n.q.R for n in nodes], [n.span for n in nodes], fixes, groups)
+        for g, (lbr, ubr) in enumerate(ref):
+            assert np.array_equal(lb[offs[g]:offs[g + 1]], lbr) and np.array_equal(ub[offs[g]:offs[g + 1]], ubr)
+    reg.close()
