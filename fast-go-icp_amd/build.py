@@ -24,7 +24,8 @@ SOURCES = [
 CLI_SOURCES = [os.path.join(CSRC, "cli", "main.cpp")]
 
 # -ffp-contract=off: the arithmetic contract with oracle/ spells out every fma (kernels.hip header)
-COMMON_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+EXTRA = os.environ.get("FGOICP_EXTRA_CXXFLAGS", "").split()
+COMMON_FLAGS = [*EXTRA, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
                 "-I" + os.path.join(REPO, "include")]
 
 

@@ -1,0 +1,110 @@
+"""GPU: degenerate and tiny inputs through the C ABI — every case must give the oracle's answer or a
+loud error, never a fault (the reference tests none of these; they are the domain's edge cases:
+single points, duplicates, coplanar / collinear clouds, queries far outside the LUT, odd sizes)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+B3 = np.array([[-1, 1]] * 3, f32)
+
+
+def _cmp_ops(fg, oracle, tgt, src, bounds, res, seed=0):
+    hip = fg.Registration(tgt, src, bounds, res)
+    orc = oracle.Registration(tgt, src, bounds, res)
+    assert np.array_equal(hip.lut_read().view(np.uint32), orc.lut_get().view(np.uint32))
+    rng = np.random.default_rng(seed)
+    rn = fg.RotNode(0.2, -0.1, 0.3, 0.25)
+    tn = np.concatenate([rng.uniform(-0.5, 0.5, (9, 3)), rng.choice([1.0, 0.25, 0.0625], (9, 1))], 1).astype(f32)
+    for fix in (True, False):
+        lb, ub = hip.compute_sse_error(rn, tn, fix)
+        lbo, ubo = orc.compute_bounds(rn.q.R, rn.span, tn, fix)
+        assert np.allclose(ub, ubo, rtol=1e-6, atol=1e-12) and np.allclose(lb, lbo, rtol=1e-6, atol=1e-6 * max(float(ubo.max()), 1e-12))
+    R = fg.synth.random_rotation(rng, 40.0).astype(f32)
+    t = rng.uniform(-0.2, 0.2, 3).astype(f32)
+    a, b = float(hip.compute_sse_error(R, t)), float(orc.compute_sse_error(R, t))
+    assert a == pytest.approx(b, rel=1e-6, abs=1e-12)
+    w = (src @ R.T + t).astype(f32)
+    Rh, th, cen, ABt, idx = hip.procrustes(w)
+    Ro, to, ceno, ABto, idxo = orc.procrustes(w)
+    assert np.array_equal(idx, idxo)
+    assert np.allclose(cen, ceno, rtol=1e-6, atol=1e-7)
+    sse, Ri, ti = fg.IterativeClosestPoint3D(hip, None, None, 20, 0.005, R, t).run()
+    sse_o, Ri_o, ti_o, it_o = orc.icp(R, t, 20, 0.005)
+    assert float(sse) == pytest.approx(float(sse_o), rel=1e-5, abs=1e-10)
+    hip.close()
+    return Rh, Ro
+
+
+@pytest.mark.parametrize("nt,ns", [(1, 1), (2, 3), (3, 1), (33, 65), (257, 511), (1000, 1)])
+def test_tiny_and_odd_sizes(fg, oracle, gpu_required, nt, ns):
+    rng = np.random.default_rng(nt * 1000 + ns)
+    tgt = rng.uniform(-0.8, 0.8, (nt, 3)).astype(f32)
+    src = rng.uniform(-0.8, 0.8, (ns, 3)).astype(f32)
+    _cmp_ops(fg, oracle, tgt, src, B3, 0.25)
+
+
+def test_duplicate_points_and_exact_ties(fg, oracle, gpu_required):
+    rng = np.random.default_rng(3)
+    base = rng.uniform(-0.7, 0.7, (40, 3)).astype(f32)
+    tgt = np.concatenate([base, base, base[::-1]])          # every target three times
+    src = np.concatenate([base[:20], base[:20]])            # sources sit exactly ON targets, twice each
+    _cmp_ops(fg, oracle, tgt, src, B3, 0.2)
+
+
+def test_coplanar_and_collinear_clouds(fg, oracle, gpu_required):
+    """Rank-deficient cross-covariance: the SVD-based rotation must still be a proper rotation."""
+    rng = np.random.default_rng(4)
+    plane = np.concatenate([rng.uniform(-0.8, 0.8, (200, 2)), np.full((200, 1), 0.1)], 1).astype(f32)
+    bounds = np.array([[-1, 1], [-1, 1], [-0.2, 0.4]], f32)
+    Rh, Ro = _cmp_ops(fg, oracle, plane, plane[:150].copy(), bounds, 0.1)
+    for R in (Rh, Ro):
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-4) and np.linalg.det(R.astype(np.float64)) == pytest.approx(1.0, abs=1e-4)
+    line = np.stack([np.linspace(-0.8, 0.8, 120), np.full(120, 0.05), np.full(120, -0.05)], 1).astype(f32)
+    bounds = np.array([[-1, 1], [-0.2, 0.2], [-0.2, 0.2]], f32)
+    Rh, Ro = _cmp_ops(fg, oracle, line, line[10:90].copy(), bounds, 0.05)
+    assert np.allclose(Rh @ Rh.T, np.eye(3), atol=1e-4) and np.linalg.det(Rh.astype(np.float64)) == pytest.approx(1.0, abs=1e-4)
+
+
+def test_queries_far_outside_the_lut(fg, oracle, gpu_required):
+    rng = np.random.default_rng(5)
+    tgt = rng.uniform(-0.3, 0.3, (500, 3)).astype(f32)
+    src = rng.uniform(-0.3, 0.3, (300, 3)).astype(f32)
+    bounds = np.array([[-0.3, 0.3]] * 3, f32)
+    hip = fg.Registration(tgt, src, bounds, 0.05)
+    orc = oracle.Registration(tgt, src, bounds, 0.05)
+    for shift in (5.0, 1e3, 1e6):
+        t = np.array([shift, -shift, 0.5 * shift], f32)
+        a, b = float(hip.compute_sse_error(np.eye(3, dtype=f32), t)), float(orc.compute_sse_error(np.eye(3, dtype=f32), t))
+        assert a == pytest.approx(b, rel=1e-6)
+        tn = np.array([[shift, 0, 0, 0.5], [0, -shift, 0, 0.0625]], f32)
+        lb, ub = hip.compute_sse_error(fg.RotNode(0, 0, 0, 0.5), tn, True)
+        lbo, ubo = orc.compute_bounds(np.eye(3, dtype=f32), 0.5, tn, True)
+        assert np.allclose(ub, ubo, rtol=1e-6) and np.allclose(lb, lbo, rtol=1e-6)
+    hip.close()
+
+
+def test_degenerate_inputs_fail_loudly(fg, gpu_required):
+    pts = np.random.default_rng(6).uniform(-1, 1, (8, 3)).astype(f32)
+    with pytest.raises(fg.FgoicpError):   # zero-extent axis: LUT dimension 0 (the reference would allocate an empty texture)
+        fg.Registration(pts, pts, np.array([[-1, 1], [0.5, 0.5], [-1, 1]], f32), 0.1)
+    with pytest.raises(fg.FgoicpError):
+        fg.Registration(pts[:0], pts, B3, 0.1)
+    with pytest.raises(fg.FgoicpError):
+        fg.Registration(pts, pts, B3, 0.0)
+    with pytest.raises(fg.FgoicpError):   # absurd resolution: dims beyond the supported range
+        fg.Registration(pts, pts, B3, 1e-5)
+
+
+def test_full_run_on_tiny_and_identical_clouds(fg, oracle, gpu_required):
+    rng = np.random.default_rng(7)
+    pts = rng.uniform(-0.5, 0.5, (64, 3)).astype(f32)
+    for sched in (fg.SCHEDULE_SERIAL, fg.SCHEDULE_ROUND):
+        s = fg.FastGoICP(pts, pts.copy(), 0.05, 1e-3, schedule=sched, round_width=2)
+        R, t = s.run()
+        assert np.allclose(R, np.eye(3), atol=1e-5) and np.allclose(t, 0, atol=1e-5) and float(s.get_best_error()) < 1e-8
+        st = s.stats()
+        assert st["rot_cubes"] == 0 and st["icp_runs"] == 2   # initial ICP solves it; the BnB stops at the root (fgoicp.cpp:44)
+        s.close()
+    o = oracle.FastGoICP(pts, pts.copy(), 0.05, 1e-3).run()
+    assert o["stats"]["rot_cubes"] == 0
