@@ -17,7 +17,7 @@ class Exchange(C.Structure):
 
 
 class SolverOpts(C.Structure):
-    _fields_ = [("schedule", C.c_int), ("round_width", C.c_int), ("ctx_flags", C.c_uint), ("device", C.c_int)]
+    _fields_ = [("schedule", C.c_int), ("round_width", C.c_int), ("ctx_flags", C.c_uint), ("device", C.c_int), ("trim_fraction", C.c_float)]
 
 
 class RunStats(C.Structure):
@@ -54,6 +54,7 @@ _SIGS = {
     "fgoicp_sse": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_float_p]),
     "fgoicp_icp": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_size_t, C.c_float, c_float_p, c_float_p, c_float_p, c_int_p]),
     "fgoicp_procrustes": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_int_p]),
+    "fgoicp_ctx_set_inliers": (C.c_int, [C.c_void_p, C.c_size_t]),
     "fgoicp_ctx_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
     "fgoicp_ctx_set_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "fgoicp_ctx_ns": (C.c_size_t, [C.c_void_p]),

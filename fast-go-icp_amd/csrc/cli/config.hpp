@@ -117,6 +117,7 @@ struct Config {
         long long seed = -1;       // < 0: std::random_device, as the reference (utilities.hpp:149-150)
         std::string schedule = "serial";
         int round_width = 1;
+        float trim_fraction = 0.0f;  // EXTENSION: > 0 enables trimmed Go-ICP; `trim` itself stays parsed-and-ignored as upstream
     } params;
 
     explicit Config(const std::string& toml_filepath) {
@@ -151,6 +152,7 @@ struct Config {
         io.source = str("io", "source", "");
         io.output = str("io", "output", "");                // declared in test/bunny.toml:10, unparsed upstream
         io.visualization = str("io", "visualization", "");  // declared in test/bunny.toml:11, unparsed upstream
+        auto clampf0 = [](float x) { return x < 0.0f ? 0.0f : (x > 0.9f ? 0.9f : x); };
         if (tbl.count("params")) {
             params.trim = boolean("params", "trim", false);
             params.target_subsample = (float)num("params", "target_subsample", 1.0);
@@ -160,6 +162,7 @@ struct Config {
             params.seed = (long long)num("params", "seed", -1);
             params.schedule = str("params", "schedule", "serial");
             params.round_width = (int)num("params", "round_width", 1);
+            params.trim_fraction = clampf0((float)num("params", "trim_fraction", 0.0));
             auto clampf = [](float x, float lo, float hi) { return x < hi ? (x > lo ? x : lo) : hi; };
             params.target_subsample = clampf(params.target_subsample, 1e-5f, 1.0f);  // utilities.hpp:101-104
             params.source_subsample = clampf(params.source_subsample, 1e-5f, 1.0f);

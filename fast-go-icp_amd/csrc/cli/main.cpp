@@ -47,7 +47,7 @@ int main(int argc, char* argv[]) {
 
     const int schedule = config.params.schedule == "round" ? FGOICP_SCHEDULE_ROUND : FGOICP_SCHEDULE_SERIAL;
     icp::FastGoICP fgoicp(std::move(pct), std::move(pcs), config.params.lut_resolution, config.params.mse_threshold, schedule,
-                          config.params.round_width);
+                          config.params.round_width, 0, config.params.trim_fraction);
 
     auto start = std::chrono::high_resolution_clock::now();
     auto [R, t] = fgoicp.run();

@@ -69,8 +69,9 @@ static int tick_enqueue_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl, int G, c
     const double t0 = g_tt.on ? now_s() : 0;
     int g = 0;
     while (g < G && offsets[g + 1] <= pos) ++g;
+    const int cap = c->inliers ? std::min(c->max_subcubes, c->vals_rows) : c->max_subcubes;  // subcubes per window
     int end = pos, ng = 0;
-    for (int gg = g; gg < G && ng < c->max_groups && end - pos < c->max_subcubes; ++gg) {
+    for (int gg = g; gg < G && ng < c->max_groups && end - pos < cap; ++gg) {
         TickGroup& tg = sl.h_groups[ng];
         std::memcpy(tg.R, R9 + 9 * gg, sizeof(tg.R));
         const float half_angle = rot_span[gg] * kSqrt3 * kPi / 2.0f;  // registration.cu:42
@@ -78,7 +79,7 @@ static int tick_enqueue_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl, int G, c
         tg.fix_rot = fix_rot[gg] ? 1 : 0;
         tg.pad_ = 0;
         const int first = std::max(offsets[gg], pos);
-        const int last = std::min(offsets[gg + 1], pos + c->max_subcubes);
+        const int last = std::min(offsets[gg + 1], pos + cap);
         for (int i = first; i < last; ++i) {
             TickSub& ts = sl.h_subs[i - pos];
             ts.tx = tn4[4 * (size_t)i]; ts.ty = tn4[4 * (size_t)i + 1]; ts.tz = tn4[4 * (size_t)i + 2]; ts.span = tn4[4 * (size_t)i + 3];
@@ -109,8 +110,11 @@ static int tick_enqueue_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl, int G, c
         c->prof_subcubes += rows;
     }
     launch_bounds_sorted(c->d_src, (int)c->ns, c->d_lut, c->d_lut_zp, c->geom, c->d_chunk_cen, c->nchunk1, sl.d_groups, sl.d_subs, rows, c->cell_shift,
-                         sl.d_keys, sl.d_hist, sl.d_cursor, sl.d_sorted, sl.d_partials, e0, e1, sl.stream);
-    launch_bounds_finalize(sl.d_partials, c->nchunk1, rows, sl.hd_lb, sl.hd_ub, sl.stream);
+                         sl.d_keys, sl.d_hist, sl.d_cursor, sl.d_sorted, sl.d_partials, c->inliers ? sl.d_vals : nullptr, e0, e1, sl.stream);
+    if (c->inliers)  // trimmed: the k smallest ub terms (column 0) and the k smallest lb terms (column 1) of every subcube
+        launch_trim_select(reinterpret_cast<const float*>(sl.d_vals), 2 * c->ns, 2, (int)c->ns, (int)c->inliers, rows, sl.hd_ub, sl.hd_lb, nullptr, sl.stream);
+    else
+        launch_bounds_finalize(sl.d_partials, c->nchunk1, rows, sl.hd_lb, sl.hd_ub, sl.stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(sl.done, sl.stream));
     sl.win_pos = pos;
@@ -188,6 +192,7 @@ int ctx_bounds_multi(fgoicp_ctx* c, int G, const float* R9, const float* rot_spa
                      const float* tn4, float* lb_out, float* ub_out) {
     HIPCHK(hipSetDevice(c->device));
     if (c->sorted_bounds) return ctx_bounds_multi_sorted(c, G, R9, rot_span, fix_rot, offsets, tn4, lb_out, ub_out);
+    if (c->inliers) { set_error("trimmed bounds need the sorted bounds path (FGOICP_BOUNDS_SORTED=0 is set)"); return FGOICP_ERR_INVALID_ARG; }
     struct Piece { int g, pos, B; };
     std::vector<Piece> pieces;
     for (int g = 0; g < G; ++g)
@@ -250,6 +255,13 @@ int ctx_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out) {
     } else {
         launch_nn_scan(c->d_src, ns, c->bvh_tgt.view(), c->d_lut, c->geom, R9, t3, 1, 0, c->d_min_bits, c->stream);
     }
+    if (c->inliers) {  // trimmed SSE: the k smallest nearest-neighbour terms
+        launch_trim_select(reinterpret_cast<const float*>(c->d_min_bits), 0, 1, ns, (int)c->inliers, 1, c->hd_trim, nullptr, nullptr, c->stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));
+        *sse_out = c->h_trim[0];
+        return FGOICP_OK;
+    }
     const int nb = reduce_blocks_for(ns);
     launch_sum_f32_as_f64(c->d_min_bits, ns, c->d_bp, nb, c->stream);
     launch_sum_partials(c->d_bp, nb, 1, c->hd_sums, c->stream);
@@ -273,9 +285,16 @@ int ctx_procrustes_device(fgoicp_ctx* c, Mat3f* R_out, Vec3f* t_out, float* cent
         launch_nn_scan(c->d_work, ns, c->bvh_tgt.view(), c->d_lut, c->geom, nullptr, nullptr, 0, 1, c->d_first_idx, c->stream);
     }
     const int nb = reduce_blocks_for(ns);
-    launch_icp_sums(c->d_work, c->d_tgt, c->d_first_idx, ns, nt, c->d_bp, nb, c->stream);
-    launch_icp_centroids(c->d_bp, nb, ns, c->d_cen, c->hd_cen, c->stream);  // icp3d.cu:152-156, no host round trip
-    launch_icp_cov(c->d_work, c->d_tgt, c->d_first_idx, ns, nt, c->d_cen, c->d_bp2, nb, c->stream);
+    const unsigned char* use = nullptr;
+    int ncount = ns;
+    if (c->inliers) {  // trimmed ICP: only the k closest correspondences enter the Procrustes sums
+        launch_icp_inliers(c->d_work, c->d_tgt, c->d_first_idx, ns, nt, (int)c->inliers, c->d_d2, c->d_sel, c->d_eq, c->d_slot_of_orig, c->d_use, c->stream);
+        use = c->d_use;
+        ncount = (int)c->inliers;
+    }
+    launch_icp_sums(c->d_work, c->d_tgt, c->d_first_idx, ns, nt, use, c->d_bp, nb, c->stream);
+    launch_icp_centroids(c->d_bp, nb, ncount, c->d_cen, c->hd_cen, c->stream);  // icp3d.cu:152-156, no host round trip
+    launch_icp_cov(c->d_work, c->d_tgt, c->d_first_idx, ns, nt, c->d_cen, use, c->d_bp2, nb, c->stream);
     launch_sum_partials(c->d_bp2, nb, 9, c->hd_sums, c->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -330,6 +349,33 @@ int ctx_icp(fgoicp_ctx* c, const float* R0, const float* t0, size_t max_iter, fl
     std::memcpy(R_out9, Ro.m, sizeof(Ro.m));
     t_out3[0] = to.x; t_out3[1] = to.y; t_out3[2] = to.z;
     if (iters_out) *iters_out = iters;
+    return FGOICP_OK;
+}
+
+// EXTENSION: trimmed Go-ICP.  k = 0 (or k >= ns) switches trimming off.
+int ctx_set_inliers(fgoicp_ctx* c, size_t k) {
+    HIPCHK(hipSetDevice(c->device));
+    if (k >= c->ns) k = 0;
+    if (k && !c->sorted_bounds) { set_error("trimming needs the sorted bounds path (FGOICP_BOUNDS_SORTED=0 is set)"); return FGOICP_ERR_INVALID_ARG; }
+    if (c->slots[0].inflight || c->slots[1].inflight) { set_error("fgoicp_ctx_set_inliers: a bounds submission is in flight"); return FGOICP_ERR_INVALID_ARG; }
+    if (k && !c->d_use) {
+        const size_t budget = (size_t)3 << 29;  // 1.5 GiB of per-point terms per slot
+        size_t rows = budget / (sizeof(float2) * c->ns);
+        rows = std::max<size_t>(1, std::min<size_t>(rows, (size_t)c->max_subcubes));
+        c->vals_rows = (int)rows;
+        for (auto& sl : c->slots) HIPCHK(hipMalloc(&sl.d_vals, sizeof(float2) * c->ns * rows));
+        HIPCHK(hipMalloc(&c->d_d2, sizeof(float) * c->ns));
+        HIPCHK(hipMalloc(&c->d_sel, sizeof(uint32_t) * 8));
+        HIPCHK(hipMalloc(&c->d_eq, sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&c->d_use, c->ns));
+        HIPCHK(hipMalloc(&c->d_slot_of_orig, sizeof(uint32_t) * c->ns));
+        std::vector<uint32_t> inv(c->ns);
+        for (size_t i = 0; i < c->ns; ++i) inv[c->perm[i]] = (uint32_t)i;
+        HIPCHK(hipMemcpy(c->d_slot_of_orig, inv.data(), sizeof(uint32_t) * c->ns, hipMemcpyHostToDevice));
+        HIPCHK(hipHostMalloc((void**)&c->h_trim, sizeof(float) * 4, hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer((void**)&c->hd_trim, c->h_trim, 0));
+    }
+    c->inliers = k;
     return FGOICP_OK;
 }
 
@@ -548,9 +594,12 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
     if (c->h_cen) (void)hipHostFree(c->h_cen);
     bvh_free(&c->bvh_tgt);
     (void)hipFree(c->d_chunk_cen);
+    (void)hipFree(c->d_d2); (void)hipFree(c->d_sel); (void)hipFree(c->d_eq); (void)hipFree(c->d_use); (void)hipFree(c->d_slot_of_orig);
+    if (c->h_trim) (void)hipHostFree(c->h_trim);
     for (int k = 0; k < 2; ++k) {
         fgoicp_ctx::TickSlot& sl = c->slots[k];
         if (sl.done) (void)hipEventDestroy(sl.done);
+        (void)hipFree(sl.d_vals);
         (void)hipFree(sl.d_groups); (void)hipFree(sl.d_subs); (void)hipFree(sl.d_keys); (void)hipFree(sl.d_hist);
         (void)hipFree(sl.d_cursor); (void)hipFree(sl.d_sorted); (void)hipFree(sl.d_partials);
         if (sl.h_groups) (void)hipHostFree(sl.h_groups);
@@ -667,6 +716,11 @@ int fgoicp_procrustes(fgoicp_ctx* c, const float* working_xyz, float* R_out9, fl
         for (size_t i = 0; i < c->ns; ++i) corr_idx[c->perm[i]] = (int)idx[i];
     }
     return FGOICP_OK;
+}
+
+int fgoicp_ctx_set_inliers(fgoicp_ctx* c, size_t k) {
+    if (!c) return FGOICP_ERR_INVALID_ARG;
+    return ctx_set_inliers(c, k);
 }
 
 int fgoicp_ctx_profile(fgoicp_ctx* c, double* kernel_ms, uint64_t* launches, uint64_t* subcubes, int reset) {

@@ -47,6 +47,7 @@ struct fgoicp_ctx {
         unsigned *d_hist = nullptr, *d_cursor = nullptr, *d_sorted = nullptr;
         double2* d_partials = nullptr;           // [max_subcubes][nchunk1]
         float *h_lb = nullptr, *h_ub = nullptr, *hd_lb = nullptr, *hd_ub = nullptr;  // pinned results of the window in flight
+        float2* d_vals = nullptr;                // trimmed mode: per-point {ub, lb} terms, [vals_rows][ns]
         std::vector<float> lb, ub;               // results of the whole submission
         int total = 0, win_pos = 0, win_rows = 0;
         bool inflight = false;
@@ -55,6 +56,14 @@ struct fgoicp_ctx {
     int nchunk1 = 0, max_groups = 0, cell_shift = 4;
     float4* d_chunk_cen = nullptr;           // centroid of every chunk (source frame)
     TickSlot slots[2];
+
+    // EXTENSION: trimmed Go-ICP (sum of the `inliers` smallest per-point terms; 0 = off)
+    size_t inliers = 0;
+    int vals_rows = 0;                       // subcubes per window in trimmed mode (memory budget)
+    float* d_d2 = nullptr;                   // squared correspondence distances
+    uint32_t *d_sel = nullptr, *d_eq = nullptr, *d_slot_of_orig = nullptr;
+    unsigned char* d_use = nullptr;          // inlier mask of the current Procrustes step
+    float *h_trim = nullptr, *hd_trim = nullptr;   // pinned trimmed SSE
 
     // exact-NN / ICP scratch
     uint32_t *d_min_bits = nullptr, *d_thr_bits = nullptr, *d_first_idx = nullptr;
@@ -77,6 +86,7 @@ int ctx_bounds_multi(fgoicp_ctx* c, int G, const float* R9, const float* rot_spa
                      const float* tn4, float* lb_out, float* ub_out);
 int ctx_bounds_submit(fgoicp_ctx* c, int slot, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets, const float* tn4);
 int ctx_bounds_collect(fgoicp_ctx* c, int slot, float* lb_out, float* ub_out);
+int ctx_set_inliers(fgoicp_ctx* c, size_t k);
 int ctx_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out);
 int ctx_icp(fgoicp_ctx* c, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3,
             int* iters_out);

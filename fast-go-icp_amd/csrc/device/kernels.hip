@@ -286,11 +286,12 @@ __global__ __launch_bounds__(kBlock) void tick_scatter_kernel(const unsigned sho
 // THREADS x P = 256 points per item.  Measured on MI355X (2048 subcubes per launch): 256x1 2.35 / 6.4 TB/s
 // algorithmic (bunny / dragon shape), 128x2 2.45 / 7.6 TB/s (default), 64x4 2.32 TB/s; fewer resident
 // blocks per CU (LDS padding) only hurts — the kernel wants every wave slot and many gathers in flight.
-template <int THREADS, int P, int ZPAIR>
+template <int THREADS, int P, int ZPAIR, int TRIM>
 __global__ __launch_bounds__(THREADS) void bounds_sorted_kernel(const float4* __restrict__ src, int ns, const float* __restrict__ lut,
                                                                 const float2* __restrict__ zp, LutGeom g,
                                                                 const TickGroup* __restrict__ groups, const TickSub* __restrict__ subs,
-                                                                const unsigned* __restrict__ sorted, int nchunk, double2* __restrict__ partials) {
+                                                                const unsigned* __restrict__ sorted, int nchunk, double2* __restrict__ partials,
+                                                                float2* __restrict__ vals) {
     static_assert(THREADS * P == kBlock, "an item is 256 points");
     __shared__ double red[2 * (THREADS / 64)];
     const unsigned item = sorted[xcd_remap(blockIdx.x, gridDim.x)];
@@ -332,13 +333,127 @@ __global__ __launch_bounds__(THREADS) void bounds_sorted_kernel(const float4* __
         const float ubv = d > 0.0f ? d * d : 0.0f;                            // :54
         const float l = d - trans_uncertain_radius;                           // :57
         const float lbv = l > 0.0f ? l * l : 0.0f;                            // :58
-        const bool valid = chunk * kBlock + k * THREADS + (int)threadIdx.x < ns;
-        acc[0] += valid ? (double)ubv : 0.0;
-        acc[1] += valid ? (double)lbv : 0.0;
+        const int i = chunk * kBlock + k * THREADS + (int)threadIdx.x;
+        const bool valid = i < ns;
+        if (TRIM) {  // trimmed Go-ICP: the per-point terms themselves (the selection runs in trim_select_kernel)
+            if (valid) vals[(size_t)s * ns + i] = make_float2(ubv, lbv);
+        } else {
+            acc[0] += valid ? (double)ubv : 0.0;
+            acc[1] += valid ? (double)lbv : 0.0;
+        }
     }
-    const double r = block_sum<2, THREADS / 64>(acc, red);
-    double* out = reinterpret_cast<double*>(partials + ((size_t)s * nchunk + chunk));
-    if (threadIdx.x < 2) out[threadIdx.x] = r;
+    if (!TRIM) {
+        const double r = block_sum<2, THREADS / 64>(acc, red);
+        double* out = reinterpret_cast<double*>(partials + ((size_t)s * nchunk + chunk));
+        if (threadIdx.x < 2) out[threadIdx.x] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// EXTENSION — trimmed Go-ICP (no reference behaviour: `params.trim` is parsed and ignored upstream).
+// Sum of the k smallest of n non-negative floats, exactly: a 3-level radix select on the bit pattern
+// (11 + 11 + 10 bits, LDS histograms) finds the k-th smallest value v_k and how many copies of it are
+// needed, then  sum = sum_{v < v_k} v + need * v_k  in fp64, fixed order.  One block per (row, column).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void trim_select_kernel(const float* __restrict__ vals, size_t row_stride, int ncols, int elem_stride, int n, int k,
+                                                             float* __restrict__ out0, float* __restrict__ out1, uint32_t* __restrict__ sel_info) {
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned scan[kBlock];
+    __shared__ unsigned s_bin, s_below;
+    __shared__ double red[8];
+    const int tid = threadIdx.x;
+    const int row = blockIdx.x, col = blockIdx.y;
+    const float* v = vals + (size_t)row * row_stride + col;
+    unsigned prefix = 0, prevmask = 0;
+    unsigned need = (unsigned)k;  // rank (1-based) of the wanted element inside the current candidate set
+    const int shifts[3] = {21, 10, 0}, nbits[3] = {11, 11, 10};
+    for (int lvl = 0; lvl < 3; ++lvl) {
+        const int shift = shifts[lvl], nb = 1 << nbits[lvl];
+        for (int b = tid; b < 2048; b += kBlock) hist[b] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += kBlock) {
+            const unsigned u = __float_as_uint(v[(size_t)i * elem_stride]);
+            if ((u & prevmask) == prefix) atomicAdd(&hist[(u >> shift) & (nb - 1)], 1u);
+        }
+        __syncthreads();
+        const int per = nb / kBlock;  // 8 or 4 consecutive bins per thread
+        unsigned mine = 0;
+        for (int b = 0; b < per; ++b) mine += hist[tid * per + b];
+        scan[tid] = mine;
+        __syncthreads();
+        for (int off = 1; off < kBlock; off <<= 1) {  // inclusive Hillis-Steele scan
+            const unsigned add = tid >= off ? scan[tid - off] : 0u;
+            __syncthreads();
+            scan[tid] += add;
+            __syncthreads();
+        }
+        const unsigned excl = scan[tid] - mine;
+        if (excl < need && need <= excl + mine) {  // exactly one thread
+            unsigned below = excl;
+            int b = 0;
+            for (; b < per; ++b) {
+                const unsigned c = hist[tid * per + b];
+                if (need <= below + c) break;
+                below += c;
+            }
+            s_bin = (unsigned)(tid * per + b);
+            s_below = below;
+        }
+        __syncthreads();
+        prefix |= s_bin << shift;
+        prevmask |= (unsigned)(nb - 1) << shift;
+        need -= s_below;
+        __syncthreads();
+    }
+    // prefix = bits of v_k, need = copies of v_k among the k smallest
+    double acc[1] = {0.0};
+    for (int i = tid; i < n; i += kBlock) {
+        const float x = v[(size_t)i * elem_stride];
+        if (__float_as_uint(x) < prefix) acc[0] += (double)x;
+    }
+    const double ssum = block_sum<1>(acc, red);
+    if (tid == 0) {
+        const float r = (float)(ssum + (double)need * (double)__uint_as_float(prefix));
+        if (col == 0 && out0) out0[row] = r;
+        if (col == 1 && out1) out1[row] = r;
+        if (sel_info) { sel_info[2 * (row * ncols + col)] = prefix; sel_info[2 * (row * ncols + col) + 1] = need; }
+    }
+}
+
+// ICP with trimming: squared distance of every working point to its correspondence ...
+__global__ __launch_bounds__(kBlock) void icp_corr_d2_kernel(const float4* __restrict__ work, const float4* __restrict__ tgt, const uint32_t* __restrict__ idx,
+                                                             int n, int nt, float* __restrict__ d2) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = work[i];
+    const float4 c = tgt[min(idx[i], (uint32_t)(nt - 1))];
+    d2[i] = dist_sq(a.x, a.y, a.z, c.x, c.y, c.z);
+}
+// ... and the inlier mask: d2 < v_k, plus `need` of the points with d2 == v_k.  When all copies of v_k are needed
+// (always, unless distances tie exactly at the cut) the mask is complete here; otherwise tie_pending is set
+// and icp_inlier_ties_kernel admits the lowest ORIGINAL indices.
+__global__ __launch_bounds__(kBlock) void icp_inlier_mask_kernel(const float* __restrict__ d2, int n, const uint32_t* __restrict__ sel_info,
+                                                                 unsigned char* __restrict__ use, uint32_t* __restrict__ equal_count) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t u = __float_as_uint(d2[i]), vk = sel_info[0];
+    use[i] = u < vk ? 1 : (u == vk ? 2 : 0);  // 2 = at the cut, resolved below
+    if (u == vk) atomicAdd(equal_count, 1u);
+}
+__global__ __launch_bounds__(kBlock) void icp_inlier_ties_kernel(int n, const uint32_t* __restrict__ sel_info, const uint32_t* __restrict__ equal_count,
+                                                                 const uint32_t* __restrict__ slot_of_orig, unsigned char* __restrict__ use) {
+    const uint32_t need = sel_info[1];
+    if (*equal_count == need) {  // every point at the cut is an inlier
+        for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+            if (use[i] == 2) use[i] = 1;
+        return;
+    }
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint32_t taken = 0;  // exact distance ties at the cut: lowest caller index first (serial, rare)
+    for (int o = 0; o < n; ++o) {
+        const uint32_t slot = slot_of_orig[o];
+        if (use[slot] == 2) use[slot] = taken++ < need ? 1 : 0;
+    }
 }
 
 // One block (one wave) per subcube: fixed-order sum of its chunk partials, rounded once to fp32.
@@ -859,10 +974,12 @@ __global__ __launch_bounds__(kBlock) void transform_inplace_kernel(float4* __res
 
 // Sum of the working cloud and of its correspondences (icp3d.cu:152-153).
 __global__ __launch_bounds__(kBlock) void icp_sums_kernel(const float4* __restrict__ work, const float4* __restrict__ tgt,
-                                                          const uint32_t* __restrict__ idx, int n, int nt, double* __restrict__ bp) {
+                                                          const uint32_t* __restrict__ idx, int n, int nt, const unsigned char* __restrict__ use,
+                                                          double* __restrict__ bp) {
     __shared__ double red[24];
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        if (use && !use[i]) continue;  // trimmed ICP: inliers only
         const float4 a = work[i];
         const float4 c = tgt[min(idx[i], (uint32_t)(nt - 1))];  // an index is always found for finite clouds; never read out of bounds
         acc[0] += (double)a.x; acc[1] += (double)a.y; acc[2] += (double)a.z;
@@ -877,10 +994,11 @@ __global__ __launch_bounds__(kBlock) void icp_sums_kernel(const float4* __restri
 // ABt[col][row] = sum a[row]*b[col]  (glm::outerProduct(c, r): m[i] = c * r[i]).
 __global__ __launch_bounds__(kBlock) void icp_cov_kernel(const float4* __restrict__ work, const float4* __restrict__ tgt,
                                                          const uint32_t* __restrict__ idx, int n, int nt, const float* __restrict__ cen,
-                                                         double* __restrict__ bp) {
+                                                         const unsigned char* __restrict__ use, double* __restrict__ bp) {
     __shared__ double red[36];
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        if (use && !use[i]) continue;
         const float4 p = work[i];
         const float4 q = tgt[min(idx[i], (uint32_t)(nt - 1))];
         const float a[3] = {p.x - cen[0], p.y - cen[1], p.z - cen[2]};
@@ -944,7 +1062,7 @@ void launch_bounds(const float4* src, int ns, const float* lut, const LutGeom& g
 
 void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* zp, const LutGeom& g, const float4* chunk_cen, int nchunk, const TickGroup* groups,
                           const TickSub* subs, int nsub, int cell_shift, unsigned short* keys, unsigned* hist, unsigned* cursor, unsigned* sorted,
-                          double2* partials, hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s) {
+                          double2* partials, float2* vals, hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s) {
     const size_t nitems = (size_t)nsub * nchunk;
     const TickGroup* gp = groups;
     const TickSub* sp = subs;
@@ -956,15 +1074,16 @@ void launch_bounds_sorted(const float4* src, int ns, const float* lut, const flo
     if (ev_start) (void)hipEventRecord(ev_start, s);
     static const int variant = [] { const char* e = std::getenv("FGOICP_BOUNDS_VARIANT"); return e ? std::atoi(e) : 1; }();  // tuning knob (1 = default)
     const dim3 grid((unsigned)nitems);
-    if (zp) {
-        if (variant == 0) hipLaunchKernelGGL((bounds_sorted_kernel<256, 1, 1>), grid, dim3(256), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, partials);
-        else if (variant == 2) hipLaunchKernelGGL((bounds_sorted_kernel<64, 4, 1>), grid, dim3(64), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, partials);
-        else hipLaunchKernelGGL((bounds_sorted_kernel<128, 2, 1>), grid, dim3(128), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, partials);
+#define FGOICP_LAUNCH_SORTED(T, PP, Z, TR) \
+    hipLaunchKernelGGL((bounds_sorted_kernel<T, PP, Z, TR>), grid, dim3(T), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, partials, vals)
+    if (vals) {
+        if (zp) FGOICP_LAUNCH_SORTED(128, 2, 1, 1); else FGOICP_LAUNCH_SORTED(128, 2, 0, 1);
+    } else if (zp) {
+        if (variant == 0) FGOICP_LAUNCH_SORTED(256, 1, 1, 0); else if (variant == 2) FGOICP_LAUNCH_SORTED(64, 4, 1, 0); else FGOICP_LAUNCH_SORTED(128, 2, 1, 0);
     } else {
-        if (variant == 0) hipLaunchKernelGGL((bounds_sorted_kernel<256, 1, 0>), grid, dim3(256), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, partials);
-        else if (variant == 2) hipLaunchKernelGGL((bounds_sorted_kernel<64, 4, 0>), grid, dim3(64), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, partials);
-        else hipLaunchKernelGGL((bounds_sorted_kernel<128, 2, 0>), grid, dim3(128), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, partials);
+        if (variant == 0) FGOICP_LAUNCH_SORTED(256, 1, 0, 0); else if (variant == 2) FGOICP_LAUNCH_SORTED(64, 4, 0, 0); else FGOICP_LAUNCH_SORTED(128, 2, 0, 0);
     }
+#undef FGOICP_LAUNCH_SORTED
     if (ev_stop) (void)hipEventRecord(ev_stop, s);
 }
 
@@ -1055,17 +1174,34 @@ void launch_transform_inplace(float4* pts, int n, const float* R9, const float* 
     hipLaunchKernelGGL(transform_inplace_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, n, make_rt(R9, t3));
 }
 
-void launch_icp_sums(const float4* work, const float4* tgt, const uint32_t* idx, int n, int nt, double* bp, int nblocks, hipStream_t s) {
-    hipLaunchKernelGGL(icp_sums_kernel, dim3(nblocks), dim3(kBlock), 0, s, work, tgt, idx, n, nt, bp);
+void launch_icp_sums(const float4* work, const float4* tgt, const uint32_t* idx, int n, int nt, const unsigned char* use, double* bp, int nblocks,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(icp_sums_kernel, dim3(nblocks), dim3(kBlock), 0, s, work, tgt, idx, n, nt, use, bp);
 }
 
 void launch_icp_centroids(const double* bp, int nblocks, int ns, float* cen_dev, float* cen_host, hipStream_t s) {
     hipLaunchKernelGGL(icp_centroids_kernel, dim3(1), dim3(384), 0, s, bp, nblocks, ns, cen_dev, cen_host);
 }
 
-void launch_icp_cov(const float4* work, const float4* tgt, const uint32_t* idx, int n, int nt, const float* cen_dev, double* bp, int nblocks,
-                    hipStream_t s) {
-    hipLaunchKernelGGL(icp_cov_kernel, dim3(nblocks), dim3(kBlock), 0, s, work, tgt, idx, n, nt, cen_dev, bp);
+void launch_icp_cov(const float4* work, const float4* tgt, const uint32_t* idx, int n, int nt, const float* cen_dev, const unsigned char* use,
+                    double* bp, int nblocks, hipStream_t s) {
+    hipLaunchKernelGGL(icp_cov_kernel, dim3(nblocks), dim3(kBlock), 0, s, work, tgt, idx, n, nt, cen_dev, use, bp);
+}
+
+// trimmed sums: out0[row] / out1[row] = sum of the k smallest of column 0 / 1 of row `row` (ncols = 1 or 2)
+void launch_trim_select(const float* vals, size_t row_stride, int ncols, int n, int k, int rows, float* out0, float* out1, uint32_t* sel_info,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(trim_select_kernel, dim3(rows, ncols), dim3(kBlock), 0, s, vals, row_stride, ncols, ncols, n, k, out0, out1, sel_info);
+}
+
+void launch_icp_inliers(const float4* work, const float4* tgt, const uint32_t* idx, int n, int nt, int k, float* d2, uint32_t* sel_info,
+                        uint32_t* equal_count, const uint32_t* slot_of_orig, unsigned char* use, hipStream_t s) {
+    const int nb = (n + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(icp_corr_d2_kernel, dim3(nb), dim3(kBlock), 0, s, work, tgt, idx, n, nt, d2);
+    launch_trim_select(d2, 0, 1, n, k, 1, nullptr, nullptr, sel_info, s);
+    (void)hipMemsetAsync(equal_count, 0, sizeof(uint32_t), s);
+    hipLaunchKernelGGL(icp_inlier_mask_kernel, dim3(nb), dim3(kBlock), 0, s, d2, n, sel_info, use, equal_count);
+    hipLaunchKernelGGL(icp_inlier_ties_kernel, dim3(nb < 256 ? nb : 256), dim3(kBlock), 0, s, n, sel_info, equal_count, slot_of_orig, use);
 }
 
 }  // namespace fgoicp

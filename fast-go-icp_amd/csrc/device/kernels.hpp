@@ -60,7 +60,13 @@ struct TickSub {     // one translation node + its rotation node
 constexpr int kTickNumKeys = 1 << 15;
 void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* zpair_or_null, const LutGeom& g, const float4* chunk_cen, int nchunk, const TickGroup* groups,
                           const TickSub* subs, int nsub, int cell_shift, unsigned short* keys, unsigned* hist, unsigned* cursor, unsigned* sorted,
-                          double2* partials, hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s);
+                          double2* partials, float2* vals_or_null, hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s);
+// EXTENSION (trimmed Go-ICP): sum of the k smallest entries of each row/column of `vals` (exact radix select, kernels.hip)
+void launch_trim_select(const float* vals, size_t row_stride, int ncols, int n, int k, int rows, float* out0, float* out1, uint32_t* sel_info,
+                        hipStream_t s);
+// use[i] = 1 for the k correspondences with the smallest squared distance (ties at the cut: lowest caller index)
+void launch_icp_inliers(const float4* work, const float4* tgt, const uint32_t* idx, int n, int nt, int k, float* d2, uint32_t* sel_info,
+                        uint32_t* equal_count, const uint32_t* slot_of_orig, unsigned char* use, hipStream_t s);
 // out_lb[i], out_ub[i] = float(sum over chunks), fixed order → bit-reproducible
 void launch_bounds_finalize(const double2* partials, int nchunk, int total, float* out_lb, float* out_ub, hipStream_t s);
 
@@ -94,11 +100,11 @@ void launch_sum_partials(const double* block_partials, int nblocks, int width, d
 
 // ICP pieces (fgoicp/icp3d.cu:30-52)
 void launch_transform_inplace(float4* pts, int n, const float* R9, const float* t3, hipStream_t s);
-void launch_icp_sums(const float4* work, const float4* tgt, const uint32_t* idx, int n, int nt, double* block_partials, int nblocks,
-                     hipStream_t s);  // width 6: sum src xyz, sum corr xyz
+void launch_icp_sums(const float4* work, const float4* tgt, const uint32_t* idx, int n, int nt, const unsigned char* use_or_null,
+                     double* block_partials, int nblocks, hipStream_t s);  // width 6: sum src xyz, sum corr xyz
 void launch_icp_centroids(const double* block_partials, int nblocks, int ns, float* cen_dev, float* cen_host, hipStream_t s);
-void launch_icp_cov(const float4* work, const float4* tgt, const uint32_t* idx, int n, int nt, const float* cen_dev, double* block_partials,
-                    int nblocks, hipStream_t s);  // width 9: glm mat3 order
+void launch_icp_cov(const float4* work, const float4* tgt, const uint32_t* idx, int n, int nt, const float* cen_dev, const unsigned char* use_or_null,
+                    double* block_partials, int nblocks, hipStream_t s);  // width 9: glm mat3 order
 
 int reduce_blocks_for(int n);
 

@@ -58,7 +58,7 @@ int fgoicp_solver_create(const float* tgt_xyz, size_t nt, const float* src_xyz, 
         set_error("fgoicp_solver_create: invalid argument");
         return FGOICP_ERR_INVALID_ARG;
     }
-    fgoicp_solver_opts o{FGOICP_SCHEDULE_SERIAL, 1, 0u, 0};
+    fgoicp_solver_opts o{FGOICP_SCHEDULE_SERIAL, 1, 0u, 0, 0.0f};
     if (opts) o = *opts;
     auto s = std::make_unique<fgoicp_solver>();
     s->ns = ns;
@@ -76,7 +76,17 @@ int fgoicp_solver_create(const float* tgt_xyz, size_t nt, const float* src_xyz, 
                                s->bounds6, lut_resolution, o.device, o.ctx_flags, &s->ctx);
     if (rc) return rc;
     s->ops.ctx = s->ctx;
-    s->driver.reset(new GoIcpDriver<HipOps>(s->ops, ns, mse_threshold, o.schedule, o.round_width));
+    size_t n_thr = ns;  // sse_threshold = n * mse_threshold (fgoicp.hpp:23); over the inliers when trimming
+    if (o.trim_fraction > 0.0f) {  // inlierNum = (int)(Nd * (1 - trimFraction)), as in Go-ICP
+        size_t k = (size_t)((double)ns * (1.0 - (double)o.trim_fraction));
+        if (k < 1) k = 1;
+        if (k < ns) {
+            rc = ctx_set_inliers(s->ctx, k);
+            if (rc) { fgoicp_ctx_destroy(s->ctx); return rc; }
+            n_thr = k;
+        }
+    }
+    s->driver.reset(new GoIcpDriver<HipOps>(s->ops, n_thr, mse_threshold, o.schedule, o.round_width));
     *out = s.release();
     return FGOICP_OK;
 }

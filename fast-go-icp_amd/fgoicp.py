@@ -11,11 +11,11 @@ from .registration import Registration, _cloud, _fp
 
 class FastGoICP:
     def __init__(self, pct, pcs, lut_resolution=0.005, mse_threshold=1e-3, schedule=_lib.SCHEDULE_SERIAL, round_width=1,
-                 device=0, flags=0):
+                 device=0, flags=0, trim_fraction=0.0):
         self._lib = _lib.load()
         pct, pcs = _cloud(pct), _cloud(pcs)
         self.nt, self.ns = len(pct), len(pcs)
-        opts = _lib.SolverOpts(int(schedule), int(round_width), int(flags), int(device))
+        opts = _lib.SolverOpts(int(schedule), int(round_width), int(flags), int(device), float(trim_fraction))
         self._h = C.c_void_p()
         _lib.check(self._lib.fgoicp_solver_create(_fp(pct), self.nt, _fp(pcs), self.ns, float(lut_resolution), float(mse_threshold),
                                                   C.byref(opts), C.byref(self._h)), "fgoicp_solver_create")

@@ -131,6 +131,10 @@ class Registration:
                    "fgoicp_procrustes")
         return from_glm(R), t, cen, ABt, idx
 
+    def set_inliers(self, k):
+        """EXTENSION (trimmed Go-ICP): every sum over source points runs over the k smallest terms; 0 = off."""
+        _lib.check(self._lib.fgoicp_ctx_set_inliers(self._h, int(k)), "fgoicp_ctx_set_inliers")
+
     def set_profile(self, enabled):
         _lib.check(self._lib.fgoicp_ctx_set_profile(self._h, int(bool(enabled))), "fgoicp_ctx_set_profile")
 

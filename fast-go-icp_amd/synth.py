@@ -11,6 +11,8 @@ WORKLOADS = {
     "bunny": dict(nt=40256, ns=40097, box=(0.156, 0.152, 0.118), seed=1),
     "dragon": dict(nt=437645, ns=437645, box=(0.22, 0.22, 0.18), seed=2),
     "synthetic1m": dict(nt=1_000_000, ns=1_000_000, box=(0.2, 0.2, 0.2), seed=3),
+    # BASELINE config 5: 20 % of the source replaced by uniform outliers in 1.5x the box (use with trim_fraction=0.2)
+    "synthetic1m_outliers": dict(nt=1_000_000, ns=1_000_000, box=(0.2, 0.2, 0.2), seed=3, outlier_frac=0.2),
     "tiny": dict(nt=1500, ns=1200, box=(0.156, 0.152, 0.118), seed=7),
     "small": dict(nt=6000, ns=5000, box=(0.156, 0.152, 0.118), seed=11),
 }
@@ -54,7 +56,7 @@ class BumpySurface:
         return d * r[:, None] * self.box[None, :]
 
 
-def make_pair(nt, ns, box, seed, overlap=0.7, noise=1e-3, angle_deg=None, min_angle_deg=0.0, t_frac=0.25):
+def make_pair(nt, ns, box, seed, overlap=0.7, noise=1e-3, angle_deg=None, min_angle_deg=0.0, t_frac=0.25, outlier_frac=0.0):
     """Returns (target (nt,3) f32, source (ns,3) f32, R_gt (3,3) f64, t_gt (3,) f64)."""
     rng = np.random.default_rng(seed)
     surf = BumpySurface(rng, box)
@@ -66,6 +68,10 @@ def make_pair(nt, ns, box, seed, overlap=0.7, noise=1e-3, angle_deg=None, min_an
     R_gt = random_rotation(rng, angle_deg, min_angle_deg)
     t_gt = rng.uniform(-t_frac, t_frac, size=3) * np.asarray(box)
     src = (on_target - t_gt[None, :]) @ R_gt  # rows: R_gt^T (x - t)
+    if outlier_frac > 0:
+        n_out = int(ns * outlier_frac)
+        idx = rng.choice(ns, n_out, replace=False)
+        src[idx] = rng.uniform(-0.75, 0.75, size=(n_out, 3)) * np.asarray(box)
     return tgt.astype(np.float32), src.astype(np.float32), R_gt, t_gt
 
 

@@ -12,8 +12,8 @@ class FastGoICP {
 public:
     // fgoicp.hpp:13 (+ optional schedule: FGOICP_SCHEDULE_SERIAL reproduces the reference's order)
     FastGoICP(std::vector<vec3> pct, std::vector<vec3> pcs, float lut_resolution, float mse_threshold,
-              int schedule = FGOICP_SCHEDULE_SERIAL, int round_width = 1, int device = 0) {
-        fgoicp_solver_opts o{schedule, round_width, 0u, device};
+              int schedule = FGOICP_SCHEDULE_SERIAL, int round_width = 1, int device = 0, float trim_fraction = 0.0f) {
+        fgoicp_solver_opts o{schedule, round_width, 0u, device, trim_fraction};
         check_status(fgoicp_solver_create(&pct.data()->x, pct.size(), &pcs.data()->x, pcs.size(), lut_resolution, mse_threshold, &o, &s_),
                      "fgoicp_solver_create");
     }

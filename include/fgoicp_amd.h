@@ -112,6 +112,13 @@ int fgoicp_icp(fgoicp_ctx* ctx, const float* R0_9, const float* t0_3, size_t max
 int fgoicp_procrustes(fgoicp_ctx* ctx, const float* working_xyz, float* R_out9, float* t_out3, float* centroids6,
                       float* ABt9, int* corr_idx);
 
+/*
+ * EXTENSION — trimmed Go-ICP.  The reference parses `params.trim` (src/utilities.hpp:94) but never uses it, so
+ * there is no reference behaviour; this follows Yang et al.'s Go-ICP: with k inliers every sum over source
+ * points (bounds, SSE, the Procrustes means) runs over the k smallest per-point terms.  k = 0 or k >= ns: off.
+ */
+int fgoicp_ctx_set_inliers(fgoicp_ctx* ctx, size_t k);
+
 /* Accumulated HIP-event timing of the bounds kernel since the last reset (FGOICP_FLAG_PROFILE):
  * kernel_ms = sum of launch durations, launches = kernel launches, subcubes = (rot, trans) pairs. */
 int fgoicp_ctx_profile(fgoicp_ctx* ctx, double* kernel_ms, uint64_t* launches, uint64_t* subcubes, int reset);
@@ -150,6 +157,7 @@ typedef struct fgoicp_solver_opts {
     int round_width;     /* ROUND: rotation cubes popped per expansion round (K >= 1)  */
     unsigned ctx_flags;  /* FGOICP_FLAG_*                                              */
     int device;          /* HIP device ordinal                                         */
+    float trim_fraction; /* EXTENSION: fraction of source points treated as outliers (0 = the reference's behaviour) */
 } fgoicp_solver_opts;
 
 typedef struct fgoicp_run_stats {

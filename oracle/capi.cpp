@@ -74,6 +74,7 @@ void* orc_reg_create(const float* tgt, size_t nt, const float* src, size_t ns, c
     return h;
 }
 void orc_reg_destroy(void* p) { delete static_cast<RegHandle*>(p); }
+void orc_reg_set_inliers(void* p, size_t k) { static_cast<RegHandle*>(p)->reg->inliers = k; }
 void orc_reg_lut_dims(void* p, int* dims3) {
     auto* h = static_cast<RegHandle*>(p);
     for (int i = 0; i < 3; ++i) dims3[i] = h->reg->nnlut.dims[i];
@@ -135,6 +136,11 @@ void orc_svd3(const double* A9, double* U9, double* S3, double* V9) { svd3_rowma
 void* orc_goicp_create(const float* tgt, size_t nt, const float* src, size_t ns, float lut_res, float mse_thr) {
     auto* h = new GoicpHandle;
     h->g.reset(new FastGoICP(to_cloud(tgt, nt), to_cloud(src, ns), lut_res, mse_thr));
+    return h;
+}
+void* orc_goicp_create_trim(const float* tgt, size_t nt, const float* src, size_t ns, float lut_res, float mse_thr, float trim) {
+    auto* h = new GoicpHandle;
+    h->g.reset(new FastGoICP(to_cloud(tgt, nt), to_cloud(src, ns), lut_res, mse_thr, trim));
     return h;
 }
 void orc_goicp_destroy(void* p) { delete static_cast<GoicpHandle*>(p); }

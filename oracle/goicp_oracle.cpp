@@ -163,12 +163,35 @@ float brute_force_find_nearest_neighbor(const Vec3& q, const PointCloud& pct) { 
     return best;
 }
 
+// EXTENSION: trimmed sums (see header).  The k smallest terms, added in ascending order in fp64.
+float trimmed_sum(std::vector<float>& v, size_t k) {
+    if (k == 0 || k >= v.size()) {
+        double s = 0.0;
+        for (float x : v) s += (double)x;
+        return (float)s;
+    }
+    std::nth_element(v.begin(), v.begin() + (k - 1), v.end());
+    std::sort(v.begin(), v.begin() + k);
+    double s = 0.0;
+    for (size_t i = 0; i < k; ++i) s += (double)v[i];
+    return (float)s;
+}
+
 // Sums over points: fixed 1024-point chunks, one fp64 partial per chunk, chunks combined in index
 // order — independent of the OpenMP thread count, so fixtures reproduce on any host.
 static constexpr long kChunk = 1024;
 
 float Registration::compute_sse_error(const Mat3& R, const Vec3& t) const {  // :62-86 + kernel :14-25
     const long ns = (long)pcs.size();
+    if (inliers > 0 && inliers < (size_t)ns) {  // EXTENSION: trimmed SSE
+        std::vector<float> e(ns);
+#pragma omp parallel for schedule(static)
+        for (long i = 0; i < ns; ++i) {
+            Vec3 rp = dev_mul(R, pcs[i]);
+            e[i] = brute_force_find_nearest_neighbor(Vec3{rp.x + t.x, rp.y + t.y, rp.z + t.z}, pct);
+        }
+        return trimmed_sum(e, inliers);
+    }
     const long nchunk = (ns + kChunk - 1) / kChunk;
     std::vector<double> part(nchunk, 0.0);
 #pragma omp parallel for schedule(dynamic, 1)
@@ -194,6 +217,27 @@ Registration::compute_sse_error(const RotNode& rnode, const std::vector<TransNod
     // kernComputeBounds :27-60; the per-kernel constants are hoisted (they do not depend on the point)
     float half_angle = rnode.span * kSqrt3 * kPi / 2.0f;  // :42
     float sin_half = std::sin(half_angle);                // float overload, as device sin(float)
+    if (inliers > 0 && inliers < (size_t)ns) {  // EXTENSION: trimmed bounds — the k smallest ub terms and the k smallest lb terms
+#pragma omp parallel for schedule(dynamic, 1)
+        for (long b = 0; b < B; ++b) {
+            const TransNode& tn = tnodes[b];
+            const float trans_uncertain_radius = kSqrt3 * tn.span;
+            std::vector<float> vu(ns), vl(ns);
+            for (long i = 0; i < ns; ++i) {
+                const Vec3 p = pcs[i];
+                Vec3 rp = dev_mul(rnode.q.R, p);
+                Vec3 q{rp.x + tn.t.x, rp.y + tn.t.y, rp.z + tn.t.z};
+                float d = std::sqrt(nnlut.search(q));
+                if (!fix_rot) d -= 2.0f * std::fmaf(p.z, p.z, std::fmaf(p.y, p.y, p.x * p.x)) * sin_half;
+                vu[i] = d > 0.0f ? d * d : 0.0f;
+                const float l = d - trans_uncertain_radius;
+                vl[i] = l > 0.0f ? l * l : 0.0f;
+            }
+            upper[b] = trimmed_sum(vu, inliers);
+            lower[b] = trimmed_sum(vl, inliers);
+        }
+        return {lower, upper};
+    }
     const long nchunk = (ns + kChunk - 1) / kChunk;
     std::vector<double> part_ub(B * nchunk, 0.0), part_lb(B * nchunk, 0.0);
 #pragma omp parallel for collapse(2) schedule(dynamic, 1)
@@ -395,20 +439,35 @@ std::tuple<Mat3, Vec3> IterativeClosestPoint3D::procrustes(ProcrustesDebug* dbg)
         corrs[i] = corr;
         corr_idx_[i] = best;
     }
+    // EXTENSION: trimmed ICP — only the `inliers` correspondences with the smallest squared distance take part
+    // (ties at the cut: lowest index first); every mean below is then over the inliers.
+    std::vector<char> use(ns, 1);
+    long nuse = ns;
+    if (reg_.inliers > 0 && reg_.inliers < (size_t)ns) {
+        std::vector<std::pair<float, long>> d(ns);
+        for (long i = 0; i < ns; ++i)
+            d[i] = {dev_dist_sq(pcs_buf_[i].x, pcs_buf_[i].y, pcs_buf_[i].z, corrs[i].x, corrs[i].y, corrs[i].z), i};
+        std::sort(d.begin(), d.end());
+        std::fill(use.begin(), use.end(), 0);
+        nuse = (long)reg_.inliers;
+        for (long k = 0; k < nuse; ++k) use[d[k].second] = 1;
+    }
     // thrust::reduce of Point3D x2 (:152-153) → double sums rounded to fp32
     double sx = 0, sy = 0, sz = 0, cx = 0, cy = 0, cz = 0;
     for (long i = 0; i < ns; ++i) {
+        if (!use[i]) continue;
         sx += pcs_buf_[i].x; sy += pcs_buf_[i].y; sz += pcs_buf_[i].z;
         cx += corrs[i].x; cy += corrs[i].y; cz += corrs[i].z;
     }
     Vec3 src_centroid{(float)sx, (float)sy, (float)sz};
     Vec3 cor_centroid{(float)cx, (float)cy, (float)cz};
-    float fn = static_cast<float>(ns);
+    float fn = static_cast<float>(nuse);
     src_centroid = Vec3{src_centroid.x / fn, src_centroid.y / fn, src_centroid.z / fn};  // :155-156
     cor_centroid = Vec3{cor_centroid.x / fn, cor_centroid.y / fn, cor_centroid.z / fn};
     // kernCentralize x2 (:38-44), kernOuterProduct (:46-52), reduce mat3 (:165-166)
     double acc[3][3] = {{0}};
     for (long i = 0; i < ns; ++i) {
+        if (!use[i]) continue;
         float a[3] = {pcs_buf_[i].x - src_centroid.x, pcs_buf_[i].y - src_centroid.y, pcs_buf_[i].z - src_centroid.z};
         float b[3] = {corrs[i].x - cor_centroid.x, corrs[i].y - cor_centroid.y, corrs[i].z - cor_centroid.z};
         // glm::outerProduct(c=a, r=b): m[col i][row k] = a[k]*b[i]
@@ -488,13 +547,22 @@ Bounds get_point_cloud_ranges(const PointCloud& pc) {
 // ---------------------------------------------------------------------------------------------
 // FastGoICP — fgoicp.hpp:13-25 (member init order :47-58), fgoicp.cpp:10-174
 // ---------------------------------------------------------------------------------------------
-FastGoICP::FastGoICP(PointCloud pct_, PointCloud pcs_, float lut_resolution, float mse_thr)
+FastGoICP::FastGoICP(PointCloud pct_, PointCloud pcs_, float lut_resolution, float mse_thr, float trim_fraction)
     : pcs(std::move(pcs_)), pct(std::move(pct_)), ns(pcs.size()), nt(pct.size()),
       offset_pcs(center_point_cloud(pcs)), offset_pct(center_point_cloud(pct)),
       scaling_factor(scale_point_clouds(pct, pcs)), target_bounds(get_point_cloud_ranges(pct)),
       registration(pct, pcs, target_bounds, lut_resolution),
       best_sse(kInf), best_rotation(mat3_identity()), best_translation{0, 0, 0},
-      mse_threshold(mse_thr), sse_threshold(ns * mse_thr) {}
+      mse_threshold(mse_thr), sse_threshold(ns * mse_thr) {
+    if (trim_fraction > 0.0f) {  // EXTENSION: inlierNum = (int)(Nd * (1 - trimFraction)) as in Go-ICP; threshold over the inliers
+        size_t k = (size_t)((double)ns * (1.0 - (double)trim_fraction));
+        if (k < 1) k = 1;
+        if (k < ns) {
+            registration.inliers = k;
+            sse_threshold = k * mse_thr;
+        }
+    }
+}
 
 Vec3 FastGoICP::restore_translation(const Mat3& R, const Vec3& t) const {  // fgoicp.hpp:87-90
     Vec3 ro = host_mul(R, offset_pcs);

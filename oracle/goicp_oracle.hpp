@@ -115,7 +115,13 @@ public:
     const PointCloud& pct;
     const PointCloud& pcs;
     NearestNeighborLUT nnlut;
+    // EXTENSION (no reference behaviour: `params.trim` is parsed but never used upstream).
+    // Trimmed Go-ICP as in Yang et al.'s Go-ICP: every sum over source points becomes the sum of the
+    // `inliers` smallest per-point terms (0 = no trimming).
+    size_t inliers = 0;
 };
+// sum of the k smallest values (fp64 accumulation in ascending order, rounded once); k = 0 or k >= n: plain sum in index order
+float trimmed_sum(std::vector<float>& values, size_t k);
 
 float brute_force_find_nearest_neighbor(const Vec3& q, const PointCloud& pct);  // registration.cu:162-174
 
@@ -155,7 +161,7 @@ struct RunStats {
 
 class FastGoICP {
 public:
-    FastGoICP(PointCloud pct, PointCloud pcs, float lut_resolution, float mse_threshold);
+    FastGoICP(PointCloud pct, PointCloud pcs, float lut_resolution, float mse_threshold, float trim_fraction = 0.0f);
     std::tuple<Mat3, Vec3> run();
     float get_best_error() const { return best_sse; }
     std::tuple<Mat3, Vec3> get_best_transform() const { return {best_rotation, best_translation}; }

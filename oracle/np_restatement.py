@@ -74,7 +74,7 @@ def lut_search(lut, bounds, res, q, quant=True):
     return lerp(lerp(c00, c10, bb), lerp(c01, c11, bb), c)
 
 
-def bounds(lut, lut_bounds, res, src, R, rot_span, tnodes4, fix_rot, quant=True):
+def bounds(lut, lut_bounds, res, src, R, rot_span, tnodes4, fix_rot, quant=True, inliers=0):
     src = np.asarray(src, f32)
     rp = rot_apply(R, src)
     half_angle = f32(f32(f32(f32(rot_span) * SQRT3) * PI) / f32(2.0))
@@ -89,6 +89,9 @@ def bounds(lut, lut_bounds, res, src, R, rot_span, tnodes4, fix_rot, quant=True)
         ub = np.where(d > 0, (d * d).astype(f32), f32(0))
         l = (d - f32(SQRT3 * f32(span))).astype(f32)
         lb = np.where(l > 0, (l * l).astype(f32), f32(0))
+        if inliers and inliers < len(src):  # trimmed Go-ICP extension: the k smallest terms of each bound
+            ub = np.sort(ub)[:inliers]
+            lb = np.sort(lb)[:inliers]
         ubs.append(f32(ub.astype(np.float64).sum()))
         lbs.append(f32(lb.astype(np.float64).sum()))
     return np.array(lbs, f32), np.array(ubs, f32)

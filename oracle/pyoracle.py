@@ -38,6 +38,9 @@ def lib():
         L.orc_reg_create.argtypes = [_fp, C.c_size_t, _fp, C.c_size_t, _fp, C.c_float, C.c_int, C.c_int]
         L.orc_reg_create.restype = C.c_void_p
         L.orc_reg_destroy.argtypes = [C.c_void_p]
+        L.orc_reg_set_inliers.argtypes = [C.c_void_p, C.c_size_t]
+        L.orc_goicp_create_trim.argtypes = [_fp, C.c_size_t, _fp, C.c_size_t, C.c_float, C.c_float, C.c_float]
+        L.orc_goicp_create_trim.restype = C.c_void_p
         L.orc_reg_lut_dims.argtypes = [C.c_void_p, _ip]
         L.orc_reg_lut_get.argtypes = [C.c_void_p, _fp]
         L.orc_reg_lut_set.argtypes = [C.c_void_p, _fp]
@@ -115,6 +118,10 @@ class Registration:
             lib().orc_reg_destroy(self._h)
             self._h = None
 
+    def set_inliers(self, k):
+        """EXTENSION: trimmed sums over the k smallest per-point terms (0 = off)."""
+        lib().orc_reg_set_inliers(self._h, int(k))
+
     def lut_dims(self):
         d = (C.c_int * 3)()
         lib().orc_reg_lut_dims(self._h, d)
@@ -165,10 +172,10 @@ class Registration:
 class FastGoICP:
     """goicp_oracle::FastGoICP (restates fgoicp/fgoicp.hpp, fgoicp.cpp)."""
 
-    def __init__(self, pct, pcs, lut_resolution, mse_threshold):
+    def __init__(self, pct, pcs, lut_resolution, mse_threshold, trim_fraction=0.0):
         pct = np.ascontiguousarray(pct, np.float32); pcs = np.ascontiguousarray(pcs, np.float32)
         self.nt, self.ns = len(pct), len(pcs)
-        self._h = C.c_void_p(lib().orc_goicp_create(_f(pct), self.nt, _f(pcs), self.ns, lut_resolution, mse_threshold))
+        self._h = C.c_void_p(lib().orc_goicp_create_trim(_f(pct), self.nt, _f(pcs), self.ns, lut_resolution, mse_threshold, trim_fraction))
 
     def __del__(self):
         if getattr(self, "_h", None):

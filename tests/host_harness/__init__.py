@@ -35,6 +35,8 @@ def lib():
         L = C.CDLL(build())
         L.harness_create.argtypes = [_fp, C.c_size_t, _fp, C.c_size_t, C.c_float, C.c_float, C.c_int, C.c_int]
         L.harness_create.restype = C.c_void_p
+        L.harness_create_trim.argtypes = [_fp, C.c_size_t, _fp, C.c_size_t, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float]
+        L.harness_create_trim.restype = C.c_void_p
         L.harness_destroy.argtypes = [C.c_void_p]
         L.harness_set_exchange.argtypes = [C.c_void_p, C.c_int, C.c_int, AR, AG]
         L.harness_preproc.argtypes = [C.c_void_p, _fp, _fp, _fp]
@@ -54,9 +56,9 @@ def _f(a):
 class HostDriver:
     """Product driver template over oracle operators."""
 
-    def __init__(self, pct, pcs, lut_res, mse_thr, schedule=0, round_width=1):
+    def __init__(self, pct, pcs, lut_res, mse_thr, schedule=0, round_width=1, trim_fraction=0.0):
         pct = np.ascontiguousarray(pct, np.float32); pcs = np.ascontiguousarray(pcs, np.float32)
-        self._h = C.c_void_p(lib().harness_create(_f(pct), len(pct), _f(pcs), len(pcs), lut_res, mse_thr, schedule, round_width))
+        self._h = C.c_void_p(lib().harness_create_trim(_f(pct), len(pct), _f(pcs), len(pcs), lut_res, mse_thr, schedule, round_width, trim_fraction))
         self._cbs = None
 
     def __del__(self):

@@ -73,7 +73,8 @@ extern "C" {
 typedef int (*ar_fn)(float*, size_t, void*);
 typedef int (*ag_fn)(const float*, float*, size_t, void*);
 
-void* harness_create(const float* tgt, size_t nt, const float* src, size_t ns, float lut_res, float mse_thr, int schedule, int round_width) {
+void* harness_create_trim(const float* tgt, size_t nt, const float* src, size_t ns, float lut_res, float mse_thr, int schedule, int round_width,
+                          float trim_fraction) {
     auto* h = new Harness;
     h->pcs.resize(ns); h->pct.resize(nt);
     std::memcpy(h->pcs.data(), src, sizeof(Vec3f) * ns);
@@ -90,8 +91,17 @@ void* harness_create(const float* tgt, size_t nt, const float* src, size_t ns, f
     h->ops.reg = h->reg.get(); h->ops.pct = &h->opct; h->ops.pcs = &h->opcs;
     h->ops.use_async = schedule >= 2;  // schedule 2 = ROUND with the two-slot pipelined task loop
     if (schedule >= 2) schedule = 1;
-    h->drv.reset(new GoIcpDriver<OracleOps>(h->ops, ns, mse_thr, schedule, round_width));
+    size_t n_thr = ns;  // as solver.cpp: the threshold runs over the inliers when trimming
+    if (trim_fraction > 0.0f) {
+        size_t k = (size_t)((double)ns * (1.0 - (double)trim_fraction));
+        if (k < 1) k = 1;
+        if (k < ns) { h->reg->inliers = k; n_thr = k; }
+    }
+    h->drv.reset(new GoIcpDriver<OracleOps>(h->ops, n_thr, mse_thr, schedule, round_width));
     return h;
+}
+void* harness_create(const float* tgt, size_t nt, const float* src, size_t ns, float lut_res, float mse_thr, int schedule, int round_width) {
+    return harness_create_trim(tgt, nt, src, ns, lut_res, mse_thr, schedule, round_width, 0.0f);
 }
 void harness_destroy(void* p) { delete static_cast<Harness*>(p); }
 void harness_set_exchange(void* p, int rank, int world, ar_fn ar, ag_fn ag) {

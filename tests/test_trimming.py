@@ -1,0 +1,160 @@
+"""EXTENSION — trimmed Go-ICP.  The reference parses `params.trim` and ignores it, so there is
+no reference behaviour; the definition follows Yang et al.'s Go-ICP (sum of the inlierNum smallest per-point
+terms).  CPU: the oracle against numpy and against the product's host driver; GPU: HIP against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import np_restatement as npr
+from tests import host_harness as hh
+
+f32 = np.float32
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "goicp_golden.npz"))
+
+
+def outlier_pair(fg, nt=700, ns=500, frac=0.2, seed=9, angle=(100.0, 120.0)):
+    """Source = exact copies of target points under a known motion, `frac` of them replaced by uniform outliers."""
+    tgt, _, _, _ = fg.synth.make_pair(nt, 8, (0.156, 0.152, 0.118), seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    R_gt = fg.synth.random_rotation(rng, angle[1], angle[0])
+    t_gt = rng.uniform(-0.02, 0.02, 3)
+    src = ((tgt[:ns].astype(np.float64) - t_gt) @ R_gt).astype(f32)  # R_gt @ src + t_gt == tgt[:ns]
+    n_out = int(ns * frac)
+    idx = rng.choice(ns, n_out, replace=False)
+    src[idx] = rng.uniform(-0.12, 0.12, (n_out, 3)).astype(f32)
+    return tgt, src, R_gt, t_gt
+
+
+@pytest.fixture(scope="module")
+def small_case(oracle):
+    rng = np.random.default_rng(3)
+    tgt = rng.uniform(-0.5, 0.45, size=(60, 3)).astype(f32)
+    src = rng.uniform(-0.4, 0.4, size=(97, 3)).astype(f32)
+    bounds = np.array([[tgt[:, k].min(), tgt[:, k].max()] for k in range(3)], f32)
+    return tgt, src, bounds, 0.07
+
+
+@pytest.mark.parametrize("k", [1, 40, 96])
+def test_oracle_trimmed_bounds_and_sse_match_numpy(oracle, small_case, k):
+    tgt, src, bounds, res = small_case
+    reg = oracle.Registration(tgt, src, bounds, res)
+    R, _, _ = oracle.rotation(0.2, -0.3, 0.1)
+    rng = np.random.default_rng(2)
+    tn = np.concatenate([rng.uniform(-0.3, 0.3, (6, 3)), rng.choice([0.5, 0.25, 0.0625], (6, 1))], 1).astype(f32)
+    full = reg.compute_bounds(R, 0.25, tn, False)
+    reg.set_inliers(k)
+    lb, ub = reg.compute_bounds(R, 0.25, tn, False)
+    lbn, ubn = npr.bounds(reg.lut_get(), bounds, res, src, R, 0.25, tn, False, inliers=k)
+    assert np.allclose(ub, ubn, rtol=2e-6, atol=1e-9) and np.allclose(lb, lbn, rtol=2e-6, atol=1e-7)
+    assert np.all(ub <= full[1] * (1 + 1e-6)) and np.all(lb <= full[0] * (1 + 1e-6) + 1e-9)
+    t = np.array([0.05, -0.02, 0.01], f32)
+    rp = npr.rot_apply(R, src) + t
+    d2 = np.min(npr.dist_sq(rp[:, None, :].astype(f32), tgt[None, :, :]), axis=1)
+    assert float(reg.compute_sse_error(R, t)) == pytest.approx(float(np.sort(d2)[:k].astype(np.float64).sum()), rel=2e-6)
+    reg.set_inliers(0)
+    assert np.array_equal(reg.compute_bounds(R, 0.25, tn, False)[1], full[1])  # k = 0 restores the reference behaviour
+
+
+def test_oracle_trimmed_procrustes_uses_the_k_closest(oracle):
+    rng = np.random.default_rng(5)
+    tgt = rng.uniform(-1, 1, (300, 3)).astype(f32)
+    work = tgt[:100].copy()
+    work[:20] += rng.uniform(0.3, 0.5, (20, 3)).astype(f32)  # 20 gross outliers
+    reg = oracle.Registration(tgt, work, np.array([[-1, 1]] * 3, f32), 0.5, build_lut=False)
+    R_full, t_full, *_ = reg.procrustes(work)
+    reg.set_inliers(80)
+    R, t, cen, ABt, idx = reg.procrustes(work)
+    assert np.allclose(R, np.eye(3), atol=1e-6) and np.allclose(t, 0, atol=1e-6)       # inliers are exact copies
+    assert not np.allclose(t_full, 0, atol=1e-3)                                         # the untrimmed step is dragged away
+    assert np.allclose(cen[:3], work[20:].mean(0), atol=1e-6)
+
+
+def test_trimmed_search_rejects_outliers(oracle, fg):
+    """20 % uniform outliers: the plain optimum is biased, the trimmed run finds the ground truth."""
+    tgt, src, R_gt, t_gt = outlier_pair(fg, nt=600, ns=400, frac=0.2, seed=9, angle=(20.0, 30.0))
+    trim = oracle.FastGoICP(tgt, src, 0.05, 1e-3, trim_fraction=0.25).run()
+    plain = oracle.FastGoICP(tgt, src, 0.05, 1e-3).run()
+    ang = lambda R: np.degrees(np.arccos(np.clip((np.trace(R.astype(np.float64).T @ R_gt) - 1) / 2, -1, 1)))
+    assert ang(trim["R"]) < 0.05 and np.linalg.norm(trim["t"] - t_gt) < 1e-4 and float(trim["best_sse"]) < 1e-6
+    assert ang(plain["R"]) > 10 * ang(trim["R"]) and float(plain["best_sse"]) > 1.0
+
+
+def test_product_driver_with_trimming_follows_the_oracle_driver(oracle, fg):
+    tgt, src, R_gt, t_gt = outlier_pair(fg, nt=500, ns=300, frac=0.2, seed=4, angle=(100.0, 130.0))
+    o = oracle.FastGoICP(tgt, src, 0.05, 1e-3, trim_fraction=0.25).run()
+    h = hh.HostDriver(tgt, src, 0.05, 1e-3, schedule=0, trim_fraction=0.25).run()
+    assert [h["stats"][k] for k in ("trans_cubes", "bounds_calls", "rot_cubes", "icp_runs", "icp_iters", "inner_bnb")] == \
+           [o["stats"][k] for k in ("trans_cubes", "bounds_calls", "rot_cubes", "icp_runs", "icp_iters", "inner_bnb")]
+    assert np.array_equal(h["R"], o["R"]) and np.array_equal(h["t"], o["t"]) and h["best_sse"] == o["best_sse"]
+    r = hh.HostDriver(tgt, src, 0.05, 1e-3, schedule=1, round_width=4, trim_fraction=0.25).run()
+    assert float(r["best_sse"]) == pytest.approx(float(o["best_sse"]), rel=1e-5, abs=1e-6) and np.allclose(r["R"], o["R"], atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("k_frac", [0.8, 0.5, 0.013])
+def test_hip_trimmed_operators_match_oracle(fg, oracle, tiny_case, gpu_required, k_frac):
+    c = tiny_case
+    k = max(1, int(len(c["pcs"]) * k_frac))
+    hip = fg.Registration(c["pct"], c["pcs"], c["bounds"], c["res"])
+    orc = oracle.Registration(c["pct"], c["pcs"], c["bounds"], c["res"])
+    hip.set_inliers(k); orc.set_inliers(k)
+    rng = np.random.default_rng(17)
+    rn = fg.RotNode(0.25, -0.125, 0.375, 0.125)
+    tn = np.concatenate([rng.uniform(-0.6, 0.6, (45, 3)), rng.choice([0.5, 0.25, 0.0625], (45, 1))], 1).astype(f32)
+    for fix in (True, False):
+        lb, ub = hip.compute_sse_error(rn, tn, fix)
+        lbo, ubo = orc.compute_bounds(rn.q.R, rn.span, tn, fix)
+        assert np.allclose(ub, ubo, rtol=1e-6, atol=1e-12)
+        assert np.allclose(lb, lbo, rtol=1e-6, atol=1e-6 * max(float(ubo.max()), 1e-12))
+    R = fg.synth.random_rotation(rng, 30.0).astype(f32)
+    t = rng.uniform(-0.1, 0.1, 3).astype(f32)
+    assert float(hip.compute_sse_error(R, t)) == pytest.approx(float(orc.compute_sse_error(R, t)), rel=1e-6)
+    w = (c["pcs"] @ R.T + t).astype(f32)
+    Rh, th, cen, ABt, idx = hip.procrustes(w)
+    Ro, to, ceno, ABto, idxo = orc.procrustes(w)
+    assert np.array_equal(idx, idxo) and np.allclose(cen, ceno, rtol=1e-6, atol=1e-7)
+    assert np.allclose(ABt, ABto, rtol=1e-5, atol=1e-5) and np.allclose(Rh, Ro, atol=2e-6) and np.allclose(th, to, atol=2e-6)
+    sse, Ri, ti = fg.IterativeClosestPoint3D(hip, None, None, 100, 0.005, R, t).run()
+    sse_o, Ri_o, ti_o, it_o = orc.icp(R, t, 100, 0.005)
+    assert float(sse) == pytest.approx(float(sse_o), rel=1e-5) and np.allclose(Ri, Ri_o, atol=1e-5)
+    hip.set_inliers(0)  # back to the reference behaviour
+    lb, ub = hip.compute_sse_error(rn, tn, False)
+    orc.set_inliers(0)
+    assert np.allclose(ub, orc.compute_bounds(rn.q.R, rn.span, tn, False)[1], rtol=1e-6)
+    hip.close()
+
+
+@pytest.mark.gpu
+def test_hip_trimmed_ties_at_the_cut_take_the_lowest_index(fg, oracle, gpu_required):
+    rng = np.random.default_rng(2)
+    tgt = rng.uniform(-0.8, 0.8, (50, 3)).astype(f32)
+    off = np.array([0.0625, 0.0, 0.0], f32)
+    work = np.concatenate([tgt[:10], tgt[10:30] + off, tgt[30:40] + 3 * off]).astype(f32)  # 20 points tie exactly at the cut
+    bounds = np.array([[-1, 1]] * 3, f32)
+    hip = fg.Registration(tgt, work, bounds, 0.25)
+    orc = oracle.Registration(tgt, work, bounds, 0.25, build_lut=False)
+    for k in (15, 22, 29):
+        hip.set_inliers(k); orc.set_inliers(k)
+        Rh, th, cen, *_ = hip.procrustes(work)
+        Ro, to, ceno, *_ = orc.procrustes(work)
+        assert np.allclose(cen, ceno, rtol=1e-6, atol=1e-7) and np.allclose(Rh, Ro, atol=2e-6) and np.allclose(th, to, atol=2e-6)
+    hip.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sched,K", [(0, 1), (1, 4)])
+def test_hip_trimmed_full_run_matches_oracle(fg, oracle, gpu_required, sched, K):
+    tgt, src, R_gt, t_gt = outlier_pair(fg, nt=500, ns=300, frac=0.2, seed=4, angle=(100.0, 130.0))
+    o = oracle.FastGoICP(tgt, src, 0.05, 1e-3, trim_fraction=0.25).run()
+    s = fg.FastGoICP(tgt, src, 0.05, 1e-3, schedule=sched, round_width=K, trim_fraction=0.25)
+    R, t = s.run()
+    assert float(s.get_best_error()) == pytest.approx(float(o["best_sse"]), rel=1e-5, abs=1e-6)
+    assert np.allclose(R, o["R"], atol=1e-5) and np.allclose(t, o["t"], atol=1e-5)
+    if sched == 0:
+        st = s.stats()
+        assert [st[k] for k in ("trans_cubes", "rot_cubes", "icp_runs", "icp_iters")] == [o["stats"][k] for k in ("trans_cubes", "rot_cubes", "icp_runs", "icp_iters")]
+    s.close()
