@@ -94,8 +94,13 @@ static int tick_enqueue_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl, int G, c
     *end_out = end;
     if (rows <= 0) return FGOICP_OK;
     const double t1 = g_tt.on ? now_s() : 0;
-    HIPCHK(hipMemcpyAsync(sl.d_groups, sl.h_groups, sizeof(TickGroup) * ng, hipMemcpyHostToDevice, sl.stream));
-    HIPCHK(hipMemcpyAsync(sl.d_subs, sl.h_subs, sizeof(TickSub) * rows, hipMemcpyHostToDevice, sl.stream));
+    // descriptors + locality sort on the slot's side stream (overlaps the other slot's bounds kernel); the main stream joins behind it
+    HIPCHK(hipMemcpyAsync(sl.d_groups, sl.h_groups, sizeof(TickGroup) * ng, hipMemcpyHostToDevice, sl.sort_stream));
+    HIPCHK(hipMemcpyAsync(sl.d_subs, sl.h_subs, sizeof(TickSub) * rows, hipMemcpyHostToDevice, sl.sort_stream));
+    launch_tick_sort(c->geom, c->d_chunk_cen, c->nchunk1, sl.d_groups, sl.d_subs, rows, c->cell_shift, sl.d_keys, sl.d_hist, sl.d_cursor, sl.d_sorted,
+                     sl.sort_stream);
+    HIPCHK(hipEventRecord(sl.sorted_ev, sl.sort_stream));
+    HIPCHK(hipStreamWaitEvent(sl.stream, sl.sorted_ev, 0));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profile) {
         if (c->ev_used == (int)c->ev_start.size()) {  // drain both slots before recycling events
@@ -109,8 +114,8 @@ static int tick_enqueue_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl, int G, c
         c->prof_launches++;
         c->prof_subcubes += rows;
     }
-    launch_bounds_sorted(c->d_src, (int)c->ns, c->d_lut, c->d_lut_zp, c->geom, c->d_chunk_cen, c->nchunk1, sl.d_groups, sl.d_subs, rows, c->cell_shift,
-                         sl.d_keys, sl.d_hist, sl.d_cursor, sl.d_sorted, sl.d_partials, c->inliers ? sl.d_vals : nullptr, e0, e1, sl.stream);
+    launch_bounds_sorted(c->d_src, (int)c->ns, c->d_lut, c->d_lut_zp, c->geom, c->nchunk1, sl.d_groups, sl.d_subs, rows, sl.d_sorted, sl.d_partials,
+                         c->inliers ? sl.d_vals : nullptr, e0, e1, sl.stream);
     if (c->inliers)  // trimmed: the k smallest ub terms (column 0) and the k smallest lb terms (column 1) of every subcube
         launch_trim_select(reinterpret_cast<const float*>(sl.d_vals), 2 * c->ns, 2, (int)c->ns, (int)c->inliers, rows, sl.hd_ub, sl.hd_lb, nullptr, sl.stream);
     else
@@ -538,6 +543,12 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
             fgoicp_ctx::TickSlot& sl = c->slots[k];
             sl.stream = c->stream;
             CHK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+            {
+                const char* e = std::getenv("FGOICP_SORT_STREAM");  // tuning knob: 0 = sort on the main stream
+                if (e && std::atoi(e) == 0) sl.sort_stream = c->stream;
+                else CHK(hipStreamCreateWithFlags(&sl.sort_stream, hipStreamNonBlocking));
+            }
+            CHK(hipEventCreateWithFlags(&sl.sorted_ev, hipEventDisableTiming));
             CHK(hipMalloc(&sl.d_groups, sizeof(TickGroup) * c->max_groups));
             CHK(hipMalloc(&sl.d_subs, sizeof(TickSub) * c->max_subcubes));
             CHK(hipHostMalloc((void**)&sl.h_groups, sizeof(TickGroup) * c->max_groups, hipHostMallocDefault));
@@ -599,6 +610,8 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
     for (int k = 0; k < 2; ++k) {
         fgoicp_ctx::TickSlot& sl = c->slots[k];
         if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.sorted_ev) (void)hipEventDestroy(sl.sorted_ev);
+        if (sl.sort_stream && sl.sort_stream != c->stream) { (void)hipStreamSynchronize(sl.sort_stream); (void)hipStreamDestroy(sl.sort_stream); }
         (void)hipFree(sl.d_vals);
         (void)hipFree(sl.d_groups); (void)hipFree(sl.d_subs); (void)hipFree(sl.d_keys); (void)hipFree(sl.d_hist);
         (void)hipFree(sl.d_cursor); (void)hipFree(sl.d_sorted); (void)hipFree(sl.d_partials);

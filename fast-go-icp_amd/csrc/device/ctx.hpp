@@ -41,6 +41,8 @@ struct fgoicp_ctx {
         hipStream_t stream = nullptr;            // both slots queue on the context stream: their kernels run back to back, never
                                                  // concurrently (two sorted kernels at once would thrash each other's L2 neighbourhoods)
         hipEvent_t done = nullptr;               // recorded behind the slot's last kernel; collect waits on it, not on the stream
+        hipStream_t sort_stream = nullptr;       // descriptors upload + locality sort of THIS slot run here, next to the other
+        hipEvent_t sorted_ev = nullptr;          //   slot's bounds kernel on the main stream, which then waits for sorted_ev
         fgoicp::TickGroup *d_groups = nullptr, *h_groups = nullptr;   // device / pinned staging
         fgoicp::TickSub *d_subs = nullptr, *h_subs = nullptr;
         unsigned short* d_keys = nullptr;

@@ -1060,17 +1060,23 @@ void launch_bounds(const float4* src, int ns, const float* lut, const LutGeom& g
     }
 }
 
-void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* zp, const LutGeom& g, const float4* chunk_cen, int nchunk, const TickGroup* groups,
-                          const TickSub* subs, int nsub, int cell_shift, unsigned short* keys, unsigned* hist, unsigned* cursor, unsigned* sorted,
-                          double2* partials, float2* vals, hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s) {
+// The locality sort of one tick (descriptors must already be on the device): keys + histogram, scan, scatter.
+void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, const TickGroup* groups, const TickSub* subs, int nsub, int cell_shift,
+                      unsigned short* keys, unsigned* hist, unsigned* cursor, unsigned* sorted, hipStream_t s) {
+    const size_t nitems = (size_t)nsub * nchunk;
+    (void)hipMemsetAsync(hist, 0, sizeof(unsigned) * kNumKeys, s);
+    const unsigned kb = (unsigned)std::min<size_t>((nitems + kBlock - 1) / kBlock, 2048);
+    hipLaunchKernelGGL(tick_keys_kernel, dim3(kb), dim3(kBlock), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, hist);
+    hipLaunchKernelGGL(tick_scan_kernel, dim3(1), dim3(1024), 0, s, hist, cursor);
+    hipLaunchKernelGGL(tick_scatter_kernel, dim3(kb), dim3(kBlock), 0, s, keys, nitems, cursor, sorted);
+}
+
+void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* zp, const LutGeom& g, int nchunk, const TickGroup* groups,
+                          const TickSub* subs, int nsub, const unsigned* sorted, double2* partials, float2* vals, hipEvent_t ev_start,
+                          hipEvent_t ev_stop, hipStream_t s) {
     const size_t nitems = (size_t)nsub * nchunk;
     const TickGroup* gp = groups;
     const TickSub* sp = subs;
-    (void)hipMemsetAsync(hist, 0, sizeof(unsigned) * kNumKeys, s);
-    const unsigned kb = (unsigned)std::min<size_t>((nitems + kBlock - 1) / kBlock, 2048);
-    hipLaunchKernelGGL(tick_keys_kernel, dim3(kb), dim3(kBlock), 0, s, chunk_cen, nchunk, gp, sp, nsub, g, cell_shift, keys, hist);
-    hipLaunchKernelGGL(tick_scan_kernel, dim3(1), dim3(1024), 0, s, hist, cursor);
-    hipLaunchKernelGGL(tick_scatter_kernel, dim3(kb), dim3(kBlock), 0, s, keys, nitems, cursor, sorted);
     if (ev_start) (void)hipEventRecord(ev_start, s);
     static const int variant = [] { const char* e = std::getenv("FGOICP_BOUNDS_VARIANT"); return e ? std::atoi(e) : 1; }();  // tuning knob (1 = default)
     const dim3 grid((unsigned)nitems);

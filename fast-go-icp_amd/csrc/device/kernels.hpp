@@ -58,9 +58,11 @@ struct TickSub {     // one translation node + its rotation node
     int pad_[3];
 };
 constexpr int kTickNumKeys = 1 << 15;
-void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* zpair_or_null, const LutGeom& g, const float4* chunk_cen, int nchunk, const TickGroup* groups,
-                          const TickSub* subs, int nsub, int cell_shift, unsigned short* keys, unsigned* hist, unsigned* cursor, unsigned* sorted,
-                          double2* partials, float2* vals_or_null, hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s);
+void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, const TickGroup* groups, const TickSub* subs, int nsub, int cell_shift,
+                      unsigned short* keys, unsigned* hist, unsigned* cursor, unsigned* sorted, hipStream_t s);
+void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* zpair_or_null, const LutGeom& g, int nchunk,
+                          const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials, float2* vals_or_null,
+                          hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s);
 // EXTENSION (trimmed Go-ICP): sum of the k smallest entries of each row/column of `vals` (exact radix select, kernels.hip)
 void launch_trim_select(const float* vals, size_t row_stride, int ncols, int n, int k, int rows, float* out0, float* out1, uint32_t* sel_info,
                         hipStream_t s);

@@ -43,3 +43,13 @@ def test_world_size_2_round_schedule(tmp_path, case, K):
     assert float(a["sse"]) == pytest.approx(float(G[case + "sse"]), rel=1e-5)
     assert np.allclose(a["R"], G[case + "R"], atol=1e-5)
     assert np.allclose(a["t"], G[case + "t"], atol=1e-5 * max(1.0, float(np.abs(G[case + "t"]).max())))
+
+
+def test_world_size_3_uneven_sharding(tmp_path):
+    """8 children over 3 ranks (3 + 3 + 2): padded all-gather slots, identical replicated state everywhere."""
+    ranks = launch(tmp_path, "runsyn_", 1, 3)
+    for r in ranks[1:]:
+        assert np.array_equal(ranks[0]["R"], r["R"]) and np.array_equal(ranks[0]["t"], r["t"]) and ranks[0]["sse"] == r["sse"]
+    assert sorted(int(r["rot_cubes"]) for r in ranks) == [2, 3, 3]
+    assert float(ranks[0]["sse"]) == pytest.approx(float(G["runsyn_sse"]), rel=1e-5)
+    assert np.allclose(ranks[0]["R"], G["runsyn_R"], atol=1e-5)
