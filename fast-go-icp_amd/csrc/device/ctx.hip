@@ -114,7 +114,7 @@ static int tick_enqueue_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl, int G, c
         c->prof_launches++;
         c->prof_subcubes += rows;
     }
-    launch_bounds_sorted(c->d_src, (int)c->ns, c->d_lut, c->d_lut_zp, c->geom, c->nchunk1, sl.d_groups, sl.d_subs, rows, sl.d_sorted, sl.d_partials,
+    launch_bounds_sorted(c->d_src, (int)c->ns, c->d_lut, c->d_lut_zp, c->lut_layout, c->geom, c->nchunk1, sl.d_groups, sl.d_subs, rows, sl.d_sorted, sl.d_partials,
                          c->inliers ? sl.d_vals : nullptr, e0, e1, sl.stream);
     if (c->inliers)  // trimmed: the k smallest ub terms (column 0) and the k smallest lb terms (column 1) of every subcube
         launch_trim_select(reinterpret_cast<const float*>(sl.d_vals), 2 * c->ns, 2, (int)c->ns, (int)c->inliers, rows, sl.hd_ub, sl.hd_lb, nullptr, sl.stream);
@@ -491,11 +491,22 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
             bvh_free(&shifted);
         }
         if (e3 != hipSuccess) { set_error(std::string("LUT build failed: ") + hipGetErrorString(e3)); return fail(e3 == hipErrorOutOfMemory ? FGOICP_ERR_OOM : FGOICP_ERR_HIP); }
-        bool zpair = true;
-        if (const char* e = std::getenv("FGOICP_LUT_ZPAIR")) zpair = std::atoi(e) != 0;
-        if (zpair) {
+        // Packed copy for the bounds kernel: 0 none, 1 z-pair (2x bytes, two rows per lookup), 2 yz-quad (4x bytes, one
+        // line per lookup).  Measured: the quad wins on sparse clouds (every lane-gather its own line; +8 % at 40k
+        // points), loses on dense ones (lanes share lines and the 4x footprint falls out of cache; -5 % at 437k), so it
+        // is chosen by the number of source points per voxel of the LUT's projected faces.
+        const double face_voxels = (double)g.dx * g.dy + (double)g.dy * g.dz + (double)g.dx * g.dz;
+        int layout = ((double)ns / face_voxels < 0.5 && total * sizeof(float4) <= ((size_t)16 << 30)) ? 2 : 1;
+        if (const char* e = std::getenv("FGOICP_LUT_ZPAIR")) layout = std::atoi(e);  // tuning knob
+        c->lut_layout = layout;
+        if (layout == 2) {
+            CHK(hipMalloc(&c->d_lut_zp, total * sizeof(float4)));
+            launch_lut_quad(c->d_lut, g, reinterpret_cast<float4*>(c->d_lut_zp), c->stream);
+        } else if (layout == 1) {
             CHK(hipMalloc(&c->d_lut_zp, total * sizeof(float2)));
             launch_lut_zpair(c->d_lut, g, c->d_lut_zp, c->stream);
+        }
+        if (layout) {
             CHK(hipGetLastError());
             CHK(hipStreamSynchronize(c->stream));
         }

@@ -140,6 +140,25 @@ __device__ __forceinline__ void zpair_gather(const float2* __restrict__ zp, cons
     v11 = float2u{b.y, b.w};  // (x0, x1) at (y1, z1)
 }
 
+// yz-quad copy: q[o] = {T[o], T[o + z-slice], T[o + row], T[o + row + z-slice]} — a lookup is then 32 CONTIGUOUS bytes
+// (q[o], q[o+1]: x0 and x1), i.e. one cache line (two when x0 % 8 == 7) instead of two rows.  4x the bytes of the LUT.
+typedef float float4a __attribute__((ext_vector_type(4), aligned(16)));
+__device__ __forceinline__ void quad_gather(const float4* __restrict__ qd, const TexAddr& t, float2u& v00, float2u& v10, float2u& v01, float2u& v11) {
+    const float4a a = *(const float4a*)(qd + t.o);
+    const float4a b = *(const float4a*)(qd + t.o + 1);
+    v00 = float2u{a.x, b.x};  // (x0, x1) at (y0, z0)
+    v01 = float2u{a.y, b.y};  // (y0, z1)
+    v10 = float2u{a.z, b.z};  // (y1, z0)
+    v11 = float2u{a.w, b.w};  // (y1, z1)
+}
+__global__ __launch_bounds__(kBlock) void lut_quad_kernel(const float* __restrict__ lut, LutGeom g, float4* __restrict__ qd) {
+    const size_t total = (size_t)g.px * g.py * g.pz, sy = (size_t)g.px, sz = (size_t)g.px * g.py;
+    for (size_t n = (size_t)blockIdx.x * kBlock + threadIdx.x; n < total; n += (size_t)gridDim.x * kBlock) {
+        const size_t nz = n + sz < total ? n + sz : n, ny = n + sy < total ? n + sy : n, nyz = n + sy + sz < total ? n + sy + sz : n;
+        qd[n] = make_float4(lut[n], lut[nz], lut[ny], lut[nyz]);  // out-of-range neighbours belong to texels no lookup uses as (y0, z0)
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void lut_zpair_kernel(const float* __restrict__ lut, LutGeom g, float2* __restrict__ zp) {
     const size_t total = (size_t)g.px * g.py * g.pz, sz = (size_t)g.px * g.py;
     for (size_t n = (size_t)blockIdx.x * kBlock + threadIdx.x; n < total; n += (size_t)gridDim.x * kBlock)
@@ -314,7 +333,9 @@ __global__ __launch_bounds__(THREADS) void bounds_sorted_kernel(const float4* __
     }
 #pragma unroll
     for (int k = 0; k < P; ++k) {
-        if (ZPAIR) {
+        if (ZPAIR == 2) {
+            quad_gather(reinterpret_cast<const float4*>(zp), ta[k], v00[k], v10[k], v01[k], v11[k]);
+        } else if (ZPAIR == 1) {
             zpair_gather(zp, g, ta[k], v00[k], v10[k], v01[k], v11[k]);
         } else {
             const float* q = lut + ta[k].o;
@@ -1071,9 +1092,9 @@ void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, con
     hipLaunchKernelGGL(tick_scatter_kernel, dim3(kb), dim3(kBlock), 0, s, keys, nitems, cursor, sorted);
 }
 
-void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* zp, const LutGeom& g, int nchunk, const TickGroup* groups,
-                          const TickSub* subs, int nsub, const unsigned* sorted, double2* partials, float2* vals, hipEvent_t ev_start,
-                          hipEvent_t ev_stop, hipStream_t s) {
+void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* zp, int layout, const LutGeom& g, int nchunk,
+                          const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials, float2* vals,
+                          hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s) {
     const size_t nitems = (size_t)nsub * nchunk;
     const TickGroup* gp = groups;
     const TickSub* sp = subs;
@@ -1083,7 +1104,9 @@ void launch_bounds_sorted(const float4* src, int ns, const float* lut, const flo
 #define FGOICP_LAUNCH_SORTED(T, PP, Z, TR) \
     hipLaunchKernelGGL((bounds_sorted_kernel<T, PP, Z, TR>), grid, dim3(T), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, partials, vals)
     if (vals) {
-        if (zp) FGOICP_LAUNCH_SORTED(128, 2, 1, 1); else FGOICP_LAUNCH_SORTED(128, 2, 0, 1);
+        if (zp && layout == 2) FGOICP_LAUNCH_SORTED(128, 2, 2, 1); else if (zp) FGOICP_LAUNCH_SORTED(128, 2, 1, 1); else FGOICP_LAUNCH_SORTED(128, 2, 0, 1);
+    } else if (zp && layout == 2) {
+        if (variant == 0) FGOICP_LAUNCH_SORTED(256, 1, 2, 0); else if (variant == 2) FGOICP_LAUNCH_SORTED(64, 4, 2, 0); else FGOICP_LAUNCH_SORTED(128, 2, 2, 0);
     } else if (zp) {
         if (variant == 0) FGOICP_LAUNCH_SORTED(256, 1, 1, 0); else if (variant == 2) FGOICP_LAUNCH_SORTED(64, 4, 1, 0); else FGOICP_LAUNCH_SORTED(128, 2, 1, 0);
     } else {
@@ -1102,6 +1125,10 @@ void launch_lut_build(const float4* tgt_shifted, int nt, const LutGeom& g, float
     const size_t per_block = (size_t)kBlock * kLutNodes;
     const unsigned blocks = (unsigned)((total + per_block - 1) / per_block);
     hipLaunchKernelGGL(lut_build_kernel, dim3(blocks), dim3(kBlock), 0, s, tgt_shifted, nt, g, lut_padded);
+}
+
+void launch_lut_quad(const float* lut_padded, const LutGeom& g, float4* qd, hipStream_t s) {
+    hipLaunchKernelGGL(lut_quad_kernel, dim3(8192), dim3(kBlock), 0, s, lut_padded, g, qd);
 }
 
 void launch_lut_zpair(const float* lut_padded, const LutGeom& g, float2* zp, hipStream_t s) {

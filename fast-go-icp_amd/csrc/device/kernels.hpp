@@ -60,7 +60,7 @@ struct TickSub {     // one translation node + its rotation node
 constexpr int kTickNumKeys = 1 << 15;
 void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, const TickGroup* groups, const TickSub* subs, int nsub, int cell_shift,
                       unsigned short* keys, unsigned* hist, unsigned* cursor, unsigned* sorted, hipStream_t s);
-void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* zpair_or_null, const LutGeom& g, int nchunk,
+void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* packed_or_null, int layout /* 1 z-pair, 2 yz-quad */, const LutGeom& g, int nchunk,
                           const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials, float2* vals_or_null,
                           hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s);
 // EXTENSION (trimmed Go-ICP): sum of the k smallest entries of each row/column of `vals` (exact radix select, kernels.hip)
@@ -75,6 +75,7 @@ void launch_bounds_finalize(const double2* partials, int nchunk, int total, floa
 void launch_lut_build(const float4* tgt_shifted, int nt, const LutGeom& g, float* lut_padded, hipStream_t s);
 // zp[o] = {lut[o], lut[o + one z-slice]}: the z-paired copy the sorted bounds kernel gathers from (kernels.hip)
 void launch_lut_zpair(const float* lut_padded, const LutGeom& g, float2* zp, hipStream_t s);
+void launch_lut_quad(const float* lut_padded, const LutGeom& g, float4* qd, hipStream_t s);
 void launch_lut_unpad(const float* lut_padded, const LutGeom& g, float* out, hipStream_t s);
 void launch_lut_search(const float* lut, const LutGeom& g, const float* q_xyz, size_t n, float* out, hipStream_t s);
 
