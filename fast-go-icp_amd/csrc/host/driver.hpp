@@ -187,6 +187,7 @@ struct InnerTask {
 struct Task : InnerTask {
     bool done = false;
     bool has_batch = false;
+    uint64_t batches = 0;  // operator calls this task took part in (= compute_sse_error calls of the reference for it)
 };
 
 // A few host threads for the per-task queue work of a tick (the inner BnBs of a round are independent:
@@ -271,7 +272,7 @@ public:
         const int hw = (int)std::thread::hardware_concurrency();
         if (hw > 0 && nthreads > hw) nthreads = hw;
         if (nthreads < 1) nthreads = 1;
-        pool_.reset(new WorkerPool(schedule == kScheduleRound ? nthreads : 1));
+        pool_.reset(new WorkerPool(nthreads));
     }
 
     void set_exchange(const Exchange& ex) { ex_ = ex; }
@@ -340,23 +341,18 @@ private:
     void set_best_sse_only(float sse) { std::lock_guard<std::mutex> g(mu_); best_sse_ = sse; }
     void set_last(const Mat3f& R, const Vec3f& t) { std::lock_guard<std::mutex> g(mu_); last_R_ = R; last_t_ = t; }
 
-    // branch_and_bound_R3 (fgoicp.cpp:102-174) for one rotation cube, run to completion
-    int bnb_r3(const RotCube& rnode, bool fix_rot, float best_sse_now, float& best_ub, Vec3f& best_t) {
-        Task task;
-        task.start(fix_rot, best_sse_now, rnode.ub);
-        stats_.inner_bnb++;
-        std::vector<Task*> v{&task};
-        std::vector<const RotCube*> c{&rnode};
-        int rc = run_task_list(v, c);
-        best_ub = task.best_ub;
-        best_t = task.best_t;
-        return rc;
-    }
-
     // -------------------------------------------------------------------------------------------
-    // SERIAL: fgoicp.cpp:32-100 verbatim in behaviour
+    // SERIAL: fgoicp.cpp:32-100 verbatim in behaviour — same pops, same pushes, same counters — but not
+    // verbatim in execution.  The children of a popped node couple only through `best_sse`, and that
+    // changes only when an ICP improves it (a handful of times per run).  So the UB and LB inner BnBs
+    // of all remaining children are evaluated SPECULATIVELY in lock-step with the current `best_sse`
+    // (one operator submission per tick instead of one per 32 subcubes), then committed in the
+    // reference's order; the moment an ICP improves `best_sse`, everything after that point is
+    // discarded and re-evaluated.  Committed work is exactly the reference's; discarded work is not
+    // counted.  FGOICP_SERIAL_SPECULATE=0 restores the literal one-task-at-a-time execution.
     // -------------------------------------------------------------------------------------------
     int bnb_so3_serial() {
+        static const bool speculate = [] { const char* e = std::getenv("FGOICP_SERIAL_SPECULATE"); return !e || std::atoi(e) != 0; }();
         std::priority_queue<RotCube> rcand;
         rcand.push(RotCube(0.f, 0.f, 0.f, 1.0f, 0.f, best_sse()));
         while (!rcand.empty()) {
@@ -365,27 +361,62 @@ private:
             stats_.rounds++;
             if (best_sse() - rnode.lb <= sse_threshold_) break;  // :44
             const float span = rnode.span / 2.0f;
+            // the children in the reference's j order: kind 0 = push unevaluated (centre outside the ball), 1 = evaluate
+            std::vector<RotCube> kids;
+            std::vector<int> kind;
             for (char j = 0; j < 8; ++j) {
                 if (span < 0.05f) continue;  // :53
                 RotCube child(rnode.q.x - span + (j >> 0 & 1) * rnode.span, rnode.q.y - span + (j >> 1 & 1) * rnode.span,
                               rnode.q.z - span + (j >> 2 & 1) * rnode.span, span, rnode.lb, rnode.ub);
                 if (!child.overlaps_SO3()) continue;
-                if (!child.q.in_SO3()) { rcand.push(child); continue; }
+                kids.push_back(child);
+                kind.push_back(child.q.in_SO3() ? 1 : 0);
+            }
+            // per evaluated child: its UB task [2k] and LB task [2k+1]; valid[] = computed with the CURRENT best_sse
+            std::vector<Task> tk(2 * kids.size());
+            std::vector<char> valid(2 * kids.size(), 0);
+            auto speculate_from = [&](size_t first_task) -> int {  // (re)evaluate every task >= first_task that is not valid
+                std::vector<Task*> tasks;
+                std::vector<const RotCube*> cubes;
+                const float snap = best_sse();
+                for (size_t t = first_task; t < tk.size(); ++t) {
+                    if (kind[t / 2] != 1 || valid[t]) continue;
+                    tk[t] = Task();
+                    tk[t].start((t & 1) == 0, snap, kids[t / 2].ub);
+                    tasks.push_back(&tk[t]);
+                    cubes.push_back(&kids[t / 2]);
+                    valid[t] = 1;
+                    if (!speculate) break;  // literal execution: one task at a time
+                }
+                if (tasks.empty()) return kDriverOk;
+                account_submissions_ = false;
+                const int rc = run_task_list(tasks, cubes);
+                account_submissions_ = true;
+                return rc;
+            };
+            auto commit = [&](const Task& t) { stats_.inner_bnb++; stats_.trans_cubes += t.count; stats_.bounds_calls += t.batches; };
+            for (size_t k = 0; k < kids.size(); ++k) {
+                RotCube& child = kids[k];
+                if (kind[k] == 0) { rcand.push(child); continue; }  // :62-66
                 stats_.rot_cubes++;
-                float ub; Vec3f bt;
-                int rc = bnb_r3(child, true, best_sse(), ub, bt);  // :69
-                if (rc) return rc;
+                if (!valid[2 * k]) { int rc = speculate_from(2 * k); if (rc) return rc; }
+                commit(tk[2 * k]);
+                const float ub = tk[2 * k].best_ub;  // :69
+                const Vec3f bt = tk[2 * k].best_t;
                 set_last(child.q.R, bt);  // :71-72
                 if (ub < best_sse() * 1.8) {  // :74, double compare
                     float sse; Mat3f R; Vec3f t;
-                    rc = icp(child.q.R, bt, 0.005f, sse, R, t);
+                    int rc = icp(child.q.R, bt, 0.005f, sse, R, t);
                     if (rc) return rc;
-                    if (sse < best_sse()) { std::lock_guard<std::mutex> g(mu_); best_sse_ = sse; best_R_ = R; best_t_ = t; }
+                    if (sse < best_sse()) {
+                        { std::lock_guard<std::mutex> g(mu_); best_sse_ = sse; best_R_ = R; best_t_ = t; }
+                        for (size_t t2 = 2 * k + 1; t2 < valid.size(); ++t2) valid[t2] = 0;  // everything later saw a stale best_sse
+                    }
                 }
-                float lb; Vec3f unused;
-                rc = bnb_r3(child, false, best_sse(), lb, unused);  // :90
-                if (rc) return rc;
-                if (lb >= best_sse()) continue;  // :92
+                if (!valid[2 * k + 1]) { int rc = speculate_from(2 * k + 1); if (rc) return rc; }
+                commit(tk[2 * k + 1]);
+                const float lb = tk[2 * k + 1].best_ub;  // :90 — the LB pass' best_ub is the cube's lower bound
+                if (lb >= best_sse()) continue;            // :92
                 child.lb = lb;
                 child.ub = ub;
                 rcand.push(child);
@@ -528,6 +559,7 @@ private:
             if (tk.done) return;
             if (!tk.next_batch(sse_threshold_)) { tk.done = true; return; }
             tk.has_batch = true;
+            tk.batches++;
         };
         if (par) pool_->parallel_for(h.members.size(), pop_fn);
         else for (size_t k = 0; k < h.members.size(); ++k) pop_fn(k);
@@ -554,8 +586,10 @@ private:
         const std::function<void(size_t)> push_fn = [&](size_t k) { tasks[h.live[k]]->consume(h.lb.data() + h.offsets[k], h.ub.data() + h.offsets[k]); };
         if (par) pool_->parallel_for(h.live.size(), push_fn);
         else for (size_t k = 0; k < h.live.size(); ++k) push_fn(k);
-        stats_.bounds_calls++;
-        stats_.trans_cubes += h.tn4.size() / 4;
+        if (account_submissions_) {  // ROUND: one operator submission serves many tasks
+            stats_.bounds_calls++;
+            stats_.trans_cubes += h.tn4.size() / 4;
+        }
     }
 
     // Advance a set of inner tasks to completion.  Every submission carries the current batch of every
@@ -618,6 +652,7 @@ private:
 
     Ops& ops_;
     double t_pop_ = 0, t_ops_ = 0, t_push_ = 0;
+    bool account_submissions_ = true;   // false while SERIAL speculates: work is accounted per committed task instead
     std::unique_ptr<WorkerPool> pool_;
     float sse_threshold_;
     int schedule_, round_width_;
