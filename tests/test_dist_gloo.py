@@ -21,7 +21,7 @@ def free_port():
 
 def launch(tmp_path, case, K, world):
     prefix = str(tmp_path / f"out_{case}{K}_{world}")
-    env = dict(os.environ, OMP_NUM_THREADS="2")
+    env = dict(os.environ, OMP_NUM_THREADS="1" if world > 3 else "2", FGOICP_HOST_THREADS="1" if world > 3 else "4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(REPO, "tests", "dist_worker.py"), prefix, case, str(K)]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -53,3 +53,20 @@ def test_world_size_3_uneven_sharding(tmp_path):
     assert sorted(int(r["rot_cubes"]) for r in ranks) == [2, 3, 3]
     assert float(ranks[0]["sse"]) == pytest.approx(float(G["runsyn_sse"]), rel=1e-5)
     assert np.allclose(ranks[0]["R"], G["runsyn_R"], atol=1e-5)
+
+
+def test_world_size_8_one_child_per_rank(tmp_path, fg):
+    """The 8-GPU shape of the benchmark's first round: 8 children, one per rank; then K = 2 -> 16 children, two per rank.
+    Exact-copy clouds under a known motion (one unambiguous optimum: with a loose threshold different exploration
+    orders may return different epsilon-optimal solutions — 8 ranks triggering 8 ICPs at once usually find a better one)."""
+    rng = np.random.default_rng(21)
+    R_gt = fg.synth.random_rotation(rng, 150.0, 140.0)
+    t_gt = np.array([0.01, -0.02, 0.015])
+    for K in (1, 2):
+        ranks = launch(tmp_path, "kat_", K, 8)
+        for r in ranks[1:]:
+            assert np.array_equal(ranks[0]["R"], r["R"]) and np.array_equal(ranks[0]["t"], r["t"]) and ranks[0]["sse"] == r["sse"]
+            assert r["rounds"] == ranks[0]["rounds"] and r["exchange_calls"] == 2 * r["rounds"]
+        assert all(int(r["rot_cubes"]) >= 1 for r in ranks)
+        ang = np.degrees(np.arccos(np.clip((np.trace(ranks[0]["R"].astype(np.float64).T @ R_gt) - 1) / 2, -1, 1)))
+        assert ang < 0.05 and np.linalg.norm(ranks[0]["t"] - t_gt) < 1e-4 and float(ranks[0]["sse"]) < 1e-6
