@@ -33,10 +33,6 @@ void set_error(const std::string& s) { g_last_error = s; }
         }                                                                                              \
     } while (0)
 
-namespace {
-
-}  // namespace
-
 int ctx_flush_profile(fgoicp_ctx* c) {
     for (int i = 0; i < c->ev_used; ++i) {
         float ms = 0.f;
@@ -114,14 +110,20 @@ static int tick_enqueue_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl, int G, c
         c->prof_launches++;
         c->prof_subcubes += rows;
     }
-    launch_bounds_sorted(c->d_src, (int)c->ns, c->d_lut, c->d_lut_zp, c->lut_layout, c->geom, c->nchunk1, sl.d_groups, sl.d_subs, rows, sl.d_sorted, sl.d_partials,
+    launch_bounds_sorted(c->d_src, (int)c->ns, c->d_lut, c->d_lut_zp, c->lut_layout, c->geom, c->nchunk1, c->chunk_pts, sl.d_groups, sl.d_subs, rows, sl.d_sorted, sl.d_partials,
                          c->inliers ? sl.d_vals : nullptr, e0, e1, sl.stream);
+    // the per-subcube sums run on the slot's side stream, so the main stream holds nothing but bounds kernels back to back
+    hipStream_t fin = c->finalize_on_side ? sl.sort_stream : sl.stream;
+    if (fin != sl.stream) {
+        HIPCHK(hipEventRecord(sl.bounds_ev, sl.stream));
+        HIPCHK(hipStreamWaitEvent(fin, sl.bounds_ev, 0));
+    }
     if (c->inliers)  // trimmed: the k smallest ub terms (column 0) and the k smallest lb terms (column 1) of every subcube
-        launch_trim_select(reinterpret_cast<const float*>(sl.d_vals), 2 * c->ns, 2, (int)c->ns, (int)c->inliers, rows, sl.hd_ub, sl.hd_lb, nullptr, sl.stream);
+        launch_trim_select(reinterpret_cast<const float*>(sl.d_vals), 2 * c->ns, 2, (int)c->ns, (int)c->inliers, rows, sl.hd_ub, sl.hd_lb, nullptr, fin);
     else
-        launch_bounds_finalize(sl.d_partials, c->nchunk1, rows, sl.hd_lb, sl.hd_ub, sl.stream);
+        launch_bounds_finalize(sl.d_partials, c->nchunk1, rows, sl.hd_lb, sl.hd_ub, fin);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(sl.done, sl.stream));
+    HIPCHK(hipEventRecord(sl.done, fin));
     sl.win_pos = pos;
     sl.win_rows = rows;
     if (g_tt.on) { g_tt.pack += t1 - t0; g_tt.enqueue += now_s() - t1; g_tt.ticks++; }
@@ -251,14 +253,14 @@ int ctx_bounds_multi(fgoicp_ctx* c, int G, const float* R9, const float* rot_spa
 }
 
 // float Registration::compute_sse_error(glm::mat3, glm::vec3) — registration.cu:62-86
-int ctx_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out) {
+int ctx_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out, const uint32_t* seed_idx) {
     HIPCHK(hipSetDevice(c->device));
     const int ns = (int)c->ns;
     if (c->brute_force_nn) {
         launch_fill_u32(c->d_min_bits, 0x501502F9u /* bits(1e10f) */, c->ns, c->stream);
         launch_nn_min(c->d_src, ns, c->d_tgt, (int)c->nt, R9, t3, 1, c->d_min_bits, c->stream);
     } else {
-        launch_nn_scan(c->d_src, ns, c->bvh_tgt.view(), c->d_lut, c->geom, R9, t3, 1, 0, c->d_min_bits, c->stream);
+        launch_nn_scan(c->d_src, ns, c->bvh_tgt.view(), c->d_lut, c->geom, R9, t3, 1, 0, c->d_tgt, (int)c->nt, seed_idx, c->d_min_bits, c->stream);
     }
     if (c->inliers) {  // trimmed SSE: the k smallest nearest-neighbour terms
         launch_trim_select(reinterpret_cast<const float*>(c->d_min_bits), 0, 1, ns, (int)c->inliers, 1, c->hd_trim, nullptr, nullptr, c->stream);
@@ -277,7 +279,7 @@ int ctx_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out) {
 }
 
 // IterativeClosestPoint3D::procrustes() on c->d_work — icp3d.cu:140-172
-int ctx_procrustes_device(fgoicp_ctx* c, Mat3f* R_out, Vec3f* t_out, float* centroids6_out, Mat3f* ABt_out) {
+int ctx_procrustes_device(fgoicp_ctx* c, Mat3f* R_out, Vec3f* t_out, float* centroids6_out, Mat3f* ABt_out, bool seeded) {
     const int ns = (int)c->ns, nt = (int)c->nt;
     // kernFindNearestNeighbor (icp3d.cu:11-28): min distance, tie set, lowest index
     if (c->brute_force_nn) {
@@ -287,7 +289,7 @@ int ctx_procrustes_device(fgoicp_ctx* c, Mat3f* R_out, Vec3f* t_out, float* cent
         launch_nn_tie_threshold(c->d_min_bits, ns, c->d_thr_bits, c->stream);
         launch_nn_first_index(c->d_work, ns, c->d_tgt, nt, c->d_thr_bits, c->d_first_idx, c->stream);
     } else {
-        launch_nn_scan(c->d_work, ns, c->bvh_tgt.view(), c->d_lut, c->geom, nullptr, nullptr, 0, 1, c->d_first_idx, c->stream);
+        launch_nn_scan(c->d_work, ns, c->bvh_tgt.view(), c->d_lut, c->geom, nullptr, nullptr, 0, 1, c->d_tgt, nt, seeded ? c->d_first_idx : nullptr, c->d_first_idx, c->stream);
     }
     const int nb = reduce_blocks_for(ns);
     const unsigned char* use = nullptr;
@@ -336,14 +338,15 @@ int ctx_icp(fgoicp_ctx* c, const float* R0, const float* t0, size_t max_iter, fl
         last_t = t;
         Mat3f Rn;
         Vec3f tn;
-        int rc = ctx_procrustes_device(c, &Rn, &tn, nullptr, nullptr);
+        // every pass after the first seeds its exact search with the correspondences of the pass before it (d_first_idx)
+        int rc = ctx_procrustes_device(c, &Rn, &tn, nullptr, nullptr, iters > 0 && c->icp_seeding);
         if (rc) return rc;
         const float tn3[3] = {tn.x, tn.y, tn.z};
         launch_transform_inplace(c->d_work, ns, Rn.m, tn3, c->stream);  // :100
         R = Rn * R;                                                      // :101
         t = Rn * t + tn;                                                 // :102
         const float t3[3] = {t.x, t.y, t.z};
-        rc = ctx_sse(c, R.m, t3, &sse);                                  // :103
+        rc = ctx_sse(c, R.m, t3, &sse, c->icp_seeding && !c->brute_force_nn ? c->d_first_idx : nullptr);  // :103
         if (rc) return rc;
         ++iters;
     }
@@ -521,7 +524,35 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
         }
         c->pts_per_thread = P;
         c->nchunk = (int)((ns + (size_t)kBlock * P - 1) / ((size_t)kBlock * P));
-        c->max_subcubes = 4096;
+        // subcubes per window: as many as 4 GiB of per-(subcube, chunk) scratch per slot hold, 4096..32768 (wide rounds submit
+        // tens of thousands per tick; bigger launches sort into longer runs of items per LUT cell and re-use the L2 better)
+        {
+            // points per work item of the sorted path: the patch of 256 Morton-consecutive points of a sparse cloud spans
+            // ~28 voxels; in a dense cloud (>= 1 point per voxel of the LUT's faces) it shrinks to ~6, so the items grow to
+            // 2048 points — 8x fewer items to sort, 8x fewer partials, same locality.  Measured (437k points, density 1.8,
+            // one certify run): 256 / 512 / 1024 / 2048 / 4096 points per item -> 4.68 / 3.34 / 2.70 / 2.48 / 2.60 s;
+            // 40k points, density 0.1: 256 -> 512 points 8 % slower.
+            {
+                const double face_voxels = (double)g.dx * g.dy + (double)g.dy * g.dz + (double)g.dx * g.dz;
+                const double density = (double)ns / face_voxels;
+                c->chunk_pts = density >= 1.0 ? 2048 : density >= 0.5 ? 1024 : density >= 0.25 ? 512 : 256;
+                if (const char* e = std::getenv("FGOICP_CHUNK_PTS")) {  // tuning knob
+                    const int v = std::atoi(e);
+                    if (v == 256 || v == 512 || v == 1024 || v == 2048 || v == 4096) c->chunk_pts = v;
+                }
+            }
+            const size_t nchunk1 = (ns + c->chunk_pts - 1) / c->chunk_pts;
+            const size_t fit = ((size_t)4 << 30) / (nchunk1 * (sizeof(double2) + sizeof(unsigned) + sizeof(unsigned short)));
+            c->max_subcubes = (int)std::max<size_t>(4096, std::min<size_t>(32768, fit));
+            if (const char* e = std::getenv("FGOICP_MAX_SUBCUBES")) c->max_subcubes = std::max(kMaxBatch, std::min(1 << 16, std::atoi(e)));  // tuning knob: subcubes per window
+            // one launch = one workgroup per (subcube, chunk) item: keep items x 256 threads inside the 32-bit grid
+            const size_t launch_fit = (((size_t)1 << 24) - 1) / nchunk1;
+            if (launch_fit < (size_t)kMaxBatch) {
+                set_error("fgoicp_ctx_create: source cloud too large for one bounds launch per batch (ns > ~134M)");
+                return fail(FGOICP_ERR_TOO_LARGE);
+            }
+            c->max_subcubes = (int)std::min<size_t>((size_t)c->max_subcubes, launch_fit);
+        }
         CHK(hipMalloc(&c->d_partials, sizeof(double2) * (size_t)c->max_subcubes * c->nchunk));
         CHK(hipHostMalloc((void**)&c->h_lb, sizeof(float) * c->max_subcubes, hipHostMallocMapped));
         CHK(hipHostMalloc((void**)&c->h_ub, sizeof(float) * c->max_subcubes, hipHostMallocMapped));
@@ -531,15 +562,17 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
     // locality-sorted whole-tick path
     {
         if (const char* e = std::getenv("FGOICP_BOUNDS_SORTED")) c->sorted_bounds = std::atoi(e) != 0;
-        c->nchunk1 = (int)((ns + kBlock - 1) / kBlock);
-        c->max_groups = 512;
+        c->nchunk1 = (int)((ns + c->chunk_pts - 1) / c->chunk_pts);
+        c->max_groups = std::max(512, c->max_subcubes / 8);
+        if (const char* e = std::getenv("FGOICP_FINALIZE_SIDE")) c->finalize_on_side = std::atoi(e) != 0;  // tuning knob
+        if (const char* e = std::getenv("FGOICP_ICP_SEED")) c->icp_seeding = std::atoi(e) != 0;             // tuning knob
         int maxd = std::max(g.dx, std::max(g.dy, g.dz));
         c->cell_shift = 0;
         while ((maxd >> c->cell_shift) > 32) ++c->cell_shift;  // 5 bits per axis
         std::vector<float4> cen(c->nchunk1);
         for (int k = 0; k < c->nchunk1; ++k) {
             double sx = 0, sy = 0, sz = 0;
-            const size_t a = (size_t)k * kBlock, b = std::min(ns, a + kBlock);
+            const size_t a = (size_t)k * c->chunk_pts, b = std::min(ns, a + (size_t)c->chunk_pts);
             for (size_t i = a; i < b; ++i) {
                 const float* p = src_xyz + 3 * (size_t)c->perm[i];
                 sx += p[0]; sy += p[1]; sz += p[2];
@@ -560,6 +593,7 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
                 else CHK(hipStreamCreateWithFlags(&sl.sort_stream, hipStreamNonBlocking));
             }
             CHK(hipEventCreateWithFlags(&sl.sorted_ev, hipEventDisableTiming));
+            CHK(hipEventCreateWithFlags(&sl.bounds_ev, hipEventDisableTiming));
             CHK(hipMalloc(&sl.d_groups, sizeof(TickGroup) * c->max_groups));
             CHK(hipMalloc(&sl.d_subs, sizeof(TickSub) * c->max_subcubes));
             CHK(hipHostMalloc((void**)&sl.h_groups, sizeof(TickGroup) * c->max_groups, hipHostMallocDefault));
@@ -622,6 +656,7 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
         fgoicp_ctx::TickSlot& sl = c->slots[k];
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.sorted_ev) (void)hipEventDestroy(sl.sorted_ev);
+        if (sl.bounds_ev) (void)hipEventDestroy(sl.bounds_ev);
         if (sl.sort_stream && sl.sort_stream != c->stream) { (void)hipStreamSynchronize(sl.sort_stream); (void)hipStreamDestroy(sl.sort_stream); }
         (void)hipFree(sl.d_vals);
         (void)hipFree(sl.d_groups); (void)hipFree(sl.d_subs); (void)hipFree(sl.d_keys); (void)hipFree(sl.d_hist);
@@ -709,7 +744,7 @@ int fgoicp_bounds_batch(fgoicp_ctx* c, const float* R9, float rot_span, const fl
 
 int fgoicp_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out) {
     if (!c || !R9 || !t3 || !sse_out) return FGOICP_ERR_INVALID_ARG;
-    return ctx_sse(c, R9, t3, sse_out);
+    return ctx_sse(c, R9, t3, sse_out, nullptr);
 }
 
 int fgoicp_icp(fgoicp_ctx* c, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3,
@@ -729,7 +764,7 @@ int fgoicp_procrustes(fgoicp_ctx* c, const float* working_xyz, float* R_out9, fl
     HIPCHK(hipMemcpy(c->d_work, h.data(), sizeof(float4) * c->ns, hipMemcpyHostToDevice));
     Mat3f R, ABt;
     Vec3f t;
-    int rc = ctx_procrustes_device(c, &R, &t, centroids6, &ABt);
+    int rc = ctx_procrustes_device(c, &R, &t, centroids6, &ABt, false);
     if (rc) return rc;
     std::memcpy(R_out9, R.m, sizeof(R.m));
     t_out3[0] = t.x; t_out3[1] = t.y; t_out3[2] = t.z;

@@ -43,6 +43,7 @@ struct fgoicp_ctx {
                                                  // concurrently (two sorted kernels at once would thrash each other's L2 neighbourhoods)
         hipEvent_t done = nullptr;               // recorded behind the slot's last kernel; collect waits on it, not on the stream
         hipStream_t sort_stream = nullptr;       // descriptors upload + locality sort of THIS slot run here, next to the other
+        hipEvent_t bounds_ev = nullptr;          // bounds kernel of this slot finished (the finalize on the side stream waits for it)
         hipEvent_t sorted_ev = nullptr;          //   slot's bounds kernel on the main stream, which then waits for sorted_ev
         fgoicp::TickGroup *d_groups = nullptr, *h_groups = nullptr;   // device / pinned staging
         fgoicp::TickSub *d_subs = nullptr, *h_subs = nullptr;
@@ -57,6 +58,9 @@ struct fgoicp_ctx {
     };
     bool sorted_bounds = true;
     int nchunk1 = 0, max_groups = 0, cell_shift = 4;
+    int chunk_pts = 256;                     // points per (subcube, chunk) work item of the sorted path
+    bool finalize_on_side = true;
+    bool icp_seeding = true;                 // ICP passes seed their exact NN search with the previous pass's correspondences
     float4* d_chunk_cen = nullptr;           // centroid of every chunk (source frame)
     TickSlot slots[2];
 
@@ -90,7 +94,7 @@ int ctx_bounds_multi(fgoicp_ctx* c, int G, const float* R9, const float* rot_spa
 int ctx_bounds_submit(fgoicp_ctx* c, int slot, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets, const float* tn4);
 int ctx_bounds_collect(fgoicp_ctx* c, int slot, float* lb_out, float* ub_out);
 int ctx_set_inliers(fgoicp_ctx* c, size_t k);
-int ctx_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out);
+int ctx_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out, const uint32_t* seed_idx = nullptr);
 int ctx_icp(fgoicp_ctx* c, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3,
             int* iters_out);
 }  // namespace fgoicp

@@ -309,9 +309,9 @@ template <int THREADS, int P, int ZPAIR, int TRIM>
 __global__ __launch_bounds__(THREADS) void bounds_sorted_kernel(const float4* __restrict__ src, int ns, const float* __restrict__ lut,
                                                                 const float2* __restrict__ zp, LutGeom g,
                                                                 const TickGroup* __restrict__ groups, const TickSub* __restrict__ subs,
-                                                                const unsigned* __restrict__ sorted, int nchunk, double2* __restrict__ partials,
-                                                                float2* __restrict__ vals) {
-    static_assert(THREADS * P == kBlock, "an item is 256 points");
+                                                                const unsigned* __restrict__ sorted, int nchunk, int chunk_pts,
+                                                                double2* __restrict__ partials, float2* __restrict__ vals) {
+    static_assert(THREADS * P == kBlock, "one pass covers 256 points");
     __shared__ double red[2 * (THREADS / 64)];
     const unsigned item = sorted[xcd_remap(blockIdx.x, gridDim.x)];
     const int s = (int)(item / (unsigned)nchunk);
@@ -320,47 +320,52 @@ __global__ __launch_bounds__(THREADS) void bounds_sorted_kernel(const float4* __
     const TickGroup& gr = groups[sb.group];
     const float trans_uncertain_radius = kSqrt3 * sb.span;  // registration.cu:33
     const size_t sy = (size_t)g.px, sz = (size_t)g.px * g.py;
-    float4 p[P];
-    TexAddr ta[P];
-    float2u v00[P], v10[P], v01[P], v11[P];
-#pragma unroll
-    for (int k = 0; k < P; ++k) {
-        const int i = chunk * kBlock + k * THREADS + threadIdx.x;
-        p[k] = src[i < ns ? i : ns - 1];
-        float rx, ry, rz;
-        rotate(gr.R, p[k].x, p[k].y, p[k].z, rx, ry, rz);
-        ta[k] = lut_address(g, rx + sb.tx, ry + sb.ty, rz + sb.tz);  // :34, :323-325
-    }
-#pragma unroll
-    for (int k = 0; k < P; ++k) {
-        if (ZPAIR == 2) {
-            quad_gather(reinterpret_cast<const float4*>(zp), ta[k], v00[k], v10[k], v01[k], v11[k]);
-        } else if (ZPAIR == 1) {
-            zpair_gather(zp, g, ta[k], v00[k], v10[k], v01[k], v11[k]);
-        } else {
-            const float* q = lut + ta[k].o;
-            v00[k] = *(const float2u*)(q);  // default cache policy: non-temporal loads measured 2x slower here
-            v10[k] = *(const float2u*)(q + sy);
-            v01[k] = *(const float2u*)(q + sz);
-            v11[k] = *(const float2u*)(q + sz + sy);
-        }
-    }
     double acc[2] = {0.0, 0.0};
+    // an item is chunk_pts (256, 512 or 1024) Morton-consecutive points, walked in passes of 256: dense clouds take bigger
+    // items (the patch of 256 points is only a few voxels wide there), which divides the items to sort and the partials
+    for (int pass = 0; pass < chunk_pts; pass += kBlock) {
+        float4 p[P];
+        TexAddr ta[P];
+        float2u v00[P], v10[P], v01[P], v11[P];
+        const int first = chunk * chunk_pts + pass + (int)threadIdx.x;
 #pragma unroll
-    for (int k = 0; k < P; ++k) {
-        const float dsq = lut_blend(ta[k], v00[k], v10[k], v01[k], v11[k]);  // :46
-        float d = sqrtf(dsq);                                                 // :48
-        if (!gr.fix_rot) d -= 2.0f * p[k].w * gr.sin_half;                    // :39-43, :49-52
-        const float ubv = d > 0.0f ? d * d : 0.0f;                            // :54
-        const float l = d - trans_uncertain_radius;                           // :57
-        const float lbv = l > 0.0f ? l * l : 0.0f;                            // :58
-        const int i = chunk * kBlock + k * THREADS + (int)threadIdx.x;
-        const bool valid = i < ns;
-        if (TRIM) {  // trimmed Go-ICP: the per-point terms themselves (the selection runs in trim_select_kernel)
-            if (valid) vals[(size_t)s * ns + i] = make_float2(ubv, lbv);
-        } else {
-            acc[0] += valid ? (double)ubv : 0.0;
-            acc[1] += valid ? (double)lbv : 0.0;
+        for (int k = 0; k < P; ++k) {
+            const int i = first + k * THREADS;
+            p[k] = src[i < ns ? i : ns - 1];
+            float rx, ry, rz;
+            rotate(gr.R, p[k].x, p[k].y, p[k].z, rx, ry, rz);
+            ta[k] = lut_address(g, rx + sb.tx, ry + sb.ty, rz + sb.tz);  // :34, :323-325
+        }
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            if (ZPAIR == 2) {
+                quad_gather(reinterpret_cast<const float4*>(zp), ta[k], v00[k], v10[k], v01[k], v11[k]);
+            } else if (ZPAIR == 1) {
+                zpair_gather(zp, g, ta[k], v00[k], v10[k], v01[k], v11[k]);
+            } else {
+                const float* q = lut + ta[k].o;
+                v00[k] = *(const float2u*)(q);  // default cache policy: non-temporal loads measured 2x slower here
+                v10[k] = *(const float2u*)(q + sy);
+                v01[k] = *(const float2u*)(q + sz);
+                v11[k] = *(const float2u*)(q + sz + sy);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const float dsq = lut_blend(ta[k], v00[k], v10[k], v01[k], v11[k]);  // :46
+            float d = sqrtf(dsq);                                                 // :48
+            if (!gr.fix_rot) d -= 2.0f * p[k].w * gr.sin_half;                    // :39-43, :49-52
+            const float ubv = d > 0.0f ? d * d : 0.0f;                            // :54
+            const float l = d - trans_uncertain_radius;                           // :57
+            const float lbv = l > 0.0f ? l * l : 0.0f;                            // :58
+            const int i = first + k * THREADS;
+            const bool valid = i < ns;
+            if (TRIM) {  // trimmed Go-ICP: the per-point terms themselves (the selection runs in trim_select_kernel)
+                if (valid) vals[(size_t)s * ns + i] = make_float2(ubv, lbv);
+            } else {
+                acc[0] += valid ? (double)ubv : 0.0;
+                acc[1] += valid ? (double)lbv : 0.0;
+            }
         }
     }
     if (!TRIM) {
@@ -845,7 +850,8 @@ __device__ __forceinline__ float tie_threshold(float best) {  // see nn_tie_thre
 constexpr int kMaxParts = 16;
 
 __global__ __launch_bounds__(64 * kMaxParts) void nn_scan_kernel(const float4* __restrict__ pts, int n, BvhView t, const float* __restrict__ lut,
-                                                                 LutGeom g, Rt rt, int apply, int want_index, uint32_t* __restrict__ out) {
+                                                                 LutGeom g, Rt rt, int apply, int want_index, const float4* __restrict__ tgt, int nt,
+                                                                 const uint32_t* seed_idx, uint32_t* out) {
     __shared__ uint32_t comb[kMaxParts][64];
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6, nparts = blockDim.x >> 6;
     const int i = blockIdx.x * 64 + lane;
@@ -857,7 +863,15 @@ __global__ __launch_bounds__(64 * kMaxParts) void nn_scan_kernel(const float4* _
         qx += rt.t[0]; qy += rt.t[1]; qz += rt.t[2];
     }
     // pass 1: minimum.  `found` = min over the points this wave visited, `best` additionally seeded.
-    const float ub = lut_upper_bound_d2(lut, g, qx, qy, qz);
+    float ub = lut_upper_bound_d2(lut, g, qx, qy, qz);
+    if (seed_idx) {  // ICP: the previous pass's correspondence — the distance to ANY target point bounds the minimum, and
+        const uint32_t j = seed_idx[i < n ? i : n - 1];  // one ICP step later it usually still IS the minimum (may alias `out`:
+        if (j < (uint32_t)nt) {                          // every lane reads its own slot here and writes it at the very end)
+            const float4 c = tgt[j];
+            const float d = dist_sq(qx, qy, qz, c.x, c.y, c.z);
+            ub = d < ub ? d : ub;
+        }
+    }
     float best = ub < kInf ? ub : kInf, found = kInf;
     box_scan(t, qx, qy, qz, active, part, nparts,
              [&](const float4 c) {
@@ -1092,7 +1106,7 @@ void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, con
     hipLaunchKernelGGL(tick_scatter_kernel, dim3(kb), dim3(kBlock), 0, s, keys, nitems, cursor, sorted);
 }
 
-void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* zp, int layout, const LutGeom& g, int nchunk,
+void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* zp, int layout, const LutGeom& g, int nchunk, int chunk_pts,
                           const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials, float2* vals,
                           hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s) {
     const size_t nitems = (size_t)nsub * nchunk;
@@ -1102,7 +1116,7 @@ void launch_bounds_sorted(const float4* src, int ns, const float* lut, const flo
     static const int variant = [] { const char* e = std::getenv("FGOICP_BOUNDS_VARIANT"); return e ? std::atoi(e) : 1; }();  // tuning knob (1 = default)
     const dim3 grid((unsigned)nitems);
 #define FGOICP_LAUNCH_SORTED(T, PP, Z, TR) \
-    hipLaunchKernelGGL((bounds_sorted_kernel<T, PP, Z, TR>), grid, dim3(T), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, partials, vals)
+    hipLaunchKernelGGL((bounds_sorted_kernel<T, PP, Z, TR>), grid, dim3(T), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, chunk_pts, partials, vals)
     if (vals) {
         if (zp && layout == 2) FGOICP_LAUNCH_SORTED(128, 2, 2, 1); else if (zp) FGOICP_LAUNCH_SORTED(128, 2, 1, 1); else FGOICP_LAUNCH_SORTED(128, 2, 0, 1);
     } else if (zp && layout == 2) {
@@ -1172,11 +1186,16 @@ void launch_nn_first_index(const float4* pts, int n, const float4* tgt, int nt, 
 }
 
 void launch_nn_scan(const float4* pts, int n, const BvhView& t, const float* lut, const LutGeom& g, const float* R9, const float* t3, int apply,
-                    int want_index, uint32_t* out, hipStream_t s) {
+                    int want_index, const float4* tgt, int nt, const uint32_t* seed_idx, uint32_t* out, hipStream_t s) {
     const int groups = (n + 63) / 64;
-    int nparts = 1;  // enough waves to occupy the chip: >= ~8 per CU
-    while (nparts < kMaxParts && groups * nparts < 2048) nparts <<= 1;
-    hipLaunchKernelGGL(nn_scan_kernel, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, want_index, out);
+    // waves per 64 queries.  The scan is a chain of dependent steps per wave (boxes -> leaf boxes -> points), so its run time is
+    // that chain's latency: splitting the candidate leaves of a query group over 4-8 waves shortens the chain even when the
+    // chip is already full (measured: 437k queries 1 -> 4 waves 1.75x faster, 40k queries 4 -> 8 waves +4 %, 16 waves slower).
+    int nparts = 4;
+    while (nparts < 8 && groups * nparts < 4096) nparts <<= 1;
+    static const int forced = [] { const char* e = std::getenv("FGOICP_NN_PARTS"); const int v = e ? std::atoi(e) : 0; return v; }();  // tuning knob
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16) nparts = forced;
+    hipLaunchKernelGGL(nn_scan_kernel, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, want_index, tgt, nt, seed_idx, out);
 }
 
 // `scratch` must hold as many floats as the padded LUT; it receives the coarse pass.

@@ -61,7 +61,7 @@ constexpr int kTickNumKeys = 1 << 15;
 void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, const TickGroup* groups, const TickSub* subs, int nsub, int cell_shift,
                       unsigned short* keys, unsigned* hist, unsigned* cursor, unsigned* sorted, hipStream_t s);
 void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* packed_or_null, int layout /* 1 z-pair, 2 yz-quad */, const LutGeom& g, int nchunk,
-                          const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials, float2* vals_or_null,
+                          int chunk_pts /* 256, 512 or 1024 points per item */, const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials, float2* vals_or_null,
                           hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s);
 // EXTENSION (trimmed Go-ICP): sum of the k smallest entries of each row/column of `vals` (exact radix select, kernels.hip)
 void launch_trim_select(const float* vals, size_t row_stride, int ncols, int n, int k, int rows, float* out0, float* out1, uint32_t* sel_info,
@@ -93,8 +93,10 @@ void launch_nn_first_index(const float4* pts, int n, const float4* tgt, int nt, 
 
 // Exact NN through the two-level box scan (bvh.hpp) — bit-identical to the brute-force kernels above.
 //   want_index = 0: out[i] = bits(min squared distance);  1: out[i] = lowest index in the sqrt-tie set
+// seed_idx (optional, may alias out): per query the caller-order index of some target point, e.g. the correspondence of the
+// previous ICP pass; its distance tightens the pruning bound, the result is the same exact minimum.
 void launch_nn_scan(const float4* pts, int n, const BvhView& t, const float* lut, const LutGeom& g, const float* R9, const float* t3, int apply,
-                    int want_index, uint32_t* out, hipStream_t s);
+                    int want_index, const float4* tgt, int nt, const uint32_t* seed_idx, uint32_t* out, hipStream_t s);
 void launch_lut_build_scan(const BvhView& shifted_targets, const LutGeom& g, float* scratch_padded, float* lut_padded, hipStream_t s);
 
 // deterministic double sums: out[k] = sum_i vals[i*stride + k]  (k < width <= 16)

@@ -266,7 +266,7 @@ template <class Ops>
 class GoIcpDriver {
 public:
     GoIcpDriver(Ops& ops, size_t ns, float mse_threshold, int schedule, int round_width)
-        : ops_(ops), sse_threshold_(ns * mse_threshold), schedule_(schedule), round_width_(round_width < 1 ? 1 : round_width) {
+        : ops_(ops), sse_threshold_(ns * mse_threshold), schedule_(schedule), round_width_(round_width < 0 ? 0 : round_width) {
         int nthreads = 4;
         if (const char* e = std::getenv("FGOICP_HOST_THREADS")) nthreads = std::atoi(e);
         const int hw = (int)std::thread::hardware_concurrency();
@@ -336,6 +336,7 @@ private:
         stats_.icp_runs++;
         stats_.icp_iters += (uint64_t)iters;
         stats_.seconds_icp += seconds_since(t_icp);
+        if (std::getenv("FGOICP_TIMING")) std::fprintf(stderr, "[fgoicp timing] icp thr %g: %d iterations, %.3f ms, sse %g\n", (double)thr, iters, seconds_since(t_icp) * 1e3, (double)sse);
         return rc;
     }
     void set_best_sse_only(float sse) { std::lock_guard<std::mutex> g(mu_); best_sse_ = sse; }
@@ -434,10 +435,16 @@ private:
         rcand.push(RotCube(0.f, 0.f, 0.f, 1.0f, 0.f, best_sse()));
         const int rank = ex_.rank, world = ex_.world < 1 ? 1 : ex_.world;
         std::vector<RotCube> children;
+        // round_width 0 = adaptive: start at 32 cubes per rank, double after every round that leaves the incumbent
+        // standing (the search is certifying: every cube below the threshold gap has to be expanded anyway, wide rounds
+        // waste nothing and feed the device bigger ticks), fall back to the base width when the incumbent improves.
+        const bool adaptive = round_width_ <= 0;
+        const int base_width = adaptive ? 32 * world : round_width_;
+        int width = base_width;
         while (!rcand.empty()) {
             children.clear();
             int popped = 0;
-            while (popped < round_width_ && !rcand.empty()) {
+            while (popped < width && !rcand.empty()) {
                 if (best_sse() - rcand.top().lb <= sse_threshold_) break;  // :44 (the top is the global min lb)
                 const RotCube rnode = rcand.top();
                 rcand.pop();
@@ -530,6 +537,7 @@ private:
                 }
             }
             const float now = best_sse();
+            if (adaptive) width = now < snapshot ? base_width : std::min(width * 2, 1 << 14);
             for (size_t i = 0; i < nchild; ++i) {
                 if (lbs[i] >= now) continue;  // :92
                 children[i].lb = lbs[i];
@@ -566,6 +574,7 @@ private:
         h.live.clear();
         h.R9.clear(); h.spans.clear(); h.fix.clear(); h.tn4.clear();
         h.offsets.assign(1, 0);
+        h.members.erase(std::remove_if(h.members.begin(), h.members.end(), [&](size_t i) { return tasks[i]->done; }), h.members.end());
         for (size_t i : h.members) {
             Task& tk = *tasks[i];
             if (!tk.has_batch) continue;
@@ -581,6 +590,23 @@ private:
         h.lb.resize(h.tn4.size() / 4);
         h.ub.resize(h.tn4.size() / 4);
         return !h.live.empty();
+    }
+    // Tasks finish at very different times (an UB task may need 5 batches, its neighbour 50): when the idle half `from`
+    // holds many more unfinished tasks than the other, it hands over the surplus so that both slots stay busy and the
+    // device never waits for the host.  A task's own sequence of batches does not depend on the half it sits in.
+    static void rebalance(Half& from, Half& to) {
+        if (from.members.size() < to.members.size() + 2 + to.members.size() / 4) return;
+        const size_t move = (from.members.size() - to.members.size()) / 2;
+        // every other member from the back: keeps the UB/LB mix of both halves
+        std::vector<size_t> keep;
+        keep.reserve(from.members.size());
+        size_t moved = 0;
+        for (size_t k = from.members.size(); k-- > 0;) {
+            if (moved < move && ((from.members.size() - 1 - k) & 1) == 0) { to.members.push_back(from.members[k]); ++moved; }
+            else keep.push_back(from.members[k]);
+        }
+        std::reverse(keep.begin(), keep.end());
+        from.members.swap(keep);
     }
     void consume_half(Half& h, std::vector<Task*>& tasks, bool par) {
         const std::function<void(size_t)> push_fn = [&](size_t k) { tasks[h.live[k]]->consume(h.lb.data() + h.offsets[k], h.ub.data() + h.offsets[k]); };
@@ -602,35 +628,36 @@ private:
         const bool timing = std::getenv("FGOICP_TIMING") != nullptr;
         if (tasks.size() >= 4 && ops_.async()) {
             Half h[2];
-            for (size_t i = 0; i < tasks.size(); ++i) h[i & 1].members.push_back(i);
-            for (int k = 0; k < 2; ++k)
-                if (prepare_half(h[k], tasks, cubes, par)) {
-                    int rc = ops_.bounds_submit(k, (int)h[k].live.size(), h[k].R9.data(), h[k].spans.data(), h[k].fix.data(), h[k].offsets.data(), h[k].tn4.data());
-                    if (rc) return rc;
-                    h[k].inflight = true;
-                }
-            while (h[0].inflight || h[1].inflight)
+            // tasks come in (UB, LB) pairs per child: deal whole pairs so both halves hold both kinds
+            for (size_t i = 0; i < tasks.size(); ++i) h[(i >> 1) & 1].members.push_back(i);
+            for (;;) {
+                bool any = false;
                 for (int k = 0; k < 2; ++k) {
-                    if (!h[k].inflight) continue;
                     const auto ta = clock::now();
-                    int rc = ops_.bounds_collect(k, h[k].lb.data(), h[k].ub.data());
-                    if (rc) return rc;
-                    h[k].inflight = false;
+                    if (h[k].inflight) {
+                        int rc = ops_.bounds_collect(k, h[k].lb.data(), h[k].ub.data());
+                        if (rc) return rc;
+                        h[k].inflight = false;
+                    }
                     const auto tb = clock::now();
-                    consume_half(h[k], tasks, par);
+                    if (!h[k].live.empty()) consume_half(h[k], tasks, par);
+                    h[k].live.clear();
                     const auto tc = clock::now();
-                    if (prepare_half(h[k], tasks, cubes, par)) {
-                        rc = ops_.bounds_submit(k, (int)h[k].live.size(), h[k].R9.data(), h[k].spans.data(), h[k].fix.data(), h[k].offsets.data(), h[k].tn4.data());
+                    rebalance(h[k], h[1 - k]);
+                    if (!h[k].members.empty() && prepare_half(h[k], tasks, cubes, par)) {
+                        int rc = ops_.bounds_submit(k, (int)h[k].live.size(), h[k].R9.data(), h[k].spans.data(), h[k].fix.data(), h[k].offsets.data(), h[k].tn4.data());
                         if (rc) return rc;
                         h[k].inflight = true;
                     }
+                    any = any || h[k].inflight;
                     if (timing) {
                         t_ops_ += std::chrono::duration<double>(tb - ta).count();
                         t_push_ += std::chrono::duration<double>(tc - tb).count();
                         t_pop_ += std::chrono::duration<double>(clock::now() - tc).count();
                     }
                 }
-            return kDriverOk;
+                if (!any && h[0].members.empty() && h[1].members.empty()) return kDriverOk;
+            }
         }
         Half h;
         for (size_t i = 0; i < tasks.size(); ++i) h.members.push_back(i);

@@ -154,7 +154,8 @@ typedef struct fgoicp_exchange {
 
 typedef struct fgoicp_solver_opts {
     int schedule;        /* fgoicp_schedule                                            */
-    int round_width;     /* ROUND: rotation cubes popped per expansion round (K >= 1)  */
+    int round_width;     /* ROUND: rotation cubes popped per expansion round (K >= 1); 0 = adaptive: 32 per rank,
+                            doubled after every round that does not improve the incumbent, reset when one does */
     unsigned ctx_flags;  /* FGOICP_FLAG_*                                              */
     int device;          /* HIP device ordinal                                         */
     float trim_fraction; /* EXTENSION: fraction of source points treated as outliers (0 = the reference's behaviour) */

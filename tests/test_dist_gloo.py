@@ -29,7 +29,7 @@ def launch(tmp_path, case, K, world):
     return [np.load(f"{prefix}.rank{r}.npz") for r in range(world)]
 
 
-@pytest.mark.parametrize("case,K", [("runsyn_", 1), ("runbun_", 2)])
+@pytest.mark.parametrize("case,K", [("runsyn_", 1), ("runbun_", 2), ("runbun_", 0)])
 def test_world_size_2_round_schedule(tmp_path, case, K):
     ranks = launch(tmp_path, case, K, 2)
     a, b = ranks
