@@ -538,7 +538,7 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
                 c->chunk_pts = density >= 1.0 ? 2048 : density >= 0.5 ? 1024 : density >= 0.25 ? 512 : 256;
                 if (const char* e = std::getenv("FGOICP_CHUNK_PTS")) {  // tuning knob
                     const int v = std::atoi(e);
-                    if (v == 256 || v == 512 || v == 1024 || v == 2048 || v == 4096) c->chunk_pts = v;
+                    if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024 || v == 2048 || v == 4096) c->chunk_pts = v;  // 64 / 128 need FGOICP_BOUNDS_VARIANT 4 / 3
                 }
             }
             const size_t nchunk1 = (ns + c->chunk_pts - 1) / c->chunk_pts;

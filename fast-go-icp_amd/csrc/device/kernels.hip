@@ -236,8 +236,9 @@ __global__ __launch_bounds__(kBlock) void bounds_kernel(const float4* __restrict
 // reads a compact region of the LUT.  One tick's items together want every LUT line ~25 times, but
 // in submission order two users of a line run far apart in time, the 203 MB LUT streams through the
 // 4 MiB L2s over and over, and the kernel runs at the fabric rate instead of the L2 rate.  So the
-// items are ordered by the Morton code of the LUT cell their patch centre lands in (counting sort on
-// the device, 15-bit keys), and the XCD-aware remap hands each XCD one contiguous run of that order:
+// items are ordered by the Hilbert index of the LUT cell their patch centre lands in (counting sort on
+// the device, 15-bit keys; Hilbert rather than Z-order: +5 % kernel throughput, no long jumps between
+// consecutive cells), and the XCD-aware remap hands each XCD one contiguous run of that order:
 // blocks resident together on an XCD read the same neighbourhood of the LUT.  Every item writes the
 // same partial it would write in any order, and the finalize sum is ordered by (s, c) — results
 // are bit-identical to the plain kernel.
@@ -253,6 +254,30 @@ __device__ __forceinline__ unsigned part1by2_5(unsigned v) {  // spread 5 bits t
     return v;
 }
 
+// 15-bit Hilbert index of a cell (5 bits per axis, Skilling's transpose algorithm): consecutive keys are always face
+// neighbours, without the long jumps a Z-order curve makes at every power-of-two boundary.
+__device__ __forceinline__ unsigned hilbert15(unsigned x, unsigned y, unsigned z) {
+    unsigned X[3] = {x & 31u, y & 31u, z & 31u};
+#pragma unroll
+    for (unsigned Q = 16u; Q > 1u; Q >>= 1) {
+        const unsigned P = Q - 1u;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (X[i] & Q) X[0] ^= P;
+            else { const unsigned t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
+        }
+    }
+    X[1] ^= X[0];
+    X[2] ^= X[1];
+    unsigned t = 0;
+#pragma unroll
+    for (unsigned Q = 16u; Q > 1u; Q >>= 1)
+        if (X[2] & Q) t ^= Q - 1u;
+    X[0] ^= t; X[1] ^= t; X[2] ^= t;
+    return part1by2_5(X[2]) | (part1by2_5(X[1]) << 1) | (part1by2_5(X[0]) << 2);
+}
+
+template <int HILBERT>
 __global__ __launch_bounds__(kBlock) void tick_keys_kernel(const float4* __restrict__ chunk_cen, int nchunk, const TickGroup* __restrict__ groups,
                                                            const TickSub* __restrict__ subs, int nsub, LutGeom g, int cell_shift,
                                                            unsigned short* __restrict__ keys, unsigned* __restrict__ hist) {
@@ -267,33 +292,48 @@ __global__ __launch_bounds__(kBlock) void tick_keys_kernel(const float4* __restr
         const int vx = (int)fminf(fmaxf((rx + sb.tx + g.off_x) * g.scale, 0.0f), (float)(g.dx - 1)) >> cell_shift;
         const int vy = (int)fminf(fmaxf((ry + sb.ty + g.off_y) * g.scale, 0.0f), (float)(g.dy - 1)) >> cell_shift;
         const int vz = (int)fminf(fmaxf((rz + sb.tz + g.off_z) * g.scale, 0.0f), (float)(g.dz - 1)) >> cell_shift;
-        const unsigned key = part1by2_5((unsigned)vx) | (part1by2_5((unsigned)vy) << 1) | (part1by2_5((unsigned)vz) << 2);
+        const unsigned key = HILBERT ? hilbert15((unsigned)vx, (unsigned)vy, (unsigned)vz)
+                                     : part1by2_5((unsigned)vx) | (part1by2_5((unsigned)vy) << 1) | (part1by2_5((unsigned)vz) << 2);
         keys[i] = (unsigned short)key;
         atomicAdd(&hist[key], 1u);
     }
 }
 
-// exclusive scan of the 32768-bin histogram, one block of 1024 threads (32 bins each)
-__global__ __launch_bounds__(1024) void tick_scan_kernel(const unsigned* __restrict__ hist, unsigned* __restrict__ cursor) {
-    __shared__ unsigned wsum[16];
+// exclusive scan of the 32768-bin histogram: one block of 256 threads, 128 bins each.  It runs next to the other slot's bounds
+// kernel, which keeps every CU full of 2-wave workgroups: a 4-wave block finds a home quickly where a 16-wave block had to wait
+// for a whole CU to drain (measured 380 us per scan next to a busy device), and every memory latency is stretched, so all the
+// loads of a thread are 16-byte and issued together.
+__global__ __launch_bounds__(kBlock) void tick_scan_kernel(const unsigned* __restrict__ hist, unsigned* __restrict__ cursor) {
+    __shared__ unsigned wsum[kBlock / 64];
+    constexpr int kPer = kNumKeys / kBlock;  // 128 bins per thread
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned loc[32];
+    const uint4* h4 = reinterpret_cast<const uint4*>(hist) + tid * (kPer / 4);
+    uint4 v[kPer / 4];
+#pragma unroll
+    for (int k = 0; k < kPer / 4; ++k) v[k] = h4[k];
     unsigned sum = 0;
 #pragma unroll
-    for (int k = 0; k < 32; ++k) { loc[k] = sum; sum += hist[tid * 32 + k]; }
+    for (int k = 0; k < kPer / 4; ++k) sum += v[k].x + v[k].y + v[k].z + v[k].w;
     unsigned incl = sum;  // inclusive scan of `sum` across the wave
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        const unsigned v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
+        const unsigned u = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += u;
     }
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    unsigned base = 0;
-    for (int w = 0; w < wave; ++w) base += wsum[w];
-    base += incl - sum;
+    unsigned run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+    uint4* c4 = reinterpret_cast<uint4*>(cursor) + tid * (kPer / 4);
 #pragma unroll
-    for (int k = 0; k < 32; ++k) cursor[tid * 32 + k] = base + loc[k];
+    for (int k = 0; k < kPer / 4; ++k) {
+        uint4 o;
+        o.x = run; run += v[k].x;
+        o.y = run; run += v[k].y;
+        o.z = run; run += v[k].z;
+        o.w = run; run += v[k].w;
+        c4[k] = o;
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void tick_scatter_kernel(const unsigned short* __restrict__ keys, size_t nitems, unsigned* __restrict__ cursor,
@@ -302,16 +342,17 @@ __global__ __launch_bounds__(kBlock) void tick_scatter_kernel(const unsigned sho
         sorted[atomicAdd(&cursor[keys[i]], 1u)] = (unsigned)i;  // order inside a bin is irrelevant (scheduling only)
 }
 
-// THREADS x P = 256 points per item.  Measured on MI355X (2048 subcubes per launch): 256x1 2.35 / 6.4 TB/s
-// algorithmic (bunny / dragon shape), 128x2 2.45 / 7.6 TB/s (default), 64x4 2.32 TB/s; fewer resident
-// blocks per CU (LDS padding) only hurts — the kernel wants every wave slot and many gathers in flight.
+// One pass = THREADS x P points.  Measured on MI355X, bunny shape, whole benchmark step, yz-quad layout, wide rounds:
+// 64x4 (default: one wave per item, no block-level reduction) 2.94 M subcubes/s, 128x2 2.81, 256x1 2.54; 128- and 64-point
+// items (64x2, 64x1) 2.77 / 2.26 — smaller items do not buy locality, they only add items.  Dragon shape: 64x4 = 128x2.
+// Fewer resident blocks per CU (LDS padding) only hurts — the kernel wants every wave slot and many gathers in flight.
 template <int THREADS, int P, int ZPAIR, int TRIM>
 __global__ __launch_bounds__(THREADS) void bounds_sorted_kernel(const float4* __restrict__ src, int ns, const float* __restrict__ lut,
                                                                 const float2* __restrict__ zp, LutGeom g,
                                                                 const TickGroup* __restrict__ groups, const TickSub* __restrict__ subs,
                                                                 const unsigned* __restrict__ sorted, int nchunk, int chunk_pts,
                                                                 double2* __restrict__ partials, float2* __restrict__ vals) {
-    static_assert(THREADS * P == kBlock, "one pass covers 256 points");
+    static_assert(THREADS % 64 == 0 && THREADS * P <= kBlock, "one pass covers THREADS * P points");
     __shared__ double red[2 * (THREADS / 64)];
     const unsigned item = sorted[xcd_remap(blockIdx.x, gridDim.x)];
     const int s = (int)(item / (unsigned)nchunk);
@@ -321,9 +362,9 @@ __global__ __launch_bounds__(THREADS) void bounds_sorted_kernel(const float4* __
     const float trans_uncertain_radius = kSqrt3 * sb.span;  // registration.cu:33
     const size_t sy = (size_t)g.px, sz = (size_t)g.px * g.py;
     double acc[2] = {0.0, 0.0};
-    // an item is chunk_pts (256, 512 or 1024) Morton-consecutive points, walked in passes of 256: dense clouds take bigger
+    // an item is chunk_pts (256 .. 2048) Morton-consecutive points, walked in passes of THREADS * P: dense clouds take bigger
     // items (the patch of 256 points is only a few voxels wide there), which divides the items to sort and the partials
-    for (int pass = 0; pass < chunk_pts; pass += kBlock) {
+    for (int pass = 0; pass < chunk_pts; pass += THREADS * P) {
         float4 p[P];
         TexAddr ta[P];
         float2u v00[P], v10[P], v01[P], v11[P];
@@ -1101,8 +1142,10 @@ void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, con
     const size_t nitems = (size_t)nsub * nchunk;
     (void)hipMemsetAsync(hist, 0, sizeof(unsigned) * kNumKeys, s);
     const unsigned kb = (unsigned)std::min<size_t>((nitems + kBlock - 1) / kBlock, 2048);
-    hipLaunchKernelGGL(tick_keys_kernel, dim3(kb), dim3(kBlock), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, hist);
-    hipLaunchKernelGGL(tick_scan_kernel, dim3(1), dim3(1024), 0, s, hist, cursor);
+    static const int hilbert = [] { const char* e = std::getenv("FGOICP_SORT_CURVE"); return e ? std::atoi(e) : 1; }();  // tuning knob: 1 = Hilbert (default), 0 = Z-order
+    if (hilbert) hipLaunchKernelGGL(tick_keys_kernel<1>, dim3(kb), dim3(kBlock), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, hist);
+    else hipLaunchKernelGGL(tick_keys_kernel<0>, dim3(kb), dim3(kBlock), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, hist);
+    hipLaunchKernelGGL(tick_scan_kernel, dim3(1), dim3(kBlock), 0, s, hist, cursor);
     hipLaunchKernelGGL(tick_scatter_kernel, dim3(kb), dim3(kBlock), 0, s, keys, nitems, cursor, sorted);
 }
 
@@ -1113,16 +1156,18 @@ void launch_bounds_sorted(const float4* src, int ns, const float* lut, const flo
     const TickGroup* gp = groups;
     const TickSub* sp = subs;
     if (ev_start) (void)hipEventRecord(ev_start, s);
-    static const int variant = [] { const char* e = std::getenv("FGOICP_BOUNDS_VARIANT"); return e ? std::atoi(e) : 1; }();  // tuning knob (1 = default)
+    static const int variant = [] { const char* e = std::getenv("FGOICP_BOUNDS_VARIANT"); return e ? std::atoi(e) : 2; }();  // tuning knob (2 = default: one wave, 4 points per lane)
     const dim3 grid((unsigned)nitems);
 #define FGOICP_LAUNCH_SORTED(T, PP, Z, TR) \
     hipLaunchKernelGGL((bounds_sorted_kernel<T, PP, Z, TR>), grid, dim3(T), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, chunk_pts, partials, vals)
     if (vals) {
         if (zp && layout == 2) FGOICP_LAUNCH_SORTED(128, 2, 2, 1); else if (zp) FGOICP_LAUNCH_SORTED(128, 2, 1, 1); else FGOICP_LAUNCH_SORTED(128, 2, 0, 1);
     } else if (zp && layout == 2) {
-        if (variant == 0) FGOICP_LAUNCH_SORTED(256, 1, 2, 0); else if (variant == 2) FGOICP_LAUNCH_SORTED(64, 4, 2, 0); else FGOICP_LAUNCH_SORTED(128, 2, 2, 0);
+        if (variant == 0) FGOICP_LAUNCH_SORTED(256, 1, 2, 0); else if (variant == 2) FGOICP_LAUNCH_SORTED(64, 4, 2, 0);
+        else if (variant == 3) FGOICP_LAUNCH_SORTED(64, 2, 2, 0); else if (variant == 4) FGOICP_LAUNCH_SORTED(64, 1, 2, 0); else FGOICP_LAUNCH_SORTED(128, 2, 2, 0);
     } else if (zp) {
-        if (variant == 0) FGOICP_LAUNCH_SORTED(256, 1, 1, 0); else if (variant == 2) FGOICP_LAUNCH_SORTED(64, 4, 1, 0); else FGOICP_LAUNCH_SORTED(128, 2, 1, 0);
+        if (variant == 0) FGOICP_LAUNCH_SORTED(256, 1, 1, 0); else if (variant == 2) FGOICP_LAUNCH_SORTED(64, 4, 1, 0);
+        else if (variant == 3) FGOICP_LAUNCH_SORTED(64, 2, 1, 0); else if (variant == 4) FGOICP_LAUNCH_SORTED(64, 1, 1, 0); else FGOICP_LAUNCH_SORTED(128, 2, 1, 0);
     } else {
         if (variant == 0) FGOICP_LAUNCH_SORTED(256, 1, 0, 0); else if (variant == 2) FGOICP_LAUNCH_SORTED(64, 4, 0, 0); else FGOICP_LAUNCH_SORTED(128, 2, 0, 0);
     }
