@@ -240,9 +240,12 @@ def test_sorted_and_plain_bounds_paths_agree(fg, tiny_case, gpu_required, monkey
         assert np.max(np.abs(lb1.astype(np.float64) - lb0)) <= REL * max(float(np.max(ub0)), 1e-30)
 
 
-def test_bounds_multi_many_groups_and_windows(fg, tiny_case, gpu_required):
-    """More subcubes than one window (4096) and many rotation nodes: windows split mid-group."""
+@pytest.mark.parametrize("window", [300, 4096, 0])
+def test_bounds_multi_many_groups_and_windows(fg, tiny_case, gpu_required, monkeypatch, window):
+    """More subcubes than one window and many rotation nodes: windows split mid-group (window 0 = the default size)."""
     c = tiny_case
+    if window:
+        monkeypatch.setenv("FGOICP_MAX_SUBCUBES", str(window))
     reg = fg.Registration(c["pct"], c["pcs"], c["bounds"], c["res"])
     rng = np.random.default_rng(10)
     nodes = [fg.RotNode(*rng.uniform(-0.4, 0.4, 3), 0.125) for _ in range(40)]
@@ -253,6 +256,25 @@ def test_bounds_multi_many_groups_and_windows(fg, tiny_case, gpu_required):
     for k in (0, 7, 23, 39):
         lb1, ub1 = reg.compute_sse_error(nodes[k], groups[k], fixes[k])
         assert np.array_equal(multi[k][0], lb1) and np.array_equal(multi[k][1], ub1)
+    reg.close()
+
+
+@pytest.mark.parametrize("chunk", [256, 512, 1024, 2048])
+def test_work_item_sizes_agree_with_the_oracle(fg, oracle, tiny_case, gpu_required, monkeypatch, chunk):
+    """Dense clouds use bigger work items in the sorted bounds kernel (512..2048 points per item): same per-point values,
+    only the fp64 partial sums are cut differently."""
+    c = tiny_case
+    monkeypatch.setenv("FGOICP_CHUNK_PTS", str(chunk))
+    reg = fg.Registration(c["pct"], c["pcs"], c["bounds"], c["res"])
+    orc = oracle.Registration(c["pct"], c["pcs"], c["bounds"], c["res"])
+    rng = np.random.default_rng(21)
+    rn = fg.RotNode(0.25, -0.125, 0.375, 0.125)
+    tn = _tnodes(rng, 50, 0.25)
+    for fix in (True, False):
+        lb, ub = reg.compute_sse_error(rn, tn, fix)
+        lbo, ubo = orc.compute_bounds(rn.q.R, rn.span, tn, fix)
+        assert rel(ub, ubo) <= REL
+        assert np.max(np.abs(lb.astype(np.float64) - lbo)) <= REL * max(float(np.max(ubo)), 1e-30)
     reg.close()
 
 
@@ -328,13 +350,15 @@ def test_full_size_run_schedules_agree(fg, gpu_required):
     """SERIAL (reference order) and ROUND reach the same optimum on the 40k benchmark pair, default threshold."""
     tgt, src, R_gt, t_gt = fg.synth.workload("bunny", angle_deg=150.0, min_angle_deg=110.0)
     res = {}
-    for name, (sched, K) in {"serial": (fg.SCHEDULE_SERIAL, 1), "round": (fg.SCHEDULE_ROUND, 32)}.items():
+    for name, (sched, K) in {"serial": (fg.SCHEDULE_SERIAL, 1), "round": (fg.SCHEDULE_ROUND, 32), "adaptive": (fg.SCHEDULE_ROUND, 0)}.items():
         s = fg.FastGoICP(tgt, src, 0.005, 1e-3, schedule=sched, round_width=K)
         R, t = s.run()
         res[name] = (R, t, float(s.get_best_error()), s.stats())
         s.close()
-    (Rs, ts, es, _), (Rr, tr, er, _) = res["serial"], res["round"]
-    assert er == pytest.approx(es, rel=1e-5) and np.allclose(Rs, Rr, atol=1e-5) and np.allclose(ts, tr, atol=1e-5 * max(1.0, float(np.abs(ts).max())))
+    (Rs, ts, es, _) = res["serial"]
+    for other in ("round", "adaptive"):
+        Rr, tr, er, _ = res[other]
+        assert er == pytest.approx(es, rel=1e-5) and np.allclose(Rs, Rr, atol=1e-5) and np.allclose(ts, tr, atol=1e-5 * max(1.0, float(np.abs(ts).max())))
     ang = np.degrees(np.arccos(np.clip((np.trace(Rs.astype(np.float64).T @ R_gt) - 1) / 2, -1, 1)))
     assert ang < 0.5 and np.linalg.norm(ts - t_gt) < 1e-3
 
