@@ -48,7 +48,7 @@ struct fgoicp_ctx {
         fgoicp::TickGroup *d_groups = nullptr, *h_groups = nullptr;   // device / pinned staging
         fgoicp::TickSub *d_subs = nullptr, *h_subs = nullptr;
         unsigned short* d_keys = nullptr;
-        unsigned *d_hist = nullptr, *d_cursor = nullptr, *d_sorted = nullptr;
+        unsigned *d_hist = nullptr, *d_block_sums = nullptr, *d_cursor = nullptr, *d_sorted = nullptr;
         double2* d_partials = nullptr;           // [max_subcubes][nchunk1]
         float *h_lb = nullptr, *h_ub = nullptr, *hd_lb = nullptr, *hd_ub = nullptr;  // pinned results of the window in flight
         float2* d_vals = nullptr;                // trimmed mode: per-point {ub, lb} terms, [vals_rows][ns]

@@ -278,11 +278,11 @@ __device__ __forceinline__ unsigned hilbert15(unsigned x, unsigned y, unsigned z
 }
 
 template <int HILBERT>
-__global__ __launch_bounds__(kBlock) void tick_keys_kernel(const float4* __restrict__ chunk_cen, int nchunk, const TickGroup* __restrict__ groups,
+__global__ __launch_bounds__(64) void tick_keys_kernel(const float4* __restrict__ chunk_cen, int nchunk, const TickGroup* __restrict__ groups,
                                                            const TickSub* __restrict__ subs, int nsub, LutGeom g, int cell_shift,
                                                            unsigned short* __restrict__ keys, unsigned* __restrict__ hist) {
     const size_t nitems = (size_t)nsub * nchunk;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nitems; i += (size_t)gridDim.x * kBlock) {
+    for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < nitems; i += (size_t)gridDim.x * 64) {
         const int s = (int)(i / nchunk), c = (int)(i - (size_t)s * nchunk);
         const TickSub sb = subs[s];
         const TickGroup& gr = groups[sb.group];
@@ -299,46 +299,64 @@ __global__ __launch_bounds__(kBlock) void tick_keys_kernel(const float4* __restr
     }
 }
 
-// exclusive scan of the 32768-bin histogram: one block of 256 threads, 128 bins each.  It runs next to the other slot's bounds
-// kernel, which keeps every CU full of 2-wave workgroups: a 4-wave block finds a home quickly where a 16-wave block had to wait
-// for a whole CU to drain (measured 380 us per scan next to a busy device), and every memory latency is stretched, so all the
-// loads of a thread are 16-byte and issued together.
-__global__ __launch_bounds__(kBlock) void tick_scan_kernel(const unsigned* __restrict__ hist, unsigned* __restrict__ cursor) {
-    __shared__ unsigned wsum[kBlock / 64];
-    constexpr int kPer = kNumKeys / kBlock;  // 128 bins per thread
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint4* h4 = reinterpret_cast<const uint4*>(hist) + tid * (kPer / 4);
-    uint4 v[kPer / 4];
+// The sort kernels run next to the other slot's bounds kernel, which keeps every wave slot of every CU taken by one-wave
+// workgroups: a multi-wave workgroup has to wait until several slots of ONE CU are free at the same time (measured: a
+// 16-wave scan block 380 us, a 4-wave block 250 us, against ~10 us on an idle device), a one-wave workgroup takes the
+// next free slot.  So all three sort kernels use 64-thread workgroups.
+//
+// exclusive scan of the 32768-bin histogram in two one-round-trip kernels of 64 one-wave blocks (512 bins per block,
+// 8 per lane): block sums, then every block scans the 64 block sums and its own bins.  Next to a saturated memory system a
+// dependent load costs several microseconds, so the chain is kept to two loads deep (a single block walking all bins took
+// 250-600 us there).  The second kernel leaves the histogram zeroed for the next tick (it must be zero before the first).
+constexpr int kScanBlocks = kNumKeys / 512;
+
+__global__ __launch_bounds__(64) void tick_scan_sums_kernel(const unsigned* __restrict__ hist, unsigned* __restrict__ block_sums) {
+    const int lane = threadIdx.x;
+    const uint4* h4 = reinterpret_cast<const uint4*>(hist) + (size_t)blockIdx.x * 128 + 2 * lane;
+    const uint4 a = h4[0], b = h4[1];
+    unsigned sum = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
 #pragma unroll
-    for (int k = 0; k < kPer / 4; ++k) v[k] = h4[k];
-    unsigned sum = 0;
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane == 0) block_sums[blockIdx.x] = sum;
+}
+
+__global__ __launch_bounds__(64) void tick_scan_apply_kernel(unsigned* __restrict__ hist, const unsigned* __restrict__ block_sums,
+                                                             unsigned* __restrict__ cursor) {
+    static_assert(kScanBlocks == 64, "one lane per block sum");
+    const int lane = threadIdx.x;
+    uint4* h4 = reinterpret_cast<uint4*>(hist) + (size_t)blockIdx.x * 128 + 2 * lane;
+    const uint4 a = h4[0], b = h4[1];
+    const unsigned bs = lane < (int)blockIdx.x ? block_sums[lane] : 0u;
+    h4[0] = make_uint4(0u, 0u, 0u, 0u);
+    h4[1] = make_uint4(0u, 0u, 0u, 0u);
+    unsigned base = bs;
 #pragma unroll
-    for (int k = 0; k < kPer / 4; ++k) sum += v[k].x + v[k].y + v[k].z + v[k].w;
-    unsigned incl = sum;  // inclusive scan of `sum` across the wave
+    for (int off = 32; off > 0; off >>= 1) base += __shfl_xor(base, off, 64);
+    const unsigned sum = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+    unsigned incl = sum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const unsigned u = __shfl_up(incl, off, 64);
         if (lane >= off) incl += u;
     }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    unsigned run = incl - sum;
-    for (int w = 0; w < wave; ++w) run += wsum[w];
-    uint4* c4 = reinterpret_cast<uint4*>(cursor) + tid * (kPer / 4);
-#pragma unroll
-    for (int k = 0; k < kPer / 4; ++k) {
-        uint4 o;
-        o.x = run; run += v[k].x;
-        o.y = run; run += v[k].y;
-        o.z = run; run += v[k].z;
-        o.w = run; run += v[k].w;
-        c4[k] = o;
-    }
+    unsigned run = base + incl - sum;
+    uint4 o0, o1;
+    o0.x = run; run += a.x;
+    o0.y = run; run += a.y;
+    o0.z = run; run += a.z;
+    o0.w = run; run += a.w;
+    o1.x = run; run += b.x;
+    o1.y = run; run += b.y;
+    o1.z = run; run += b.z;
+    o1.w = run;
+    uint4* c4 = reinterpret_cast<uint4*>(cursor) + (size_t)blockIdx.x * 128 + 2 * lane;
+    c4[0] = o0;
+    c4[1] = o1;
 }
 
-__global__ __launch_bounds__(kBlock) void tick_scatter_kernel(const unsigned short* __restrict__ keys, size_t nitems, unsigned* __restrict__ cursor,
-                                                              unsigned* __restrict__ sorted) {
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nitems; i += (size_t)gridDim.x * kBlock)
+__global__ __launch_bounds__(64) void tick_scatter_kernel(const unsigned short* __restrict__ keys, size_t nitems, unsigned* __restrict__ cursor,
+                                                          unsigned* __restrict__ sorted) {
+    for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < nitems; i += (size_t)gridDim.x * 64)
         sorted[atomicAdd(&cursor[keys[i]], 1u)] = (unsigned)i;  // order inside a bin is irrelevant (scheduling only)
 }
 
@@ -1138,15 +1156,15 @@ void launch_bounds(const float4* src, int ns, const float* lut, const LutGeom& g
 
 // The locality sort of one tick (descriptors must already be on the device): keys + histogram, scan, scatter.
 void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, const TickGroup* groups, const TickSub* subs, int nsub, int cell_shift,
-                      unsigned short* keys, unsigned* hist, unsigned* cursor, unsigned* sorted, hipStream_t s) {
+                      unsigned short* keys, unsigned* hist, unsigned* block_sums, unsigned* cursor, unsigned* sorted, hipStream_t s) {
     const size_t nitems = (size_t)nsub * nchunk;
-    (void)hipMemsetAsync(hist, 0, sizeof(unsigned) * kNumKeys, s);
-    const unsigned kb = (unsigned)std::min<size_t>((nitems + kBlock - 1) / kBlock, 2048);
+    const unsigned kb = (unsigned)std::min<size_t>((nitems + 63) / 64, 8192);  // `hist` is zero here: tick_scan_apply_kernel re-zeroes it
     static const int hilbert = [] { const char* e = std::getenv("FGOICP_SORT_CURVE"); return e ? std::atoi(e) : 1; }();  // tuning knob: 1 = Hilbert (default), 0 = Z-order
-    if (hilbert) hipLaunchKernelGGL(tick_keys_kernel<1>, dim3(kb), dim3(kBlock), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, hist);
-    else hipLaunchKernelGGL(tick_keys_kernel<0>, dim3(kb), dim3(kBlock), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, hist);
-    hipLaunchKernelGGL(tick_scan_kernel, dim3(1), dim3(kBlock), 0, s, hist, cursor);
-    hipLaunchKernelGGL(tick_scatter_kernel, dim3(kb), dim3(kBlock), 0, s, keys, nitems, cursor, sorted);
+    if (hilbert) hipLaunchKernelGGL(tick_keys_kernel<1>, dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, hist);
+    else hipLaunchKernelGGL(tick_keys_kernel<0>, dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, hist);
+    hipLaunchKernelGGL(tick_scan_sums_kernel, dim3(kScanBlocks), dim3(64), 0, s, hist, block_sums);
+    hipLaunchKernelGGL(tick_scan_apply_kernel, dim3(kScanBlocks), dim3(64), 0, s, hist, block_sums, cursor);
+    hipLaunchKernelGGL(tick_scatter_kernel, dim3(kb), dim3(64), 0, s, keys, nitems, cursor, sorted);
 }
 
 void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* zp, int layout, const LutGeom& g, int nchunk, int chunk_pts,
