@@ -367,7 +367,11 @@ int ctx_set_inliers(fgoicp_ctx* c, size_t k) {
     if (k && !c->sorted_bounds) { set_error("trimming needs the sorted bounds path (FGOICP_BOUNDS_SORTED=0 is set)"); return FGOICP_ERR_INVALID_ARG; }
     if (c->slots[0].inflight || c->slots[1].inflight) { set_error("fgoicp_ctx_set_inliers: a bounds submission is in flight"); return FGOICP_ERR_INVALID_ARG; }
     if (k && !c->d_use) {
-        const size_t budget = (size_t)3 << 29;  // 1.5 GiB of per-point terms per slot
+        // per-point {ub, lb} terms of one window, per slot: up to 12 GiB (a sixth of what is free): 1500 subcubes of a 1M-point
+        // cloud per window instead of 190 — the select kernel launches one block per (subcube, bound) and needs >= 512 of them
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const size_t budget = std::max<size_t>((size_t)3 << 29, std::min<size_t>((size_t)12 << 30, free_b / 6));
         size_t rows = budget / (sizeof(float2) * c->ns);
         rows = std::max<size_t>(1, std::min<size_t>(rows, (size_t)c->max_subcubes));
         c->vals_rows = (int)rows;

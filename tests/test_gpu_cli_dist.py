@@ -81,3 +81,34 @@ def test_nccl_exchange_callbacks(fg, gpu_required):
         s.close()
     finally:
         dist.destroy_process_group()
+
+
+def _launch_gpu_ranks(tmp_path, world, workload, mse, K):
+    import socket
+    import sys
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    prefix = str(tmp_path / f"w{world}")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(REPO, "tests", "gpu_dist_worker.py"), prefix, workload, repr(mse), str(K)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    return [np.load(f"{prefix}.rank{r}.npz") for r in range(world)]
+
+
+def test_two_ranks_shard_the_search_on_the_gpu(fg, gpu_required, tmp_path):
+    """The N > 1 path end to end on the HIP operators: two ranks (sharing this box's one GPU, exchange on gloo) shard every
+    round's rotation cubes, keep identical replicated state, and certify the optimum a single rank certifies."""
+    tgt, src, R_gt, t_gt = fg.synth.workload("small", angle_deg=150.0, min_angle_deg=110.0)
+    one = fg.FastGoICP(tgt, src, 0.02, 2e-5, schedule=fg.SCHEDULE_ROUND, round_width=0)
+    R1, t1 = one.run()
+    e1, st1 = float(one.get_best_error()), one.stats()
+    one.close()
+    a, b = _launch_gpu_ranks(tmp_path, 2, "small", 2e-5, 0)
+    assert np.array_equal(a["R"], b["R"]) and np.array_equal(a["t"], b["t"]) and a["sse"] == b["sse"]
+    assert a["rounds"] == b["rounds"] and a["exchange_calls"] == b["exchange_calls"] == 2 * a["rounds"]
+    assert float(a["sse"]) == pytest.approx(e1, rel=1e-5) and np.allclose(a["R"], R1, atol=1e-5) and np.allclose(a["t"], t1, atol=1e-5 * max(1.0, float(np.abs(t1).max())))
+    # the work is sharded, not replicated
+    assert int(a["rot_cubes"]) > 0 and int(b["rot_cubes"]) > 0
+    assert abs(int(a["rot_cubes"]) + int(b["rot_cubes"]) - int(st1["rot_cubes"])) <= 0.25 * int(st1["rot_cubes"]) + 16

@@ -1,5 +1,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 || exit 1
-B="python bench.py --no-cpu-baseline --no-default-threshold-run --no-dragon --steps 3 --warmup 1"
-for i in 1 2; do (timeout -k 10 200 $B 2>&1 | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"achieved": [0-9.]*' | tr '\n' ' '); echo; done
+export TMPDIR=/tmp
+REPO=$GRAFT_REPO_ROOT
+rm -rf /tmp/ktrace
+cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktrace -- python3 $REPO/tools/dragon_probe.py 0 1e-3 synthetic1m_outliers 0.2 150 > $REPO/gpurun_out/ktrace.log 2>&1
+cp /tmp/ktrace/*/*kernel_stats.csv $REPO/gpurun_out/kstats_m1.csv
