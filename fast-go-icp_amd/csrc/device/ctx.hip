@@ -119,7 +119,7 @@ static int tick_enqueue_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl, int G, c
         HIPCHK(hipStreamWaitEvent(fin, sl.bounds_ev, 0));
     }
     if (c->inliers)  // trimmed: the k smallest ub terms (column 0) and the k smallest lb terms (column 1) of every subcube
-        launch_trim_select(reinterpret_cast<const float*>(sl.d_vals), 2 * c->ns, 2, (int)c->ns, (int)c->inliers, rows, sl.hd_ub, sl.hd_lb, nullptr, fin);
+        launch_trim_select(reinterpret_cast<const float*>(sl.d_vals), 2 * c->ns, 2, (int)c->ns, (int)c->inliers, rows, sl.hd_ub, sl.hd_lb, nullptr, nullptr, fin);
     else
         launch_bounds_finalize(sl.d_partials, c->nchunk1, rows, sl.hd_lb, sl.hd_ub, fin);
     HIPCHK(hipGetLastError());
@@ -263,7 +263,7 @@ int ctx_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out, con
         launch_nn_scan(c->d_src, ns, c->bvh_tgt.view(), c->d_lut, c->geom, R9, t3, 1, 0, c->d_tgt, (int)c->nt, seed_idx, c->d_min_bits, c->stream);
     }
     if (c->inliers) {  // trimmed SSE: the k smallest nearest-neighbour terms
-        launch_trim_select(reinterpret_cast<const float*>(c->d_min_bits), 0, 1, ns, (int)c->inliers, 1, c->hd_trim, nullptr, nullptr, c->stream);
+        launch_trim_select(reinterpret_cast<const float*>(c->d_min_bits), 0, 1, ns, (int)c->inliers, 1, c->hd_trim, nullptr, nullptr, c->d_sel_wide, c->stream);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c->stream));
         *sse_out = c->h_trim[0];
@@ -295,7 +295,7 @@ int ctx_procrustes_device(fgoicp_ctx* c, Mat3f* R_out, Vec3f* t_out, float* cent
     const unsigned char* use = nullptr;
     int ncount = ns;
     if (c->inliers) {  // trimmed ICP: only the k closest correspondences enter the Procrustes sums
-        launch_icp_inliers(c->d_work, c->d_tgt, c->d_first_idx, ns, nt, (int)c->inliers, c->d_d2, c->d_sel, c->d_eq, c->d_slot_of_orig, c->d_use, c->stream);
+        launch_icp_inliers(c->d_work, c->d_tgt, c->d_first_idx, ns, nt, (int)c->inliers, c->d_d2, c->d_sel, c->d_eq, c->d_slot_of_orig, c->d_use, c->d_sel_wide, c->stream);
         use = c->d_use;
         ncount = (int)c->inliers;
     }
@@ -379,6 +379,10 @@ int ctx_set_inliers(fgoicp_ctx* c, size_t k) {
         HIPCHK(hipMalloc(&c->d_d2, sizeof(float) * c->ns));
         HIPCHK(hipMalloc(&c->d_sel, sizeof(uint32_t) * 8));
         HIPCHK(hipMalloc(&c->d_eq, sizeof(uint32_t)));
+        {
+            const char* e = std::getenv("FGOICP_SELECT_WIDE");  // tuning knob: 0 = always the one-block-per-row selection
+            if (!(e && std::atoi(e) == 0)) HIPCHK(hipMalloc(&c->d_sel_wide, 65536));
+        }
         HIPCHK(hipMalloc(&c->d_use, c->ns));
         HIPCHK(hipMalloc(&c->d_slot_of_orig, sizeof(uint32_t) * c->ns));
         std::vector<uint32_t> inv(c->ns);
@@ -656,7 +660,7 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
     if (c->h_cen) (void)hipHostFree(c->h_cen);
     bvh_free(&c->bvh_tgt);
     (void)hipFree(c->d_chunk_cen);
-    (void)hipFree(c->d_d2); (void)hipFree(c->d_sel); (void)hipFree(c->d_eq); (void)hipFree(c->d_use); (void)hipFree(c->d_slot_of_orig);
+    (void)hipFree(c->d_d2); (void)hipFree(c->d_sel); (void)hipFree(c->d_eq); (void)hipFree(c->d_use); (void)hipFree(c->d_slot_of_orig); (void)hipFree(c->d_sel_wide);
     if (c->h_trim) (void)hipHostFree(c->h_trim);
     for (int k = 0; k < 2; ++k) {
         fgoicp_ctx::TickSlot& sl = c->slots[k];

@@ -68,7 +68,7 @@ struct fgoicp_ctx {
     size_t inliers = 0;
     int vals_rows = 0;                       // subcubes per window in trimmed mode (memory budget)
     float* d_d2 = nullptr;                   // squared correspondence distances
-    uint32_t *d_sel = nullptr, *d_eq = nullptr, *d_slot_of_orig = nullptr;
+    uint32_t *d_sel = nullptr, *d_eq = nullptr, *d_slot_of_orig = nullptr, *d_sel_wide = nullptr;
     unsigned char* d_use = nullptr;          // inlier mask of the current Procrustes step
     float *h_trim = nullptr, *hd_trim = nullptr;   // pinned trimmed SSE
 

@@ -505,6 +505,86 @@ __global__ __launch_bounds__(kBlock) void trim_select_kernel(const float* __rest
     }
 }
 
+// The same selection for ONE long row (trimmed SSE and the ICP inlier cut: n = ns values, a single (row, column)), spread over
+// the whole device: per level a histogram kernel (LDS histograms merged with global atomics) and a one-block pick, then ordered
+// block partial sums.  A single block needs 3-4 ms for 1M values; this takes nine small launches.
+// scratch layout (uint32): [0, 6144) three 2048-bin histograms, [6144] prefix, [6145] prevmask, [6146] need; doubles from byte 32768.
+constexpr int kSelWideBlocks = 512;
+__device__ __forceinline__ double* sel_partials(uint32_t* scratch) { return reinterpret_cast<double*>(scratch + 8192); }
+
+__global__ __launch_bounds__(kBlock) void select_wide_init_kernel(uint32_t* __restrict__ scratch, int k) {
+    for (int i = threadIdx.x; i < 6144; i += kBlock) scratch[i] = 0u;
+    if (threadIdx.x == 0) { scratch[6144] = 0u; scratch[6145] = 0u; scratch[6146] = (uint32_t)k; }
+}
+__global__ __launch_bounds__(kBlock) void select_wide_hist_kernel(const float* __restrict__ v, int n, int lvl, uint32_t* __restrict__ scratch) {
+    __shared__ unsigned hist[2048];
+    const int shift = lvl == 0 ? 21 : lvl == 1 ? 10 : 0, nb = lvl == 2 ? 1024 : 2048;
+    const unsigned prefix = scratch[6144], prevmask = scratch[6145];
+    for (int b = threadIdx.x; b < 2048; b += kBlock) hist[b] = 0;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < (size_t)n; i += (size_t)gridDim.x * kBlock) {
+        const unsigned u = __float_as_uint(v[i]);
+        if ((u & prevmask) == prefix) atomicAdd(&hist[(u >> shift) & (nb - 1)], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nb; b += kBlock)
+        if (hist[b]) atomicAdd(&scratch[lvl * 2048 + b], hist[b]);
+}
+__global__ __launch_bounds__(kBlock) void select_wide_pick_kernel(int lvl, uint32_t* __restrict__ scratch) {
+    __shared__ unsigned scan[kBlock];
+    const int tid = threadIdx.x;
+    const int shift = lvl == 0 ? 21 : lvl == 1 ? 10 : 0, nb = lvl == 2 ? 1024 : 2048;
+    const unsigned* hist = scratch + lvl * 2048;
+    const unsigned need = scratch[6146];
+    const int per = nb / kBlock;
+    unsigned mine = 0;
+    for (int b = 0; b < per; ++b) mine += hist[tid * per + b];
+    scan[tid] = mine;
+    __syncthreads();
+    for (int off = 1; off < kBlock; off <<= 1) {
+        const unsigned add = tid >= off ? scan[tid - off] : 0u;
+        __syncthreads();
+        scan[tid] += add;
+        __syncthreads();
+    }
+    const unsigned excl = scan[tid] - mine;
+    if (excl < need && need <= excl + mine) {  // exactly one thread
+        unsigned below = excl;
+        int b = 0;
+        for (; b < per; ++b) {
+            const unsigned c = hist[tid * per + b];
+            if (need <= below + c) break;
+            below += c;
+        }
+        scratch[6144] |= (unsigned)(tid * per + b) << shift;
+        scratch[6145] |= (unsigned)(nb - 1) << shift;
+        scratch[6146] = need - below;
+    }
+}
+__global__ __launch_bounds__(kBlock) void select_wide_sum_kernel(const float* __restrict__ v, int n, uint32_t* __restrict__ scratch) {
+    __shared__ double red[8];
+    const unsigned vk = scratch[6144];
+    const size_t per = ((size_t)n + gridDim.x - 1) / gridDim.x;  // contiguous slice per block: the order of the sum is fixed
+    const size_t a = per * blockIdx.x, b = a + per < (size_t)n ? a + per : (size_t)n;
+    double acc[1] = {0.0};
+    for (size_t i = a + threadIdx.x; i < b; i += kBlock) {
+        const float x = v[i];
+        if (__float_as_uint(x) < vk) acc[0] += (double)x;
+    }
+    const double r = block_sum<1>(acc, red);
+    if (threadIdx.x == 0) sel_partials(scratch)[blockIdx.x] = r;
+}
+__global__ __launch_bounds__(64) void select_wide_final_kernel(uint32_t* __restrict__ scratch, int nblocks, float* __restrict__ out, uint32_t* __restrict__ sel_info) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 64) s += sel_partials(scratch)[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) {
+        const unsigned vk = scratch[6144], need = scratch[6146];
+        if (out) out[0] = (float)(s + (double)need * (double)__uint_as_float(vk));
+        if (sel_info) { sel_info[0] = vk; sel_info[1] = need; }
+    }
+}
+
 // ICP with trimming: squared distance of every working point to its correspondence ...
 __global__ __launch_bounds__(kBlock) void icp_corr_d2_kernel(const float4* __restrict__ work, const float4* __restrict__ tgt, const uint32_t* __restrict__ idx,
                                                              int n, int nt, float* __restrict__ d2) {
@@ -1305,15 +1385,26 @@ void launch_icp_cov(const float4* work, const float4* tgt, const uint32_t* idx, 
 
 // trimmed sums: out0[row] / out1[row] = sum of the k smallest of column 0 / 1 of row `row` (ncols = 1 or 2)
 void launch_trim_select(const float* vals, size_t row_stride, int ncols, int n, int k, int rows, float* out0, float* out1, uint32_t* sel_info,
-                        hipStream_t s) {
+                        uint32_t* wide_scratch, hipStream_t s) {
+    if (wide_scratch && rows == 1 && ncols == 1 && n >= 32768) {  // one long row: spread the selection over the device
+        const int nb = std::min(kSelWideBlocks, (n + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(select_wide_init_kernel, dim3(1), dim3(kBlock), 0, s, wide_scratch, k);
+        for (int lvl = 0; lvl < 3; ++lvl) {
+            hipLaunchKernelGGL(select_wide_hist_kernel, dim3(nb), dim3(kBlock), 0, s, vals, n, lvl, wide_scratch);
+            hipLaunchKernelGGL(select_wide_pick_kernel, dim3(1), dim3(kBlock), 0, s, lvl, wide_scratch);
+        }
+        hipLaunchKernelGGL(select_wide_sum_kernel, dim3(nb), dim3(kBlock), 0, s, vals, n, wide_scratch);
+        hipLaunchKernelGGL(select_wide_final_kernel, dim3(1), dim3(64), 0, s, wide_scratch, nb, out0, sel_info);
+        return;
+    }
     hipLaunchKernelGGL(trim_select_kernel, dim3(rows, ncols), dim3(kBlock), 0, s, vals, row_stride, ncols, ncols, n, k, out0, out1, sel_info);
 }
 
 void launch_icp_inliers(const float4* work, const float4* tgt, const uint32_t* idx, int n, int nt, int k, float* d2, uint32_t* sel_info,
-                        uint32_t* equal_count, const uint32_t* slot_of_orig, unsigned char* use, hipStream_t s) {
+                        uint32_t* equal_count, const uint32_t* slot_of_orig, unsigned char* use, uint32_t* wide_scratch, hipStream_t s) {
     const int nb = (n + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(icp_corr_d2_kernel, dim3(nb), dim3(kBlock), 0, s, work, tgt, idx, n, nt, d2);
-    launch_trim_select(d2, 0, 1, n, k, 1, nullptr, nullptr, sel_info, s);
+    launch_trim_select(d2, 0, 1, n, k, 1, nullptr, nullptr, sel_info, wide_scratch, s);
     (void)hipMemsetAsync(equal_count, 0, sizeof(uint32_t), s);
     hipLaunchKernelGGL(icp_inlier_mask_kernel, dim3(nb), dim3(kBlock), 0, s, d2, n, sel_info, use, equal_count);
     hipLaunchKernelGGL(icp_inlier_ties_kernel, dim3(nb < 256 ? nb : 256), dim3(kBlock), 0, s, n, sel_info, equal_count, slot_of_orig, use);

@@ -62,14 +62,14 @@ void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, con
                       unsigned short* keys, unsigned* hist /* kTickNumKeys, zero on entry and on exit */, unsigned* block_sums /* 64 */, unsigned* cursor,
                       unsigned* sorted, hipStream_t s);
 void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* packed_or_null, int layout /* 1 z-pair, 2 yz-quad */, const LutGeom& g, int nchunk,
-                          int chunk_pts /* 256, 512 or 1024 points per item */, const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials, float2* vals_or_null,
+                          int chunk_pts /* 256 .. 2048 points per item */, const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials, float2* vals_or_null,
                           hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s);
 // EXTENSION (trimmed Go-ICP): sum of the k smallest entries of each row/column of `vals` (exact radix select, kernels.hip)
 void launch_trim_select(const float* vals, size_t row_stride, int ncols, int n, int k, int rows, float* out0, float* out1, uint32_t* sel_info,
+                        uint32_t* wide_scratch /* 64 KiB, optional: one long row (rows = ncols = 1, n >= 32768) is then selected by the whole device */,
                         hipStream_t s);
-// use[i] = 1 for the k correspondences with the smallest squared distance (ties at the cut: lowest caller index)
 void launch_icp_inliers(const float4* work, const float4* tgt, const uint32_t* idx, int n, int nt, int k, float* d2, uint32_t* sel_info,
-                        uint32_t* equal_count, const uint32_t* slot_of_orig, unsigned char* use, hipStream_t s);
+                        uint32_t* equal_count, const uint32_t* slot_of_orig, unsigned char* use, uint32_t* wide_scratch, hipStream_t s);
 // out_lb[i], out_ub[i] = float(sum over chunks), fixed order → bit-reproducible
 void launch_bounds_finalize(const double2* partials, int nchunk, int total, float* out_lb, float* out_ub, hipStream_t s);
 

@@ -46,6 +46,13 @@ int orc_num_threads() {
     return 1;
 #endif
 }
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 
 // ---- types -------------------------------------------------------------------------------
 void orc_rotation(float x, float y, float z, float* R9, float* r, int* in_so3) {

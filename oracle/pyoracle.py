@@ -24,6 +24,27 @@ def build(force=False):
 _lib = None
 
 
+def usable_cpus(cap=16):
+    """CPUs this process may really use: affinity mask, cgroup CPU quota, and at most `cap` (a GPU box shows every core of
+    the host but grants a share of ~16; 256 OpenMP threads spinning on a 16-CPU quota turn a 0.4 s run into minutes)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and per > 0:
+            n = min(n, max(1, q // per))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -31,6 +52,9 @@ def lib():
             build()
         L = C.CDLL(_PATH)
         L.orc_num_threads.restype = C.c_int
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        want = os.environ.get("FGOICP_ORACLE_THREADS") or os.environ.get("OMP_NUM_THREADS")
+        L.orc_set_num_threads(int(want) if want and want.isdigit() else usable_cpus())
         L.orc_rotation.argtypes = [C.c_float, C.c_float, C.c_float, _fp, _fp, _ip]
         L.orc_rotnode_overlaps.argtypes = [C.c_float] * 4
         L.orc_rotnode_overlaps.restype = C.c_int

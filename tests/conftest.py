@@ -8,6 +8,11 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+# OpenMP (the oracle, the host harness) must not start one thread per visible core: a GPU box shows 256 cores and grants ~16
+from oracle.pyoracle import usable_cpus  # noqa: E402
+
+os.environ.setdefault("OMP_NUM_THREADS", str(usable_cpus()))
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -158,3 +158,34 @@ def test_hip_trimmed_full_run_matches_oracle(fg, oracle, gpu_required, sched, K)
         st = s.stats()
         assert [st[k] for k in ("trans_cubes", "rot_cubes", "icp_runs", "icp_iters")] == [o["stats"][k] for k in ("trans_cubes", "rot_cubes", "icp_runs", "icp_iters")]
     s.close()
+
+
+@pytest.mark.gpu
+def test_hip_device_wide_selection_equals_the_one_block_selection(fg, gpu_required, monkeypatch):
+    """Trimmed SSE and the ICP inlier cut of a long row (ns >= 32768) are selected by the whole device (nine small launches
+    instead of one block walking 40k..1M values four times): same k-th value, same trimmed sum up to the fp64 summation
+    order, same ICP result."""
+    tgt, src, R_gt, t_gt = fg.synth.workload("bunny", angle_deg=20.0)
+    pct, pcs, off_t, off_s, scale, bounds = fg.synth.preprocess(tgt, src)
+    rng = np.random.default_rng(5)
+    pcs = pcs.copy()
+    bad = rng.choice(len(pcs), len(pcs) // 5, replace=False)
+    pcs[bad] = rng.uniform(-1.2, 1.2, (len(bad), 3)).astype(f32)  # 20 % outliers
+    k = int(len(pcs) * 0.8)
+    R = fg.synth.random_rotation(rng, 10.0).astype(f32)
+    t = rng.uniform(-0.02, 0.02, 3).astype(f32)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FGOICP_SELECT_WIDE", mode)
+        reg = fg.Registration(pct, pcs, bounds, 0.02)
+        reg.set_inliers(k)
+        sse = float(reg.compute_sse_error(R, t))
+        icp = fg.IterativeClosestPoint3D(reg, None, None, 20, 0.005, R, t)
+        out[mode] = (sse, *icp.run(), icp.iterations)
+        reg.set_inliers(0)
+        full = float(reg.compute_sse_error(R, t))
+        assert sse < 0.5 * full  # the outliers carried most of the untrimmed error
+        reg.close()
+    (s1, e1, R1, t1, it1), (s0, e0, R0, t0, it0) = out["1"], out["0"]
+    assert s1 == pytest.approx(s0, rel=1e-6) and it1 == it0
+    assert float(e1) == pytest.approx(float(e0), rel=1e-5) and np.allclose(R1, R0, atol=1e-5) and np.allclose(t1, t0, atol=1e-5)

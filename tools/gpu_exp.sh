@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-export TMPDIR=/tmp
-REPO=$GRAFT_REPO_ROOT
-rm -rf /tmp/ktrace
-cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktrace -- python3 $REPO/tools/dragon_probe.py 0 1e-3 synthetic1m_outliers 0.2 150 > $REPO/gpurun_out/ktrace.log 2>&1
-cp /tmp/ktrace/*/*kernel_stats.csv $REPO/gpurun_out/kstats_m1.csv
+timeout -k 10 600 python -m pytest tests -m gpu -x -q > gpurun_out/t20.log 2>&1; echo "exit $?" >> gpurun_out/t20.log
+tail -4 gpurun_out/t20.log
+grep -q "exit 0" gpurun_out/t20.log || exit 1
+(timeout -k 10 500 python bench.py > gpurun_out/bench20.log 2>&1; echo "exit $?" >> gpurun_out/bench20.log)
+tail -2 gpurun_out/bench20.log | cut -c1-300
