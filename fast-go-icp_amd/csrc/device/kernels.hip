@@ -151,6 +151,31 @@ __device__ __forceinline__ void quad_gather(const float4* __restrict__ qd, const
     v10 = float2u{a.z, b.z};  // (y1, z0)
     v11 = float2u{a.w, b.w};  // (y1, z1)
 }
+// The same lookup with the two 16-byte halves fetched by a PAIR of neighbouring lanes in ONE instruction: load 1 brings
+// q[o], q[o+1] of the even lane's point (even lane: q[o], odd lane: q[o+1]), load 2 those of the odd lane's point, and the
+// lanes swap what the other one needs (DPP quad_perm, no LDS).  The texture addresser merges the two lanes' accesses to the
+// same line, so a lookup costs the L1 one tag access instead of a miss plus a hit on the still-pending line (PMC: the L1
+// spends half its cycles in pending stalls with the per-lane form).
+__device__ __forceinline__ int swap_lane_pair(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true); }
+__device__ __forceinline__ float swap_lane_pair(float v) { return __int_as_float(swap_lane_pair(__float_as_int(v))); }
+struct QuadPairLoads { float4a r1, r2; };
+__device__ __forceinline__ QuadPairLoads quad_pair_issue(const float4* __restrict__ qd, const TexAddr& t, int odd) {
+    const int own = (int)t.o, other = swap_lane_pair(own);
+    const int o_even = odd ? other : own, o_odd = odd ? own : other;
+    QuadPairLoads q;
+    q.r1 = *(const float4a*)(qd + (size_t)(o_even + odd));
+    q.r2 = *(const float4a*)(qd + (size_t)(o_odd + odd));
+    return q;
+}
+__device__ __forceinline__ void quad_pair_finish(const QuadPairLoads& q, int odd, float2u& v00, float2u& v10, float2u& v01, float2u& v11) {
+    float4a send = odd ? q.r1 : q.r2, recv;
+    recv.x = swap_lane_pair(send.x); recv.y = swap_lane_pair(send.y); recv.z = swap_lane_pair(send.z); recv.w = swap_lane_pair(send.w);
+    const float4a a = odd ? recv : q.r1, b = odd ? q.r2 : recv;
+    v00 = float2u{a.x, b.x};
+    v01 = float2u{a.y, b.y};
+    v10 = float2u{a.z, b.z};
+    v11 = float2u{a.w, b.w};
+}
 __global__ __launch_bounds__(kBlock) void lut_quad_kernel(const float* __restrict__ lut, LutGeom g, float4* __restrict__ qd) {
     const size_t total = (size_t)g.px * g.py * g.pz, sy = (size_t)g.px, sz = (size_t)g.px * g.py;
     for (size_t n = (size_t)blockIdx.x * kBlock + threadIdx.x; n < total; n += (size_t)gridDim.x * kBlock) {
@@ -395,9 +420,18 @@ __global__ __launch_bounds__(THREADS) void bounds_sorted_kernel(const float4* __
             rotate(gr.R, p[k].x, p[k].y, p[k].z, rx, ry, rz);
             ta[k] = lut_address(g, rx + sb.tx, ry + sb.ty, rz + sb.tz);  // :34, :323-325
         }
+        QuadPairLoads qp[ZPAIR == 3 ? P : 1];
+        const int odd = (int)threadIdx.x & 1;
+        if (ZPAIR == 3) {
+#pragma unroll
+            for (int k = 0; k < P; ++k) qp[k] = quad_pair_issue(reinterpret_cast<const float4*>(zp), ta[k], odd);
+#pragma unroll
+            for (int k = 0; k < P; ++k) quad_pair_finish(qp[k], odd, v00[k], v10[k], v01[k], v11[k]);
+        }
 #pragma unroll
         for (int k = 0; k < P; ++k) {
-            if (ZPAIR == 2) {
+            if (ZPAIR == 3) {
+            } else if (ZPAIR == 2) {
                 quad_gather(reinterpret_cast<const float4*>(zp), ta[k], v00[k], v10[k], v01[k], v11[k]);
             } else if (ZPAIR == 1) {
                 zpair_gather(zp, g, ta[k], v00[k], v10[k], v01[k], v11[k]);
@@ -1261,6 +1295,8 @@ void launch_bounds_sorted(const float4* src, int ns, const float* lut, const flo
     if (vals) {
         if (zp && layout == 2) FGOICP_LAUNCH_SORTED(128, 2, 2, 1); else if (zp) FGOICP_LAUNCH_SORTED(128, 2, 1, 1); else FGOICP_LAUNCH_SORTED(128, 2, 0, 1);
     } else if (zp && layout == 2) {
+        static const int paired = [] { const char* e = std::getenv("FGOICP_QUAD_PAIRED"); return e ? std::atoi(e) : 1; }();  // tuning knob (1 = default)
+        if (variant == 2 && paired) FGOICP_LAUNCH_SORTED(64, 4, 3, 0); else
         if (variant == 0) FGOICP_LAUNCH_SORTED(256, 1, 2, 0); else if (variant == 2) FGOICP_LAUNCH_SORTED(64, 4, 2, 0);
         else if (variant == 3) FGOICP_LAUNCH_SORTED(64, 2, 2, 0); else if (variant == 4) FGOICP_LAUNCH_SORTED(64, 1, 2, 0); else FGOICP_LAUNCH_SORTED(128, 2, 2, 0);
     } else if (zp) {

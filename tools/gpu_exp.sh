@@ -1,7 +1,10 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 600 python -m pytest tests -m gpu -x -q > gpurun_out/t20.log 2>&1; echo "exit $?" >> gpurun_out/t20.log
-tail -4 gpurun_out/t20.log
-grep -q "exit 0" gpurun_out/t20.log || exit 1
-(timeout -k 10 500 python bench.py > gpurun_out/bench20.log 2>&1; echo "exit $?" >> gpurun_out/bench20.log)
-tail -2 gpurun_out/bench20.log | cut -c1-300
+B="python bench.py --no-cpu-baseline --no-default-threshold-run --no-dragon --no-trimmed --steps 3 --warmup 1"
+run() { echo "== $*" >> gpurun_out/exp22.log; (env "$@" timeout -k 10 200 $B 2>&1 | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"achieved": [0-9.]*\|"avg_launch_us": [0-9.]*\|"launches": [0-9]*' | tr '\n' ' ' >> gpurun_out/exp22.log); echo >> gpurun_out/exp22.log; }
+rm -f gpurun_out/exp22.log
+run FGOICP_MAX_SUBCUBES=32768
+run FGOICP_MAX_SUBCUBES=65536
+run FGOICP_MAX_SUBCUBES=16384
+run FGOICP_MAX_SUBCUBES=32768
+cat gpurun_out/exp22.log
