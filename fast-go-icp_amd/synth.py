@@ -13,6 +13,9 @@ WORKLOADS = {
     "synthetic1m": dict(nt=1_000_000, ns=1_000_000, box=(0.2, 0.2, 0.2), seed=3),
     # BASELINE config 5: 20 % of the source replaced by uniform outliers in 1.5x the box (use with trim_fraction=0.2)
     "synthetic1m_outliers": dict(nt=1_000_000, ns=1_000_000, box=(0.2, 0.2, 0.2), seed=3, outlier_frac=0.2),
+    # BASELINE configs[0] shape: test/bunny.toml subsamples data/bunny to ~0.5 * 35 947 target and ~0.1 * 30 379 source points
+    # and builds the LUT at resolution 0.002 (923 x 906 x 711 nodes on the real clouds)
+    "bunny_toml": dict(nt=17973, ns=3037, box=(0.156, 0.152, 0.118), seed=5),
     "tiny": dict(nt=1500, ns=1200, box=(0.156, 0.152, 0.118), seed=7),
     "small": dict(nt=6000, ns=5000, box=(0.156, 0.152, 0.118), seed=11),
 }

@@ -20,9 +20,11 @@ def build():
     deps = [os.path.join(_DIR, "harness.cpp"), os.path.join(_REPO, "fast-go-icp_amd/csrc/host/driver.hpp"),
             os.path.join(_REPO, "fast-go-icp_amd/csrc/host/math3.hpp"), os.path.join(_REPO, "oracle/libgoicp_oracle.so")]
     if not os.path.exists(_SO) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fopenmp", "-shared", "-o", _SO,
+        tmp = f"{_SO}.{os.getpid()}.tmp"  # several ranks of a world-size-N test may get here together: build aside, rename atomically
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fopenmp", "-shared", "-o", tmp,
                         os.path.join(_DIR, "harness.cpp"), "-L" + os.path.join(_REPO, "oracle"), "-lgoicp_oracle",
                         "-Wl,-rpath," + os.path.join(_REPO, "oracle")], check=True)
+        os.replace(tmp, _SO)
     return _SO
 
 

@@ -20,6 +20,8 @@ def free_port():
 
 
 def launch(tmp_path, case, K, world):
+    from tests import host_harness
+    host_harness.build()  # once, here: the ranks only load it
     prefix = str(tmp_path / f"out_{case}{K}_{world}")
     env = dict(os.environ, OMP_NUM_THREADS="1" if world > 3 else "2", FGOICP_HOST_THREADS="1" if world > 3 else "4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",

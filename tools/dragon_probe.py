@@ -9,7 +9,8 @@ trim = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
 ang = float(sys.argv[5]) if len(sys.argv) > 5 else 150.0
 tgt, src, R_gt, t_gt = fg.synth.workload(wl, angle_deg=ang, min_angle_deg=min(110.0, ang * 0.7))
 t0 = time.perf_counter()
-s = fg.FastGoICP(tgt, src, 0.005, mse, schedule=fg.SCHEDULE_ROUND, round_width=K, device=0, trim_fraction=trim)
+res = float(os.environ.get('PROBE_RES', '0.005'))
+s = fg.FastGoICP(tgt, src, res, mse, schedule=fg.SCHEDULE_ROUND, round_width=K, device=0, trim_fraction=trim)
 setup = time.perf_counter() - t0
 reg = s.registration; reg.set_profile(True); reg.profile(reset=True)
 t0 = time.perf_counter(); R, t = s.run(); e = time.perf_counter() - t0
