@@ -90,13 +90,21 @@ static int tick_enqueue_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl, int G, c
     *end_out = end;
     if (rows <= 0) return FGOICP_OK;
     const double t1 = g_tt.on ? now_s() : 0;
-    // descriptors + locality sort on the slot's side stream (overlaps the other slot's bounds kernel); the main stream joins behind it
-    HIPCHK(hipMemcpyAsync(sl.d_groups, sl.h_groups, sizeof(TickGroup) * ng, hipMemcpyHostToDevice, sl.sort_stream));
-    HIPCHK(hipMemcpyAsync(sl.d_subs, sl.h_subs, sizeof(TickSub) * rows, hipMemcpyHostToDevice, sl.sort_stream));
-    launch_tick_sort(c->geom, c->d_chunk_cen, c->nchunk1, sl.d_groups, sl.d_subs, rows, c->cell_shift, sl.d_keys, sl.d_hist, sl.d_block_sums, sl.d_cursor, sl.d_sorted,
-                     sl.sort_stream);
-    HIPCHK(hipEventRecord(sl.sorted_ev, sl.sort_stream));
-    HIPCHK(hipStreamWaitEvent(sl.stream, sl.sorted_ev, 0));
+    // A small tick (the tail of a round: a few long-running tasks left, or one of many ranks) is pure latency: its bounds
+    // kernel reads the descriptors straight from the pinned staging buffers and takes the items in submission order —
+    // two copies and four sort launches fewer on the critical path.  Results do not depend on the item order.
+    const bool small = (size_t)rows * c->nchunk1 <= (size_t)c->small_tick_items;
+    const TickGroup* dev_groups = small ? sl.hd_groups : sl.d_groups;
+    const TickSub* dev_subs = small ? sl.hd_subs : sl.d_subs;
+    if (!small) {
+        // descriptors + locality sort on the slot's side stream (overlaps the other slot's bounds kernel); the main stream joins behind it
+        HIPCHK(hipMemcpyAsync(sl.d_groups, sl.h_groups, sizeof(TickGroup) * ng, hipMemcpyHostToDevice, sl.sort_stream));
+        HIPCHK(hipMemcpyAsync(sl.d_subs, sl.h_subs, sizeof(TickSub) * rows, hipMemcpyHostToDevice, sl.sort_stream));
+        launch_tick_sort(c->geom, c->d_chunk_cen, c->nchunk1, sl.d_groups, sl.d_subs, rows, c->cell_shift, sl.d_keys, sl.d_hist, sl.d_block_sums, sl.d_cursor, sl.d_sorted,
+                         sl.sort_stream);
+        HIPCHK(hipEventRecord(sl.sorted_ev, sl.sort_stream));
+        HIPCHK(hipStreamWaitEvent(sl.stream, sl.sorted_ev, 0));
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profile) {
         if (c->ev_used == (int)c->ev_start.size()) {  // drain both slots before recycling events
@@ -110,7 +118,7 @@ static int tick_enqueue_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl, int G, c
         c->prof_launches++;
         c->prof_subcubes += rows;
     }
-    launch_bounds_sorted(c->d_src, (int)c->ns, c->d_lut, c->d_lut_zp, c->lut_layout, c->geom, c->nchunk1, c->chunk_pts, sl.d_groups, sl.d_subs, rows, sl.d_sorted, sl.d_partials,
+    launch_bounds_sorted(c->d_src, (int)c->ns, c->d_lut, c->d_lut_zp, c->lut_layout, c->geom, c->nchunk1, c->chunk_pts, dev_groups, dev_subs, rows, small ? nullptr : sl.d_sorted, sl.d_partials,
                          c->inliers ? sl.d_vals : nullptr, e0, e1, sl.stream);
     // the per-subcube sums run on the slot's side stream, so the main stream holds nothing but bounds kernels back to back
     hipStream_t fin = c->finalize_on_side ? sl.sort_stream : sl.stream;
@@ -574,6 +582,7 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
         c->max_groups = std::max(512, c->max_subcubes / 8);
         if (const char* e = std::getenv("FGOICP_FINALIZE_SIDE")) c->finalize_on_side = std::atoi(e) != 0;  // tuning knob
         if (const char* e = std::getenv("FGOICP_ICP_SEED")) c->icp_seeding = std::atoi(e) != 0;             // tuning knob
+        if (const char* e = std::getenv("FGOICP_SMALL_TICK")) c->small_tick_items = std::max(0, std::atoi(e));  // tuning knob: items
         int maxd = std::max(g.dx, std::max(g.dy, g.dz));
         c->cell_shift = 0;
         while ((maxd >> c->cell_shift) > 32) ++c->cell_shift;  // 5 bits per axis
@@ -604,8 +613,10 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
             CHK(hipEventCreateWithFlags(&sl.bounds_ev, hipEventDisableTiming));
             CHK(hipMalloc(&sl.d_groups, sizeof(TickGroup) * c->max_groups));
             CHK(hipMalloc(&sl.d_subs, sizeof(TickSub) * c->max_subcubes));
-            CHK(hipHostMalloc((void**)&sl.h_groups, sizeof(TickGroup) * c->max_groups, hipHostMallocDefault));
-            CHK(hipHostMalloc((void**)&sl.h_subs, sizeof(TickSub) * c->max_subcubes, hipHostMallocDefault));
+            CHK(hipHostMalloc((void**)&sl.h_groups, sizeof(TickGroup) * c->max_groups, hipHostMallocMapped));
+            CHK(hipHostMalloc((void**)&sl.h_subs, sizeof(TickSub) * c->max_subcubes, hipHostMallocMapped));
+            CHK(hipHostGetDevicePointer((void**)&sl.hd_groups, sl.h_groups, 0));
+            CHK(hipHostGetDevicePointer((void**)&sl.hd_subs, sl.h_subs, 0));
             CHK(hipMalloc(&sl.d_keys, sizeof(unsigned short) * max_items));
             CHK(hipMalloc(&sl.d_hist, sizeof(unsigned) * kTickNumKeys));
             CHK(hipMemset(sl.d_hist, 0, sizeof(unsigned) * kTickNumKeys));  // the scan kernel re-zeroes it after every tick

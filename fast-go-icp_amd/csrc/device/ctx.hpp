@@ -45,8 +45,8 @@ struct fgoicp_ctx {
         hipStream_t sort_stream = nullptr;       // descriptors upload + locality sort of THIS slot run here, next to the other
         hipEvent_t bounds_ev = nullptr;          // bounds kernel of this slot finished (the finalize on the side stream waits for it)
         hipEvent_t sorted_ev = nullptr;          //   slot's bounds kernel on the main stream, which then waits for sorted_ev
-        fgoicp::TickGroup *d_groups = nullptr, *h_groups = nullptr;   // device / pinned staging
-        fgoicp::TickSub *d_subs = nullptr, *h_subs = nullptr;
+        fgoicp::TickGroup *d_groups = nullptr, *h_groups = nullptr, *hd_groups = nullptr;   // device / pinned staging / its device alias
+        fgoicp::TickSub *d_subs = nullptr, *h_subs = nullptr, *hd_subs = nullptr;
         unsigned short* d_keys = nullptr;
         unsigned *d_hist = nullptr, *d_block_sums = nullptr, *d_cursor = nullptr, *d_sorted = nullptr;
         double2* d_partials = nullptr;           // [max_subcubes][nchunk1]
@@ -60,6 +60,7 @@ struct fgoicp_ctx {
     int nchunk1 = 0, max_groups = 0, cell_shift = 4;
     int chunk_pts = 256;                     // points per (subcube, chunk) work item of the sorted path
     bool finalize_on_side = true;
+    int small_tick_items = 4096;             // ticks of at most this many items skip the descriptor copies and the locality sort
     bool icp_seeding = true;                 // ICP passes seed their exact NN search with the previous pass's correspondences
     float4* d_chunk_cen = nullptr;           // centroid of every chunk (source frame)
     TickSlot slots[2];

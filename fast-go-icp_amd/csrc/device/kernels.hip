@@ -397,7 +397,8 @@ __global__ __launch_bounds__(THREADS) void bounds_sorted_kernel(const float4* __
                                                                 double2* __restrict__ partials, float2* __restrict__ vals) {
     static_assert(THREADS % 64 == 0 && THREADS * P <= kBlock, "one pass covers THREADS * P points");
     __shared__ double red[2 * (THREADS / 64)];
-    const unsigned item = sorted[xcd_remap(blockIdx.x, gridDim.x)];
+    const unsigned slot = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned item = sorted ? sorted[slot] : slot;  // small ticks come unsorted
     const int s = (int)(item / (unsigned)nchunk);
     const int chunk = (int)(item - (unsigned)s * (unsigned)nchunk);
     const TickSub sb = subs[s];

@@ -278,6 +278,27 @@ def test_work_item_sizes_agree_with_the_oracle(fg, oracle, tiny_case, gpu_requir
     reg.close()
 
 
+def test_small_tick_path_equals_sorted_path(fg, oracle, tiny_case, gpu_required, monkeypatch):
+    """Small ticks skip the descriptor copies and the locality sort (descriptors read from pinned host memory, items in
+    submission order); big ticks are sorted.  Same partial sums either way: bit-identical bounds, and both match the oracle."""
+    c = tiny_case
+    rng = np.random.default_rng(33)
+    rn = fg.RotNode(-0.125, 0.25, 0.125, 0.25)
+    tn = _tnodes(rng, 64, 0.125)
+    out = {}
+    for items in ("0", "1000000"):  # never small / always small
+        monkeypatch.setenv("FGOICP_SMALL_TICK", items)
+        reg = fg.Registration(c["pct"], c["pcs"], c["bounds"], c["res"])
+        out[items] = [reg.compute_sse_error(rn, tn, fix) for fix in (True, False)]
+        reg.close()
+    orc = oracle.Registration(c["pct"], c["pcs"], c["bounds"], c["res"])
+    for k, fix in enumerate((True, False)):
+        (lb0, ub0), (lb1, ub1) = out["0"][k], out["1000000"][k]
+        assert np.array_equal(lb0, lb1) and np.array_equal(ub0, ub1)
+        lbo, ubo = orc.compute_bounds(rn.q.R, rn.span, tn, fix)
+        assert rel(ub0, ubo) <= REL
+
+
 # ---- size-independent properties at the benchmark's full size (the CPU oracle cannot reach it) ----
 @pytest.fixture(scope="module")
 def bunny_full(fg, gpu_required):
