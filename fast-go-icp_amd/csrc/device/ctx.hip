@@ -260,59 +260,68 @@ int ctx_bounds_multi(fgoicp_ctx* c, int G, const float* R9, const float* rot_spa
     return FGOICP_OK;
 }
 
-// float Registration::compute_sse_error(glm::mat3, glm::vec3) — registration.cu:62-86
-int ctx_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out, const uint32_t* seed_idx) {
-    HIPCHK(hipSetDevice(c->device));
+// float Registration::compute_sse_error(glm::mat3, glm::vec3) — registration.cu:62-86.  Enqueue only: the result lands in
+// pinned memory (sse_result) once `st` has drained.
+static int sse_enqueue(fgoicp_ctx* c, const float* R9, const float* t3, const uint32_t* seed_idx, hipStream_t st) {
     const int ns = (int)c->ns;
     if (c->brute_force_nn) {
-        launch_fill_u32(c->d_min_bits, 0x501502F9u /* bits(1e10f) */, c->ns, c->stream);
-        launch_nn_min(c->d_src, ns, c->d_tgt, (int)c->nt, R9, t3, 1, c->d_min_bits, c->stream);
+        launch_fill_u32(c->d_min_bits, 0x501502F9u /* bits(1e10f) */, c->ns, st);
+        launch_nn_min(c->d_src, ns, c->d_tgt, (int)c->nt, R9, t3, 1, c->d_min_bits, st);
     } else {
-        launch_nn_scan(c->d_src, ns, c->bvh_tgt.view(), c->d_lut, c->geom, R9, t3, 1, 0, c->d_tgt, (int)c->nt, seed_idx, c->d_min_bits, c->stream);
+        launch_nn_scan(c->d_src, ns, c->bvh_tgt.view(), c->d_lut, c->geom, R9, t3, 1, 0, c->d_tgt, (int)c->nt, seed_idx, c->d_min_bits, st);
     }
     if (c->inliers) {  // trimmed SSE: the k smallest nearest-neighbour terms
-        launch_trim_select(reinterpret_cast<const float*>(c->d_min_bits), 0, 1, ns, (int)c->inliers, 1, c->hd_trim, nullptr, nullptr, c->d_sel_wide, c->stream);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(c->stream));
-        *sse_out = c->h_trim[0];
-        return FGOICP_OK;
+        launch_trim_select(reinterpret_cast<const float*>(c->d_min_bits), 0, 1, ns, (int)c->inliers, 1, c->hd_trim, nullptr, nullptr, c->d_sel_wide, st);
+    } else {
+        const int nb = reduce_blocks_for(ns);
+        launch_sum_f32_as_f64(c->d_min_bits, ns, c->d_bp3, nb, st);
+        launch_sum_partials(c->d_bp3, nb, 1, c->hd_sums + 12, st);
     }
-    const int nb = reduce_blocks_for(ns);
-    launch_sum_f32_as_f64(c->d_min_bits, ns, c->d_bp, nb, c->stream);
-    launch_sum_partials(c->d_bp, nb, 1, c->hd_sums, c->stream);
     HIPCHK(hipGetLastError());
+    return FGOICP_OK;
+}
+static float sse_result(const fgoicp_ctx* c) { return c->inliers ? c->h_trim[0] : (float)c->h_sums[12]; }
+
+int ctx_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out, const uint32_t* seed_idx) {
+    HIPCHK(hipSetDevice(c->device));
+    int rc = sse_enqueue(c, R9, t3, seed_idx, c->stream);
+    if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
-    *sse_out = (float)c->h_sums[0];
+    *sse_out = sse_result(c);
     return FGOICP_OK;
 }
 
-// IterativeClosestPoint3D::procrustes() on c->d_work — icp3d.cu:140-172
-int ctx_procrustes_device(fgoicp_ctx* c, Mat3f* R_out, Vec3f* t_out, float* centroids6_out, Mat3f* ABt_out, bool seeded) {
+// IterativeClosestPoint3D::procrustes() on c->d_work — icp3d.cu:140-172.  The device half (enqueue only): correspondences
+// into `idx`, centroids and covariance into pinned memory; `wide` is the selection scratch of the trimmed variant.
+static int procrustes_enqueue(fgoicp_ctx* c, const uint32_t* seed_idx, uint32_t* idx, uint32_t* wide, hipStream_t st) {
     const int ns = (int)c->ns, nt = (int)c->nt;
     // kernFindNearestNeighbor (icp3d.cu:11-28): min distance, tie set, lowest index
     if (c->brute_force_nn) {
-        launch_fill_u32(c->d_min_bits, 0x501502F9u, c->ns, c->stream);
-        launch_fill_u32(c->d_first_idx, 0x7fffffffu, c->ns, c->stream);
-        launch_nn_min(c->d_work, ns, c->d_tgt, nt, nullptr, nullptr, 0, c->d_min_bits, c->stream);
-        launch_nn_tie_threshold(c->d_min_bits, ns, c->d_thr_bits, c->stream);
-        launch_nn_first_index(c->d_work, ns, c->d_tgt, nt, c->d_thr_bits, c->d_first_idx, c->stream);
+        launch_fill_u32(c->d_min_bits, 0x501502F9u, c->ns, st);
+        launch_fill_u32(idx, 0x7fffffffu, c->ns, st);
+        launch_nn_min(c->d_work, ns, c->d_tgt, nt, nullptr, nullptr, 0, c->d_min_bits, st);
+        launch_nn_tie_threshold(c->d_min_bits, ns, c->d_thr_bits, st);
+        launch_nn_first_index(c->d_work, ns, c->d_tgt, nt, c->d_thr_bits, idx, st);
     } else {
-        launch_nn_scan(c->d_work, ns, c->bvh_tgt.view(), c->d_lut, c->geom, nullptr, nullptr, 0, 1, c->d_tgt, nt, seeded ? c->d_first_idx : nullptr, c->d_first_idx, c->stream);
+        launch_nn_scan(c->d_work, ns, c->bvh_tgt.view(), c->d_lut, c->geom, nullptr, nullptr, 0, 1, c->d_tgt, nt, seed_idx, idx, st);
     }
     const int nb = reduce_blocks_for(ns);
     const unsigned char* use = nullptr;
     int ncount = ns;
     if (c->inliers) {  // trimmed ICP: only the k closest correspondences enter the Procrustes sums
-        launch_icp_inliers(c->d_work, c->d_tgt, c->d_first_idx, ns, nt, (int)c->inliers, c->d_d2, c->d_sel, c->d_eq, c->d_slot_of_orig, c->d_use, c->d_sel_wide, c->stream);
+        launch_icp_inliers(c->d_work, c->d_tgt, idx, ns, nt, (int)c->inliers, c->d_d2, c->d_sel, c->d_eq, c->d_slot_of_orig, c->d_use, wide, st);
         use = c->d_use;
         ncount = (int)c->inliers;
     }
-    launch_icp_sums(c->d_work, c->d_tgt, c->d_first_idx, ns, nt, use, c->d_bp, nb, c->stream);
-    launch_icp_centroids(c->d_bp, nb, ncount, c->d_cen, c->hd_cen, c->stream);  // icp3d.cu:152-156, no host round trip
-    launch_icp_cov(c->d_work, c->d_tgt, c->d_first_idx, ns, nt, c->d_cen, use, c->d_bp2, nb, c->stream);
-    launch_sum_partials(c->d_bp2, nb, 9, c->hd_sums, c->stream);
+    launch_icp_sums(c->d_work, c->d_tgt, idx, ns, nt, use, c->d_bp, nb, st);
+    launch_icp_centroids(c->d_bp, nb, ncount, c->d_cen, c->hd_cen, st);  // icp3d.cu:152-156, no host round trip
+    launch_icp_cov(c->d_work, c->d_tgt, idx, ns, nt, c->d_cen, use, c->d_bp2, nb, st);
+    launch_sum_partials(c->d_bp2, nb, 9, c->hd_sums, st);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(c->stream));
+    return FGOICP_OK;
+}
+// ... and the host half, once the stream has drained: 3x3 SVD, icp3d.cu:168-169
+static void procrustes_finish(const fgoicp_ctx* c, Mat3f* R_out, Vec3f* t_out, float* centroids6_out, Mat3f* ABt_out) {
     float cen[6];
     std::memcpy(cen, c->h_cen, sizeof(cen));
     Mat3f ABt;
@@ -323,16 +332,33 @@ int ctx_procrustes_device(fgoicp_ctx* c, Mat3f* R_out, Vec3f* t_out, float* cent
     *t_out = cc - Rn * sc;  // icp3d.cu:169
     if (centroids6_out) std::memcpy(centroids6_out, cen, sizeof(cen));
     if (ABt_out) *ABt_out = ABt;
+}
+
+int ctx_procrustes_device(fgoicp_ctx* c, Mat3f* R_out, Vec3f* t_out, float* centroids6_out, Mat3f* ABt_out, bool seeded) {
+    int rc = procrustes_enqueue(c, seeded ? c->d_first_idx : nullptr, c->d_first_idx, c->d_sel_wide, c->stream);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    procrustes_finish(c, R_out, t_out, centroids6_out, ABt_out);
     return FGOICP_OK;
 }
 
-// IterativeClosestPoint3D ctor + run() — icp3d.cu:55-108
+// IterativeClosestPoint3D ctor + run() — icp3d.cu:55-108.
+// Two streams: the exact SSE of iteration k (pristine source under the composed transform, main stream) and the
+// correspondence + covariance pass of iteration k+1 (working cloud, side stream) depend on nothing but the transform of
+// iteration k, so they run next to each other — both are latency chains that fill half the device at 40k points.  The pass of
+// iteration k+1 is speculative (the loop may end on the SSE of iteration k); it is drained before returning.  Same kernels,
+// same arithmetic, same order of every sum as the one-stream loop (FGOICP_ICP_OVERLAP=0).
 int ctx_icp(fgoicp_ctx* c, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3,
             int* iters_out) {
     HIPCHK(hipSetDevice(c->device));
     const int ns = (int)c->ns;
-    HIPCHK(hipMemcpyAsync(c->d_work, c->d_src, sizeof(float4) * c->ns, hipMemcpyDeviceToDevice, c->stream));
-    launch_transform_inplace(c->d_work, ns, R0, t0, c->stream);  // icp3d.cu:85
+    const bool overlap = c->icp_overlap && !c->brute_force_nn;
+    const bool seeding = c->icp_seeding && !c->brute_force_nn;
+    hipStream_t A = c->stream, B = overlap ? c->icp_stream : c->stream;
+    uint32_t* idx[2] = {c->d_first_idx, overlap ? c->d_first_idx2 : c->d_first_idx};
+    int cur = 0;
+    HIPCHK(hipMemcpyAsync(c->d_work, c->d_src, sizeof(float4) * c->ns, hipMemcpyDeviceToDevice, A));
+    launch_transform_inplace(c->d_work, ns, R0, t0, A);  // icp3d.cu:85
     Mat3f R = Mat3f::from(R0);
     Vec3f t{t0[0], t0[1], t0[2]};
     size_t iter = 0;
@@ -340,28 +366,60 @@ int ctx_icp(fgoicp_ctx* c, const float* R0, const float* t0, size_t max_iter, fl
     Mat3f last_R = Mat3f::identity();
     Vec3f last_t{0, 0, 0};
     int iters = 0;
+    bool chain_pending = false;  // a correspondence pass is in flight on B
+    if (overlap && max_iter > 0) {
+        HIPCHK(hipEventRecord(c->icp_ev_w, A));
+        HIPCHK(hipStreamWaitEvent(B, c->icp_ev_w, 0));
+        int rc = procrustes_enqueue(c, nullptr, idx[0], c->d_sel_wide2, B);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(c->icp_ev_b, B));
+        chain_pending = true;
+    }
     while (iter++ < max_iter && (last_sse - sse) > thr * last_sse) {  // icp3d.cu:94
         last_sse = sse;
         last_R = R;
         last_t = t;
         Mat3f Rn;
         Vec3f tn;
-        // every pass after the first seeds its exact search with the correspondences of the pass before it (d_first_idx)
-        int rc = ctx_procrustes_device(c, &Rn, &tn, nullptr, nullptr, iters > 0 && c->icp_seeding);
-        if (rc) return rc;
+        if (overlap) {
+            HIPCHK(hipEventSynchronize(c->icp_ev_b));
+            chain_pending = false;
+            procrustes_finish(c, &Rn, &tn, nullptr, nullptr);
+        } else {
+            // every pass after the first seeds its exact search with the correspondences of the pass before it
+            int rc = ctx_procrustes_device(c, &Rn, &tn, nullptr, nullptr, iters > 0 && seeding);
+            if (rc) return rc;
+        }
         const float tn3[3] = {tn.x, tn.y, tn.z};
-        launch_transform_inplace(c->d_work, ns, Rn.m, tn3, c->stream);  // :100
-        R = Rn * R;                                                      // :101
-        t = Rn * t + tn;                                                 // :102
+        launch_transform_inplace(c->d_work, ns, Rn.m, tn3, A);  // :100
+        R = Rn * R;                                              // :101
+        t = Rn * t + tn;                                         // :102
         const float t3[3] = {t.x, t.y, t.z};
-        rc = ctx_sse(c, R.m, t3, &sse, c->icp_seeding && !c->brute_force_nn ? c->d_first_idx : nullptr);  // :103
-        if (rc) return rc;
+        if (overlap) {
+            HIPCHK(hipEventRecord(c->icp_ev_w, A));
+            int rc = sse_enqueue(c, R.m, t3, seeding ? idx[cur] : nullptr, A);  // :103
+            if (rc) return rc;
+            if (iter < max_iter) {  // the next iteration's pass, next to this iteration's SSE
+                HIPCHK(hipStreamWaitEvent(B, c->icp_ev_w, 0));
+                rc = procrustes_enqueue(c, seeding ? idx[cur] : nullptr, idx[cur ^ 1], c->d_sel_wide2, B);
+                if (rc) return rc;
+                HIPCHK(hipEventRecord(c->icp_ev_b, B));
+                chain_pending = true;
+                cur ^= 1;
+            }
+            HIPCHK(hipStreamSynchronize(A));
+            sse = sse_result(c);
+        } else {
+            int rc = ctx_sse(c, R.m, t3, &sse, seeding ? c->d_first_idx : nullptr);  // :103
+            if (rc) return rc;
+        }
         ++iters;
     }
-    const bool cur = sse < last_sse;  // :106-107
-    *sse_out = cur ? sse : last_sse;
-    const Mat3f& Ro = cur ? R : last_R;
-    const Vec3f& to = cur ? t : last_t;
+    if (chain_pending) HIPCHK(hipEventSynchronize(c->icp_ev_b));  // the speculative pass: drained, not used
+    const bool cur_best = sse < last_sse;  // :106-107
+    *sse_out = cur_best ? sse : last_sse;
+    const Mat3f& Ro = cur_best ? R : last_R;
+    const Vec3f& to = cur_best ? t : last_t;
     std::memcpy(R_out9, Ro.m, sizeof(Ro.m));
     t_out3[0] = to.x; t_out3[1] = to.y; t_out3[2] = to.z;
     if (iters_out) *iters_out = iters;
@@ -389,7 +447,7 @@ int ctx_set_inliers(fgoicp_ctx* c, size_t k) {
         HIPCHK(hipMalloc(&c->d_eq, sizeof(uint32_t)));
         {
             const char* e = std::getenv("FGOICP_SELECT_WIDE");  // tuning knob: 0 = always the one-block-per-row selection
-            if (!(e && std::atoi(e) == 0)) HIPCHK(hipMalloc(&c->d_sel_wide, 65536));
+            if (!(e && std::atoi(e) == 0)) { HIPCHK(hipMalloc(&c->d_sel_wide, 65536)); HIPCHK(hipMalloc(&c->d_sel_wide2, 65536)); }
         }
         HIPCHK(hipMalloc(&c->d_use, c->ns));
         HIPCHK(hipMalloc(&c->d_slot_of_orig, sizeof(uint32_t) * c->ns));
@@ -639,6 +697,12 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
     CHK(hipMalloc(&c->d_first_idx, sizeof(uint32_t) * ns));
     CHK(hipMalloc(&c->d_bp, sizeof(double) * 1024 * 16));
     CHK(hipMalloc(&c->d_bp2, sizeof(double) * 1024 * 16));
+    CHK(hipMalloc(&c->d_bp3, sizeof(double) * 1024 * 16));
+    CHK(hipMalloc(&c->d_first_idx2, sizeof(uint32_t) * ns));
+    CHK(hipStreamCreateWithFlags(&c->icp_stream, hipStreamNonBlocking));
+    CHK(hipEventCreateWithFlags(&c->icp_ev_w, hipEventDisableTiming));
+    CHK(hipEventCreateWithFlags(&c->icp_ev_b, hipEventDisableTiming));
+    if (const char* e = std::getenv("FGOICP_ICP_OVERLAP")) c->icp_overlap = std::atoi(e) != 0;  // tuning knob
     CHK(hipMalloc(&c->d_cen, sizeof(float) * 8));
     CHK(hipHostMalloc((void**)&c->h_cen, sizeof(float) * 8, hipHostMallocMapped));
     CHK(hipHostGetDevicePointer((void**)&c->hd_cen, c->h_cen, 0));
@@ -667,11 +731,14 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
     for (auto& e : c->ev_stop) if (e) (void)hipEventDestroy(e);
     (void)hipFree(c->d_src); (void)hipFree(c->d_work); (void)hipFree(c->d_tgt); (void)hipFree(c->d_lut); (void)hipFree(c->d_lut_zp);
     (void)hipFree(c->d_partials); (void)hipFree(c->d_min_bits); (void)hipFree(c->d_thr_bits); (void)hipFree(c->d_first_idx);
-    (void)hipFree(c->d_bp); (void)hipFree(c->d_bp2); (void)hipFree(c->d_cen);
+    (void)hipFree(c->d_bp); (void)hipFree(c->d_bp2); (void)hipFree(c->d_bp3); (void)hipFree(c->d_cen); (void)hipFree(c->d_first_idx2);
+    if (c->icp_stream) { (void)hipStreamSynchronize(c->icp_stream); (void)hipStreamDestroy(c->icp_stream); }
+    if (c->icp_ev_w) (void)hipEventDestroy(c->icp_ev_w);
+    if (c->icp_ev_b) (void)hipEventDestroy(c->icp_ev_b);
     if (c->h_cen) (void)hipHostFree(c->h_cen);
     bvh_free(&c->bvh_tgt);
     (void)hipFree(c->d_chunk_cen);
-    (void)hipFree(c->d_d2); (void)hipFree(c->d_sel); (void)hipFree(c->d_eq); (void)hipFree(c->d_use); (void)hipFree(c->d_slot_of_orig); (void)hipFree(c->d_sel_wide);
+    (void)hipFree(c->d_d2); (void)hipFree(c->d_sel); (void)hipFree(c->d_eq); (void)hipFree(c->d_use); (void)hipFree(c->d_slot_of_orig); (void)hipFree(c->d_sel_wide); (void)hipFree(c->d_sel_wide2);
     if (c->h_trim) (void)hipHostFree(c->h_trim);
     for (int k = 0; k < 2; ++k) {
         fgoicp_ctx::TickSlot& sl = c->slots[k];

@@ -69,15 +69,19 @@ struct fgoicp_ctx {
     size_t inliers = 0;
     int vals_rows = 0;                       // subcubes per window in trimmed mode (memory budget)
     float* d_d2 = nullptr;                   // squared correspondence distances
-    uint32_t *d_sel = nullptr, *d_eq = nullptr, *d_slot_of_orig = nullptr, *d_sel_wide = nullptr;
+    uint32_t *d_sel = nullptr, *d_eq = nullptr, *d_slot_of_orig = nullptr, *d_sel_wide = nullptr, *d_sel_wide2 = nullptr;
     unsigned char* d_use = nullptr;          // inlier mask of the current Procrustes step
     float *h_trim = nullptr, *hd_trim = nullptr;   // pinned trimmed SSE
 
     // exact-NN / ICP scratch
-    uint32_t *d_min_bits = nullptr, *d_thr_bits = nullptr, *d_first_idx = nullptr;
+    uint32_t *d_min_bits = nullptr, *d_thr_bits = nullptr, *d_first_idx = nullptr, *d_first_idx2 = nullptr;
     double* d_bp = nullptr;      // per-block partial sums
     double *h_sums = nullptr, *hd_sums = nullptr;  // pinned result of the last reduction (<= 16 doubles)
     double* d_bp2 = nullptr;     // second partial buffer (covariance), so both reductions of a Procrustes step queue back to back
+    double* d_bp3 = nullptr;     // third one: the exact SSE runs next to the Procrustes pass of the following ICP iteration
+    hipStream_t icp_stream = nullptr;        // side stream of the ICP loop (correspondence + covariance pass)
+    hipEvent_t icp_ev_w = nullptr, icp_ev_b = nullptr;  // working cloud transformed / side-stream pass finished
+    bool icp_overlap = true;
     float* d_cen = nullptr;      // centroids {src, corr} on the device
     float *h_cen = nullptr, *hd_cen = nullptr;  // ... and their pinned host copy
 
