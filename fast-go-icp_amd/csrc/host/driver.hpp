@@ -25,7 +25,9 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
+#include <array>
 #include <functional>
+#include <map>
 #include <thread>
 #include <cstdint>
 #include <cstdio>
@@ -344,66 +346,120 @@ private:
 
     // -------------------------------------------------------------------------------------------
     // SERIAL: fgoicp.cpp:32-100 verbatim in behaviour — same pops, same pushes, same counters — but not
-    // verbatim in execution.  The children of a popped node couple only through `best_sse`, and that
-    // changes only when an ICP improves it (a handful of times per run).  So the UB and LB inner BnBs
-    // of all remaining children are evaluated SPECULATIVELY in lock-step with the current `best_sse`
-    // (one operator submission per tick instead of one per 32 subcubes), then committed in the
-    // reference's order; the moment an ICP improves `best_sse`, everything after that point is
-    // discarded and re-evaluated.  Committed work is exactly the reference's; discarded work is not
-    // counted.  FGOICP_SERIAL_SPECULATE=0 restores the literal one-task-at-a-time execution.
+    // verbatim in execution.  A node's evaluation (the UB and LB inner BnBs of its children) depends on
+    // the search state only through `best_sse`, and that changes only when an ICP improves it (a handful
+    // of times per run).  So the children of the node being popped AND of the nodes that top the queue
+    // behind it are evaluated SPECULATIVELY in lock-step with the current `best_sse` (one operator
+    // submission per tick for thousands of tasks instead of one per 32 subcubes), kept in a cache, and
+    // committed when — and in the order in which — the reference pops them.  The moment an ICP improves
+    // `best_sse` every cached result that has not been committed is discarded and re-evaluated.
+    // Committed work is exactly the reference's; discarded work is not counted.  The speculation width
+    // adapts like ROUND's: one node while the incumbent improves, doubling (up to 256) while it stands.
+    // FGOICP_SERIAL_SPECULATE=1 speculates inside the popped node only, =0 executes literally.
     // -------------------------------------------------------------------------------------------
+    struct SpecNode {
+        std::vector<RotCube> kids;   // the children in the reference's j order
+        std::vector<int> kind;       // 0 = push unevaluated (centre outside the ball), 1 = evaluate
+        std::vector<Task> tk;        // per evaluated child: its UB task [2k] and LB task [2k+1]
+        std::vector<char> valid;     // computed with the best_sse of `epoch`
+        uint64_t epoch = 0;
+    };
+    using SpecKey = std::array<uint32_t, 4>;
+    static SpecKey spec_key(const RotCube& n) {
+        SpecKey k;
+        std::memcpy(&k[0], &n.q.x, 4); std::memcpy(&k[1], &n.q.y, 4); std::memcpy(&k[2], &n.q.z, 4); std::memcpy(&k[3], &n.span, 4);
+        return k;
+    }
+    static void spec_make_kids(const RotCube& rnode, SpecNode& sp) {
+        sp = SpecNode();
+        const float span = rnode.span / 2.0f;
+        for (char j = 0; j < 8; ++j) {
+            if (span < 0.05f) continue;  // :53
+            RotCube child(rnode.q.x - span + (j >> 0 & 1) * rnode.span, rnode.q.y - span + (j >> 1 & 1) * rnode.span,
+                          rnode.q.z - span + (j >> 2 & 1) * rnode.span, span, rnode.lb, rnode.ub);
+            if (!child.overlaps_SO3()) continue;
+            sp.kids.push_back(child);
+            sp.kind.push_back(child.q.in_SO3() ? 1 : 0);
+        }
+        sp.tk.assign(2 * sp.kids.size(), Task());
+        sp.valid.assign(2 * sp.kids.size(), 0);
+    }
+
     int bnb_so3_serial() {
-        static const bool speculate = [] { const char* e = std::getenv("FGOICP_SERIAL_SPECULATE"); return !e || std::atoi(e) != 0; }();
+        static const int mode = [] { const char* e = std::getenv("FGOICP_SERIAL_SPECULATE"); return e ? std::atoi(e) : 2; }();
         std::priority_queue<RotCube> rcand;
         rcand.push(RotCube(0.f, 0.f, 0.f, 1.0f, 0.f, best_sse()));
+        std::map<SpecKey, SpecNode> cache;
+        uint64_t epoch = 1, epoch_of_last_speculation = 0;
+        int width = 1;
+        // (re)evaluates, in ONE task list, every evaluable task >= first_task[i] of batch[i] that is not valid
+        auto evaluate = [&](const std::vector<SpecNode*>& batch, const std::vector<size_t>& first_task) -> int {
+            std::vector<Task*> tasks;
+            std::vector<const RotCube*> cubes;
+            const float snap = best_sse();
+            for (size_t b = 0; b < batch.size() && (mode != 0 || tasks.empty()); ++b) {
+                SpecNode& sp = *batch[b];
+                for (size_t t = first_task[b]; t < sp.tk.size(); ++t) {
+                    if (sp.kind[t / 2] != 1 || sp.valid[t]) continue;
+                    sp.tk[t] = Task();
+                    sp.tk[t].start((t & 1) == 0, snap, sp.kids[t / 2].ub);
+                    tasks.push_back(&sp.tk[t]);
+                    cubes.push_back(&sp.kids[t / 2]);
+                    sp.valid[t] = 1;
+                    if (mode == 0) break;  // literal execution: one task at a time
+                }
+            }
+            if (tasks.empty()) return kDriverOk;
+            account_submissions_ = false;
+            const int rc = run_task_list(tasks, cubes);
+            account_submissions_ = true;
+            return rc;
+        };
+        auto commit = [&](const Task& t) { stats_.inner_bnb++; stats_.trans_cubes += t.count; stats_.bounds_calls += t.batches; };
         while (!rcand.empty()) {
             const RotCube rnode = rcand.top();
             rcand.pop();
             stats_.rounds++;
             if (best_sse() - rnode.lb <= sse_threshold_) break;  // :44
-            const float span = rnode.span / 2.0f;
-            // the children in the reference's j order: kind 0 = push unevaluated (centre outside the ball), 1 = evaluate
-            std::vector<RotCube> kids;
-            std::vector<int> kind;
-            for (char j = 0; j < 8; ++j) {
-                if (span < 0.05f) continue;  // :53
-                RotCube child(rnode.q.x - span + (j >> 0 & 1) * rnode.span, rnode.q.y - span + (j >> 1 & 1) * rnode.span,
-                              rnode.q.z - span + (j >> 2 & 1) * rnode.span, span, rnode.lb, rnode.ub);
-                if (!child.overlaps_SO3()) continue;
-                kids.push_back(child);
-                kind.push_back(child.q.in_SO3() ? 1 : 0);
-            }
-            // per evaluated child: its UB task [2k] and LB task [2k+1]; valid[] = computed with the CURRENT best_sse
-            std::vector<Task> tk(2 * kids.size());
-            std::vector<char> valid(2 * kids.size(), 0);
-            auto speculate_from = [&](size_t first_task) -> int {  // (re)evaluate every task >= first_task that is not valid
-                std::vector<Task*> tasks;
-                std::vector<const RotCube*> cubes;
-                const float snap = best_sse();
-                for (size_t t = first_task; t < tk.size(); ++t) {
-                    if (kind[t / 2] != 1 || valid[t]) continue;
-                    tk[t] = Task();
-                    tk[t].start((t & 1) == 0, snap, kids[t / 2].ub);
-                    tasks.push_back(&tk[t]);
-                    cubes.push_back(&kids[t / 2]);
-                    valid[t] = 1;
-                    if (!speculate) break;  // literal execution: one task at a time
+            const SpecKey key = spec_key(rnode);
+            {
+                auto it = cache.find(key);
+                if (it == cache.end() || it->second.epoch != epoch) {  // not evaluated yet, or evaluated against a stale best_sse
+                    if (mode >= 2) width = epoch_of_last_speculation == epoch ? std::min(width * 2, 256) : 1;
+                    epoch_of_last_speculation = epoch;
+                    std::vector<SpecNode*> batch;
+                    SpecNode& mine = cache[key];
+                    spec_make_kids(rnode, mine);
+                    mine.epoch = epoch;
+                    batch.push_back(&mine);
+                    if (mode >= 2 && width > 1) {  // the nodes the reference pops next if nothing changes: the tops of the queue
+                        std::priority_queue<RotCube> peek = rcand;
+                        while ((int)batch.size() < width && !peek.empty()) {
+                            const RotCube n = peek.top();
+                            peek.pop();
+                            if (best_sse() - n.lb <= sse_threshold_) break;
+                            const SpecKey kn = spec_key(n);
+                            auto jt = cache.find(kn);
+                            if (jt != cache.end() && jt->second.epoch == epoch) continue;
+                            SpecNode& sp = cache[kn];
+                            spec_make_kids(n, sp);
+                            sp.epoch = epoch;
+                            batch.push_back(&sp);
+                        }
+                    }
+                    const int rc = evaluate(batch, std::vector<size_t>(batch.size(), 0));
+                    if (rc) return rc;
                 }
-                if (tasks.empty()) return kDriverOk;
-                account_submissions_ = false;
-                const int rc = run_task_list(tasks, cubes);
-                account_submissions_ = true;
-                return rc;
-            };
-            auto commit = [&](const Task& t) { stats_.inner_bnb++; stats_.trans_cubes += t.count; stats_.bounds_calls += t.batches; };
-            for (size_t k = 0; k < kids.size(); ++k) {
-                RotCube& child = kids[k];
-                if (kind[k] == 0) { rcand.push(child); continue; }  // :62-66
+            }
+            SpecNode& sp = cache[key];
+            for (size_t k = 0; k < sp.kids.size(); ++k) {
+                RotCube& child = sp.kids[k];
+                if (sp.kind[k] == 0) { rcand.push(child); continue; }  // :62-66
                 stats_.rot_cubes++;
-                if (!valid[2 * k]) { int rc = speculate_from(2 * k); if (rc) return rc; }
-                commit(tk[2 * k]);
-                const float ub = tk[2 * k].best_ub;  // :69
-                const Vec3f bt = tk[2 * k].best_t;
+                if (!sp.valid[2 * k]) { int rc = evaluate({&sp}, {2 * k}); if (rc) return rc; }
+                commit(sp.tk[2 * k]);
+                const float ub = sp.tk[2 * k].best_ub;  // :69
+                const Vec3f bt = sp.tk[2 * k].best_t;
                 set_last(child.q.R, bt);  // :71-72
                 if (ub < best_sse() * 1.8) {  // :74, double compare
                     float sse; Mat3f R; Vec3f t;
@@ -411,17 +467,22 @@ private:
                     if (rc) return rc;
                     if (sse < best_sse()) {
                         { std::lock_guard<std::mutex> g(mu_); best_sse_ = sse; best_R_ = R; best_t_ = t; }
-                        for (size_t t2 = 2 * k + 1; t2 < valid.size(); ++t2) valid[t2] = 0;  // everything later saw a stale best_sse
+                        ++epoch;  // every uncommitted result saw a stale best_sse: this node's later tasks ...
+                        sp.epoch = epoch;
+                        for (size_t t2 = 2 * k + 1; t2 < sp.valid.size(); ++t2) sp.valid[t2] = 0;
+                        for (auto it = cache.begin(); it != cache.end();)  // ... and every other cached node
+                            it = it->second.epoch != epoch ? cache.erase(it) : std::next(it);
                     }
                 }
-                if (!valid[2 * k + 1]) { int rc = speculate_from(2 * k + 1); if (rc) return rc; }
-                commit(tk[2 * k + 1]);
-                const float lb = tk[2 * k + 1].best_ub;  // :90 — the LB pass' best_ub is the cube's lower bound
+                if (!sp.valid[2 * k + 1]) { int rc = evaluate({&sp}, {2 * k + 1}); if (rc) return rc; }
+                commit(sp.tk[2 * k + 1]);
+                const float lb = sp.tk[2 * k + 1].best_ub;  // :90 — the LB pass' best_ub is the cube's lower bound
                 if (lb >= best_sse()) continue;            // :92
                 child.lb = lb;
                 child.ub = ub;
                 rcand.push(child);
             }
+            cache.erase(key);
         }
         return kDriverOk;
     }
