@@ -387,6 +387,7 @@ private:
 
     int bnb_so3_serial() {
         static const int mode = [] { const char* e = std::getenv("FGOICP_SERIAL_SPECULATE"); return e ? std::atoi(e) : 2; }();
+        static const int spec_cap = [] { const char* e = std::getenv("FGOICP_SERIAL_WIDTH"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();  // tuning knob
         std::priority_queue<RotCube> rcand;
         rcand.push(RotCube(0.f, 0.f, 0.f, 1.0f, 0.f, best_sse()));
         std::map<SpecKey, SpecNode> cache;
@@ -425,7 +426,7 @@ private:
             {
                 auto it = cache.find(key);
                 if (it == cache.end() || it->second.epoch != epoch) {  // not evaluated yet, or evaluated against a stale best_sse
-                    if (mode >= 2) width = epoch_of_last_speculation == epoch ? std::min(width * 2, 256) : 1;
+                    if (mode >= 2) width = epoch_of_last_speculation == epoch ? std::min(width * 2, spec_cap) : 1;
                     epoch_of_last_speculation = epoch;
                     std::vector<SpecNode*> batch;
                     SpecNode& mine = cache[key];

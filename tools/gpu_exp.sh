@@ -1,9 +1,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 600 python -m pytest tests -m gpu -x -q > gpurun_out/t27.log 2>&1; echo "exit $?" >> gpurun_out/t27.log
-tail -4 gpurun_out/t27.log
-grep -q "exit 0" gpurun_out/t27.log || exit 1
-for M in 2 1; do
-(FGOICP_SERIAL_SPECULATE=$M FGOICP_TIMING=1 timeout -k 10 300 python bench.py --schedule serial --no-cpu-baseline --no-default-threshold-run --no-dragon --no-trimmed --steps 2 --warmup 1 2>&1 | grep "timing\] run\|value" | cut -c1-330 | tail -2) >> gpurun_out/serial2.log 2>&1
+for W in 64 256 1024 4096; do
+echo "width $W" >> gpurun_out/serial3.log
+(FGOICP_SERIAL_WIDTH=$W timeout -k 10 300 python bench.py --schedule serial --no-cpu-baseline --no-default-threshold-run --no-dragon --no-trimmed --steps 2 --warmup 1 2>&1 | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"subcubes_per_step": [0-9.]*' | tr '\n' ' ') >> gpurun_out/serial3.log 2>&1; echo >> gpurun_out/serial3.log
 done
-cat gpurun_out/serial2.log
+cat gpurun_out/serial3.log
