@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--no-dragon", action="store_true", help="skip the secondary dragon-shape (437k points) measurement")
     ap.add_argument("--no-trimmed", action="store_true", help="skip the secondary 1M-point trimmed Go-ICP measurement (20 %% outliers)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 rehearsal on a one-GPU box: every rank uses device 0 and the exchange runs on gloo (timings are meaningless)")
     return ap.parse_args()
 
 
@@ -105,11 +107,18 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (fgoicp_amd has no CPU path)")
+    if a.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
+    red_dev = "cuda"  # where the few scalars of the final reduction live
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+            red_dev = "cpu"
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # synthetic pair: rotation far outside the ICP basin, so the search has real work to do
     tgt, src, R_gt, t_gt = fg.synth.workload(a.workload, angle_deg=150.0, min_angle_deg=110.0)
@@ -148,7 +157,7 @@ def main():
     prof = reg.profile(reset=True)
     reg.set_profile(False)
 
-    tot = torch.tensor([float(sub), elapsed, prof["kernel_ms"], float(prof["launches"]), float(prof["subcubes"])], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(sub), elapsed, prof["kernel_ms"], float(prof["launches"]), float(prof["subcubes"])], dtype=torch.float64, device=red_dev)
     if dist is not None:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -172,7 +181,7 @@ def main():
             sub2 += s2.stats()["trans_cubes"]
         barrier()
         e2 = time.perf_counter() - t1
-        tt = torch.tensor([float(sub2), e2], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([float(sub2), e2], dtype=torch.float64, device=red_dev)
         if dist is not None:
             m2 = tt.clone()
             dist.all_reduce(m2, op=dist.ReduceOp.MAX)
@@ -202,7 +211,7 @@ def main():
         e3 = time.perf_counter() - t1
         p3 = reg3.profile(reset=True)
         st3 = s3.stats()
-        tt = torch.tensor([float(st3["trans_cubes"]), e3], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([float(st3["trans_cubes"]), e3], dtype=torch.float64, device=red_dev)
         if dist is not None:
             m3 = tt.clone()
             dist.all_reduce(m3, op=dist.ReduceOp.MAX)
@@ -231,7 +240,7 @@ def main():
         barrier()
         e4 = time.perf_counter() - t1
         st4 = s4.stats()
-        tt = torch.tensor([float(st4["trans_cubes"]), e4], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([float(st4["trans_cubes"]), e4], dtype=torch.float64, device=red_dev)
         if dist is not None:
             m4 = tt.clone()
             dist.all_reduce(m4, op=dist.ReduceOp.MAX)

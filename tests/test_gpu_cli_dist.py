@@ -112,3 +112,26 @@ def test_two_ranks_shard_the_search_on_the_gpu(fg, gpu_required, tmp_path):
     # the work is sharded, not replicated
     assert int(a["rot_cubes"]) > 0 and int(b["rot_cubes"]) > 0
     assert abs(int(a["rot_cubes"]) + int(b["rot_cubes"]) - int(st1["rot_cubes"])) <= 0.25 * int(st1["rot_cubes"]) + 16
+
+
+def test_bench_two_rank_path_rehearsal(gpu_required):
+    """bench.py's N > 1 branch (torch.distributed.run, sharded search, max-over-ranks timing, whole-job aggregate), rehearsed
+    with both ranks on this box's one GPU and the exchange on gloo: the JSON contract holds and the sharded run evaluates
+    exactly the subcubes the single-rank certify run evaluates."""
+    import json
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--rehearse-on-one-gpu", "--no-dragon", "--no-trimmed"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "strong" and d["unit"] == "subcubes/s" and d["vs_baseline"] is None
+    assert d["value"] == pytest.approx(d["subcubes_per_step"] / (d["ms_per_step"] * 1e-3), rel=1e-6)
+    assert d["result"]["rotation_error_deg_vs_ground_truth"] < 0.5 and d["reference_default_threshold"]["same_optimum_as_headline"]
+    assert 0 < d["rot_cubes_rank0"] < 2236 and "cpu_baseline" not in d  # sharded; the CPU leg is an N = 1 thing
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
