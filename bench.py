@@ -158,6 +158,7 @@ def main():
     reg.set_profile(False)
 
     tot = torch.tensor([float(sub), elapsed, prof["kernel_ms"], float(prof["launches"]), float(prof["subcubes"])], dtype=torch.float64, device=red_dev)
+    profiled_all = bool(prof["subcubes"] == sub)  # every counted subcube went through the profiled kernel
     if dist is not None:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -282,6 +283,10 @@ def main():
                          "frac": ach / HBM_PEAK_GBS, "traffic": None,
                          "avg_launch_us": kms * 1e3 / launches if launches else None, "launches": int(launches),
                          "subcubes_per_launch": ksub / launches if launches else None,
+                         "evaluations_per_launch": prof["evaluations"] / launches if launches else None,
+                         "every_counted_subcube_profiled": profiled_all,
+                         "note": "achieved = algorithmic bytes of the SUBCUBES a launch serves (SURVEY 8d) / its duration; a translation node held by both the "
+                                 "UB and the LB task of a rotation cube in the same tick is two subcubes and one evaluation (one lookup per point, both variants)",
                          "algorithmic_bytes_per_subcube": ns * 32.0 + ns * 12.0 * launches / max(ksub, 1)},
         }
         pmc = os.path.join(REPO, "profiles", "bench_pmc.json")  # written from separate rocprofv3 --pmc passes of this same command

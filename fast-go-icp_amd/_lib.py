@@ -50,12 +50,14 @@ _SIGS = {
     "fgoicp_bounds_multi": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_int_p, c_int_p, c_float_p, c_float_p,
                                       c_float_p]),
     "fgoicp_bounds_submit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_float_p, c_float_p, c_int_p, c_int_p, c_float_p]),
+    "fgoicp_bounds_submit_twins": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_float_p, c_float_p, c_int_p, c_int_p, c_float_p, c_int_p]),
     "fgoicp_bounds_collect": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p]),
     "fgoicp_sse": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_float_p]),
     "fgoicp_icp": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_size_t, C.c_float, c_float_p, c_float_p, c_float_p, c_int_p]),
     "fgoicp_procrustes": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_int_p]),
     "fgoicp_ctx_set_inliers": (C.c_int, [C.c_void_p, C.c_size_t]),
     "fgoicp_ctx_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
+    "fgoicp_ctx_profile_evaluations": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "fgoicp_ctx_set_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "fgoicp_ctx_ns": (C.c_size_t, [C.c_void_p]),
     "fgoicp_ctx_nt": (C.c_size_t, [C.c_void_p]),

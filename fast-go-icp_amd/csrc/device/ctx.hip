@@ -61,46 +61,73 @@ inline double now_s() { return std::chrono::duration<double>(std::chrono::steady
 // Enqueues the window [pos, pos+rows) of a submission on its slot: descriptors -> device, sort the
 // (subcube, chunk) items by LUT cell, one bounds launch, one finalize.  Returns the window end.
 static int tick_enqueue_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl, int G, const float* R9, const float* rot_span, const int* fix_rot,
-                               const int* offsets, const float* tn4, int pos, int* end_out) {
+                               const int* offsets, const float* tn4, const int* twin, int pos, int* end_out) {
     const double t0 = g_tt.on ? now_s() : 0;
     int g = 0;
     while (g < G && offsets[g + 1] <= pos) ++g;
     const int cap = c->inliers ? std::min(c->max_subcubes, c->vals_rows) : c->max_subcubes;  // subcubes per window
     int end = pos, ng = 0;
+    sl.row_group.resize((size_t)cap);
     for (int gg = g; gg < G && ng < c->max_groups && end - pos < cap; ++gg) {
         TickGroup& tg = sl.h_groups[ng];
         std::memcpy(tg.R, R9 + 9 * gg, sizeof(tg.R));
         const float half_angle = rot_span[gg] * kSqrt3 * kPi / 2.0f;  // registration.cu:42
         tg.sin_half = std::sin(half_angle);
         tg.fix_rot = fix_rot[gg] ? 1 : 0;
-        tg.pad_ = 0;
+        tg.pad_ = gg;  // the submission's group index (twin validation below)
         const int first = std::max(offsets[gg], pos);
         const int last = std::min(offsets[gg + 1], pos + cap);
-        for (int i = first; i < last; ++i) {
-            TickSub& ts = sl.h_subs[i - pos];
-            ts.tx = tn4[4 * (size_t)i]; ts.ty = tn4[4 * (size_t)i + 1]; ts.tz = tn4[4 * (size_t)i + 2]; ts.span = tn4[4 * (size_t)i + 3];
-            ts.group = ng;
-            ts.pad_[0] = ts.pad_[1] = ts.pad_[2] = 0;
-        }
+        for (int i = first; i < last; ++i) sl.row_group[(size_t)(i - pos)] = ng;
         end = std::max(end, last);
         ++ng;
         if (last < offsets[gg + 1]) break;  // window full in the middle of a group
     }
-    const int rows = end - pos;
+    const int rows = end - pos;  // output rows of this window
     *end_out = end;
     if (rows <= 0) return FGOICP_OK;
+    // evaluations: one per output row, or one per twin pair (both inside this window, same rotation, same translation node,
+    // one in a fix_rot group and one not — checked here, the caller's hint is not trusted)
+    int neval = 0;
+    for (int r = 0; r < rows; ++r) {
+        const int i = pos + r;
+        const int gi = sl.row_group[(size_t)r];
+        int j = twin ? twin[i] : -1;
+        if (j >= pos && j < end && j != i && twin[j] == i) {
+            const int gj = sl.row_group[(size_t)(j - pos)];
+            const TickGroup &a = sl.h_groups[gi], &b = sl.h_groups[gj];
+            const bool ok = a.fix_rot != b.fix_rot && a.sin_half == b.sin_half && std::memcmp(a.R, b.R, sizeof(a.R)) == 0 &&
+                            std::memcmp(tn4 + 4 * (size_t)i, tn4 + 4 * (size_t)j, 4 * sizeof(float)) == 0;
+            if (ok) {
+                if (j < i) continue;  // evaluated with its twin
+                TickSub& ts = sl.h_subs[neval++];
+                ts.tx = tn4[4 * (size_t)i]; ts.ty = tn4[4 * (size_t)i + 1]; ts.tz = tn4[4 * (size_t)i + 2]; ts.span = tn4[4 * (size_t)i + 3];
+                ts.group = gi;
+                ts.out0 = a.fix_rot ? r : j - pos;  // the fix_rot = 1 variant belongs to the fix_rot group's row
+                ts.out1 = a.fix_rot ? j - pos : r;
+                ts.dual = 1;
+                continue;
+            }
+        }
+        TickSub& ts = sl.h_subs[neval++];
+        ts.tx = tn4[4 * (size_t)i]; ts.ty = tn4[4 * (size_t)i + 1]; ts.tz = tn4[4 * (size_t)i + 2]; ts.span = tn4[4 * (size_t)i + 3];
+        ts.group = gi;
+        ts.out0 = r;
+        ts.out1 = r;
+        ts.dual = 0;
+    }
+    for (int k = 0; k < ng; ++k) sl.h_groups[k].pad_ = 0;
     const double t1 = g_tt.on ? now_s() : 0;
     // A small tick (the tail of a round: a few long-running tasks left, or one of many ranks) is pure latency: its bounds
     // kernel reads the descriptors straight from the pinned staging buffers and takes the items in submission order —
     // two copies and four sort launches fewer on the critical path.  Results do not depend on the item order.
-    const bool small = (size_t)rows * c->nchunk1 <= (size_t)c->small_tick_items;
+    const bool small = (size_t)neval * c->nchunk1 <= (size_t)c->small_tick_items;
     const TickGroup* dev_groups = small ? sl.hd_groups : sl.d_groups;
     const TickSub* dev_subs = small ? sl.hd_subs : sl.d_subs;
     if (!small) {
         // descriptors + locality sort on the slot's side stream (overlaps the other slot's bounds kernel); the main stream joins behind it
         HIPCHK(hipMemcpyAsync(sl.d_groups, sl.h_groups, sizeof(TickGroup) * ng, hipMemcpyHostToDevice, sl.sort_stream));
-        HIPCHK(hipMemcpyAsync(sl.d_subs, sl.h_subs, sizeof(TickSub) * rows, hipMemcpyHostToDevice, sl.sort_stream));
-        launch_tick_sort(c->geom, c->d_chunk_cen, c->nchunk1, sl.d_groups, sl.d_subs, rows, c->cell_shift, sl.d_keys, sl.d_hist, sl.d_block_sums, sl.d_cursor, sl.d_sorted,
+        HIPCHK(hipMemcpyAsync(sl.d_subs, sl.h_subs, sizeof(TickSub) * neval, hipMemcpyHostToDevice, sl.sort_stream));
+        launch_tick_sort(c->geom, c->d_chunk_cen, c->nchunk1, sl.d_groups, sl.d_subs, neval, c->cell_shift, sl.d_keys, sl.d_hist, sl.d_block_sums, sl.d_cursor, sl.d_sorted,
                          sl.sort_stream);
         HIPCHK(hipEventRecord(sl.sorted_ev, sl.sort_stream));
         HIPCHK(hipStreamWaitEvent(sl.stream, sl.sorted_ev, 0));
@@ -117,8 +144,9 @@ static int tick_enqueue_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl, int G, c
         c->ev_used++;
         c->prof_launches++;
         c->prof_subcubes += rows;
+        c->prof_evals += neval;  // a twin pair is two subcubes and one evaluation
     }
-    launch_bounds_sorted(c->d_src, (int)c->ns, c->d_lut, c->d_lut_zp, c->lut_layout, c->geom, c->nchunk1, c->chunk_pts, dev_groups, dev_subs, rows, small ? nullptr : sl.d_sorted, sl.d_partials,
+    launch_bounds_sorted(c->d_src, (int)c->ns, c->d_lut, c->d_lut_zp, c->lut_layout, c->geom, c->nchunk1, c->chunk_pts, dev_groups, dev_subs, neval, small ? nullptr : sl.d_sorted, sl.d_partials,
                          c->inliers ? sl.d_vals : nullptr, e0, e1, sl.stream);
     // the per-subcube sums run on the slot's side stream, so the main stream holds nothing but bounds kernels back to back
     hipStream_t fin = c->finalize_on_side ? sl.sort_stream : sl.stream;
@@ -150,7 +178,7 @@ static int tick_wait_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
 
 // fgoicp_bounds_submit: all windows but the last are completed here, the last one stays in flight.
 int ctx_bounds_submit(fgoicp_ctx* c, int slot, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets,
-                      const float* tn4) {
+                      const float* tn4, const int* twin) {
     HIPCHK(hipSetDevice(c->device));
     fgoicp_ctx::TickSlot& sl = c->slots[slot];
     if (sl.inflight) { set_error("fgoicp_bounds_submit: slot still in flight (collect it first)"); return FGOICP_ERR_INVALID_ARG; }
@@ -161,7 +189,7 @@ int ctx_bounds_submit(fgoicp_ctx* c, int slot, int G, const float* R9, const flo
     int pos = 0;
     while (pos < sl.total) {
         int end = pos;
-        int rc = tick_enqueue_window(c, sl, G, R9, rot_span, fix_rot, offsets, tn4, pos, &end);
+        int rc = tick_enqueue_window(c, sl, G, R9, rot_span, fix_rot, offsets, tn4, twin, pos, &end);
         if (rc) return rc;
         if (end <= pos) break;
         pos = end;
@@ -195,7 +223,7 @@ int ctx_bounds_collect(fgoicp_ctx* c, int slot, float* lb_out, float* ub_out) {
 
 static int ctx_bounds_multi_sorted(fgoicp_ctx* c, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets,
                                    const float* tn4, float* lb_out, float* ub_out) {
-    int rc = ctx_bounds_submit(c, 0, G, R9, rot_span, fix_rot, offsets, tn4);
+    int rc = ctx_bounds_submit(c, 0, G, R9, rot_span, fix_rot, offsets, tn4, nullptr);
     if (rc) return rc;
     return ctx_bounds_collect(c, 0, lb_out, ub_out);
 }
@@ -243,6 +271,7 @@ int ctx_bounds_multi(fgoicp_ctx* c, int G, const float* R9, const float* rot_spa
                 c->ev_used++;
                 c->prof_launches++;
                 c->prof_subcubes += pc.B;
+                c->prof_evals += pc.B;
             }
             rows += pc.B;
             ++pi;
@@ -808,15 +837,20 @@ int fgoicp_bounds_multi(fgoicp_ctx* c, int G, const float* R9, const float* rot_
     return ctx_bounds_multi(c, G, R9, rot_span, fix_rot, offsets, tn4, lb_out, ub_out);
 }
 
-int fgoicp_bounds_submit(fgoicp_ctx* c, int slot, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets,
-                         const float* tn4) {
+int fgoicp_bounds_submit_twins(fgoicp_ctx* c, int slot, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets,
+                               const float* tn4, const int* twin) {
     if (!c || slot < 0 || slot > 1 || G < 0 || (G > 0 && (!R9 || !rot_span || !fix_rot || !offsets || !tn4))) return FGOICP_ERR_INVALID_ARG;
     if (!c->sorted_bounds) { set_error("fgoicp_bounds_submit needs the sorted bounds path (FGOICP_BOUNDS_SORTED=0 is set)"); return FGOICP_ERR_INVALID_ARG; }
     static const int zero[1] = {0};
     if (G == 0) offsets = zero;
     for (int g = 0; g < G; ++g)
         if (offsets[g + 1] < offsets[g] || offsets[0] != 0) { set_error("fgoicp_bounds_submit: offsets must start at 0 and be non-decreasing"); return FGOICP_ERR_INVALID_ARG; }
-    return ctx_bounds_submit(c, slot, G, R9, rot_span, fix_rot, offsets, tn4);
+    return ctx_bounds_submit(c, slot, G, R9, rot_span, fix_rot, offsets, tn4, twin);
+}
+
+int fgoicp_bounds_submit(fgoicp_ctx* c, int slot, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets,
+                         const float* tn4) {
+    return fgoicp_bounds_submit_twins(c, slot, G, R9, rot_span, fix_rot, offsets, tn4, nullptr);
 }
 
 int fgoicp_bounds_collect(fgoicp_ctx* c, int slot, float* lb_out, float* ub_out) {
@@ -880,7 +914,13 @@ int fgoicp_ctx_profile(fgoicp_ctx* c, double* kernel_ms, uint64_t* launches, uin
     if (kernel_ms) *kernel_ms = c->prof_ms;
     if (launches) *launches = c->prof_launches;
     if (subcubes) *subcubes = c->prof_subcubes;
-    if (reset) { c->prof_ms = 0; c->prof_launches = 0; c->prof_subcubes = 0; }
+    if (reset) { c->prof_ms = 0; c->prof_launches = 0; c->prof_subcubes = 0; c->prof_evals = 0; }
+    return FGOICP_OK;
+}
+
+int fgoicp_ctx_profile_evaluations(fgoicp_ctx* c, uint64_t* evaluations) {
+    if (!c || !evaluations) return FGOICP_ERR_INVALID_ARG;
+    *evaluations = c->prof_evals;
     return FGOICP_OK;
 }
 

@@ -52,7 +52,8 @@ struct fgoicp_ctx {
         double2* d_partials = nullptr;           // [max_subcubes][nchunk1]
         float *h_lb = nullptr, *h_ub = nullptr, *hd_lb = nullptr, *hd_ub = nullptr;  // pinned results of the window in flight
         float2* d_vals = nullptr;                // trimmed mode: per-point {ub, lb} terms, [vals_rows][ns]
-        std::vector<float> lb, ub;               // results of the whole submission
+        std::vector<float> lb, ub;
+        std::vector<int> row_group;              // window-local group of every output row (packing scratch)               // results of the whole submission
         int total = 0, win_pos = 0, win_rows = 0;
         bool inflight = false;
     };
@@ -89,14 +90,15 @@ struct fgoicp_ctx {
     std::vector<hipEvent_t> ev_start, ev_stop;
     int ev_used = 0;
     double prof_ms = 0.0;
-    uint64_t prof_launches = 0, prof_subcubes = 0;
+    uint64_t prof_launches = 0, prof_subcubes = 0, prof_evals = 0;
 };
 
 namespace fgoicp {
 void set_error(const std::string& s);
 int ctx_bounds_multi(fgoicp_ctx* c, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets,
                      const float* tn4, float* lb_out, float* ub_out);
-int ctx_bounds_submit(fgoicp_ctx* c, int slot, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets, const float* tn4);
+int ctx_bounds_submit(fgoicp_ctx* c, int slot, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets, const float* tn4,
+                      const int* twin = nullptr);
 int ctx_bounds_collect(fgoicp_ctx* c, int slot, float* lb_out, float* ub_out);
 int ctx_set_inliers(fgoicp_ctx* c, size_t k);
 int ctx_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out, const uint32_t* seed_idx = nullptr);

@@ -396,7 +396,7 @@ __global__ __launch_bounds__(THREADS) void bounds_sorted_kernel(const float4* __
                                                                 const unsigned* __restrict__ sorted, int nchunk, int chunk_pts,
                                                                 double2* __restrict__ partials, float2* __restrict__ vals) {
     static_assert(THREADS % 64 == 0 && THREADS * P <= kBlock, "one pass covers THREADS * P points");
-    __shared__ double red[2 * (THREADS / 64)];
+    __shared__ double red[4 * (THREADS / 64)];
     const unsigned slot = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned item = sorted ? sorted[slot] : slot;  // small ticks come unsorted
     const int s = (int)(item / (unsigned)nchunk);
@@ -405,7 +405,8 @@ __global__ __launch_bounds__(THREADS) void bounds_sorted_kernel(const float4* __
     const TickGroup& gr = groups[sb.group];
     const float trans_uncertain_radius = kSqrt3 * sb.span;  // registration.cu:33
     const size_t sy = (size_t)g.px, sz = (size_t)g.px * g.py;
-    double acc[2] = {0.0, 0.0};
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};  // {ub, lb} of the item's variant; a dual item: {ub, lb} with fix_rot = 1, then with fix_rot = 0
+    const bool dual = sb.dual != 0;
     // an item is chunk_pts (256 .. 2048) Morton-consecutive points, walked in passes of THREADS * P: dense clouds take bigger
     // items (the patch of 256 points is only a few voxels wide there), which divides the items to sort and the partials
     for (int pass = 0; pass < chunk_pts; pass += THREADS * P) {
@@ -448,14 +449,35 @@ __global__ __launch_bounds__(THREADS) void bounds_sorted_kernel(const float4* __
         for (int k = 0; k < P; ++k) {
             const float dsq = lut_blend(ta[k], v00[k], v10[k], v01[k], v11[k]);  // :46
             float d = sqrtf(dsq);                                                 // :48
+            const int i = first + k * THREADS;
+            const bool valid = i < ns;
+            if (dual) {  // wave-uniform
+                const float ub1 = d > 0.0f ? d * d : 0.0f;                        // fix_rot = 1: :54
+                const float l1 = d - trans_uncertain_radius;                      // :57
+                const float lb1 = l1 > 0.0f ? l1 * l1 : 0.0f;                     // :58
+                d -= 2.0f * p[k].w * gr.sin_half;                                 // fix_rot = 0: :39-43, :49-52
+                const float ub0 = d > 0.0f ? d * d : 0.0f;
+                const float l0 = d - trans_uncertain_radius;
+                const float lb0 = l0 > 0.0f ? l0 * l0 : 0.0f;
+                if (TRIM) {
+                    if (valid) {
+                        vals[(size_t)sb.out0 * ns + i] = make_float2(ub1, lb1);
+                        vals[(size_t)sb.out1 * ns + i] = make_float2(ub0, lb0);
+                    }
+                } else {
+                    acc[0] += valid ? (double)ub1 : 0.0;
+                    acc[1] += valid ? (double)lb1 : 0.0;
+                    acc[2] += valid ? (double)ub0 : 0.0;
+                    acc[3] += valid ? (double)lb0 : 0.0;
+                }
+                continue;
+            }
             if (!gr.fix_rot) d -= 2.0f * p[k].w * gr.sin_half;                    // :39-43, :49-52
             const float ubv = d > 0.0f ? d * d : 0.0f;                            // :54
             const float l = d - trans_uncertain_radius;                           // :57
             const float lbv = l > 0.0f ? l * l : 0.0f;                            // :58
-            const int i = first + k * THREADS;
-            const bool valid = i < ns;
             if (TRIM) {  // trimmed Go-ICP: the per-point terms themselves (the selection runs in trim_select_kernel)
-                if (valid) vals[(size_t)s * ns + i] = make_float2(ubv, lbv);
+                if (valid) vals[(size_t)sb.out0 * ns + i] = make_float2(ubv, lbv);
             } else {
                 acc[0] += valid ? (double)ubv : 0.0;
                 acc[1] += valid ? (double)lbv : 0.0;
@@ -463,9 +485,19 @@ __global__ __launch_bounds__(THREADS) void bounds_sorted_kernel(const float4* __
         }
     }
     if (!TRIM) {
-        const double r = block_sum<2, THREADS / 64>(acc, red);
-        double* out = reinterpret_cast<double*>(partials + ((size_t)s * nchunk + chunk));
-        if (threadIdx.x < 2) out[threadIdx.x] = r;
+        // sums 0, 1 land in threads 0, 1 (dual: sums 2, 3 in threads 2, 3); same reduction tree per sum either way
+        if (dual) {
+            const double r = block_sum<4, THREADS / 64>(acc, red);
+            if (threadIdx.x < 4) {
+                double* out = reinterpret_cast<double*>(partials + ((size_t)(threadIdx.x < 2 ? sb.out0 : sb.out1) * nchunk + chunk));
+                out[threadIdx.x & 1] = r;
+            }
+        } else {
+            const double a2[2] = {acc[0], acc[1]};
+            const double r = block_sum<2, THREADS / 64>(a2, red);
+            double* out = reinterpret_cast<double*>(partials + ((size_t)sb.out0 * nchunk + chunk));
+            if (threadIdx.x < 2) out[threadIdx.x] = r;
+        }
     }
 }
 

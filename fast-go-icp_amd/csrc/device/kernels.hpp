@@ -52,10 +52,13 @@ struct TickGroup {   // one rotation node
     int fix_rot;
     int pad_;
 };
-struct TickSub {     // one translation node + its rotation node
+struct TickSub {     // one EVALUATION: a translation node + its rotation node, and where its sums go
     float tx, ty, tz, span;
     int group;
-    int pad_[3];
+    int out0;        // output row of the result (dual: of the fix_rot = 1 variant)
+    int out1;        // dual only: output row of the fix_rot = 0 variant
+    int dual;        // 1 = the UB task and the LB task of one rotation cube both hold this translation node in the same
+                     // submission: one lookup per point, both variants of the bound formulae (registration.cu:39-58)
 };
 constexpr int kTickNumKeys = 1 << 15;
 void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, const TickGroup* groups, const TickSub* subs, int nsub, int cell_shift,

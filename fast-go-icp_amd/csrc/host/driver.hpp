@@ -3,7 +3,7 @@
 // fgoicp/common.hpp:30-128), written against an abstract operator backend `Ops`:
 //
 //     int    Ops::bounds_multi(G, R9, rot_span, fix_rot, offsets, tnodes4, lb, ub)   (fgoicp_bounds_multi)
-//     int    Ops::bounds_submit(slot, G, ...tnodes4) / bounds_collect(slot, lb, ub)  (fgoicp_bounds_submit / _collect)
+//     int    Ops::bounds_submit(slot, G, ...tnodes4, twin) / bounds_collect(slot, lb, ub)  (fgoicp_bounds_submit_twins / _collect)
 //     bool   Ops::async()                                                            two slots available?
 //     int    Ops::icp(R0, t0, max_iter, thr, &sse, R9, t3, &iters)                   (fgoicp_icp)
 //
@@ -618,6 +618,7 @@ private:
         std::vector<int> live;         // members with a batch in this submission
         std::vector<float> R9, spans, tn4, lb, ub;
         std::vector<int> fix, offsets;
+        std::vector<int> twin;         // per subcube: the same translation node in the paired task's batch (or -1)
         bool inflight = false;
     };
 
@@ -651,6 +652,46 @@ private:
         }
         h.lb.resize(h.tn4.size() / 4);
         h.ub.resize(h.tn4.size() / 4);
+        // twins: the UB and the LB task of one child (tasks 2c, 2c+1, neighbours in `live`) walk the top of the same translation
+        // tree; a node both hold in this submission is evaluated once (fgoicp_bounds_submit_twins).  Matched through a small
+        // open-addressing table per pair (<= 32 nodes a side).
+        h.twin.assign(h.tn4.size() / 4, -1);
+        if (use_twins_) {
+            std::vector<size_t> pairs;
+            for (size_t a = 0; a + 1 < h.live.size(); ++a)
+                if ((h.live[a] ^ 1) == h.live[a + 1] && cubes[h.live[a]] == cubes[h.live[a + 1]]) pairs.push_back(a);
+            const std::function<void(size_t)> match_fn = [&](size_t q) {
+                const size_t a = pairs[q];
+                const int o0 = h.offsets[a], n0 = h.offsets[a + 1] - o0, o1 = h.offsets[a + 1], n1 = h.offsets[a + 2] - o1;
+                if (n0 > 64 || n1 > 64) return;  // batches hold <= 32 nodes (fgoicp.cpp:122); the table below assumes it
+                int table[128];
+                for (int& x : table) x = -1;
+                auto hash = [&](const float* t) {
+                    uint32_t b[4];
+                    std::memcpy(b, t, 16);
+                    uint32_t x = b[0] * 0x9E3779B1u ^ b[1] * 0x85EBCA77u ^ b[2] * 0xC2B2AE3Du ^ b[3] * 0x27D4EB2Fu;
+                    return (x ^ (x >> 15)) & 127u;
+                };
+                for (int i = 0; i < n0; ++i) {
+                    uint32_t s = hash(&h.tn4[4 * (size_t)(o0 + i)]);
+                    while (table[s] >= 0) s = (s + 1) & 127u;
+                    table[s] = o0 + i;
+                }
+                for (int j = 0; j < n1; ++j) {
+                    const float* t = &h.tn4[4 * (size_t)(o1 + j)];
+                    for (uint32_t s = hash(t); table[s] >= 0; s = (s + 1) & 127u) {
+                        const int i = table[s];
+                        if (h.twin[(size_t)i] < 0 && std::memcmp(&h.tn4[4 * (size_t)i], t, 16) == 0) {
+                            h.twin[(size_t)i] = o1 + j;
+                            h.twin[(size_t)(o1 + j)] = i;
+                            break;
+                        }
+                    }
+                }
+            };
+            if (par && pairs.size() >= 64) pool_->parallel_for(pairs.size(), match_fn);
+            else for (size_t q = 0; q < pairs.size(); ++q) match_fn(q);
+        }
         return !h.live.empty();
     }
     // Tasks finish at very different times (an UB task may need 5 batches, its neighbour 50): when the idle half `from`
@@ -659,13 +700,21 @@ private:
     static void rebalance(Half& from, Half& to) {
         if (from.members.size() < to.members.size() + 2 + to.members.size() / 4) return;
         const size_t move = (from.members.size() - to.members.size()) / 2;
-        // every other member from the back: keeps the UB/LB mix of both halves
+        // every other UNIT from the back; a unit is a (UB, LB) pair of one child (indices 2c, 2c+1) that is still together, or a
+        // single task: pairs stay in one half, where their common subcubes can be evaluated once
         std::vector<size_t> keep;
         keep.reserve(from.members.size());
-        size_t moved = 0;
+        size_t moved = 0, unit = 0;
         for (size_t k = from.members.size(); k-- > 0;) {
-            if (moved < move && ((from.members.size() - 1 - k) & 1) == 0) { to.members.push_back(from.members[k]); ++moved; }
-            else keep.push_back(from.members[k]);
+            const bool pair = k > 0 && (from.members[k] ^ 1) == from.members[k - 1];
+            const size_t n = pair ? 2 : 1;
+            const bool go = moved + n <= move && (unit & 1) == 0;  // never more than the surplus: a lone pair stays where it is
+            for (size_t q = 0; q < n; ++q) {
+                if (go) { to.members.push_back(from.members[k - (n - 1) + q]); ++moved; }
+                else keep.push_back(from.members[k - q]);
+            }
+            if (pair) --k;
+            ++unit;
         }
         std::reverse(keep.begin(), keep.end());
         from.members.swap(keep);
@@ -707,7 +756,7 @@ private:
                     const auto tc = clock::now();
                     rebalance(h[k], h[1 - k]);
                     if (!h[k].members.empty() && prepare_half(h[k], tasks, cubes, par)) {
-                        int rc = ops_.bounds_submit(k, (int)h[k].live.size(), h[k].R9.data(), h[k].spans.data(), h[k].fix.data(), h[k].offsets.data(), h[k].tn4.data());
+                        int rc = ops_.bounds_submit(k, (int)h[k].live.size(), h[k].R9.data(), h[k].spans.data(), h[k].fix.data(), h[k].offsets.data(), h[k].tn4.data(), h[k].twin.data());
                         if (rc) return rc;
                         h[k].inflight = true;
                     }
@@ -741,6 +790,7 @@ private:
 
     Ops& ops_;
     double t_pop_ = 0, t_ops_ = 0, t_push_ = 0;
+    bool use_twins_ = [] { const char* e = std::getenv("FGOICP_TWINS"); return !e || std::atoi(e) != 0; }();  // tuning knob
     bool account_submissions_ = true;   // false while SERIAL speculates: work is accounted per committed task instead
     std::unique_ptr<WorkerPool> pool_;
     float sse_threshold_;

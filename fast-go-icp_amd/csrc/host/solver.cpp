@@ -19,8 +19,9 @@ struct HipOps {
                      float* ub) {
         return ctx_bounds_multi(ctx, G, R9, rot_span, fix_rot, offsets, tn4, lb, ub);
     }
-    int bounds_submit(int slot, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets, const float* tn4) {
-        return ctx_bounds_submit(ctx, slot, G, R9, rot_span, fix_rot, offsets, tn4);
+    int bounds_submit(int slot, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets, const float* tn4,
+                      const int* twin) {
+        return ctx_bounds_submit(ctx, slot, G, R9, rot_span, fix_rot, offsets, tn4, twin);
     }
     int bounds_collect(int slot, float* lb, float* ub) { return ctx_bounds_collect(ctx, slot, lb, ub); }
     bool async() const { return ctx->sorted_bounds && pipeline; }

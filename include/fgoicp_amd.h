@@ -95,6 +95,16 @@ int fgoicp_bounds_multi(fgoicp_ctx* ctx, int G, const float* R9, const float* ro
  */
 int fgoicp_bounds_submit(fgoicp_ctx* ctx, int slot, int G, const float* R9, const float* rot_span, const int* fix_rot,
                          const int* offsets, const float* tnodes4);
+/*
+ * The same with a hint: twin[i] = j (and twin[j] = i) says that subcubes i and j of this submission are the SAME translation
+ * node under the SAME rotation, once in a fix_rot group and once in a non-fix_rot group — what the UB and the LB inner
+ * branch-and-bound of one rotation cube (fgoicp.cpp:69, :90) produce while they walk the top of the same translation tree.
+ * Such a pair is evaluated with one LUT lookup per point and both variants of the bound formulae (registration.cu:39-58);
+ * the four sums are bit-identical to two separate evaluations.  twin[i] = -1 (or twin = NULL): no twin.  The hint is
+ * validated (rotation, span, node and fix_rot are compared), a wrong hint only costs the saving.
+ */
+int fgoicp_bounds_submit_twins(fgoicp_ctx* ctx, int slot, int G, const float* R9, const float* rot_span, const int* fix_rot,
+                               const int* offsets, const float* tnodes4, const int* twin);
 int fgoicp_bounds_collect(fgoicp_ctx* ctx, int slot, float* lb_out, float* ub_out);
 
 /* Replaces float Registration::compute_sse_error(glm::mat3 R, glm::vec3 t)
@@ -122,6 +132,9 @@ int fgoicp_ctx_set_inliers(fgoicp_ctx* ctx, size_t k);
 /* Accumulated HIP-event timing of the bounds kernel since the last reset (FGOICP_FLAG_PROFILE):
  * kernel_ms = sum of launch durations, launches = kernel launches, subcubes = (rot, trans) pairs. */
 int fgoicp_ctx_profile(fgoicp_ctx* ctx, double* kernel_ms, uint64_t* launches, uint64_t* subcubes, int reset);
+/* Evaluations behind those subcubes since the last reset: a twin pair (fgoicp_bounds_submit_twins) is two subcubes and one
+ * evaluation.  Read it before the fgoicp_ctx_profile call that resets. */
+int fgoicp_ctx_profile_evaluations(fgoicp_ctx* ctx, uint64_t* evaluations);
 /* Turns the HIP-event bracketing on or off at run time (events are created on first use). */
 int fgoicp_ctx_set_profile(fgoicp_ctx* ctx, int enabled);
 size_t fgoicp_ctx_ns(const fgoicp_ctx* ctx);

@@ -33,7 +33,8 @@ struct OracleOps {
     std::vector<float> slot_lb[2], slot_ub[2];
     bool use_async = false;
     bool async() const { return use_async; }
-    int bounds_submit(int slot, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets, const float* tn4) {
+    int bounds_submit(int slot, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets, const float* tn4,
+                      const int* /*twin: a device-side saving, the oracle evaluates every subcube*/) {
         slot_lb[slot].assign(offsets[G], 0.f);
         slot_ub[slot].assign(offsets[G], 0.f);
         return bounds_multi(G, R9, rot_span, fix_rot, offsets, tn4, slot_lb[slot].data(), slot_ub[slot].data());

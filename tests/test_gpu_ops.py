@@ -328,6 +328,53 @@ def test_icp_two_stream_loop_is_bit_identical_to_the_one_stream_loop(fg, gpu_req
     assert np.array_equal(out["1"][3], out["0"][3]) and out["1"][4] == out["0"][4]
 
 
+def test_twin_subcubes_are_evaluated_once_with_identical_sums(fg, tiny_case, gpu_required):
+    """fgoicp_bounds_submit_twins: a translation node held by the fix_rot group AND the non-fix_rot group of one rotation
+    is evaluated with one lookup per point and both variants of the formulae — bit-identical to two evaluations; a wrong
+    hint (different node, same fix_rot, other rotation) is ignored."""
+    import ctypes as C
+    c = tiny_case
+    lib = fg._lib.load()
+    reg = fg.Registration(c["pct"], c["pcs"], c["bounds"], c["res"])
+    rng = np.random.default_rng(12)
+    rn = fg.RotNode(0.125, -0.25, 0.375, 0.25)
+    other = fg.RotNode(-0.375, 0.125, 0.25, 0.25)
+    ta, tb, tc = _tnodes(rng, 20, 0.25), _tnodes(rng, 24, 0.25), _tnodes(rng, 6, 0.5)
+    tb[3:15] = ta[5:17]  # 12 common nodes between group 0 (fix_rot) and group 1 (not)
+    R9 = np.concatenate([fg.nodes.to_glm(n.q.R) for n in (rn, rn, other)]).astype(np.float32)
+    spans = np.array([rn.span, rn.span, other.span], np.float32)
+    fix = np.array([1, 0, 0], np.int32)
+    offs = np.array([0, 20, 44, 50], np.int32)
+    tn4 = np.ascontiguousarray(np.concatenate([ta, tb, tc]), np.float32)
+    twin = np.full(50, -1, np.int32)
+    for k in range(12):
+        twin[5 + k] = 20 + 3 + k
+        twin[20 + 3 + k] = 5 + k
+    twin[0], twin[45] = 45, 0      # wrong: other rotation
+    twin[1], twin[2] = 2, 1        # wrong: same group / same fix_rot, different node
+    fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
+    def run(tw):
+        lb, ub = np.zeros(50, np.float32), np.zeros(50, np.float32)
+        fn = lib.fgoicp_bounds_submit_twins
+        rc = fn(reg._h, 0, 3, R9.ctypes.data_as(fp), spans.ctypes.data_as(fp), fix.ctypes.data_as(ip), offs.ctypes.data_as(ip), tn4.ctypes.data_as(fp),
+                tw.ctypes.data_as(ip) if tw is not None else None)
+        assert rc == 0
+        assert lib.fgoicp_bounds_collect(reg._h, 0, lb.ctypes.data_as(fp), ub.ctypes.data_as(fp)) == 0
+        return lb, ub
+    reg.set_profile(True)
+    reg.profile(reset=True)
+    lb0, ub0 = run(None)
+    p0 = reg.profile(reset=True)
+    lb1, ub1 = run(twin)
+    p1 = reg.profile(reset=True)
+    assert np.array_equal(lb0, lb1) and np.array_equal(ub0, ub1)
+    assert p0["subcubes"] == p1["subcubes"] == 50 and p0["evaluations"] == 50 and p1["evaluations"] == 38  # 12 pairs evaluated once
+    # and they are the bounds of the synchronous per-node operator
+    l, u = reg.compute_sse_error(rn, tb, False)
+    assert np.array_equal(l, lb1[20:44]) and np.array_equal(u, ub1[20:44])
+    reg.close()
+
+
 # ---- size-independent properties at the benchmark's full size (the CPU oracle cannot reach it) ----
 @pytest.fixture(scope="module")
 def bunny_full(fg, gpu_required):
