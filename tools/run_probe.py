@@ -1,4 +1,4 @@
-"""One run on a synthetic pair: python tools/dragon_probe.py <round_width> [mse] [workload] [trim_fraction] [angle_deg]"""
+"""One run on a synthetic pair: python tools/run_probe.py <round_width> [mse] [workload] [trim_fraction] [angle_deg]"""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
