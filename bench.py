@@ -132,6 +132,7 @@ def main():
     if world > 1:
         from fgoicp_amd.dist import TorchExchange
         ex = TorchExchange()
+        ex.warmup()  # communicator setup is not part of a registration run
         solver.set_exchange(ex)
 
     def barrier():
