@@ -541,8 +541,11 @@ private:
                 stats_.inner_bnb += 2;
                 stats_.rot_cubes++;
             }
+            const auto t_round = clock::now();
+            const uint64_t calls_before = stats_.bounds_calls, cubes_before = stats_.trans_cubes;
             int rc = run_task_list(tasks, cubes);
             if (rc) return rc;
+            const double s_tasks = seconds_since(t_round), icp_before = stats_.seconds_icp;
 
             // ICP triggers in child order against the running local best (fgoicp.cpp:74-88)
             float loc_sse; Mat3f loc_R; Vec3f loc_t;
@@ -599,6 +602,10 @@ private:
                 }
             }
             const float now = best_sse();
+            if (std::getenv("FGOICP_TIMING"))
+                std::fprintf(stderr, "[fgoicp timing] round %llu: popped %d, children %zu (mine %zu), submissions %llu, subcubes %llu, tasks %.3f ms, icp %.3f ms, round %.3f ms\n",
+                             (unsigned long long)stats_.rounds, popped, nchild, mine.size(), (unsigned long long)(stats_.bounds_calls - calls_before),
+                             (unsigned long long)(stats_.trans_cubes - cubes_before), s_tasks * 1e3, (stats_.seconds_icp - icp_before) * 1e3, seconds_since(t_round) * 1e3);
             if (adaptive) width = now < snapshot ? base_width : std::min(width * 2, 1 << 14);
             for (size_t i = 0; i < nchild; ++i) {
                 if (lbs[i] >= now) continue;  // :92
