@@ -1,8 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-rm -f gpurun_out/scale3.log
-for M in 0 64 128 256 512; do
-echo "== merge $M" >> gpurun_out/scale3.log
-(FGOICP_MERGE_TASKS=$M REPLAY_ONLY_RANK=0 FGOICP_TIMING=1 timeout -k 10 500 python tools/scale_replay.py 4 bunny 5e-5 0.005 2>&1 | grep "timing\] round\|estimated" | tail -7 | cut -c1-200 | sed 's/.*round \([0-9]*\):.*submissions \([0-9]*\),.*tasks \([0-9.]*\) ms.*round \([0-9.]*\) ms/r\1 sub \2 tasks \3 round \4/' ) >> gpurun_out/scale3.log 2>&1
-done
-cat gpurun_out/scale3.log | cut -c1-330
+rm -f gpurun_out/scale5.log
+timeout -k 10 600 python tools/scale_replay.py 5 bunny 5e-5 0.005 >> gpurun_out/scale5.log 2>&1 || exit 1
+timeout -k 10 900 python tools/scale_replay.py 4 dragon 5e-6 0.005 >> gpurun_out/scale5.log 2>&1 || exit 1
+cat gpurun_out/scale5.log | cut -c1-700
