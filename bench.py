@@ -88,7 +88,18 @@ def cpu_baseline(fg, reg, pct, pcs, bounds, res, seconds):
         if dt >= seconds:
             break
     cores = pyoracle.lib().orc_num_threads()
-    return {"value": done / dt, "unit": "subcubes/s", "cores": int(cores), "kind": "port",
+    # the same operator on ONE core (a quarter of the time budget)
+    pyoracle.lib().orc_set_num_threads(1)
+    done1, t1 = 0, time.perf_counter()
+    while True:
+        tn = np.concatenate([rng.uniform(-0.5, 0.5, (32, 3)), np.full((32, 1), 0.125)], axis=1).astype(np.float32)
+        orc.compute_bounds(rn.q.R, rn.span, tn, False)
+        done1 += 32
+        dt1 = time.perf_counter() - t1
+        if dt1 >= seconds / 4:
+            break
+    pyoracle.lib().orc_set_num_threads(int(cores))
+    return {"value": done / dt, "unit": "subcubes/s", "cores": int(cores), "kind": "port", "value_1_core": done1 / dt1,
             "sample": f"{done} subcubes (batches of 32, fix_rot=0, ns={len(pcs)}) of the same workload in {dt:.1f}s, OpenMP over points",
             "matches_gpu": check}
 
