@@ -90,8 +90,8 @@ void* harness_create_trim(const float* tgt, size_t nt, const float* src, size_t 
     orc::Bounds b{std::make_pair(h->bounds6[0], h->bounds6[1]), std::make_pair(h->bounds6[2], h->bounds6[3]), std::make_pair(h->bounds6[4], h->bounds6[5])};
     h->reg.reset(new orc::Registration(h->opct, h->opcs, b, lut_res));
     h->ops.reg = h->reg.get(); h->ops.pct = &h->opct; h->ops.pcs = &h->opcs;
-    h->ops.use_async = schedule >= 2;  // schedule 2 = ROUND with the two-slot pipelined task loop
-    if (schedule >= 2) schedule = 1;
+    h->ops.use_async = schedule >= 2;  // schedule 2 = ROUND, 3 = SERIAL, both with the two-slot pipelined task loop
+    schedule = schedule == 2 ? 1 : schedule == 3 ? 0 : schedule;
     size_t n_thr = ns;  // as solver.cpp: the threshold runs over the inliers when trimming
     if (trim_fraction > 0.0f) {
         size_t k = (size_t)((double)ns * (1.0 - (double)trim_fraction));

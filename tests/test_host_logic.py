@@ -102,3 +102,27 @@ def test_pipelined_and_synchronous_task_loops_are_equivalent():
         assert a["stats"][k] == b["stats"][k], k
     # two balanced halves: at most two submissions where the synchronous loop needs one
     assert a["stats"]["bounds_calls"] <= b["stats"]["bounds_calls"] <= 2 * a["stats"]["bounds_calls"]
+
+
+def test_serial_speculation_modes_walk_the_same_trajectory(tmp_path):
+    """FGOICP_SERIAL_SPECULATE = 0 (literal, one task at a time), 1 (inside the popped node), 2 (across the tops of the queue,
+    default): the same pops, counters and result — speculation only changes how many tasks share an operator submission."""
+    import json
+    import subprocess
+    import sys
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); from tests import host_harness as hh; "
+            "G = np.load(%r); pre = 'runbun_'; "
+            "r = hh.HostDriver(G[pre + 'tgt'], G[pre + 'src'], float(G[pre + 'res']), float(G[pre + 'mse']), schedule=int(sys.argv[1])).run(); "
+            "print(json.dumps({'stats': {k: int(v) for k, v in r['stats'].items() if k != 'bounds_calls' or True}, 'R': r['R'].tolist(), 't': r['t'].tolist(), 'sse': float(r['best_sse'])}))"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "goicp_golden.npz")))
+    out = {}
+    for mode in ("0", "1", "2"):
+        for sched in ("0", "3"):  # 3 = SERIAL over the asynchronous (two-slot) operator path of the harness
+            env = dict(os.environ, FGOICP_SERIAL_SPECULATE=mode)
+            p = subprocess.run([sys.executable, "-c", code, sched], env=env, capture_output=True, text=True, timeout=600)
+            assert p.returncode == 0, p.stderr[-2000:]
+            out[(mode, sched)] = json.loads(p.stdout.strip().splitlines()[-1])
+    ref = out[("0", "0")]
+    assert [ref["stats"][k] for k in KEYS] == list(G["runbun_stats"])
+    for key, o in out.items():
+        assert o["stats"] == ref["stats"] and o["R"] == ref["R"] and o["t"] == ref["t"] and o["sse"] == ref["sse"], key
