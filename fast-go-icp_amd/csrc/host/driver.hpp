@@ -317,7 +317,7 @@ public:
             best_t_ = t;
         }
         stats_.seconds_total = seconds_since(t_start);
-        if (std::getenv("FGOICP_TIMING"))
+        if (timing_)
             std::fprintf(stderr, "[fgoicp timing] run %.3f s: pop+pack %.3f s, operator %.3f s, push %.3f s, icp %.3f s, calls %llu\n", stats_.seconds_total, t_pop_, t_ops_,
                          t_push_, stats_.seconds_icp, (unsigned long long)stats_.bounds_calls);
         t_pop_ = t_ops_ = t_push_ = 0;
@@ -338,7 +338,7 @@ private:
         stats_.icp_runs++;
         stats_.icp_iters += (uint64_t)iters;
         stats_.seconds_icp += seconds_since(t_icp);
-        if (std::getenv("FGOICP_TIMING")) std::fprintf(stderr, "[fgoicp timing] icp thr %g: %d iterations, %.3f ms, sse %g\n", (double)thr, iters, seconds_since(t_icp) * 1e3, (double)sse);
+        if (timing_) std::fprintf(stderr, "[fgoicp timing] icp thr %g: %d iterations, %.3f ms, sse %g\n", (double)thr, iters, seconds_since(t_icp) * 1e3, (double)sse);
         return rc;
     }
     void set_best_sse_only(float sse) { std::lock_guard<std::mutex> g(mu_); best_sse_ = sse; }
@@ -602,7 +602,7 @@ private:
                 }
             }
             const float now = best_sse();
-            if (std::getenv("FGOICP_TIMING"))
+            if (timing_)
                 std::fprintf(stderr, "[fgoicp timing] round %llu: popped %d, children %zu (mine %zu), submissions %llu, subcubes %llu, tasks %.3f ms, icp %.3f ms, round %.3f ms\n",
                              (unsigned long long)stats_.rounds, popped, nchild, mine.size(), (unsigned long long)(stats_.bounds_calls - calls_before),
                              (unsigned long long)(stats_.trans_cubes - cubes_before), s_tasks * 1e3, (stats_.seconds_icp - icp_before) * 1e3, seconds_since(t_round) * 1e3);
@@ -743,7 +743,7 @@ private:
     // either way, so results do not depend on the mode.
     int run_task_list(std::vector<Task*>& tasks, const std::vector<const RotCube*>& cubes) {
         const bool par = tasks.size() >= 8 && pool_->size() > 1;
-        const bool timing = std::getenv("FGOICP_TIMING") != nullptr;
+        const bool timing = timing_;
         if (tasks.size() >= 4 && ops_.async()) {
             Half h[2];
             // tasks come in (UB, LB) pairs per child: deal whole pairs so both halves hold both kinds
@@ -797,6 +797,7 @@ private:
 
     Ops& ops_;
     double t_pop_ = 0, t_ops_ = 0, t_push_ = 0;
+    const bool timing_ = std::getenv("FGOICP_TIMING") != nullptr;  // host-side timing lines on stderr
     bool use_twins_ = [] { const char* e = std::getenv("FGOICP_TWINS"); return !e || std::atoi(e) != 0; }();  // tuning knob
     bool account_submissions_ = true;   // false while SERIAL speculates: work is accounted per committed task instead
     std::unique_ptr<WorkerPool> pool_;
