@@ -127,7 +127,7 @@ static int tick_enqueue_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl, int G, c
         // descriptors + locality sort on the slot's side stream (overlaps the other slot's bounds kernel); the main stream joins behind it
         HIPCHK(hipMemcpyAsync(sl.d_groups, sl.h_groups, sizeof(TickGroup) * ng, hipMemcpyHostToDevice, sl.sort_stream));
         HIPCHK(hipMemcpyAsync(sl.d_subs, sl.h_subs, sizeof(TickSub) * neval, hipMemcpyHostToDevice, sl.sort_stream));
-        launch_tick_sort(c->geom, c->d_chunk_cen, c->nchunk1, sl.d_groups, sl.d_subs, neval, c->cell_shift, sl.d_keys, sl.d_hist, sl.d_block_sums, sl.d_cursor, sl.d_sorted,
+        launch_tick_sort(c->geom, c->d_chunk_cen, c->nchunk1, sl.d_groups, sl.d_subs, neval, c->cell_shift, sl.d_keys, sl.d_ranks, sl.d_hist, sl.d_block_sums, sl.d_cursor, sl.d_sorted,
                          sl.sort_stream);
         HIPCHK(hipEventRecord(sl.sorted_ev, sl.sort_stream));
         HIPCHK(hipStreamWaitEvent(sl.stream, sl.sorted_ev, 0));
@@ -645,7 +645,7 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
                 }
             }
             const size_t nchunk1 = (ns + c->chunk_pts - 1) / c->chunk_pts;
-            const size_t fit = ((size_t)4 << 30) / (nchunk1 * (sizeof(double2) + sizeof(unsigned) + sizeof(unsigned short)));
+            const size_t fit = ((size_t)4 << 30) / (nchunk1 * (sizeof(double2) + 2 * sizeof(unsigned) + sizeof(unsigned short)));
             c->max_subcubes = (int)std::max<size_t>(4096, std::min<size_t>(32768, fit));
             if (const char* e = std::getenv("FGOICP_MAX_SUBCUBES")) c->max_subcubes = std::max(kMaxBatch, std::min(1 << 16, std::atoi(e)));  // tuning knob: subcubes per window
             // one launch = one workgroup per (subcube, chunk) item: keep items x 256 threads inside the 32-bit grid
@@ -705,6 +705,7 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
             CHK(hipHostGetDevicePointer((void**)&sl.hd_groups, sl.h_groups, 0));
             CHK(hipHostGetDevicePointer((void**)&sl.hd_subs, sl.h_subs, 0));
             CHK(hipMalloc(&sl.d_keys, sizeof(unsigned short) * max_items));
+            CHK(hipMalloc(&sl.d_ranks, sizeof(unsigned) * max_items));
             CHK(hipMalloc(&sl.d_hist, sizeof(unsigned) * kTickNumKeys));
             CHK(hipMemset(sl.d_hist, 0, sizeof(unsigned) * kTickNumKeys));  // the scan kernel re-zeroes it after every tick
             CHK(hipMalloc(&sl.d_block_sums, sizeof(unsigned) * 64));
@@ -776,7 +777,7 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
         if (sl.bounds_ev) (void)hipEventDestroy(sl.bounds_ev);
         if (sl.sort_stream && sl.sort_stream != c->stream) { (void)hipStreamSynchronize(sl.sort_stream); (void)hipStreamDestroy(sl.sort_stream); }
         (void)hipFree(sl.d_vals);
-        (void)hipFree(sl.d_groups); (void)hipFree(sl.d_subs); (void)hipFree(sl.d_keys); (void)hipFree(sl.d_hist);
+        (void)hipFree(sl.d_groups); (void)hipFree(sl.d_subs); (void)hipFree(sl.d_keys); (void)hipFree(sl.d_ranks); (void)hipFree(sl.d_hist);
         (void)hipFree(sl.d_cursor); (void)hipFree(sl.d_block_sums); (void)hipFree(sl.d_sorted); (void)hipFree(sl.d_partials);
         if (sl.h_groups) (void)hipHostFree(sl.h_groups);
         if (sl.h_subs) (void)hipHostFree(sl.h_subs);

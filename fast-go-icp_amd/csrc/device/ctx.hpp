@@ -48,6 +48,7 @@ struct fgoicp_ctx {
         fgoicp::TickGroup *d_groups = nullptr, *h_groups = nullptr, *hd_groups = nullptr;   // device / pinned staging / its device alias
         fgoicp::TickSub *d_subs = nullptr, *h_subs = nullptr, *hd_subs = nullptr;
         unsigned short* d_keys = nullptr;
+        unsigned* d_ranks = nullptr;             // place of every item inside its key's bin (returned by the histogram atomic)
         unsigned *d_hist = nullptr, *d_block_sums = nullptr, *d_cursor = nullptr, *d_sorted = nullptr;
         double2* d_partials = nullptr;           // [max_subcubes][nchunk1]
         float *h_lb = nullptr, *h_ub = nullptr, *hd_lb = nullptr, *hd_ub = nullptr;  // pinned results of the window in flight

@@ -305,7 +305,7 @@ __device__ __forceinline__ unsigned hilbert15(unsigned x, unsigned y, unsigned z
 template <int HILBERT>
 __global__ __launch_bounds__(64) void tick_keys_kernel(const float4* __restrict__ chunk_cen, int nchunk, const TickGroup* __restrict__ groups,
                                                            const TickSub* __restrict__ subs, int nsub, LutGeom g, int cell_shift,
-                                                           unsigned short* __restrict__ keys, unsigned* __restrict__ hist) {
+                                                           unsigned short* __restrict__ keys, unsigned* __restrict__ ranks, unsigned* __restrict__ hist) {
     const size_t nitems = (size_t)nsub * nchunk;
     for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < nitems; i += (size_t)gridDim.x * 64) {
         const int s = (int)(i / nchunk), c = (int)(i - (size_t)s * nchunk);
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(64) void tick_keys_kernel(const float4* __restrict_
         const unsigned key = HILBERT ? hilbert15((unsigned)vx, (unsigned)vy, (unsigned)vz)
                                      : part1by2_5((unsigned)vx) | (part1by2_5((unsigned)vy) << 1) | (part1by2_5((unsigned)vz) << 2);
         keys[i] = (unsigned short)key;
-        atomicAdd(&hist[key], 1u);
+        ranks[i] = atomicAdd(&hist[key], 1u);  // the item's place inside its bin: the scatter pass needs no atomics of its own
     }
 }
 
@@ -379,10 +379,16 @@ __global__ __launch_bounds__(64) void tick_scan_apply_kernel(unsigned* __restric
     c4[1] = o1;
 }
 
-__global__ __launch_bounds__(64) void tick_scatter_kernel(const unsigned short* __restrict__ keys, size_t nitems, unsigned* __restrict__ cursor,
-                                                          unsigned* __restrict__ sorted) {
+// A/B only (FGOICP_SORT_RANKS=0): the classic scatter with its own atomic per item
+__global__ __launch_bounds__(64) void tick_scatter_atomic_kernel(const unsigned short* __restrict__ keys, size_t nitems, unsigned* __restrict__ cursor,
+                                                                 unsigned* __restrict__ sorted) {
     for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < nitems; i += (size_t)gridDim.x * 64)
-        sorted[atomicAdd(&cursor[keys[i]], 1u)] = (unsigned)i;  // order inside a bin is irrelevant (scheduling only)
+        sorted[atomicAdd(&cursor[keys[i]], 1u)] = (unsigned)i;
+}
+__global__ __launch_bounds__(64) void tick_scatter_kernel(const unsigned short* __restrict__ keys, const unsigned* __restrict__ ranks, size_t nitems,
+                                                          const unsigned* __restrict__ cursor, unsigned* __restrict__ sorted) {
+    for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < nitems; i += (size_t)gridDim.x * 64)
+        sorted[cursor[keys[i]] + ranks[i]] = (unsigned)i;  // order inside a bin is irrelevant (scheduling only)
 }
 
 // One pass = THREADS x P points.  Measured on MI355X, bunny shape, whole benchmark step, yz-quad layout, wide rounds:
@@ -1303,15 +1309,17 @@ void launch_bounds(const float4* src, int ns, const float* lut, const LutGeom& g
 
 // The locality sort of one tick (descriptors must already be on the device): keys + histogram, scan, scatter.
 void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, const TickGroup* groups, const TickSub* subs, int nsub, int cell_shift,
-                      unsigned short* keys, unsigned* hist, unsigned* block_sums, unsigned* cursor, unsigned* sorted, hipStream_t s) {
+                      unsigned short* keys, unsigned* ranks, unsigned* hist, unsigned* block_sums, unsigned* cursor, unsigned* sorted, hipStream_t s) {
     const size_t nitems = (size_t)nsub * nchunk;
     const unsigned kb = (unsigned)std::min<size_t>((nitems + 63) / 64, 8192);  // `hist` is zero here: tick_scan_apply_kernel re-zeroes it
     static const int hilbert = [] { const char* e = std::getenv("FGOICP_SORT_CURVE"); return e ? std::atoi(e) : 1; }();  // tuning knob: 1 = Hilbert (default), 0 = Z-order
-    if (hilbert) hipLaunchKernelGGL(tick_keys_kernel<1>, dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, hist);
-    else hipLaunchKernelGGL(tick_keys_kernel<0>, dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, hist);
+    if (hilbert) hipLaunchKernelGGL(tick_keys_kernel<1>, dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist);
+    else hipLaunchKernelGGL(tick_keys_kernel<0>, dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist);
     hipLaunchKernelGGL(tick_scan_sums_kernel, dim3(kScanBlocks), dim3(64), 0, s, hist, block_sums);
     hipLaunchKernelGGL(tick_scan_apply_kernel, dim3(kScanBlocks), dim3(64), 0, s, hist, block_sums, cursor);
-    hipLaunchKernelGGL(tick_scatter_kernel, dim3(kb), dim3(64), 0, s, keys, nitems, cursor, sorted);
+    static const int use_ranks = [] { const char* e = std::getenv("FGOICP_SORT_RANKS"); return e ? std::atoi(e) : 1; }();  // tuning knob
+    if (use_ranks) hipLaunchKernelGGL(tick_scatter_kernel, dim3(kb), dim3(64), 0, s, keys, ranks, nitems, cursor, sorted);
+    else hipLaunchKernelGGL(tick_scatter_atomic_kernel, dim3(kb), dim3(64), 0, s, keys, nitems, cursor, sorted);
 }
 
 void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* zp, int layout, const LutGeom& g, int nchunk, int chunk_pts,
