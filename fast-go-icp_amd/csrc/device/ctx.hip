@@ -127,7 +127,7 @@ static int tick_enqueue_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl, int G, c
         // descriptors + locality sort on the slot's side stream (overlaps the other slot's bounds kernel); the main stream joins behind it
         HIPCHK(hipMemcpyAsync(sl.d_groups, sl.h_groups, sizeof(TickGroup) * ng, hipMemcpyHostToDevice, sl.sort_stream));
         HIPCHK(hipMemcpyAsync(sl.d_subs, sl.h_subs, sizeof(TickSub) * neval, hipMemcpyHostToDevice, sl.sort_stream));
-        launch_tick_sort(c->geom, c->d_chunk_cen, c->nchunk1, sl.d_groups, sl.d_subs, neval, c->cell_shift, sl.d_keys, sl.d_ranks, sl.d_hist, sl.d_block_sums, sl.d_cursor, sl.d_sorted,
+        launch_tick_sort(c->geom, c->d_chunk_cen, c->nchunk1, sl.d_groups, sl.d_subs, neval, c->cell_shift, sl.d_keys, sl.d_ranks, sl.d_hist, sl.d_hist_xcd, sl.d_xoff, sl.d_block_sums, sl.d_cursor, sl.d_sorted,
                          sl.sort_stream);
         HIPCHK(hipEventRecord(sl.sorted_ev, sl.sort_stream));
         HIPCHK(hipStreamWaitEvent(sl.stream, sl.sorted_ev, 0));
@@ -709,6 +709,9 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
             CHK(hipMalloc(&sl.d_hist, sizeof(unsigned) * kTickNumKeys));
             CHK(hipMemset(sl.d_hist, 0, sizeof(unsigned) * kTickNumKeys));  // the scan kernel re-zeroes it after every tick
             CHK(hipMalloc(&sl.d_block_sums, sizeof(unsigned) * 64));
+            CHK(hipMalloc(&sl.d_hist_xcd, sizeof(unsigned) * 16 * kTickNumKeys));
+            CHK(hipMemset(sl.d_hist_xcd, 0, sizeof(unsigned) * 16 * kTickNumKeys));
+            CHK(hipMalloc(&sl.d_xoff, sizeof(unsigned) * 16 * kTickNumKeys));
             CHK(hipMalloc(&sl.d_cursor, sizeof(unsigned) * kTickNumKeys));
             CHK(hipMalloc(&sl.d_sorted, sizeof(unsigned) * max_items));
             CHK(hipMalloc(&sl.d_partials, sizeof(double2) * max_items));
@@ -778,7 +781,7 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
         if (sl.sort_stream && sl.sort_stream != c->stream) { (void)hipStreamSynchronize(sl.sort_stream); (void)hipStreamDestroy(sl.sort_stream); }
         (void)hipFree(sl.d_vals);
         (void)hipFree(sl.d_groups); (void)hipFree(sl.d_subs); (void)hipFree(sl.d_keys); (void)hipFree(sl.d_ranks); (void)hipFree(sl.d_hist);
-        (void)hipFree(sl.d_cursor); (void)hipFree(sl.d_block_sums); (void)hipFree(sl.d_sorted); (void)hipFree(sl.d_partials);
+        (void)hipFree(sl.d_cursor); (void)hipFree(sl.d_block_sums); (void)hipFree(sl.d_hist_xcd); (void)hipFree(sl.d_xoff); (void)hipFree(sl.d_sorted); (void)hipFree(sl.d_partials);
         if (sl.h_groups) (void)hipHostFree(sl.h_groups);
         if (sl.h_subs) (void)hipHostFree(sl.h_subs);
         if (k == 1 && sl.h_lb) (void)hipHostFree(sl.h_lb);

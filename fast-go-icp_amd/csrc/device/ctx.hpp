@@ -50,6 +50,7 @@ struct fgoicp_ctx {
         unsigned short* d_keys = nullptr;
         unsigned* d_ranks = nullptr;             // place of every item inside its key's bin (returned by the histogram atomic)
         unsigned *d_hist = nullptr, *d_block_sums = nullptr, *d_cursor = nullptr, *d_sorted = nullptr;
+        unsigned *d_hist_xcd = nullptr, *d_xoff = nullptr;   // per-XCD histograms of the tick sort and their offsets inside a bin
         double2* d_partials = nullptr;           // [max_subcubes][nchunk1]
         float *h_lb = nullptr, *h_ub = nullptr, *hd_lb = nullptr, *hd_ub = nullptr;  // pinned results of the window in flight
         float2* d_vals = nullptr;                // trimmed mode: per-point {ub, lb} terms, [vals_rows][ns]

@@ -302,7 +302,13 @@ __device__ __forceinline__ unsigned hilbert15(unsigned x, unsigned y, unsigned z
     return part1by2_5(X[2]) | (part1by2_5(X[1]) << 1) | (part1by2_5(X[0]) << 2);
 }
 
-template <int HILBERT>
+// XCD = 1: the histogram is private to the XCD the wave runs on (hist points at kTickXcds histograms; HW_REG_XCC_ID picks
+// one) and the atomic has workgroup scope, i.e. it executes in that XCD's L2.  A device-scope atomic leaves the L2 for the
+// memory side, and next to the bounds kernel every such atomic per item cost that kernel ~4 % (measured by adding dummy
+// ones).  An address is only ever touched from one XCD, so the L2 is a sufficient point of coherence; the dirty lines reach
+// memory at the end of the kernel like any other store.  The rank then carries the XCD in its top bits.
+constexpr int kTickXcds = 16;  // the XCC_ID field is 4 bits wide
+template <int HILBERT, int XCD>
 __global__ __launch_bounds__(64) void tick_keys_kernel(const float4* __restrict__ chunk_cen, int nchunk, const TickGroup* __restrict__ groups,
                                                            const TickSub* __restrict__ subs, int nsub, LutGeom g, int cell_shift,
                                                            unsigned short* __restrict__ keys, unsigned* __restrict__ ranks, unsigned* __restrict__ hist) {
@@ -320,7 +326,12 @@ __global__ __launch_bounds__(64) void tick_keys_kernel(const float4* __restrict_
         const unsigned key = HILBERT ? hilbert15((unsigned)vx, (unsigned)vy, (unsigned)vz)
                                      : part1by2_5((unsigned)vx) | (part1by2_5((unsigned)vy) << 1) | (part1by2_5((unsigned)vz) << 2);
         keys[i] = (unsigned short)key;
-        ranks[i] = atomicAdd(&hist[key], 1u);  // the item's place inside its bin: the scatter pass needs no atomics of its own
+        if (XCD) {
+            const unsigned x = __builtin_amdgcn_s_getreg(20 /* HW_REG_XCC_ID */ | (0 << 6) | ((4 - 1) << 11));
+            ranks[i] = __hip_atomic_fetch_add(&hist[(size_t)x * kNumKeys + key], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) | (x << 28);
+        } else {
+            ranks[i] = atomicAdd(&hist[key], 1u);  // the item's place inside its bin: the scatter pass needs no atomics of its own
+        }
     }
 }
 
@@ -379,6 +390,27 @@ __global__ __launch_bounds__(64) void tick_scan_apply_kernel(unsigned* __restric
     c4[1] = o1;
 }
 
+// The per-XCD histograms folded: hist[k] = sum over XCDs (input of the scan), xoff[x][k] = items of key k on XCDs before x;
+// leaves the per-XCD histograms zeroed for the next tick.
+__global__ __launch_bounds__(64) void tick_fold_xcds_kernel(unsigned* __restrict__ hist_xcd, unsigned* __restrict__ xoff, unsigned* __restrict__ hist) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    unsigned run = 0;
+#pragma unroll
+    for (int x = 0; x < kTickXcds; ++x) {
+        const unsigned v = hist_xcd[(size_t)x * kNumKeys + k];
+        xoff[(size_t)x * kNumKeys + k] = run;
+        run += v;
+        hist_xcd[(size_t)x * kNumKeys + k] = 0u;
+    }
+    hist[k] = run;
+}
+__global__ __launch_bounds__(64) void tick_scatter_xcd_kernel(const unsigned short* __restrict__ keys, const unsigned* __restrict__ ranks, size_t nitems,
+                                                              const unsigned* __restrict__ cursor, const unsigned* __restrict__ xoff, unsigned* __restrict__ sorted) {
+    for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < nitems; i += (size_t)gridDim.x * 64) {
+        const unsigned k = keys[i], r = ranks[i];
+        sorted[cursor[k] + xoff[(size_t)(r >> 28) * kNumKeys + k] + (r & 0x0FFFFFFFu)] = (unsigned)i;
+    }
+}
 // A/B only (FGOICP_SORT_RANKS=0): the classic scatter with its own atomic per item
 __global__ __launch_bounds__(64) void tick_scatter_atomic_kernel(const unsigned short* __restrict__ keys, size_t nitems, unsigned* __restrict__ cursor,
                                                                  unsigned* __restrict__ sorted) {
@@ -1309,16 +1341,26 @@ void launch_bounds(const float4* src, int ns, const float* lut, const LutGeom& g
 
 // The locality sort of one tick (descriptors must already be on the device): keys + histogram, scan, scatter.
 void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, const TickGroup* groups, const TickSub* subs, int nsub, int cell_shift,
-                      unsigned short* keys, unsigned* ranks, unsigned* hist, unsigned* block_sums, unsigned* cursor, unsigned* sorted, hipStream_t s) {
+                      unsigned short* keys, unsigned* ranks, unsigned* hist, unsigned* hist_xcd, unsigned* xoff, unsigned* block_sums, unsigned* cursor, unsigned* sorted,
+                      hipStream_t s) {
     const size_t nitems = (size_t)nsub * nchunk;
-    const unsigned kb = (unsigned)std::min<size_t>((nitems + 63) / 64, 8192);  // `hist` is zero here: tick_scan_apply_kernel re-zeroes it
+    const unsigned kb = (unsigned)std::min<size_t>((nitems + 63) / 64, 8192);  // `hist` / `hist_xcd` are zero here: the scan / fold kernels re-zero them
     static const int hilbert = [] { const char* e = std::getenv("FGOICP_SORT_CURVE"); return e ? std::atoi(e) : 1; }();  // tuning knob: 1 = Hilbert (default), 0 = Z-order
-    if (hilbert) hipLaunchKernelGGL(tick_keys_kernel<1>, dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist);
-    else hipLaunchKernelGGL(tick_keys_kernel<0>, dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist);
+    static const int use_ranks = [] { const char* e = std::getenv("FGOICP_SORT_RANKS"); return e ? std::atoi(e) : 1; }();  // tuning knob
+    static const int use_xcd = [] { const char* e = std::getenv("FGOICP_SORT_XCD"); return e ? std::atoi(e) : 1; }();      // tuning knob
+    const bool xcd = use_xcd && use_ranks && hist_xcd && xoff;
+    if (xcd) {
+        if (hilbert) hipLaunchKernelGGL((tick_keys_kernel<1, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd);
+        else hipLaunchKernelGGL((tick_keys_kernel<0, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd);
+        hipLaunchKernelGGL(tick_fold_xcds_kernel, dim3(kNumKeys / 64), dim3(64), 0, s, hist_xcd, xoff, hist);
+    } else {
+        if (hilbert) hipLaunchKernelGGL((tick_keys_kernel<1, 0>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist);
+        else hipLaunchKernelGGL((tick_keys_kernel<0, 0>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist);
+    }
     hipLaunchKernelGGL(tick_scan_sums_kernel, dim3(kScanBlocks), dim3(64), 0, s, hist, block_sums);
     hipLaunchKernelGGL(tick_scan_apply_kernel, dim3(kScanBlocks), dim3(64), 0, s, hist, block_sums, cursor);
-    static const int use_ranks = [] { const char* e = std::getenv("FGOICP_SORT_RANKS"); return e ? std::atoi(e) : 1; }();  // tuning knob
-    if (use_ranks) hipLaunchKernelGGL(tick_scatter_kernel, dim3(kb), dim3(64), 0, s, keys, ranks, nitems, cursor, sorted);
+    if (xcd) hipLaunchKernelGGL(tick_scatter_xcd_kernel, dim3(kb), dim3(64), 0, s, keys, ranks, nitems, cursor, xoff, sorted);
+    else if (use_ranks) hipLaunchKernelGGL(tick_scatter_kernel, dim3(kb), dim3(64), 0, s, keys, ranks, nitems, cursor, sorted);
     else hipLaunchKernelGGL(tick_scatter_atomic_kernel, dim3(kb), dim3(64), 0, s, keys, nitems, cursor, sorted);
 }
 

@@ -62,8 +62,9 @@ struct TickSub {     // one EVALUATION: a translation node + its rotation node, 
 };
 constexpr int kTickNumKeys = 1 << 15;
 void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, const TickGroup* groups, const TickSub* subs, int nsub, int cell_shift,
-                      unsigned short* keys, unsigned* ranks /* per item, like keys */, unsigned* hist /* kTickNumKeys, zero on entry and on exit */, unsigned* block_sums /* 64 */, unsigned* cursor,
-                      unsigned* sorted, hipStream_t s);
+                      unsigned short* keys, unsigned* ranks /* per item, like keys */, unsigned* hist /* kTickNumKeys, zero on entry and on exit */,
+                      unsigned* hist_xcd /* 16 x kTickNumKeys, zero on entry and on exit (optional) */, unsigned* xoff /* 16 x kTickNumKeys (optional) */,
+                      unsigned* block_sums /* 64 */, unsigned* cursor, unsigned* sorted, hipStream_t s);
 void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* packed_or_null, int layout /* 1 z-pair, 2 yz-quad */, const LutGeom& g, int nchunk,
                           int chunk_pts /* 256 .. 2048 points per item */, const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials, float2* vals_or_null,
                           hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s);
