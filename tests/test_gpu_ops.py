@@ -312,6 +312,35 @@ def test_small_tick_path_equals_sorted_path(fg, oracle, tiny_case, gpu_required,
             assert rel(out["0"][k][1], ubo) <= REL
 
 
+@pytest.mark.parametrize("workload,res", [("tiny", 0.05), ("bunny", 0.02)])
+def test_icp_two_stream_loop_is_bit_identical_to_the_one_stream_loop(fg, gpu_required, monkeypatch, workload, res):
+    """The ICP loop runs the exact SSE of iteration k next to the correspondence pass of iteration k+1 (two streams):
+    same kernels, same sums — every output bit equal to the sequential loop, including the iteration count."""
+    tgt, src, R_gt, t_gt = fg.synth.workload(workload, angle_deg=30.0)
+    pct, pcs, off_t, off_s, scale, bounds = fg.synth.preprocess(tgt, src)
+    rng = np.random.default_rng(3)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FGOICP_ICP_OVERLAP", mode)
+        reg = fg.Registration(pct, pcs, bounds, res)
+        runs = []
+        for thr, ang in ((0.05, 40.0), (0.005, 15.0), (0.0005, 3.0)):
+            R0 = fg.synth.random_rotation(np.random.default_rng(int(ang)), ang).astype(np.float32)
+            t0 = np.array([0.01, -0.02, 0.005], np.float32)
+            icp = fg.IterativeClosestPoint3D(reg, None, None, 100, thr, R0, t0)
+            sse, R, t = icp.run()
+            runs.append((np.float32(sse).view(np.uint32), R.copy(), t.copy(), icp.iterations))
+        # a Procrustes step and an SSE after ICP runs: the scratch buffers are back in a consistent state
+        w = (pcs @ R.T + t).astype(np.float32)
+        runs.append(reg.procrustes(w)[4].copy())
+        runs.append(np.float32(reg.compute_sse_error(R, t)).view(np.uint32))
+        out[mode] = runs
+        reg.close()
+    for a, b in zip(out["1"][:3], out["0"][:3]):
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
+    assert np.array_equal(out["1"][3], out["0"][3]) and out["1"][4] == out["0"][4]
+
+
 def test_twin_subcubes_are_evaluated_once_with_identical_sums(fg, tiny_case, gpu_required):
     """fgoicp_bounds_submit_twins: a translation node held by the fix_rot group AND the non-fix_rot group of one rotation
     is evaluated with one lookup per point and both variants of the formulae — bit-identical to two evaluations; a wrong
