@@ -21,5 +21,5 @@ pass TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum &&
 pass SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU &&
 pass SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES
 cd $REPO && python tools/pmc_generic.py gpurun_out/profiles/r01_bounds_kernel_pmc_extra.json /tmp/p1 /tmp/p2 /tmp/p3 /tmp/p4 /tmp/p5 /tmp/p6 /tmp/p7 > gpurun_out/pmc_extra.txt 2>&1
-cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/ktrace -- python3 $ARGS > $REPO/gpurun_out/ktrace.log 2>&1
-cd $REPO/tools && python trace_gaps.py /tmp/ktrace ../gpurun_out/profiles/r01_bench_trace_gaps.json > ../gpurun_out/trace_gaps.log 2>&1
+cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/ktrace -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-default-threshold-run --no-dragon --no-trimmed > $REPO/gpurun_out/ktrace.log 2>&1
+cd $REPO/tools && python trace_gaps.py /tmp/ktrace ../gpurun_out/profiles/r01_bench_trace_gaps.json 0.5 > ../gpurun_out/trace_gaps.log 2>&1

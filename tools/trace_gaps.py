@@ -2,7 +2,10 @@
 between the first and the last bounds kernel: how long the bounds kernel ran, how long ANY kernel ran, and the
 idle gaps between consecutive bounds kernels bucketed by length and by what ran inside them.
 
-    python tools/trace_gaps.py <rocprof_out_dir> <out.json>
+    python tools/trace_gaps.py <rocprof_out_dir> <out.json> [skip_fraction]
+
+skip_fraction (e.g. 0.5 for a trace of two identical steps): drop that share of the bounds launches from the front, so that the
+one-time costs of a first step (code-object loads, first-touch of buffers) stay out of the picture.
 """
 import collections
 import csv
@@ -29,6 +32,9 @@ def main():
                          int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 1)) or 1)))
     rows.sort()
     bounds = [r for r in rows if r[2] == "bounds_sorted_kernel"]
+    if len(sys.argv) > 3 and bounds:
+        bounds = bounds[int(len(bounds) * float(sys.argv[3])):]
+        rows = [r for r in rows if r[0] >= bounds[0][0]]
     if not bounds:
         json.dump({"error": "no bounds kernel in trace"}, open(outp, "w"))
         return
