@@ -504,6 +504,7 @@ private:
         const int base_width = adaptive ? 32 * world : round_width_;
         int width = base_width;
         while (!rcand.empty()) {
+            const auto t_iter = clock::now();
             children.clear();
             int popped = 0;
             while (popped < width && !rcand.empty()) {
@@ -603,9 +604,10 @@ private:
             }
             const float now = best_sse();
             if (timing_)
-                std::fprintf(stderr, "[fgoicp timing] round %llu: popped %d, children %zu (mine %zu), submissions %llu, subcubes %llu, tasks %.3f ms, icp %.3f ms, round %.3f ms\n",
+                std::fprintf(stderr, "[fgoicp timing] round %llu: popped %d, children %zu (mine %zu), submissions %llu, subcubes %llu, tasks %.3f ms, icp %.3f ms, round %.3f ms, setup %.3f ms\n",
                              (unsigned long long)stats_.rounds, popped, nchild, mine.size(), (unsigned long long)(stats_.bounds_calls - calls_before),
-                             (unsigned long long)(stats_.trans_cubes - cubes_before), s_tasks * 1e3, (stats_.seconds_icp - icp_before) * 1e3, seconds_since(t_round) * 1e3);
+                             (unsigned long long)(stats_.trans_cubes - cubes_before), s_tasks * 1e3, (stats_.seconds_icp - icp_before) * 1e3, seconds_since(t_round) * 1e3,
+                             std::chrono::duration<double>(t_round - t_iter).count() * 1e3);
             if (adaptive) width = now < snapshot ? base_width : std::min(width * 2, 1 << 14);
             for (size_t i = 0; i < nchild; ++i) {
                 if (lbs[i] >= now) continue;  // :92
