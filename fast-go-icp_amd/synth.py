@@ -16,6 +16,7 @@ WORKLOADS = {
     # BASELINE configs[0] shape: test/bunny.toml subsamples data/bunny to ~0.5 * 35 947 target and ~0.1 * 30 379 source points
     # and builds the LUT at resolution 0.002 (923 x 906 x 711 nodes on the real clouds)
     "bunny_toml": dict(nt=17973, ns=3037, box=(0.156, 0.152, 0.118), seed=5),
+    "mid": dict(nt=150_000, ns=150_000, box=(0.156, 0.152, 0.118), seed=13),  # between the two: 0.36 source points per LUT face voxel
     "tiny": dict(nt=1500, ns=1200, box=(0.156, 0.152, 0.118), seed=7),
     "small": dict(nt=6000, ns=5000, box=(0.156, 0.152, 0.118), seed=11),
 }

@@ -341,13 +341,16 @@ def test_icp_two_stream_loop_is_bit_identical_to_the_one_stream_loop(fg, gpu_req
     assert np.array_equal(out["1"][3], out["0"][3]) and out["1"][4] == out["0"][4]
 
 
-def test_twin_subcubes_are_evaluated_once_with_identical_sums(fg, tiny_case, gpu_required):
+@pytest.mark.parametrize("window", [0, 32])
+def test_twin_subcubes_are_evaluated_once_with_identical_sums(fg, tiny_case, gpu_required, monkeypatch, window):
     """fgoicp_bounds_submit_twins: a translation node held by the fix_rot group AND the non-fix_rot group of one rotation
     is evaluated with one lookup per point and both variants of the formulae — bit-identical to two evaluations; a wrong
     hint (different node, same fix_rot, other rotation) is ignored."""
     import ctypes as C
     c = tiny_case
     lib = fg._lib.load()
+    if window:  # windows of 32 subcubes: the pairs (5..16, 23..34) straddle window borders and fall back to two evaluations
+        monkeypatch.setenv("FGOICP_MAX_SUBCUBES", str(window))
     reg = fg.Registration(c["pct"], c["pcs"], c["bounds"], c["res"])
     rng = np.random.default_rng(12)
     rn = fg.RotNode(0.125, -0.25, 0.375, 0.25)
@@ -381,7 +384,9 @@ def test_twin_subcubes_are_evaluated_once_with_identical_sums(fg, tiny_case, gpu
     lb1, ub1 = run(twin)
     p1 = reg.profile(reset=True)
     assert np.array_equal(lb0, lb1) and np.array_equal(ub0, ub1)
-    assert p0["subcubes"] == p1["subcubes"] == 50 and p0["evaluations"] == 50 and p1["evaluations"] == 38  # 12 pairs evaluated once
+    assert p0["subcubes"] == p1["subcubes"] == 50 and p0["evaluations"] == 50
+    # 12 pairs evaluated once; with 32-subcube windows only the 9 pairs with both members in the first window (rows 23..31)
+    assert p1["evaluations"] == (38 if not window else 41)
     # and they are the bounds of the synchronous per-node operator
     l, u = reg.compute_sse_error(rn, tb, False)
     assert np.array_equal(l, lb1[20:44]) and np.array_equal(u, ub1[20:44])
