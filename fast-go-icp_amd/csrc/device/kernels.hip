@@ -40,9 +40,24 @@ __device__ __forceinline__ float dist_sq(float ax, float ay, float az, float bx,
     return fma_(dz, dz, fma_(dy, dy, dx * dx));
 }
 
+// Sum over the wave, valid in lane 0.  The tree is v[i] += v[i + off] for off = 32, 16, 8, 4, 2, 1; the two far steps go
+// through the LDS crossbar (ds_bpermute), the four near ones stay inside a row of 16 lanes and use DPP row_shl on the two
+// halves of the double — same operands, same order, no LDS round trip (lanes whose partner lies outside their row add 0
+// instead of themselves; they do not feed lane 0).
+template <int OFF>
+__device__ __forceinline__ double dpp_row_shl(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x100 + OFF, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x100 + OFF, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    v += __shfl_down(v, 32, 64);
+    v += __shfl_down(v, 16, 64);
+    v += dpp_row_shl<8>(v);
+    v += dpp_row_shl<4>(v);
+    v += dpp_row_shl<2>(v);
+    v += dpp_row_shl<1>(v);
     return v;
 }
 
