@@ -1,5 +1,8 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-B="python bench.py --no-cpu-baseline --no-default-threshold-run --no-dragon --no-trimmed --steps 3 --warmup 1"
-for S in 1 2; do (timeout -k 10 200 $B 2>&1 | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"avg_launch_us": [0-9.]*\|"achieved": [0-9.]*\|"best_sse": [0-9.]*' | tr '\n' ' '); echo; done
+rm -f gpurun_out/scale6.log
+for F in 1 0; do
+echo "== finalize_side $F" >> gpurun_out/scale6.log
+(FGOICP_FINALIZE_SIDE=$F REPLAY_ONLY_RANK=0 FGOICP_TIMING=1 timeout -k 10 500 python tools/scale_replay.py 4 bunny 5e-5 0.005 2>&1 | grep "timing\] round\|estimated" | tail -7 | cut -c1-200 | sed 's/.*round \([0-9]*\):.*submissions \([0-9]*\),.*tasks \([0-9.]*\) ms.*round \([0-9.]*\) ms.*/r\1 sub \2 tasks \3 round \4/' ) >> gpurun_out/scale6.log 2>&1
+done
+cat gpurun_out/scale6.log | cut -c1-300
