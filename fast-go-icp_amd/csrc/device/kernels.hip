@@ -1391,7 +1391,10 @@ void launch_bounds_sorted(const float4* src, int ns, const float* lut, const flo
 #define FGOICP_LAUNCH_SORTED(T, PP, Z, TR) \
     hipLaunchKernelGGL((bounds_sorted_kernel<T, PP, Z, TR>), grid, dim3(T), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, chunk_pts, partials, vals)
     if (vals) {
-        if (zp && layout == 2) FGOICP_LAUNCH_SORTED(128, 2, 2, 1); else if (zp) FGOICP_LAUNCH_SORTED(128, 2, 1, 1); else FGOICP_LAUNCH_SORTED(128, 2, 0, 1);
+        static const int trim_variant = [] { const char* e = std::getenv("FGOICP_TRIM_VARIANT"); return e ? std::atoi(e) : 2; }();  // tuning knob (2 = 64x4, default)
+        if (trim_variant == 2) {
+            if (zp && layout == 2) FGOICP_LAUNCH_SORTED(64, 4, 3, 1); else if (zp) FGOICP_LAUNCH_SORTED(64, 4, 1, 1); else FGOICP_LAUNCH_SORTED(64, 4, 0, 1);
+        } else if (zp && layout == 2) FGOICP_LAUNCH_SORTED(128, 2, 2, 1); else if (zp) FGOICP_LAUNCH_SORTED(128, 2, 1, 1); else FGOICP_LAUNCH_SORTED(128, 2, 0, 1);
     } else if (zp && layout == 2) {
         static const int paired = [] { const char* e = std::getenv("FGOICP_QUAD_PAIRED"); return e ? std::atoi(e) : 1; }();  // tuning knob (1 = default)
         if (variant == 2 && paired) FGOICP_LAUNCH_SORTED(64, 4, 3, 0); else
