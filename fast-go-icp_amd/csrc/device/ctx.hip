@@ -627,7 +627,7 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
         }
         c->pts_per_thread = P;
         c->nchunk = (int)((ns + (size_t)kBlock * P - 1) / ((size_t)kBlock * P));
-        // subcubes per window: as many as 4 GiB of per-(subcube, chunk) scratch per slot hold, 4096..32768 (wide rounds submit
+        // subcubes per window: as many as 4 GiB of per-(subcube, chunk) scratch per slot hold, 4096..131072 (wide rounds submit
         // tens of thousands per tick; bigger launches sort into longer runs of items per LUT cell and re-use the L2 better)
         {
             // points per work item of the sorted path: the patch of 256 Morton-consecutive points of a sparse cloud spans
@@ -646,8 +646,8 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
             }
             const size_t nchunk1 = (ns + c->chunk_pts - 1) / c->chunk_pts;
             const size_t fit = ((size_t)4 << 30) / (nchunk1 * (sizeof(double2) + 2 * sizeof(unsigned) + sizeof(unsigned short)));
-            c->max_subcubes = (int)std::max<size_t>(4096, std::min<size_t>(32768, fit));
-            if (const char* e = std::getenv("FGOICP_MAX_SUBCUBES")) c->max_subcubes = std::max(kMaxBatch, std::min(1 << 16, std::atoi(e)));  // tuning knob: subcubes per window
+            c->max_subcubes = (int)std::max<size_t>(4096, std::min<size_t>(131072, fit));
+            if (const char* e = std::getenv("FGOICP_MAX_SUBCUBES")) c->max_subcubes = std::max(kMaxBatch, std::min(1 << 18, std::atoi(e)));  // tuning knob: subcubes per window
             // one launch = one workgroup per (subcube, chunk) item: keep items x 256 threads inside the 32-bit grid
             const size_t launch_fit = (((size_t)1 << 24) - 1) / nchunk1;
             if (launch_fit < (size_t)kMaxBatch) {
