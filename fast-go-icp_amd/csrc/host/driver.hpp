@@ -644,21 +644,25 @@ private:
         if (par) pool_->parallel_for(h.members.size(), pop_fn);
         else for (size_t k = 0; k < h.members.size(); ++k) pop_fn(k);
         h.live.clear();
-        h.R9.clear(); h.spans.clear(); h.fix.clear(); h.tn4.clear();
         h.offsets.assign(1, 0);
         h.members.erase(std::remove_if(h.members.begin(), h.members.end(), [&](size_t i) { return tasks[i]->done; }), h.members.end());
-        for (size_t i : h.members) {
-            Task& tk = *tasks[i];
-            if (!tk.has_batch) continue;
+        for (size_t i : h.members) {  // a member that is not done has a batch
             h.live.push_back((int)i);
-            h.R9.insert(h.R9.end(), cubes[i]->q.R.m, cubes[i]->q.R.m + 9);
-            h.spans.push_back(cubes[i]->span);
-            h.fix.push_back(tk.fix_rot ? 1 : 0);
-            for (const TransCube& c : tk.batch) {
-                h.tn4.push_back(c.t.x); h.tn4.push_back(c.t.y); h.tn4.push_back(c.t.z); h.tn4.push_back(c.span);
-            }
-            h.offsets.push_back((int)(h.tn4.size() / 4));
+            h.offsets.push_back(h.offsets.back() + (int)tasks[i]->batch.size());
         }
+        const size_t G = h.live.size(), total = (size_t)h.offsets.back();
+        h.R9.resize(9 * G); h.spans.resize(G); h.fix.resize(G); h.tn4.resize(4 * total);
+        const std::function<void(size_t)> pack_fn = [&](size_t a) {  // groups are independent: packed in parallel
+            const int i = h.live[a];
+            const Task& tk = *tasks[i];
+            std::memcpy(&h.R9[9 * a], cubes[i]->q.R.m, 9 * sizeof(float));
+            h.spans[a] = cubes[i]->span;
+            h.fix[a] = tk.fix_rot ? 1 : 0;
+            float* out = &h.tn4[4 * (size_t)h.offsets[a]];
+            for (const TransCube& c : tk.batch) { out[0] = c.t.x; out[1] = c.t.y; out[2] = c.t.z; out[3] = c.span; out += 4; }
+        };
+        if (par && G >= 256) pool_->parallel_for(G, pack_fn);
+        else for (size_t a = 0; a < G; ++a) pack_fn(a);
         h.lb.resize(h.tn4.size() / 4);
         h.ub.resize(h.tn4.size() / 4);
         // twins: the UB and the LB task of one child (tasks 2c, 2c+1, neighbours in `live`) walk the top of the same translation
