@@ -1,3 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-(timeout -k 10 300 python bench.py --schedule serial --no-cpu-baseline --no-default-threshold-run --no-dragon --no-trimmed --steps 3 --warmup 1 2>&1 | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"subcubes_per_step": [0-9.]*'| tr '\n' ' '); echo
+rm -f gpurun_out/scale7.log
+for W in 2 4 5; do timeout -k 10 600 python tools/scale_replay.py $W bunny 5e-5 0.005 >> gpurun_out/scale7.log 2>&1 || exit 1; done
+timeout -k 10 900 python tools/scale_replay.py 4 dragon 5e-6 0.005 >> gpurun_out/scale7.log 2>&1 || exit 1
+cut -c1-420 gpurun_out/scale7.log
