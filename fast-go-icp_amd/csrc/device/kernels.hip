@@ -1108,10 +1108,13 @@ __device__ __forceinline__ float tie_threshold(float best) {  // see nn_tie_thre
 // candidate leaves, the shares are min-combined through LDS.
 constexpr int kMaxParts = 16;
 
+template <int WANT_INDEX>
 __global__ __launch_bounds__(64 * kMaxParts) void nn_scan_kernel(const float4* __restrict__ pts, int n, BvhView t, const float* __restrict__ lut,
-                                                                 LutGeom g, Rt rt, int apply, int want_index, const float4* __restrict__ tgt, int nt,
+                                                                 LutGeom g, Rt rt, int apply, const float4* __restrict__ tgt, int nt,
                                                                  const uint32_t* seed_idx, uint32_t* out) {
     __shared__ uint32_t comb[kMaxParts][64];
+    __shared__ uint32_t comb_i[WANT_INDEX ? kMaxParts : 1][64];
+    __shared__ uint32_t comb_2[WANT_INDEX ? kMaxParts : 1][64];
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6, nparts = blockDim.x >> 6;
     const int i = blockIdx.x * 64 + lane;
     const bool active = i < n;
@@ -1132,18 +1135,40 @@ __global__ __launch_bounds__(64 * kMaxParts) void nn_scan_kernel(const float4* _
         }
     }
     float best = ub < kInf ? ub : kInf, found = kInf;
+    // index mode: the same walk also keeps the lowest index attaining the minimum (i1) and the smallest distance above it
+    // (second).  The walk prunes against best * (1 + 1.5e-6) >= tie_threshold(best), so every point of the sqrt-tie set of the
+    // final minimum is visited; if `second` lies outside that set — always, but for a genuine tie of two different squared
+    // distances — i1 is the answer and the second walk below is skipped.
+    float second = kInf;
+    uint32_t i1 = 0x7fffffffu;
     box_scan(t, qx, qy, qz, active, part, nparts,
              [&](const float4 c) {
                  const float d = dist_sq(qx, qy, qz, c.x, c.y, c.z);
+                 if (WANT_INDEX) {
+                     const uint32_t j = __float_as_uint(c.w);
+                     const bool lt = d < found, eq = d == found;
+                     second = lt ? found : (!eq && d < second ? d : second);
+                     i1 = lt ? j : (eq ? min(i1, j) : i1);
+                 }
                  found = d < found ? d : found;
                  best = d < best ? d : best;
              },
-             [&]() { return best; });
+             [&]() { return WANT_INDEX ? best * 1.0000015f : best; });
     if (nparts > 1) {
         comb[part][lane] = __float_as_uint(found);  // non-negative floats order like their bit patterns
         __syncthreads();
         uint32_t m = comb[0][lane];
         for (int k = 1; k < nparts; ++k) m = min(m, comb[k][lane]);
+        if (WANT_INDEX) {  // the parts' (minimum, index, second) folded: index among the parts that hold the global minimum
+            const float gm = __uint_as_float(m);
+            comb_i[part][lane] = found == gm ? i1 : 0x7fffffffu;
+            comb_2[part][lane] = __float_as_uint(found > gm ? found : second);
+            __syncthreads();
+            uint32_t mi = comb_i[0][lane], m2 = comb_2[0][lane];
+            for (int k = 1; k < nparts; ++k) { mi = min(mi, comb_i[k][lane]); m2 = min(m2, comb_2[k][lane]); }
+            i1 = mi;
+            second = __uint_as_float(m2);
+        }
         found = __uint_as_float(m);
         __syncthreads();
     }
@@ -1167,19 +1192,25 @@ __global__ __launch_bounds__(64 * kMaxParts) void nn_scan_kernel(const float4* _
         if (redo) found = f2;
     }
     uint32_t result = __float_as_uint(found);
-    if (want_index) {
+    if (WANT_INDEX) {
         const float thr = tie_threshold(found);
-        uint32_t idx = 0x7fffffffu;
-        box_scan(t, qx, qy, qz, active, part, nparts,
-                 [&](const float4 c) {
-                     const float d = dist_sq(qx, qy, qz, c.x, c.y, c.z);
-                     idx = min(idx, d <= thr ? __float_as_uint(c.w) : 0x7fffffffu);
-                 },
-                 [&]() { return thr; });
-        if (nparts > 1) {
-            comb[part][lane] = idx;
-            __syncthreads();
-            for (int k = 0; k < nparts; ++k) idx = min(idx, comb[k][lane]);
+        // a second walk only for lanes whose tie set may hold a different squared distance (or whose first walk was redone)
+        const bool again = active && (redo || !(second > thr));
+        uint32_t idx = i1;
+        if (__syncthreads_or(again)) {
+            uint32_t idx2 = 0x7fffffffu;
+            box_scan(t, qx, qy, qz, again, part, nparts,
+                     [&](const float4 c) {
+                         const float d = dist_sq(qx, qy, qz, c.x, c.y, c.z);
+                         idx2 = min(idx2, d <= thr ? __float_as_uint(c.w) : 0x7fffffffu);
+                     },
+                     [&]() { return thr; });
+            if (nparts > 1) {
+                comb[part][lane] = idx2;
+                __syncthreads();
+                for (int k = 0; k < nparts; ++k) idx2 = min(idx2, comb[k][lane]);
+            }
+            if (again) idx = idx2;
         }
         result = idx;
     }
@@ -1475,7 +1506,8 @@ void launch_nn_scan(const float4* pts, int n, const BvhView& t, const float* lut
     while (nparts < 8 && groups * nparts < 4096) nparts <<= 1;
     static const int forced = [] { const char* e = std::getenv("FGOICP_NN_PARTS"); const int v = e ? std::atoi(e) : 0; return v; }();  // tuning knob
     if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16) nparts = forced;
-    hipLaunchKernelGGL(nn_scan_kernel, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, want_index, tgt, nt, seed_idx, out);
+    if (want_index) hipLaunchKernelGGL(nn_scan_kernel<1>, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, out);
+    else hipLaunchKernelGGL(nn_scan_kernel<0>, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, out);
 }
 
 // `scratch` must hold as many floats as the padded LUT; it receives the coarse pass.
