@@ -108,3 +108,37 @@ def test_full_run_on_tiny_and_identical_clouds(fg, oracle, gpu_required):
         s.close()
     o = oracle.FastGoICP(pts, pts.copy(), 0.05, 1e-3).run()
     assert o["stats"]["rot_cubes"] == 0
+
+
+def test_getters_can_be_polled_while_the_search_runs(fg, gpu_required):
+    """The reference's external viewer polls get_best_error / get_best_transform / get_last_transform from another thread
+    while run() is busy (README.md:19, fgoicp.hpp:31-43; upstream reads them racily).  Here they take a mutex inside the
+    library: every polled transform is a proper rotation, the best error never increases, and the run is not disturbed."""
+    import threading
+    tgt, src, R_gt, t_gt = fg.synth.workload("small", angle_deg=150.0, min_angle_deg=110.0)
+    ref = fg.FastGoICP(tgt, src, 0.02, 2e-5, schedule=fg.SCHEDULE_ROUND, round_width=0)
+    R0, t0 = ref.run()
+    e0, st0 = float(ref.get_best_error()), ref.stats()
+    ref.close()
+    s = fg.FastGoICP(tgt, src, 0.02, 2e-5, schedule=fg.SCHEDULE_ROUND, round_width=0)
+    seen, stop, bad = [], threading.Event(), []
+
+    def poll():
+        while not stop.is_set():
+            e = float(s.get_best_error())
+            for R, t in (s.get_best_transform(), s.get_last_transform()):
+                if not (np.allclose(R @ R.T, np.eye(3), atol=1e-4) and np.isfinite(t).all()):
+                    bad.append(R)
+            seen.append(e)
+
+    th = threading.Thread(target=poll)
+    th.start()
+    R1, t1 = s.run()
+    stop.set()
+    th.join()
+    assert not bad and len(seen) > 10
+    during = [e for e in seen if e < 1e9]
+    assert all(b <= a * (1 + 1e-6) for a, b in zip(during, during[1:]))  # the incumbent only improves
+    assert np.array_equal(R0, R1) and np.array_equal(t0, t1) and float(s.get_best_error()) == e0
+    assert s.stats()["trans_cubes"] == st0["trans_cubes"]
+    s.close()

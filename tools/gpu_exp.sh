@@ -1,5 +1,3 @@
-# scratch script for ad-hoc GPU experiments (edited per experiment; see tools/gpu_profile.sh for the round profile)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-bash tools/gpu_profile.sh r01 > gpurun_out/profile_run.log 2>&1
-grep '^{"metric"' gpurun_out/bench_default.log | cut -c1-200
+timeout -k 10 300 python -m pytest tests/test_gpu_edge_cases.py -m gpu -x -q -k "polled" 2>&1 | tail -12
