@@ -66,3 +66,26 @@ def test_missing_library_is_a_loud_error(fg, monkeypatch, tmp_path):
     monkeypatch.setattr(fg._lib, "lib_path", lambda: str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         fg._lib.load()
+
+
+def _build_facade_check(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "facade_check")
+    lib_dir = os.path.join(REPO, "fast-go-icp_amd", "lib")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(REPO, "include"),
+                    os.path.join(REPO, "tests", "host_harness", "facade_check.cpp"), "-o", exe, "-L" + lib_dir, "-lfgoicp_amd", "-Wl,-rpath," + lib_dir], check=True)
+    return exe
+
+
+def test_cpp_facades_compile_against_the_c_abi_alone(fg, tmp_path):
+    """include/fgoicp/*.hpp (the reference's class names over the C ABI) build with a plain C++17 compiler — no HIP headers —
+    and, without a GPU, throw the std::runtime_error the reference's CLI path expects instead of computing anything."""
+    import subprocess
+    exe = _build_facade_check(tmp_path)
+    (tmp_path / "pc.txt").write_text("2\n0 0 0\n1 1 1\n")
+    (tmp_path / "b.txt").write_text("-1 1 -1 1 -1 1\n")
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the run itself is covered by the gpu test")
+    p = subprocess.run([exe, str(tmp_path / "pc.txt"), str(tmp_path / "pc.txt"), "0.05", str(tmp_path / "b.txt")], capture_output=True, text=True)
+    assert p.returncode != 0 and "no HIP device" in (p.stderr + p.stdout)

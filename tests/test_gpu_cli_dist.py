@@ -135,3 +135,45 @@ def test_bench_two_rank_path_rehearsal(gpu_required):
     assert d["result"]["rotation_error_deg_vs_ground_truth"] < 0.5 and d["reference_default_threshold"]["same_optimum_as_headline"]
     assert 0 < d["rot_cubes_rank0"] < 2236 and "cpu_baseline" not in d  # sharded; the CPU leg is an N = 1 thing
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+
+
+def test_cpp_facades_give_the_results_of_the_python_binding(fg, gpu_required, tmp_path):
+    """icp::Registration / NearestNeighborLUT / IterativeClosestPoint3D / FastGoICP of include/fgoicp/*.hpp, driven like the
+    reference's fgoicp.cpp drives its classes, return bit for bit what the ctypes binding returns for the same calls."""
+    import json
+    from tests.test_abi import _build_facade_check
+    exe = _build_facade_check(tmp_path)
+    tgt, src, R_gt, t_gt = fg.synth.workload("tiny", angle_deg=25.0)
+    pct, pcs, off_t, off_s, scale, bounds = fg.synth.preprocess(tgt, src)
+
+    def write(path, pc):
+        with open(path, "w") as f:
+            f.write(f"{len(pc)}\n")
+            for p in pc:
+                f.write("%.9g %.9g %.9g\n" % tuple(float(v) for v in p))
+    write(tmp_path / "pct.txt", pct); write(tmp_path / "pcs.txt", pcs); write(tmp_path / "tgt.txt", tgt); write(tmp_path / "src.txt", src)
+    (tmp_path / "b.txt").write_text(" ".join("%.9g" % float(v) for v in np.asarray(bounds).reshape(-1)) + "\n")
+    p = subprocess.run([exe, str(tmp_path / "pct.txt"), str(tmp_path / "pcs.txt"), "0.05", str(tmp_path / "b.txt"), str(tmp_path / "tgt.txt"), str(tmp_path / "src.txt")],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    f32 = np.float32
+    reg = fg.Registration(pct, pcs, bounds, 0.05)
+    assert list(reg.lut_dims()) == d["dims"]
+    rn = fg.RotNode(0.25, -0.125, 0.375, 0.125)
+    tn = np.array([[0.1 * i - 0.2, 0.05 * i, -0.03 * i, 0.25] for i in range(5)], f32)
+    tn[:, :3] = np.array([[f32(0.1) * f32(i) - f32(0.2), f32(0.05) * f32(i), f32(-0.03) * f32(i)] for i in range(5)], f32)
+    lb, ub = reg.compute_sse_error(rn, tn, False)
+    assert np.array_equal(lb, np.array(d["lb"], f32)) and np.array_equal(ub, np.array(d["ub"], f32))
+    t0 = np.array([0.01, -0.02, 0.005], f32)
+    assert f32(reg.compute_sse_error(rn.q.R, t0)) == f32(d["sse"])
+    icp = fg.IterativeClosestPoint3D(reg, None, None, 100, 0.005, rn.q.R, t0)
+    sse, R, t = icp.run()
+    assert f32(sse) == f32(d["icp_sse"]) and icp.iterations == d["icp_iters"]
+    assert np.array_equal(fg.nodes.to_glm(R), np.array(d["icp_R"], f32)) and np.array_equal(t, np.array(d["icp_t"], f32))
+    reg.close()
+    s = fg.FastGoICP(tgt, src, 0.05, 1e-3)  # the façade's default: SERIAL
+    Rr, tr = s.run()
+    assert f32(s.get_best_error()) == f32(d["run_sse"])
+    assert np.array_equal(fg.nodes.to_glm(Rr), np.array(d["run_R"], f32)) and np.allclose(tr, np.array(d["run_t"], f32), rtol=0, atol=0)
+    s.close()
