@@ -1,3 +1,5 @@
+# scratch script for ad-hoc GPU experiments (edited per experiment; see tools/gpu_profile.sh for the round profile)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 300 python -m pytest tests/test_gpu_cli_dist.py -m gpu -x -q -k "facades" 2>&1 | tail -25
+timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
