@@ -111,18 +111,20 @@ def test_serial_speculation_modes_walk_the_same_trajectory(tmp_path):
     import subprocess
     import sys
     code = ("import sys, json, numpy as np; sys.path.insert(0, %r); from tests import host_harness as hh; "
-            "G = np.load(%r); pre = 'runbun_'; "
+            "G = np.load(%r); pre = sys.argv[2]; "
             "r = hh.HostDriver(G[pre + 'tgt'], G[pre + 'src'], float(G[pre + 'res']), float(G[pre + 'mse']), schedule=int(sys.argv[1])).run(); "
-            "print(json.dumps({'stats': {k: int(v) for k, v in r['stats'].items() if k != 'bounds_calls' or True}, 'R': r['R'].tolist(), 't': r['t'].tolist(), 'sse': float(r['best_sse'])}))"
+            "print(json.dumps({'stats': {k: int(v) for k, v in r['stats'].items()}, 'R': r['R'].tolist(), 't': r['t'].tolist(), 'sse': float(r['best_sse'])}))"
             % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "goicp_golden.npz")))
-    out = {}
-    for mode in ("0", "1", "2"):
-        for sched in ("0", "3"):  # 3 = SERIAL over the asynchronous (two-slot) operator path of the harness
-            env = dict(os.environ, FGOICP_SERIAL_SPECULATE=mode)
-            p = subprocess.run([sys.executable, "-c", code, sched], env=env, capture_output=True, text=True, timeout=600)
-            assert p.returncode == 0, p.stderr[-2000:]
-            out[(mode, sched)] = json.loads(p.stdout.strip().splitlines()[-1])
-    ref = out[("0", "0")]
-    assert [ref["stats"][k] for k in KEYS] == list(G["runbun_stats"])
-    for key, o in out.items():
-        assert o["stats"] == ref["stats"] and o["R"] == ref["R"] and o["t"] == ref["t"] and o["sse"] == ref["sse"], key
+
+    def run(mode, sched, pre):  # sched 3 = SERIAL over the asynchronous (two-slot) operator path of the harness
+        env = dict(os.environ, FGOICP_SERIAL_SPECULATE=mode)
+        p = subprocess.run([sys.executable, "-c", code, sched, pre], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        return json.loads(p.stdout.strip().splitlines()[-1])
+
+    for pre, combos in (("runbun_", [("0", "0"), ("2", "0"), ("2", "3")]), ("runsyn_", [("0", "0"), ("1", "0"), ("1", "3"), ("2", "3")])):
+        ref = run(*combos[0], pre)
+        assert [ref["stats"][k] for k in KEYS] == list(G[pre + "stats"])
+        for mode, sched in combos[1:]:
+            o = run(mode, sched, pre)
+            assert o["stats"] == ref["stats"] and o["R"] == ref["R"] and o["t"] == ref["t"] and o["sse"] == ref["sse"], (pre, mode, sched)
