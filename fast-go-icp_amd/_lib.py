@@ -46,6 +46,9 @@ _SIGS = {
     "fgoicp_lut_dims": (C.c_int, [C.c_void_p, c_int_p]),
     "fgoicp_lut_read": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t]),
     "fgoicp_lut_search": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t, c_float_p]),
+    "fgoicp_lut_nodes": (C.c_int, [C.c_void_p, c_int_p, C.c_size_t, c_float_p]),
+    "fgoicp_bounds_point_distances": (C.c_int, [C.c_void_p, c_float_p, C.c_float, c_float_p, C.c_int, c_float_p]),
+    "fgoicp_ctx_sort_fallbacks": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "fgoicp_bounds_batch": (C.c_int, [C.c_void_p, c_float_p, C.c_float, c_float_p, C.c_int, C.c_int, c_float_p, c_float_p]),
     "fgoicp_bounds_multi": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_int_p, c_int_p, c_float_p, c_float_p,
                                       c_float_p]),

@@ -58,8 +58,62 @@ TickTiming g_tt;
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }  // namespace
 
-// Enqueues the window [pos, pos+rows) of a submission on its slot: descriptors -> device, sort the
-// (subcube, chunk) items by LUT cell, one bounds launch, one finalize.  Returns the window end.
+// Device half of a window whose descriptors sit in the slot's staging buffers (sl.win_groups groups, sl.win_evals evaluations,
+// sl.win_rows output rows): descriptors -> device, locality sort of the (evaluation, chunk) items, one bounds launch, one
+// finalize (or, trimmed, one selection).  Called again by tick_wait_window if the sort check failed.
+static int tick_launch_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
+    const int ng = sl.win_groups, neval = sl.win_evals, rows = sl.win_rows;
+    // A small tick (the tail of a round: a few long-running tasks left, or one of many ranks) is pure latency: its bounds
+    // kernel reads the descriptors straight from the pinned staging buffers and takes the items in submission order —
+    // two copies and four sort launches fewer on the critical path.  Results do not depend on the item order.
+    const bool small = (size_t)neval * c->nchunk1 <= (size_t)c->small_tick_items;
+    const TickGroup* dev_groups = small ? sl.hd_groups : sl.d_groups;
+    const TickSub* dev_subs = small ? sl.hd_subs : sl.d_subs;
+    *sl.h_sort_err = 0u;
+    if (!small) {
+        // descriptors + locality sort on the slot's side stream (overlaps the other slot's bounds kernel); the main stream joins behind it
+        HIPCHK(hipMemcpyAsync(sl.d_groups, sl.h_groups, sizeof(TickGroup) * ng, hipMemcpyHostToDevice, sl.sort_stream));
+        HIPCHK(hipMemcpyAsync(sl.d_subs, sl.h_subs, sizeof(TickSub) * neval, hipMemcpyHostToDevice, sl.sort_stream));
+        ++c->sorted_ticks;
+        const int fault = c->sort_fault_tick && c->sorted_ticks == (uint64_t)c->sort_fault_tick;
+        launch_tick_sort(c->geom, c->d_chunk_cen, c->nchunk1, sl.d_groups, sl.d_subs, neval, c->cell_shift, sl.d_keys, sl.d_ranks, sl.d_hist, sl.d_hist_xcd, sl.d_xoff, sl.d_block_sums, sl.d_cursor, sl.d_sorted,
+                         c->sort_xcd ? 1 : 0, c->sort_check ? sl.hd_sort_err : nullptr, fault, sl.sort_stream);
+        HIPCHK(hipEventRecord(sl.sorted_ev, sl.sort_stream));
+        HIPCHK(hipStreamWaitEvent(sl.stream, sl.sorted_ev, 0));
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profile) {
+        if (c->ev_used == (int)c->ev_start.size()) {  // drain both slots before recycling events
+            HIPCHK(hipStreamSynchronize(c->stream));
+            int rc = ctx_flush_profile(c);
+            if (rc) return rc;
+        }
+        e0 = c->ev_start[c->ev_used];
+        e1 = c->ev_stop[c->ev_used];
+        c->ev_used++;
+        c->prof_launches++;
+        c->prof_subcubes += rows;
+        c->prof_evals += neval;  // a twin pair is two subcubes and one evaluation
+    }
+    launch_bounds_sorted(c->d_src, (int)c->ns, c->d_lut, c->d_lut_zp, c->lut_layout, c->geom, c->nchunk1, c->chunk_pts, dev_groups, dev_subs, neval, small ? nullptr : sl.d_sorted, sl.d_partials,
+                         c->inliers ? sl.d_evals : nullptr, c->erow, e0, e1, sl.stream);
+    // the per-subcube sums run on the slot's side stream, so the main stream holds nothing but bounds kernels back to back
+    hipStream_t fin = c->finalize_on_side ? sl.sort_stream : sl.stream;
+    if (fin != sl.stream) {
+        HIPCHK(hipEventRecord(sl.bounds_ev, sl.stream));
+        HIPCHK(hipStreamWaitEvent(fin, sl.bounds_ev, 0));
+    }
+    if (c->inliers)  // trimmed: per row one selection of the k smallest e, both sums from it
+        launch_trim_rows(sl.d_evals, c->erow, (int)c->ns, (int)c->inliers, rows, sl.hd_row_span, sl.hd_ub, sl.hd_lb, fin);
+    else
+        launch_bounds_finalize(sl.d_partials, c->nchunk1, rows, sl.hd_lb, sl.hd_ub, fin);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(sl.done, fin));
+    return FGOICP_OK;
+}
+
+// Enqueues the window [pos, pos+rows) of a submission on its slot: packs the descriptors (host), then tick_launch_window.
+// Returns the window end.
 static int tick_enqueue_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl, int G, const float* R9, const float* rot_span, const int* fix_rot,
                                const int* offsets, const float* tn4, const int* twin, int pos, int* end_out) {
     const double t0 = g_tt.on ? now_s() : 0;
@@ -91,6 +145,7 @@ static int tick_enqueue_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl, int G, c
     for (int r = 0; r < rows; ++r) {
         const int i = pos + r;
         const int gi = sl.row_group[(size_t)r];
+        sl.h_row_span[r] = tn4[4 * (size_t)i + 3];
         int j = twin ? twin[i] : -1;
         if (j >= pos && j < end && j != i && twin[j] == i) {
             const int gj = sl.row_group[(size_t)(j - pos)];
@@ -117,58 +172,32 @@ static int tick_enqueue_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl, int G, c
     }
     for (int k = 0; k < ng; ++k) sl.h_groups[k].pad_ = 0;
     const double t1 = g_tt.on ? now_s() : 0;
-    // A small tick (the tail of a round: a few long-running tasks left, or one of many ranks) is pure latency: its bounds
-    // kernel reads the descriptors straight from the pinned staging buffers and takes the items in submission order —
-    // two copies and four sort launches fewer on the critical path.  Results do not depend on the item order.
-    const bool small = (size_t)neval * c->nchunk1 <= (size_t)c->small_tick_items;
-    const TickGroup* dev_groups = small ? sl.hd_groups : sl.d_groups;
-    const TickSub* dev_subs = small ? sl.hd_subs : sl.d_subs;
-    if (!small) {
-        // descriptors + locality sort on the slot's side stream (overlaps the other slot's bounds kernel); the main stream joins behind it
-        HIPCHK(hipMemcpyAsync(sl.d_groups, sl.h_groups, sizeof(TickGroup) * ng, hipMemcpyHostToDevice, sl.sort_stream));
-        HIPCHK(hipMemcpyAsync(sl.d_subs, sl.h_subs, sizeof(TickSub) * neval, hipMemcpyHostToDevice, sl.sort_stream));
-        launch_tick_sort(c->geom, c->d_chunk_cen, c->nchunk1, sl.d_groups, sl.d_subs, neval, c->cell_shift, sl.d_keys, sl.d_ranks, sl.d_hist, sl.d_hist_xcd, sl.d_xoff, sl.d_block_sums, sl.d_cursor, sl.d_sorted,
-                         sl.sort_stream);
-        HIPCHK(hipEventRecord(sl.sorted_ev, sl.sort_stream));
-        HIPCHK(hipStreamWaitEvent(sl.stream, sl.sorted_ev, 0));
-    }
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->profile) {
-        if (c->ev_used == (int)c->ev_start.size()) {  // drain both slots before recycling events
-            HIPCHK(hipStreamSynchronize(c->stream));
-            int rc = ctx_flush_profile(c);
-            if (rc) return rc;
-        }
-        e0 = c->ev_start[c->ev_used];
-        e1 = c->ev_stop[c->ev_used];
-        c->ev_used++;
-        c->prof_launches++;
-        c->prof_subcubes += rows;
-        c->prof_evals += neval;  // a twin pair is two subcubes and one evaluation
-    }
-    launch_bounds_sorted(c->d_src, (int)c->ns, c->d_lut, c->d_lut_zp, c->lut_layout, c->geom, c->nchunk1, c->chunk_pts, dev_groups, dev_subs, neval, small ? nullptr : sl.d_sorted, sl.d_partials,
-                         c->inliers ? sl.d_vals : nullptr, e0, e1, sl.stream);
-    // the per-subcube sums run on the slot's side stream, so the main stream holds nothing but bounds kernels back to back
-    hipStream_t fin = c->finalize_on_side ? sl.sort_stream : sl.stream;
-    if (fin != sl.stream) {
-        HIPCHK(hipEventRecord(sl.bounds_ev, sl.stream));
-        HIPCHK(hipStreamWaitEvent(fin, sl.bounds_ev, 0));
-    }
-    if (c->inliers)  // trimmed: the k smallest ub terms (column 0) and the k smallest lb terms (column 1) of every subcube
-        launch_trim_select(reinterpret_cast<const float*>(sl.d_vals), 2 * c->ns, 2, (int)c->ns, (int)c->inliers, rows, sl.hd_ub, sl.hd_lb, nullptr, nullptr, fin);
-    else
-        launch_bounds_finalize(sl.d_partials, c->nchunk1, rows, sl.hd_lb, sl.hd_ub, fin);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(sl.done, fin));
     sl.win_pos = pos;
     sl.win_rows = rows;
+    sl.win_groups = ng;
+    sl.win_evals = neval;
+    const int rc = tick_launch_window(c, sl);
     if (g_tt.on) { g_tt.pack += t1 - t0; g_tt.enqueue += now_s() - t1; g_tt.ticks++; }
-    return FGOICP_OK;
+    return rc;
 }
 
 static int tick_wait_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
     const double t2 = g_tt.on ? now_s() : 0;
     HIPCHK(hipEventSynchronize(sl.done));
+    if (*sl.h_sort_err) {
+        // The tick's `sorted` was not a permutation: the XCD-private histogram (workgroup-scope atomics, see kernels.hip) is
+        // not a single point of coherence on this device.  Switch this context to device-scope atomics for good and repeat
+        // the window (its descriptors are still in the staging buffers); a second failure is an error.
+        c->sort_xcd = false;
+        c->sort_fallbacks++;
+        HIPCHK(hipStreamSynchronize(sl.sort_stream));
+        HIPCHK(hipMemsetAsync(sl.d_hist, 0, sizeof(unsigned) * kTickNumKeys, sl.sort_stream));   // state a failed sort may have left
+        HIPCHK(hipMemsetAsync(sl.d_hist_xcd, 0, sizeof(unsigned) * 16 * kTickNumKeys, sl.sort_stream));
+        int rc = tick_launch_window(c, sl);
+        if (rc) return rc;
+        HIPCHK(hipEventSynchronize(sl.done));
+        if (*sl.h_sort_err) { set_error("tick sort did not produce a permutation of the work items (device-scope atomics)"); return FGOICP_ERR_HIP; }
+    }
     const double t3 = g_tt.on ? now_s() : 0;
     std::memcpy(sl.lb.data() + sl.win_pos, sl.h_lb, sizeof(float) * sl.win_rows);
     std::memcpy(sl.ub.data() + sl.win_pos, sl.h_ub, sizeof(float) * sl.win_rows);
@@ -297,10 +326,18 @@ static int sse_enqueue(fgoicp_ctx* c, const float* R9, const float* t3, const ui
         launch_fill_u32(c->d_min_bits, 0x501502F9u /* bits(1e10f) */, c->ns, st);
         launch_nn_min(c->d_src, ns, c->d_tgt, (int)c->nt, R9, t3, 1, c->d_min_bits, st);
     } else {
-        launch_nn_scan(c->d_src, ns, c->bvh_tgt.view(), c->d_lut, c->geom, R9, t3, 1, 0, c->d_tgt, (int)c->nt, seed_idx, c->d_min_bits, st);
+        const float* skip_lb = nullptr;
+        const uint32_t* skip_u = nullptr;
+        if (c->inliers && c->trim_skip) {  // trimmed: queries provably beyond the k-th smallest distance are left out of the exact search
+            launch_nn_prep(c->d_src, ns, c->d_lut, c->geom, R9, t3, 1, c->d_tgt, (int)c->nt, seed_idx, c->bounds6, c->d_nn_ub, c->d_nn_lb, st);
+            launch_trim_select(c->d_nn_ub, ns, (int)c->inliers, nullptr, c->d_sel + 8, c->d_sel_wide, st);
+            skip_lb = c->d_nn_lb;
+            skip_u = c->d_sel + 8;
+        }
+        launch_nn_scan(c->d_src, ns, c->bvh_tgt.view(), c->d_lut, c->geom, R9, t3, 1, 0, c->d_tgt, (int)c->nt, seed_idx, skip_lb, skip_u, c->d_min_bits, st);
     }
     if (c->inliers) {  // trimmed SSE: the k smallest nearest-neighbour terms
-        launch_trim_select(reinterpret_cast<const float*>(c->d_min_bits), 0, 1, ns, (int)c->inliers, 1, c->hd_trim, nullptr, nullptr, c->d_sel_wide, st);
+        launch_trim_select(reinterpret_cast<const float*>(c->d_min_bits), ns, (int)c->inliers, c->hd_trim, nullptr, c->d_sel_wide, st);
     } else {
         const int nb = reduce_blocks_for(ns);
         launch_sum_f32_as_f64(c->d_min_bits, ns, c->d_bp3, nb, st);
@@ -332,13 +369,21 @@ static int procrustes_enqueue(fgoicp_ctx* c, const uint32_t* seed_idx, uint32_t*
         launch_nn_tie_threshold(c->d_min_bits, ns, c->d_thr_bits, st);
         launch_nn_first_index(c->d_work, ns, c->d_tgt, nt, c->d_thr_bits, idx, st);
     } else {
-        launch_nn_scan(c->d_work, ns, c->bvh_tgt.view(), c->d_lut, c->geom, nullptr, nullptr, 0, 1, c->d_tgt, nt, seed_idx, idx, st);
+        const float* skip_lb = nullptr;
+        const uint32_t* skip_u = nullptr;
+        if (c->inliers && c->trim_skip) {  // trimmed: points provably outside the inlier set get no correspondence
+            launch_nn_prep(c->d_work, ns, c->d_lut, c->geom, nullptr, nullptr, 0, c->d_tgt, nt, seed_idx, c->bounds6, c->d_nn_ub2, c->d_nn_lb2, st);
+            launch_trim_select(c->d_nn_ub2, ns, (int)c->inliers, nullptr, c->d_sel + 4, wide, st);
+            skip_lb = c->d_nn_lb2;
+            skip_u = c->d_sel + 4;
+        }
+        launch_nn_scan(c->d_work, ns, c->bvh_tgt.view(), c->d_lut, c->geom, nullptr, nullptr, 0, 1, c->d_tgt, nt, seed_idx, skip_lb, skip_u, idx, st);
     }
     const int nb = reduce_blocks_for(ns);
     const unsigned char* use = nullptr;
     int ncount = ns;
     if (c->inliers) {  // trimmed ICP: only the k closest correspondences enter the Procrustes sums
-        launch_icp_inliers(c->d_work, c->d_tgt, idx, ns, nt, (int)c->inliers, c->d_d2, c->d_sel, c->d_eq, c->d_slot_of_orig, c->d_use, wide, st);
+        launch_icp_inliers(c->d_work, c->d_tgt, idx, ns, nt, (int)c->inliers, c->d_d2, c->d_sel, c->d_eq, c->d_orig_of_slot, c->d_use, wide, st);
         use = c->d_use;
         ncount = (int)c->inliers;
     }
@@ -461,30 +506,42 @@ int ctx_set_inliers(fgoicp_ctx* c, size_t k) {
     if (k >= c->ns) k = 0;
     if (k && !c->sorted_bounds) { set_error("trimming needs the sorted bounds path (FGOICP_BOUNDS_SORTED=0 is set)"); return FGOICP_ERR_INVALID_ARG; }
     if (c->slots[0].inflight || c->slots[1].inflight) { set_error("fgoicp_ctx_set_inliers: a bounds submission is in flight"); return FGOICP_ERR_INVALID_ARG; }
-    if (k && !c->d_use) {
-        // per-point {ub, lb} terms of one window, per slot: up to 12 GiB (a sixth of what is free): 1500 subcubes of a 1M-point
-        // cloud per window instead of 190 — the select kernel launches one block per (subcube, bound) and needs >= 512 of them
+    if (k && !c->trim_ready) {
+        // per-point e of one window, per slot: up to 12 GiB (a sixth of what is free): 3000 subcubes of a 1M-point cloud per
+        // window — the selection launches one workgroup per row and wants several hundred of them
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         const size_t budget = std::max<size_t>((size_t)3 << 29, std::min<size_t>((size_t)12 << 30, free_b / 6));
-        size_t rows = budget / (sizeof(float2) * c->ns);
+        c->erow = (c->ns + 3) & ~(size_t)3;  // rows start 16-byte aligned
+        size_t rows = budget / (sizeof(float) * c->erow);
         rows = std::max<size_t>(1, std::min<size_t>(rows, (size_t)c->max_subcubes));
         c->vals_rows = (int)rows;
-        for (auto& sl : c->slots) HIPCHK(hipMalloc(&sl.d_vals, sizeof(float2) * c->ns * rows));
-        HIPCHK(hipMalloc(&c->d_d2, sizeof(float) * c->ns));
-        HIPCHK(hipMalloc(&c->d_sel, sizeof(uint32_t) * 8));
-        HIPCHK(hipMalloc(&c->d_eq, sizeof(uint32_t)));
+        // every pointer is guarded on its own: a call that failed half-way (out of memory) can be repeated without leaking
+        for (auto& sl : c->slots) if (!sl.d_evals) HIPCHK(hipMalloc(&sl.d_evals, sizeof(float) * c->erow * rows));
+        if (!c->d_d2) HIPCHK(hipMalloc(&c->d_d2, sizeof(float) * c->ns));
+        if (!c->d_nn_lb) HIPCHK(hipMalloc(&c->d_nn_lb, sizeof(float) * c->ns));
+        if (!c->d_nn_ub) HIPCHK(hipMalloc(&c->d_nn_ub, sizeof(float) * c->ns));
+        if (!c->d_nn_lb2) HIPCHK(hipMalloc(&c->d_nn_lb2, sizeof(float) * c->ns));
+        if (!c->d_nn_ub2) HIPCHK(hipMalloc(&c->d_nn_ub2, sizeof(float) * c->ns));
+        if (!c->d_sel) HIPCHK(hipMalloc(&c->d_sel, sizeof(uint32_t) * 16));
+        if (!c->d_eq) HIPCHK(hipMalloc(&c->d_eq, sizeof(uint32_t)));
         {
-            const char* e = std::getenv("FGOICP_SELECT_WIDE");  // tuning knob: 0 = always the one-block-per-row selection
-            if (!(e && std::atoi(e) == 0)) { HIPCHK(hipMalloc(&c->d_sel_wide, 65536)); HIPCHK(hipMalloc(&c->d_sel_wide2, 65536)); }
+            const char* e = std::getenv("FGOICP_SELECT_WIDE");  // tuning knob: 0 = always the one-block selection for single rows
+            if (!(e && std::atoi(e) == 0)) {
+                if (!c->d_sel_wide) HIPCHK(hipMalloc(&c->d_sel_wide, 65536));
+                if (!c->d_sel_wide2) HIPCHK(hipMalloc(&c->d_sel_wide2, 65536));
+            }
         }
-        HIPCHK(hipMalloc(&c->d_use, c->ns));
-        HIPCHK(hipMalloc(&c->d_slot_of_orig, sizeof(uint32_t) * c->ns));
-        std::vector<uint32_t> inv(c->ns);
-        for (size_t i = 0; i < c->ns; ++i) inv[c->perm[i]] = (uint32_t)i;
-        HIPCHK(hipMemcpy(c->d_slot_of_orig, inv.data(), sizeof(uint32_t) * c->ns, hipMemcpyHostToDevice));
-        HIPCHK(hipHostMalloc((void**)&c->h_trim, sizeof(float) * 4, hipHostMallocMapped));
-        HIPCHK(hipHostGetDevicePointer((void**)&c->hd_trim, c->h_trim, 0));
+        if (!c->d_use) HIPCHK(hipMalloc(&c->d_use, c->ns));
+        if (!c->d_orig_of_slot) {
+            HIPCHK(hipMalloc(&c->d_orig_of_slot, sizeof(uint32_t) * c->ns));
+            HIPCHK(hipMemcpy(c->d_orig_of_slot, c->perm.data(), sizeof(uint32_t) * c->ns, hipMemcpyHostToDevice));
+        }
+        if (!c->h_trim) {
+            HIPCHK(hipHostMalloc((void**)&c->h_trim, sizeof(float) * 4, hipHostMallocMapped));
+            HIPCHK(hipHostGetDevicePointer((void**)&c->hd_trim, c->h_trim, 0));
+        }
+        c->trim_ready = true;
     }
     c->inliers = k;
     return FGOICP_OK;
@@ -525,6 +582,11 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
     c->nt = nt;
     c->profile = (flags & FGOICP_FLAG_PROFILE) != 0;
     c->brute_force_nn = (flags & FGOICP_FLAG_BRUTE_FORCE_NN) != 0;
+    std::memcpy(c->bounds6, bounds6, sizeof(c->bounds6));
+    if (const char* e = std::getenv("FGOICP_TRIM_SKIP")) c->trim_skip = std::atoi(e) != 0;        // tuning knob
+    if (const char* e = std::getenv("FGOICP_SORT_XCD")) c->sort_xcd = std::atoi(e) != 0;          // tuning knob
+    if (const char* e = std::getenv("FGOICP_SORT_CHECK")) c->sort_check = std::atoi(e) != 0;      // tuning knob: 0 = no permutation check of the tick sort
+    if (const char* e = std::getenv("FGOICP_SORT_FAULT_TICK")) c->sort_fault_tick = std::atoi(e); // test hook: spoil the n-th sorted tick
     auto fail = [&](int rc) { fgoicp_ctx_destroy(c); return rc; };
 #define CHK(expr) do { hipError_t e2_ = (expr); if (e2_ != hipSuccess) { set_error(std::string(#expr) + " failed: " + hipGetErrorString(e2_)); return fail(e2_ == hipErrorOutOfMemory ? FGOICP_ERR_OOM : FGOICP_ERR_HIP); } } while (0)
     CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -704,6 +766,11 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
             CHK(hipHostMalloc((void**)&sl.h_subs, sizeof(TickSub) * c->max_subcubes, hipHostMallocMapped));
             CHK(hipHostGetDevicePointer((void**)&sl.hd_groups, sl.h_groups, 0));
             CHK(hipHostGetDevicePointer((void**)&sl.hd_subs, sl.h_subs, 0));
+            CHK(hipHostMalloc((void**)&sl.h_row_span, sizeof(float) * c->max_subcubes, hipHostMallocMapped));
+            CHK(hipHostGetDevicePointer((void**)&sl.hd_row_span, sl.h_row_span, 0));
+            CHK(hipHostMalloc((void**)&sl.h_sort_err, sizeof(unsigned) * 4, hipHostMallocMapped));
+            CHK(hipHostGetDevicePointer((void**)&sl.hd_sort_err, sl.h_sort_err, 0));
+            *sl.h_sort_err = 0u;
             CHK(hipMalloc(&sl.d_keys, sizeof(unsigned short) * max_items));
             CHK(hipMalloc(&sl.d_ranks, sizeof(unsigned) * max_items));
             CHK(hipMalloc(&sl.d_hist, sizeof(unsigned) * kTickNumKeys));
@@ -771,7 +838,7 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
     if (c->h_cen) (void)hipHostFree(c->h_cen);
     bvh_free(&c->bvh_tgt);
     (void)hipFree(c->d_chunk_cen);
-    (void)hipFree(c->d_d2); (void)hipFree(c->d_sel); (void)hipFree(c->d_eq); (void)hipFree(c->d_use); (void)hipFree(c->d_slot_of_orig); (void)hipFree(c->d_sel_wide); (void)hipFree(c->d_sel_wide2);
+    (void)hipFree(c->d_d2); (void)hipFree(c->d_sel); (void)hipFree(c->d_eq); (void)hipFree(c->d_use); (void)hipFree(c->d_orig_of_slot); (void)hipFree(c->d_nn_lb); (void)hipFree(c->d_nn_ub); (void)hipFree(c->d_nn_lb2); (void)hipFree(c->d_nn_ub2); (void)hipFree(c->d_sel_wide); (void)hipFree(c->d_sel_wide2);
     if (c->h_trim) (void)hipHostFree(c->h_trim);
     for (int k = 0; k < 2; ++k) {
         fgoicp_ctx::TickSlot& sl = c->slots[k];
@@ -779,7 +846,9 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
         if (sl.sorted_ev) (void)hipEventDestroy(sl.sorted_ev);
         if (sl.bounds_ev) (void)hipEventDestroy(sl.bounds_ev);
         if (sl.sort_stream && sl.sort_stream != c->stream) { (void)hipStreamSynchronize(sl.sort_stream); (void)hipStreamDestroy(sl.sort_stream); }
-        (void)hipFree(sl.d_vals);
+        (void)hipFree(sl.d_evals);
+        if (sl.h_row_span) (void)hipHostFree(sl.h_row_span);
+        if (sl.h_sort_err) (void)hipHostFree(sl.h_sort_err);
         (void)hipFree(sl.d_groups); (void)hipFree(sl.d_subs); (void)hipFree(sl.d_keys); (void)hipFree(sl.d_ranks); (void)hipFree(sl.d_hist);
         (void)hipFree(sl.d_cursor); (void)hipFree(sl.d_block_sums); (void)hipFree(sl.d_hist_xcd); (void)hipFree(sl.d_xoff); (void)hipFree(sl.d_sorted); (void)hipFree(sl.d_partials);
         if (sl.h_groups) (void)hipHostFree(sl.h_groups);
@@ -811,6 +880,23 @@ int fgoicp_lut_read(fgoicp_ctx* c, float* out, size_t capacity) {
     hipError_t e = hipMemcpyAsync(out, d, total * sizeof(float), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
+    HIPCHK(e);
+    return FGOICP_OK;
+}
+
+int fgoicp_lut_nodes(fgoicp_ctx* c, const int* xyz, size_t n, float* out) {
+    if (!c || !xyz || !out) return FGOICP_ERR_INVALID_ARG;
+    if (n == 0) return FGOICP_OK;
+    HIPCHK(hipSetDevice(c->device));
+    int* dq = nullptr;
+    float* dout = nullptr;
+    HIPCHK(hipMalloc(&dq, 3 * n * sizeof(int)));
+    hipError_t e = hipMalloc(&dout, n * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(dq, xyz, 3 * n * sizeof(int), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) { launch_lut_nodes(c->d_lut, c->geom, dq, n, dout, c->stream); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dout, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dq); (void)hipFree(dout);
     HIPCHK(e);
     return FGOICP_OK;
 }
@@ -858,7 +944,7 @@ int fgoicp_bounds_submit(fgoicp_ctx* c, int slot, int G, const float* R9, const 
 }
 
 int fgoicp_bounds_collect(fgoicp_ctx* c, int slot, float* lb_out, float* ub_out) {
-    if (!c || slot < 0 || slot > 1) return FGOICP_ERR_INVALID_ARG;
+    if (!c || slot < 0 || slot > 1 || !lb_out || !ub_out) return FGOICP_ERR_INVALID_ARG;
     return ctx_bounds_collect(c, slot, lb_out, ub_out);
 }
 
@@ -866,6 +952,28 @@ int fgoicp_bounds_batch(fgoicp_ctx* c, const float* R9, float rot_span, const fl
     if (B < 0) return FGOICP_ERR_INVALID_ARG;
     const int offsets[2] = {0, B};
     return fgoicp_bounds_multi(c, 1, R9, &rot_span, &fix_rot, offsets, tn4, lb_out, ub_out);
+}
+
+int fgoicp_bounds_point_distances(fgoicp_ctx* c, const float* R9, float rot_span, const float* tnode4, int fix_rot, float* e_out) {
+    if (!c || !R9 || !tnode4 || !e_out) return FGOICP_ERR_INVALID_ARG;
+    if (!c->inliers || !c->sorted_bounds) { set_error("fgoicp_bounds_point_distances: trimming is off (fgoicp_ctx_set_inliers)"); return FGOICP_ERR_INVALID_ARG; }
+    const int offsets[2] = {0, 1};
+    float lb = 0.f, ub = 0.f;
+    int rc = ctx_bounds_submit(c, 0, 1, R9, &rot_span, &fix_rot, offsets, tnode4, nullptr);
+    if (rc) return rc;
+    rc = ctx_bounds_collect(c, 0, &lb, &ub);
+    if (rc) return rc;
+    std::vector<float> row(c->ns);
+    HIPCHK(hipMemcpy(row.data(), c->slots[0].d_evals, sizeof(float) * c->ns, hipMemcpyDeviceToHost));  // row 0 of the window just collected
+    for (size_t i = 0; i < c->ns; ++i) e_out[c->perm[i]] = row[i];
+    return FGOICP_OK;
+}
+
+int fgoicp_ctx_sort_fallbacks(const fgoicp_ctx* c, uint64_t* sorted_ticks, uint64_t* fallbacks) {
+    if (!c) return FGOICP_ERR_INVALID_ARG;
+    if (sorted_ticks) *sorted_ticks = c->sorted_ticks;
+    if (fallbacks) *fallbacks = c->sort_fallbacks;
+    return FGOICP_OK;
 }
 
 int fgoicp_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out) {

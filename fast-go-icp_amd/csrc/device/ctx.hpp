@@ -53,13 +53,20 @@ struct fgoicp_ctx {
         unsigned *d_hist_xcd = nullptr, *d_xoff = nullptr;   // per-XCD histograms of the tick sort and their offsets inside a bin
         double2* d_partials = nullptr;           // [max_subcubes][nchunk1]
         float *h_lb = nullptr, *h_ub = nullptr, *hd_lb = nullptr, *hd_ub = nullptr;  // pinned results of the window in flight
-        float2* d_vals = nullptr;                // trimmed mode: per-point {ub, lb} terms, [vals_rows][ns]
+        float* d_evals = nullptr;                // trimmed mode: per-point e = max(d, 0) of every output row, [vals_rows][erow]
+        float *h_row_span = nullptr, *hd_row_span = nullptr;   // translation span of every output row of the window (pinned)
+        unsigned *h_sort_err = nullptr, *hd_sort_err = nullptr; // pinned: set by tick_check_kernel when `sorted` is no permutation
+        int win_groups = 0, win_evals = 0;       // the window in flight: groups and evaluations in the staging buffers
         std::vector<float> lb, ub;
         std::vector<int> row_group;              // window-local group of every output row (packing scratch)               // results of the whole submission
         int total = 0, win_pos = 0, win_rows = 0;
         bool inflight = false;
     };
     bool sorted_bounds = true;
+    bool sort_xcd = true;                    // XCD-private histograms for the tick sort (cleared for good if a permutation check fails)
+    bool sort_check = true;                  // verify on the device that every tick's `sorted` is a permutation
+    int sort_fault_tick = 0;                 // test hook
+    uint64_t sorted_ticks = 0, sort_fallbacks = 0;
     int nchunk1 = 0, max_groups = 0, cell_shift = 4;
     int chunk_pts = 256;                     // points per (subcube, chunk) work item of the sorted path
     bool finalize_on_side = true;
@@ -71,8 +78,13 @@ struct fgoicp_ctx {
     // EXTENSION: trimmed Go-ICP (sum of the `inliers` smallest per-point terms; 0 = off)
     size_t inliers = 0;
     int vals_rows = 0;                       // subcubes per window in trimmed mode (memory budget)
+    size_t erow = 0;                         // floats per row of d_evals (ns rounded up to a multiple of 4)
+    bool trim_ready = false;                 // trimmed-mode buffers allocated
+    bool trim_skip = true;                   // exact NN only for queries that can be among the k smallest (nn_prep_kernel)
+    float bounds6[6] = {0, 0, 0, 0, 0, 0};   // the target's bounding box as passed to fgoicp_ctx_create
     float* d_d2 = nullptr;                   // squared correspondence distances
-    uint32_t *d_sel = nullptr, *d_eq = nullptr, *d_slot_of_orig = nullptr, *d_sel_wide = nullptr, *d_sel_wide2 = nullptr;
+    float *d_nn_lb = nullptr, *d_nn_ub = nullptr, *d_nn_lb2 = nullptr, *d_nn_ub2 = nullptr;  // LUT brackets of the nearest distance (SSE pass / correspondence pass)
+    uint32_t *d_sel = nullptr, *d_eq = nullptr, *d_orig_of_slot = nullptr, *d_sel_wide = nullptr, *d_sel_wide2 = nullptr;
     unsigned char* d_use = nullptr;          // inlier mask of the current Procrustes step
     float *h_trim = nullptr, *hd_trim = nullptr;   // pinned trimmed SSE
 

@@ -426,6 +426,16 @@ __global__ __launch_bounds__(64) void tick_scatter_xcd_kernel(const unsigned sho
         sorted[cursor[k] + xoff[(size_t)(r >> 28) * kNumKeys + k] + (r & 0x0FFFFFFFu)] = (unsigned)i;
     }
 }
+// `sorted` was filled with 0xFFFFFFFF before the scatter, which stores exactly nitems values into its nitems slots: if no slot
+// still holds an out-of-range value every slot was written, hence written exactly once — `sorted` is a permutation of the
+// items.  Anything else (two items drew the same rank: the XCD-private histogram's workgroup-scope atomics did not behave
+// as one point of coherence) raises *err (pinned host memory); the context then repeats the tick with device-scope atomics.
+__global__ __launch_bounds__(64) void tick_check_kernel(const unsigned* __restrict__ sorted, size_t nitems, unsigned* __restrict__ err) {
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < nitems; i += (size_t)gridDim.x * 64) bad = bad || sorted[i] >= nitems;
+    if (__any(bad) && threadIdx.x == 0) *err = 1u;
+}
+__global__ void tick_fault_kernel(unsigned* sorted) { sorted[0] = 0xFFFFFFFFu; }  // test hook (FGOICP_SORT_FAULT_TICK): a slot no item was scattered to
 // A/B only (FGOICP_SORT_RANKS=0): the classic scatter with its own atomic per item
 __global__ __launch_bounds__(64) void tick_scatter_atomic_kernel(const unsigned short* __restrict__ keys, size_t nitems, unsigned* __restrict__ cursor,
                                                                  unsigned* __restrict__ sorted) {
@@ -447,11 +457,12 @@ __global__ __launch_bounds__(THREADS) void bounds_sorted_kernel(const float4* __
                                                                 const float2* __restrict__ zp, LutGeom g,
                                                                 const TickGroup* __restrict__ groups, const TickSub* __restrict__ subs,
                                                                 const unsigned* __restrict__ sorted, int nchunk, int chunk_pts,
-                                                                double2* __restrict__ partials, float2* __restrict__ vals) {
+                                                                double2* __restrict__ partials, float* __restrict__ evals, size_t erow) {
     static_assert(THREADS % 64 == 0 && THREADS * P <= kBlock, "one pass covers THREADS * P points");
     __shared__ double red[4 * (THREADS / 64)];
     const unsigned slot = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned item = sorted ? sorted[slot] : slot;  // small ticks come unsorted
+    if (item >= gridDim.x) return;  // never taken when `sorted` is a permutation (tick_check_kernel verifies that on the device)
     const int s = (int)(item / (unsigned)nchunk);
     const int chunk = (int)(item - (unsigned)s * (unsigned)nchunk);
     const TickSub sb = subs[s];
@@ -504,6 +515,21 @@ __global__ __launch_bounds__(THREADS) void bounds_sorted_kernel(const float4* __
             float d = sqrtf(dsq);                                                 // :48
             const int i = first + k * THREADS;
             const bool valid = i < ns;
+            if (TRIM) {
+                // trimmed Go-ICP: both bounds are non-decreasing functions of e = max(d, 0) (ub = e*e, lb = max(e - r_t, 0)^2 —
+                // the same fp32 values as :54-58), so ONE row of e per variant carries both selections (trim_rows_kernel)
+                if (valid) {
+                    if (dual) {
+                        evals[(size_t)sb.out0 * erow + i] = d > 0.0f ? d : 0.0f;
+                        d -= 2.0f * p[k].w * gr.sin_half;
+                        evals[(size_t)sb.out1 * erow + i] = d > 0.0f ? d : 0.0f;
+                    } else {
+                        if (!gr.fix_rot) d -= 2.0f * p[k].w * gr.sin_half;
+                        evals[(size_t)sb.out0 * erow + i] = d > 0.0f ? d : 0.0f;
+                    }
+                }
+                continue;
+            }
             if (dual) {  // wave-uniform
                 const float ub1 = d > 0.0f ? d * d : 0.0f;                        // fix_rot = 1: :54
                 const float l1 = d - trans_uncertain_radius;                      // :57
@@ -512,29 +538,18 @@ __global__ __launch_bounds__(THREADS) void bounds_sorted_kernel(const float4* __
                 const float ub0 = d > 0.0f ? d * d : 0.0f;
                 const float l0 = d - trans_uncertain_radius;
                 const float lb0 = l0 > 0.0f ? l0 * l0 : 0.0f;
-                if (TRIM) {
-                    if (valid) {
-                        vals[(size_t)sb.out0 * ns + i] = make_float2(ub1, lb1);
-                        vals[(size_t)sb.out1 * ns + i] = make_float2(ub0, lb0);
-                    }
-                } else {
-                    acc[0] += valid ? (double)ub1 : 0.0;
-                    acc[1] += valid ? (double)lb1 : 0.0;
-                    acc[2] += valid ? (double)ub0 : 0.0;
-                    acc[3] += valid ? (double)lb0 : 0.0;
-                }
+                acc[0] += valid ? (double)ub1 : 0.0;
+                acc[1] += valid ? (double)lb1 : 0.0;
+                acc[2] += valid ? (double)ub0 : 0.0;
+                acc[3] += valid ? (double)lb0 : 0.0;
                 continue;
             }
             if (!gr.fix_rot) d -= 2.0f * p[k].w * gr.sin_half;                    // :39-43, :49-52
             const float ubv = d > 0.0f ? d * d : 0.0f;                            // :54
             const float l = d - trans_uncertain_radius;                           // :57
             const float lbv = l > 0.0f ? l * l : 0.0f;                            // :58
-            if (TRIM) {  // trimmed Go-ICP: the per-point terms themselves (the selection runs in trim_select_kernel)
-                if (valid) vals[(size_t)sb.out0 * ns + i] = make_float2(ubv, lbv);
-            } else {
-                acc[0] += valid ? (double)ubv : 0.0;
-                acc[1] += valid ? (double)lbv : 0.0;
-            }
+            acc[0] += valid ? (double)ubv : 0.0;
+            acc[1] += valid ? (double)lbv : 0.0;
         }
     }
     if (!TRIM) {
@@ -556,10 +571,199 @@ __global__ __launch_bounds__(THREADS) void bounds_sorted_kernel(const float4* __
 
 // ---------------------------------------------------------------------------------------------
 // EXTENSION — trimmed Go-ICP (no reference behaviour: `params.trim` is parsed and ignored upstream).
-// Sum of the k smallest of n non-negative floats, exactly: a 3-level radix select on the bit pattern
-// (11 + 11 + 10 bits, LDS histograms) finds the k-th smallest value v_k and how many copies of it are
-// needed, then  sum = sum_{v < v_k} v + need * v_k  in fp64, fixed order.  One block per (row, column).
+// Per output row (one subcube variant) the bounds kernel leaves n values e_i = max(d_i, 0) >= 0; with r_t = sqrt3 * span
+//     ub_i = e_i * e_i,   lb_i = max(e_i - r_t, 0)^2        (registration.cu:54-58, same fp32 values)
+// are both non-decreasing in e_i, so the k smallest ub terms and the k smallest lb terms belong to the k smallest e_i:
+// ONE exact selection per row serves both sums.  One 1024-thread workgroup per row, normally two passes over the row:
+//   1. histogram of e over 8192 bins, 512 per octave on [2^-14, 4) (exact zeros — d <= rotation radius — are only counted:
+//      if the k smallest are all zero both sums are zero and the row is done after this pass);
+//   2. fp64 sums of ub_i, lb_i over everything below the cut's bin, its own members (a few hundred) gathered into LDS,
+//      sorted there (bitonic) and the first k - below of them added in sorted order.
+// A bin that holds more than kTrimCap members is refined (one more pass per 13 bits) before the gather.  Every sum has a
+// fixed order (thread-strided, wave tree, waves in order; gathered members in sorted order): bit-reproducible.
 // ---------------------------------------------------------------------------------------------
+constexpr int kTrimThreads = 1024;
+constexpr int kTrimBins = 8192;
+constexpr int kTrimCap = 8192;
+constexpr unsigned kTrimLo = 0x38800000u;  // bits(2^-14f); level-0 bins are 2^14 bit patterns wide (1/512 octave)
+
+__device__ __forceinline__ unsigned trim_bin0(unsigned u) {
+    const unsigned b = ((u > kTrimLo ? u : kTrimLo) - kTrimLo) >> 14;
+    return b < (unsigned)(kTrimBins - 1) ? b : (unsigned)(kTrimBins - 1);
+}
+
+// The bin holding the element of rank `need` (1-based) of an 8192-bin LDS histogram and how many elements lie in the bins
+// before it; every thread returns the same pair.  s_pick: two words of LDS.
+__device__ __forceinline__ void trim_pick(const unsigned* hist, unsigned need, unsigned* wsum, unsigned* s_pick, unsigned& bin, unsigned& below) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int per = kTrimBins / kTrimThreads;  // 8 consecutive bins per thread
+    unsigned mine = 0;
+#pragma unroll
+    for (int b = 0; b < per; ++b) mine += hist[tid * per + b];
+    unsigned incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned u = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += u;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    unsigned base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    const unsigned excl = base + incl - mine;
+    if (excl < need && need <= excl + mine) {  // exactly one thread
+        unsigned bl = excl;
+        int b = 0;
+        for (; b < per - 1; ++b) {
+            const unsigned c = hist[tid * per + b];
+            if (need <= bl + c) break;
+            bl += c;
+        }
+        s_pick[0] = (unsigned)(tid * per + b);
+        s_pick[1] = bl;
+    }
+    __syncthreads();
+    bin = s_pick[0];
+    below = s_pick[1];
+    __syncthreads();
+}
+
+template <class F>
+__device__ __forceinline__ void trim_for_each(const float* __restrict__ v, int n, F f) {  // rows start 16-byte aligned
+    const int n4 = n >> 2;
+    const float4* v4 = reinterpret_cast<const float4*>(v);
+    int i = threadIdx.x;
+    for (; i + kTrimThreads < n4; i += 2 * kTrimThreads) {  // two 16-byte loads in flight per lane
+        const float4 a = v4[i], b = v4[i + kTrimThreads];
+        f(a.x); f(a.y); f(a.z); f(a.w);
+        f(b.x); f(b.y); f(b.z); f(b.w);
+    }
+    if (i < n4) { const float4 a = v4[i]; f(a.x); f(a.y); f(a.z); f(a.w); }
+    const int t = (n4 << 2) + threadIdx.x;
+    if (t < n) f(v[t]);
+}
+
+__global__ __launch_bounds__(kTrimThreads) void trim_rows_kernel(const float* __restrict__ evals, size_t erow, int n, int k, const float* __restrict__ row_span,
+                                                                 float* __restrict__ out_ub, float* __restrict__ out_lb) {
+    __shared__ unsigned hist[kTrimBins];
+    __shared__ unsigned list[kTrimCap];
+    __shared__ unsigned wsum[kTrimThreads / 64];
+    __shared__ unsigned s_pick[2];
+    __shared__ unsigned s_count;
+    __shared__ double red[2 * (kTrimThreads / 64)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = blockIdx.x;
+    const float* v = evals + (size_t)row * erow;
+    const float rt = kSqrt3 * row_span[row];  // registration.cu:33
+
+    // pass 1: zeros counted, the rest into the level-0 histogram
+    for (int b = tid; b < kTrimBins; b += kTrimThreads) hist[b] = 0;
+    __syncthreads();
+    unsigned nz = 0;
+    trim_for_each(v, n, [&](float x) {
+        const unsigned u = __float_as_uint(x);
+        if (u == 0u) ++nz; else atomicAdd(&hist[trim_bin0(u)], 1u);
+    });
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nz += __shfl_xor(nz, off, 64);
+    if (lane == 0) wsum[wave] = nz;
+    __syncthreads();
+    unsigned zeros = 0;
+    for (int w = 0; w < kTrimThreads / 64; ++w) zeros += wsum[w];
+    __syncthreads();
+    if ((unsigned)k <= zeros) {  // the k smallest terms are all zero
+        if (tid == 0) { out_ub[row] = 0.0f; out_lb[row] = 0.0f; }
+        return;
+    }
+    unsigned bin, before;
+    trim_pick(hist, (unsigned)k - zeros, wsum, s_pick, bin, before);
+    unsigned below = zeros + before;  // elements strictly below the cut's range [a, b)
+    unsigned cnt = hist[bin];
+    unsigned long long a = bin == 0 ? 1ull : (unsigned long long)kTrimLo + ((unsigned long long)bin << 14);
+    unsigned long long b = bin == kTrimBins - 1 ? 0x100000000ull : (unsigned long long)kTrimLo + ((unsigned long long)(bin + 1) << 14);
+    __syncthreads();
+    // refinement (rare): more members than the gather buffer holds
+    while (cnt > (unsigned)kTrimCap && b - a > 1ull) {
+        int sh = 0;
+        while (((b - a - 1ull) >> sh) >= (unsigned long long)kTrimBins) ++sh;
+        for (int q = tid; q < kTrimBins; q += kTrimThreads) hist[q] = 0;
+        __syncthreads();
+        const unsigned lo = (unsigned)a;
+        const unsigned long long hi = b;
+        trim_for_each(v, n, [&](float x) {
+            const unsigned u = __float_as_uint(x);
+            if (u >= lo && (unsigned long long)u < hi) atomicAdd(&hist[(u - lo) >> sh], 1u);
+        });
+        __syncthreads();
+        trim_pick(hist, (unsigned)k - below, wsum, s_pick, bin, before);
+        below += before;
+        cnt = hist[bin];
+        const unsigned long long a2 = a + ((unsigned long long)bin << sh);
+        const unsigned long long b2 = a2 + (1ull << sh);
+        a = a2;
+        b = b2 < b ? b2 : b;
+        __syncthreads();
+    }
+    // pass 2: sums below the range, members of the range into LDS
+    const bool gather = cnt <= (unsigned)kTrimCap;
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    double acc[2] = {0.0, 0.0};
+    {
+        const unsigned lo = (unsigned)a;
+        const unsigned long long hi = b;
+        trim_for_each(v, n, [&](float x) {
+            const unsigned u = __float_as_uint(x);
+            if (u < lo) {
+                const float l = x - rt;
+                acc[0] += (double)(x * x);
+                acc[1] += (double)(l > 0.0f ? l * l : 0.0f);
+            } else if (gather && (unsigned long long)u < hi) {
+                list[atomicAdd(&s_count, 1u)] = u;
+            }
+        });
+    }
+    __syncthreads();
+    const unsigned m = (unsigned)k - below;  // members of the range among the k smallest (1 <= m <= cnt)
+    if (gather) {
+        unsigned P = 64;
+        while (P < cnt) P <<= 1;
+        for (unsigned q = cnt + tid; q < P; q += kTrimThreads) list[q] = 0xFFFFFFFFu;
+        __syncthreads();
+        for (unsigned size = 2; size <= P; size <<= 1) {
+            for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+                for (unsigned idx = tid; idx < (P >> 1); idx += kTrimThreads) {
+                    const unsigned i = 2 * idx - (idx & (stride - 1)), j = i + stride;
+                    const unsigned x = list[i], y = list[j];
+                    const bool up = (i & size) == 0;
+                    if ((x > y) == up) { list[i] = y; list[j] = x; }
+                }
+                __syncthreads();
+            }
+        }
+        for (unsigned q = tid; q < m; q += kTrimThreads) {
+            const float x = __uint_as_float(list[q]);
+            const float l = x - rt;
+            acc[0] += (double)(x * x);
+            acc[1] += (double)(l > 0.0f ? l * l : 0.0f);
+        }
+    }
+    const double r = block_sum<2, kTrimThreads / 64>(acc, red);
+    if (tid < 2) {
+        double extra = 0.0;
+        if (!gather) {  // b - a == 1: every member of the range is the same value
+            const float x = __uint_as_float((unsigned)a);
+            const float l = x - rt;
+            extra = (double)m * (double)(tid == 0 ? x * x : (l > 0.0f ? l * l : 0.0f));
+        }
+        (tid == 0 ? out_ub : out_lb)[row] = (float)(r + extra);
+    }
+}
+
+// Sum of the k smallest of n non-negative floats by ONE 256-thread block: a 3-level radix select on the bit pattern (11 + 11 + 10
+// bits, LDS histograms) finds the k-th smallest value v_k and how many copies of it are needed, then
+// sum = sum_{v < v_k} v + need * v_k in fp64, fixed order.  Used for single short rows (trimmed SSE and the ICP inlier cut of
+// clouds below 32768 points) and as the A/B of the device-wide selection below (FGOICP_SELECT_WIDE=0).
 __global__ __launch_bounds__(kBlock) void trim_select_kernel(const float* __restrict__ vals, size_t row_stride, int ncols, int elem_stride, int n, int k,
                                                              float* __restrict__ out0, float* __restrict__ out1, uint32_t* __restrict__ sel_info) {
     __shared__ unsigned hist[2048];
@@ -711,12 +915,13 @@ __global__ __launch_bounds__(kBlock) void icp_corr_d2_kernel(const float4* __res
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float4 a = work[i];
-    const float4 c = tgt[min(idx[i], (uint32_t)(nt - 1))];
-    d2[i] = dist_sq(a.x, a.y, a.z, c.x, c.y, c.z);
+    const uint32_t j = idx[i];
+    const float4 c = tgt[min(j, (uint32_t)(nt - 1))];
+    d2[i] = j < (uint32_t)nt ? dist_sq(a.x, a.y, a.z, c.x, c.y, c.z) : 3.0e38f;  // no correspondence: provably beyond the cut (nn_prep_kernel)
 }
 // ... and the inlier mask: d2 < v_k, plus `need` of the points with d2 == v_k.  When all copies of v_k are needed
-// (always, unless distances tie exactly at the cut) the mask is complete here; otherwise tie_pending is set
-// and icp_inlier_ties_kernel admits the lowest ORIGINAL indices.
+// (always, unless distances tie exactly at the cut) the mask is complete here; otherwise icp_inlier_ties_kernel admits the
+// lowest ORIGINAL (caller) indices.
 __global__ __launch_bounds__(kBlock) void icp_inlier_mask_kernel(const float* __restrict__ d2, int n, const uint32_t* __restrict__ sel_info,
                                                                  unsigned char* __restrict__ use, uint32_t* __restrict__ equal_count) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -725,20 +930,49 @@ __global__ __launch_bounds__(kBlock) void icp_inlier_mask_kernel(const float* __
     use[i] = u < vk ? 1 : (u == vk ? 2 : 0);  // 2 = at the cut, resolved below
     if (u == vk) atomicAdd(equal_count, 1u);
 }
-__global__ __launch_bounds__(kBlock) void icp_inlier_ties_kernel(int n, const uint32_t* __restrict__ sel_info, const uint32_t* __restrict__ equal_count,
-                                                                 const uint32_t* __restrict__ slot_of_orig, unsigned char* __restrict__ use) {
+__global__ __launch_bounds__(1024) void icp_inlier_ties_kernel(int n, const uint32_t* __restrict__ sel_info, const uint32_t* __restrict__ equal_count,
+                                                               const uint32_t* __restrict__ orig_of_slot, unsigned char* __restrict__ use) {
     const uint32_t need = sel_info[1];
     if (*equal_count == need) {  // every point at the cut is an inlier
-        for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        for (int i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024)
             if (use[i] == 2) use[i] = 1;
         return;
     }
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    uint32_t taken = 0;  // exact distance ties at the cut: lowest caller index first (serial, rare)
-    for (int o = 0; o < n; ++o) {
-        const uint32_t slot = slot_of_orig[o];
-        if (use[slot] == 2) use[slot] = taken++ < need ? 1 : 0;
+    if (blockIdx.x != 0) return;
+    // exact distance ties at the cut (rare): the `need` lowest CALLER indices among the tied points, by a radix select on the
+    // index (11 + 11 + 10 bits) in one workgroup
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned s_bin, s_below;
+    const int tid = threadIdx.x;
+    unsigned prefix = 0, mask = 0, want = need;
+    for (int lvl = 0; lvl < 3; ++lvl) {
+        const int shift = lvl == 0 ? 21 : lvl == 1 ? 10 : 0, nb = lvl == 2 ? 1024 : 2048;
+        for (int q = tid; q < 2048; q += 1024) hist[q] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += 1024) {
+            if (use[i] != 2) continue;
+            const unsigned o = orig_of_slot[i];
+            if ((o & mask) == prefix) atomicAdd(&hist[(o >> shift) & (nb - 1)], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned below = 0;
+            int q = 0;
+            for (; q < nb - 1; ++q) {
+                if (want <= below + hist[q]) break;
+                below += hist[q];
+            }
+            s_bin = (unsigned)q;
+            s_below = below;
+        }
+        __syncthreads();
+        prefix |= s_bin << shift;
+        mask |= (unsigned)(nb - 1) << shift;
+        want -= s_below;
+        __syncthreads();
     }
+    for (int i = tid; i < n; i += 1024)
+        if (use[i] == 2) use[i] = orig_of_slot[i] <= prefix ? 1 : 0;
 }
 
 // One block (one wave) per subcube: fixed-order sum of its chunk partials, rounded once to fp32.
@@ -816,6 +1050,13 @@ __global__ __launch_bounds__(kBlock) void lut_unpad_kernel(const float* __restri
         const int y = (int)(r % g.dy);
         const int z = (int)(r / g.dy);
         out[n] = lut[((size_t)(z + 1) * g.py + (y + 1)) * g.px + (x + 1)];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void lut_nodes_kernel(const float* __restrict__ lut, LutGeom g, const int* __restrict__ xyz, size_t n, float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const int x = min(max(xyz[3 * i], 0), g.dx - 1), y = min(max(xyz[3 * i + 1], 0), g.dy - 1), z = min(max(xyz[3 * i + 2], 0), g.dz - 1);
+        out[i] = lut[((size_t)(z + 1) * g.py + (y + 1)) * g.px + (x + 1)];
     }
 }
 
@@ -1102,6 +1343,49 @@ __device__ __forceinline__ float tie_threshold(float best) {  // see nn_tie_thre
     return __uint_as_float(b);
 }
 
+// EXTENSION (trimmed Go-ICP) — which queries can be left out of the exact search.  Only the k smallest nearest-neighbour
+// distances enter a trimmed sum or the inlier set.  For every query the LUT gives a rigorous bracket of its nearest
+// distance: ub (lut_upper_bound_d2, or the distance to the previous correspondence) and
+//     lb = max( (sqrt(T[c]) - |q - c|)^2 ,  squared distance from q to the target's bounding box )   (deflated for rounding)
+// for the LUT node c nearest to q (triangle inequality the other way round).  With U = the k-th smallest ub, at least k
+// queries have a nearest distance <= U, so a query with lb > U is not among the k smallest and is not in a tie at the cut:
+// it needs neither its exact distance nor a correspondence.  On a cloud with uniform far outliers those are exactly the
+// queries whose searches are expensive (a large ball around the query cuts many leaves) and that widen the region their
+// wave has to scan.  This kernel writes ub and lb; U comes from the selection kernels; nn_scan_kernel drops lb > U.
+__global__ __launch_bounds__(kBlock) void nn_prep_kernel(const float4* __restrict__ pts, int n, const float* __restrict__ lut, LutGeom g, Rt rt, int apply,
+                                                         const float4* __restrict__ tgt, int nt, const uint32_t* __restrict__ seed_idx, float4 box_lo, float4 box_hi,
+                                                         float* __restrict__ ub_out, float* __restrict__ lb_out) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    float qx = p.x, qy = p.y, qz = p.z;
+    if (apply) {
+        rotate(rt.R, p.x, p.y, p.z, qx, qy, qz);
+        qx += rt.t[0]; qy += rt.t[1]; qz += rt.t[2];
+    }
+    float ub = lut_upper_bound_d2(lut, g, qx, qy, qz);
+    if (seed_idx) {
+        const uint32_t j = seed_idx[i];
+        if (j < (uint32_t)nt) {
+            const float4 c = tgt[j];
+            const float d = dist_sq(qx, qy, qz, c.x, c.y, c.z);
+            ub = d < ub ? d : ub;
+        }
+    }
+    const float sx = qx + g.off_x, sy = qy + g.off_y, sz = qz + g.off_z;
+    const float fx = fminf(fmaxf(rintf(sx * g.scale), 0.0f), (float)(g.dx - 1));
+    const float fy = fminf(fmaxf(rintf(sy * g.scale), 0.0f), (float)(g.dy - 1));
+    const float fz = fminf(fmaxf(rintf(sz * g.scale), 0.0f), (float)(g.dz - 1));
+    const float T = lut[((size_t)((int)fz + 1) * g.py + ((int)fy + 1)) * (size_t)g.px + ((int)fx + 1)];
+    const float dx = sx - fx * g.resolution, dy = sy - fy * g.resolution, dz = sz - fz * g.resolution;
+    const float l = sqrtf(T) - sqrtf(dx * dx + dy * dy + dz * dz);
+    float lb = l > 0.0f ? l * l * 0.9999f - 1e-6f : 0.0f;
+    const float bd = box_d2(box_lo, box_hi, qx, qy, qz) * 0.9999f - 1e-6f;  // every target point lies inside its bounding box
+    lb = fmaxf(fmaxf(lb, bd), 0.0f);
+    ub_out[i] = ub < kInf ? ub : kInf;
+    lb_out[i] = lb;
+}
+
 //   want_index = 0: out[i] = bits(min_j |q_i - tgt_j|^2)                       (registration.cu:162-174)
 //   want_index = 1: out[i] = lowest j inside the sqrt-tie set of the minimum      (icp3d.cu:11-28)
 // One block = 64 queries x `nparts` waves (blockDim = 64 * nparts): each wave scans its share of the
@@ -1111,14 +1395,18 @@ constexpr int kMaxParts = 16;
 template <int WANT_INDEX>
 __global__ __launch_bounds__(64 * kMaxParts) void nn_scan_kernel(const float4* __restrict__ pts, int n, BvhView t, const float* __restrict__ lut,
                                                                  LutGeom g, Rt rt, int apply, const float4* __restrict__ tgt, int nt,
-                                                                 const uint32_t* seed_idx, uint32_t* out) {
+                                                                 const uint32_t* seed_idx, const float* __restrict__ skip_lb, const uint32_t* __restrict__ skip_u, uint32_t* out) {
     __shared__ uint32_t comb[kMaxParts][64];
     __shared__ uint32_t comb_i[WANT_INDEX ? kMaxParts : 1][64];
     __shared__ uint32_t comb_2[WANT_INDEX ? kMaxParts : 1][64];
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6, nparts = blockDim.x >> 6;
     const int i = blockIdx.x * 64 + lane;
-    const bool active = i < n;
-    const float4 p = pts[active ? i : n - 1];
+    bool active = i < n;
+    if (skip_lb && active && skip_lb[i] > __uint_as_float(skip_u[0])) {  // trimmed: provably beyond the k-th smallest distance (nn_prep_kernel)
+        active = false;
+        if (part == 0) out[i] = WANT_INDEX ? 0x7fffffffu : __float_as_uint(skip_lb[i]);  // any value above the cut / no correspondence
+    }
+    const float4 p = pts[i < n ? i : n - 1];
     float qx = p.x, qy = p.y, qz = p.z;
     if (apply) {
         rotate(rt.R, p.x, p.y, p.z, qx, qy, qz);
@@ -1388,13 +1676,13 @@ void launch_bounds(const float4* src, int ns, const float* lut, const LutGeom& g
 // The locality sort of one tick (descriptors must already be on the device): keys + histogram, scan, scatter.
 void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, const TickGroup* groups, const TickSub* subs, int nsub, int cell_shift,
                       unsigned short* keys, unsigned* ranks, unsigned* hist, unsigned* hist_xcd, unsigned* xoff, unsigned* block_sums, unsigned* cursor, unsigned* sorted,
-                      hipStream_t s) {
+                      int allow_xcd, unsigned* check_err, int inject_fault, hipStream_t s) {
     const size_t nitems = (size_t)nsub * nchunk;
     const unsigned kb = (unsigned)std::min<size_t>((nitems + 63) / 64, 8192);  // `hist` / `hist_xcd` are zero here: the scan / fold kernels re-zero them
     static const int hilbert = [] { const char* e = std::getenv("FGOICP_SORT_CURVE"); return e ? std::atoi(e) : 1; }();  // tuning knob: 1 = Hilbert (default), 0 = Z-order
     static const int use_ranks = [] { const char* e = std::getenv("FGOICP_SORT_RANKS"); return e ? std::atoi(e) : 1; }();  // tuning knob
-    static const int use_xcd = [] { const char* e = std::getenv("FGOICP_SORT_XCD"); return e ? std::atoi(e) : 1; }();      // tuning knob
-    const bool xcd = use_xcd && use_ranks && hist_xcd && xoff;
+    const bool xcd = allow_xcd && use_ranks && hist_xcd && xoff;  // allow_xcd: FGOICP_SORT_XCD per context, cleared by a failed permutation check
+    if (check_err) (void)hipMemsetAsync(sorted, 0xFF, sizeof(unsigned) * nitems, s);
     if (xcd) {
         if (hilbert) hipLaunchKernelGGL((tick_keys_kernel<1, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd);
         else hipLaunchKernelGGL((tick_keys_kernel<0, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd);
@@ -1408,10 +1696,12 @@ void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, con
     if (xcd) hipLaunchKernelGGL(tick_scatter_xcd_kernel, dim3(kb), dim3(64), 0, s, keys, ranks, nitems, cursor, xoff, sorted);
     else if (use_ranks) hipLaunchKernelGGL(tick_scatter_kernel, dim3(kb), dim3(64), 0, s, keys, ranks, nitems, cursor, sorted);
     else hipLaunchKernelGGL(tick_scatter_atomic_kernel, dim3(kb), dim3(64), 0, s, keys, nitems, cursor, sorted);
+    if (inject_fault) hipLaunchKernelGGL(tick_fault_kernel, dim3(1), dim3(1), 0, s, sorted);
+    if (check_err) hipLaunchKernelGGL(tick_check_kernel, dim3(kb), dim3(64), 0, s, sorted, nitems, check_err);
 }
 
 void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* zp, int layout, const LutGeom& g, int nchunk, int chunk_pts,
-                          const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials, float2* vals,
+                          const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials, float* evals, size_t erow,
                           hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s) {
     const size_t nitems = (size_t)nsub * nchunk;
     const TickGroup* gp = groups;
@@ -1420,8 +1710,8 @@ void launch_bounds_sorted(const float4* src, int ns, const float* lut, const flo
     static const int variant = [] { const char* e = std::getenv("FGOICP_BOUNDS_VARIANT"); return e ? std::atoi(e) : 2; }();  // tuning knob (2 = default: one wave, 4 points per lane)
     const dim3 grid((unsigned)nitems);
 #define FGOICP_LAUNCH_SORTED(T, PP, Z, TR) \
-    hipLaunchKernelGGL((bounds_sorted_kernel<T, PP, Z, TR>), grid, dim3(T), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, chunk_pts, partials, vals)
-    if (vals) {
+    hipLaunchKernelGGL((bounds_sorted_kernel<T, PP, Z, TR>), grid, dim3(T), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, chunk_pts, partials, evals, erow)
+    if (evals) {
         static const int trim_variant = [] { const char* e = std::getenv("FGOICP_TRIM_VARIANT"); return e ? std::atoi(e) : 2; }();  // tuning knob (2 = 64x4, default)
         if (trim_variant == 2) {
             if (zp && layout == 2) FGOICP_LAUNCH_SORTED(64, 4, 3, 1); else if (zp) FGOICP_LAUNCH_SORTED(64, 4, 1, 1); else FGOICP_LAUNCH_SORTED(64, 4, 0, 1);
@@ -1464,6 +1754,11 @@ void launch_lut_unpad(const float* lut_padded, const LutGeom& g, float* out, hip
     hipLaunchKernelGGL(lut_unpad_kernel, dim3(4096), dim3(kBlock), 0, s, lut_padded, g, out);
 }
 
+void launch_lut_nodes(const float* lut, const LutGeom& g, const int* xyz, size_t n, float* out, hipStream_t s) {
+    const unsigned blocks = (unsigned)((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(lut_nodes_kernel, dim3(blocks < 4096 ? (blocks ? blocks : 1) : 4096), dim3(kBlock), 0, s, lut, g, xyz, n, out);
+}
+
 void launch_lut_search(const float* lut, const LutGeom& g, const float* q_xyz, size_t n, float* out, hipStream_t s) {
     const unsigned blocks = (unsigned)((n + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(lut_search_kernel, dim3(blocks < 4096 ? (blocks ? blocks : 1) : 4096), dim3(kBlock), 0, s, lut, g, q_xyz, n, out);
@@ -1497,7 +1792,7 @@ void launch_nn_first_index(const float4* pts, int n, const float4* tgt, int nt, 
 }
 
 void launch_nn_scan(const float4* pts, int n, const BvhView& t, const float* lut, const LutGeom& g, const float* R9, const float* t3, int apply,
-                    int want_index, const float4* tgt, int nt, const uint32_t* seed_idx, uint32_t* out, hipStream_t s) {
+                    int want_index, const float4* tgt, int nt, const uint32_t* seed_idx, const float* skip_lb, const uint32_t* skip_u, uint32_t* out, hipStream_t s) {
     const int groups = (n + 63) / 64;
     // waves per 64 queries.  The scan is a chain of dependent steps per wave (boxes -> leaf boxes -> points), so its run time is
     // that chain's latency: splitting the candidate leaves of a query group over 4-8 waves shortens the chain even when the
@@ -1506,8 +1801,14 @@ void launch_nn_scan(const float4* pts, int n, const BvhView& t, const float* lut
     while (nparts < 8 && groups * nparts < 4096) nparts <<= 1;
     static const int forced = [] { const char* e = std::getenv("FGOICP_NN_PARTS"); const int v = e ? std::atoi(e) : 0; return v; }();  // tuning knob
     if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16) nparts = forced;
-    if (want_index) hipLaunchKernelGGL(nn_scan_kernel<1>, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, out);
-    else hipLaunchKernelGGL(nn_scan_kernel<0>, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, out);
+    if (want_index) hipLaunchKernelGGL(nn_scan_kernel<1>, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, skip_lb, skip_u, out);
+    else hipLaunchKernelGGL(nn_scan_kernel<0>, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, skip_lb, skip_u, out);
+}
+
+void launch_nn_prep(const float4* pts, int n, const float* lut, const LutGeom& g, const float* R9, const float* t3, int apply, const float4* tgt, int nt,
+                    const uint32_t* seed_idx, const float* box6, float* ub_out, float* lb_out, hipStream_t s) {
+    const float4 lo = make_float4(box6[0], box6[2], box6[4], 0.f), hi = make_float4(box6[1], box6[3], box6[5], 0.f);
+    hipLaunchKernelGGL(nn_prep_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, n, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, lo, hi, ub_out, lb_out);
 }
 
 // `scratch` must hold as many floats as the padded LUT; it receives the coarse pass.
@@ -1552,10 +1853,14 @@ void launch_icp_cov(const float4* work, const float4* tgt, const uint32_t* idx, 
     hipLaunchKernelGGL(icp_cov_kernel, dim3(nblocks), dim3(kBlock), 0, s, work, tgt, idx, n, nt, cen_dev, use, bp);
 }
 
-// trimmed sums: out0[row] / out1[row] = sum of the k smallest of column 0 / 1 of row `row` (ncols = 1 or 2)
-void launch_trim_select(const float* vals, size_t row_stride, int ncols, int n, int k, int rows, float* out0, float* out1, uint32_t* sel_info,
-                        uint32_t* wide_scratch, hipStream_t s) {
-    if (wide_scratch && rows == 1 && ncols == 1 && n >= 32768) {  // one long row: spread the selection over the device
+// trimmed bounds of a window: out_ub[row] / out_lb[row] from the row's k smallest e (trim_rows_kernel)
+void launch_trim_rows(const float* evals, size_t erow, int n, int k, int rows, const float* row_span, float* out_ub, float* out_lb, hipStream_t s) {
+    hipLaunchKernelGGL(trim_rows_kernel, dim3(rows), dim3(kTrimThreads), 0, s, evals, erow, n, k, row_span, out_ub, out_lb);
+}
+
+// ONE row: out[0] = sum of the k smallest of vals[0..n), sel_info = {bits of the k-th smallest, copies of it among the k}
+void launch_trim_select(const float* vals, int n, int k, float* out, uint32_t* sel_info, uint32_t* wide_scratch, hipStream_t s) {
+    if (wide_scratch && n >= 32768) {  // a long row: spread the selection over the device
         const int nb = std::min(kSelWideBlocks, (n + kBlock - 1) / kBlock);
         hipLaunchKernelGGL(select_wide_init_kernel, dim3(1), dim3(kBlock), 0, s, wide_scratch, k);
         for (int lvl = 0; lvl < 3; ++lvl) {
@@ -1563,20 +1868,20 @@ void launch_trim_select(const float* vals, size_t row_stride, int ncols, int n, 
             hipLaunchKernelGGL(select_wide_pick_kernel, dim3(1), dim3(kBlock), 0, s, lvl, wide_scratch);
         }
         hipLaunchKernelGGL(select_wide_sum_kernel, dim3(nb), dim3(kBlock), 0, s, vals, n, wide_scratch);
-        hipLaunchKernelGGL(select_wide_final_kernel, dim3(1), dim3(64), 0, s, wide_scratch, nb, out0, sel_info);
+        hipLaunchKernelGGL(select_wide_final_kernel, dim3(1), dim3(64), 0, s, wide_scratch, nb, out, sel_info);
         return;
     }
-    hipLaunchKernelGGL(trim_select_kernel, dim3(rows, ncols), dim3(kBlock), 0, s, vals, row_stride, ncols, ncols, n, k, out0, out1, sel_info);
+    hipLaunchKernelGGL(trim_select_kernel, dim3(1, 1), dim3(kBlock), 0, s, vals, (size_t)0, 1, 1, n, k, out, (float*)nullptr, sel_info);
 }
 
 void launch_icp_inliers(const float4* work, const float4* tgt, const uint32_t* idx, int n, int nt, int k, float* d2, uint32_t* sel_info,
-                        uint32_t* equal_count, const uint32_t* slot_of_orig, unsigned char* use, uint32_t* wide_scratch, hipStream_t s) {
+                        uint32_t* equal_count, const uint32_t* orig_of_slot, unsigned char* use, uint32_t* wide_scratch, hipStream_t s) {
     const int nb = (n + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(icp_corr_d2_kernel, dim3(nb), dim3(kBlock), 0, s, work, tgt, idx, n, nt, d2);
-    launch_trim_select(d2, 0, 1, n, k, 1, nullptr, nullptr, sel_info, wide_scratch, s);
+    launch_trim_select(d2, n, k, nullptr, sel_info, wide_scratch, s);
     (void)hipMemsetAsync(equal_count, 0, sizeof(uint32_t), s);
     hipLaunchKernelGGL(icp_inlier_mask_kernel, dim3(nb), dim3(kBlock), 0, s, d2, n, sel_info, use, equal_count);
-    hipLaunchKernelGGL(icp_inlier_ties_kernel, dim3(nb < 256 ? nb : 256), dim3(kBlock), 0, s, n, sel_info, equal_count, slot_of_orig, use);
+    hipLaunchKernelGGL(icp_inlier_ties_kernel, dim3(std::max(1, std::min(256, (n + 1023) / 1024))), dim3(1024), 0, s, n, sel_info, equal_count, orig_of_slot, use);
 }
 
 }  // namespace fgoicp

@@ -64,16 +64,21 @@ constexpr int kTickNumKeys = 1 << 15;
 void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, const TickGroup* groups, const TickSub* subs, int nsub, int cell_shift,
                       unsigned short* keys, unsigned* ranks /* per item, like keys */, unsigned* hist /* kTickNumKeys, zero on entry and on exit */,
                       unsigned* hist_xcd /* 16 x kTickNumKeys, zero on entry and on exit (optional) */, unsigned* xoff /* 16 x kTickNumKeys (optional) */,
-                      unsigned* block_sums /* 64 */, unsigned* cursor, unsigned* sorted, hipStream_t s);
+                      unsigned* block_sums /* 64 */, unsigned* cursor, unsigned* sorted,
+                      int allow_xcd /* 0: device-scope histogram atomics */, unsigned* check_err /* optional, host-visible: set to 1 unless `sorted` is a permutation */,
+                      int inject_fault /* test hook */, hipStream_t s);
 void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* packed_or_null, int layout /* 1 z-pair, 2 yz-quad */, const LutGeom& g, int nchunk,
-                          int chunk_pts /* 256 .. 2048 points per item */, const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials, float2* vals_or_null,
+                          int chunk_pts /* 256 .. 2048 points per item */, const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials,
+                          float* evals_or_null /* trimmed mode: row r = the per-point e = max(d, 0) of output row r */, size_t erow /* floats per row, multiple of 4 */,
                           hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s);
-// EXTENSION (trimmed Go-ICP): sum of the k smallest entries of each row/column of `vals` (exact radix select, kernels.hip)
-void launch_trim_select(const float* vals, size_t row_stride, int ncols, int n, int k, int rows, float* out0, float* out1, uint32_t* sel_info,
-                        uint32_t* wide_scratch /* 64 KiB, optional: one long row (rows = ncols = 1, n >= 32768) is then selected by the whole device */,
-                        hipStream_t s);
+// EXTENSION (trimmed Go-ICP): per output row the sums of ub = e*e and lb = max(e - sqrt3*span, 0)^2 over the row's k smallest e
+// (one exact selection per row, kernels.hip trim_rows_kernel); row_span[r] = translation span of row r (device-readable)
+void launch_trim_rows(const float* evals, size_t erow, int n, int k, int rows, const float* row_span, float* out_ub, float* out_lb, hipStream_t s);
+// one row: out[0] (optional) = sum of the k smallest of vals[0..n), sel_info (optional) = {bits of the k-th smallest, copies of it needed}
+void launch_trim_select(const float* vals, int n, int k, float* out, uint32_t* sel_info,
+                        uint32_t* wide_scratch /* 64 KiB, optional: rows of n >= 32768 are then selected by the whole device */, hipStream_t s);
 void launch_icp_inliers(const float4* work, const float4* tgt, const uint32_t* idx, int n, int nt, int k, float* d2, uint32_t* sel_info,
-                        uint32_t* equal_count, const uint32_t* slot_of_orig, unsigned char* use, uint32_t* wide_scratch, hipStream_t s);
+                        uint32_t* equal_count, const uint32_t* orig_of_slot, unsigned char* use, uint32_t* wide_scratch, hipStream_t s);
 // out_lb[i], out_ub[i] = float(sum over chunks), fixed order → bit-reproducible
 void launch_bounds_finalize(const double2* partials, int nchunk, int total, float* out_lb, float* out_ub, hipStream_t s);
 
@@ -83,6 +88,7 @@ void launch_lut_zpair(const float* lut_padded, const LutGeom& g, float2* zp, hip
 void launch_lut_quad(const float* lut_padded, const LutGeom& g, float4* qd, hipStream_t s);
 void launch_lut_unpad(const float* lut_padded, const LutGeom& g, float* out, hipStream_t s);
 void launch_lut_search(const float* lut, const LutGeom& g, const float* q_xyz, size_t n, float* out, hipStream_t s);
+void launch_lut_nodes(const float* lut_padded, const LutGeom& g, const int* xyz /* device, n node indices (clamped into the grid) */, size_t n, float* out, hipStream_t s);
 
 // Exact nearest neighbour (brute force, tiled through LDS).
 //   queries: if `apply` q_i = R*pts_i + t (fma convention) else q_i = pts_i.
@@ -101,7 +107,12 @@ void launch_nn_first_index(const float4* pts, int n, const float4* tgt, int nt, 
 // seed_idx (optional, may alias out): per query the caller-order index of some target point, e.g. the correspondence of the
 // previous ICP pass; its distance tightens the pruning bound, the result is the same exact minimum.
 void launch_nn_scan(const float4* pts, int n, const BvhView& t, const float* lut, const LutGeom& g, const float* R9, const float* t3, int apply,
-                    int want_index, const float4* tgt, int nt, const uint32_t* seed_idx, uint32_t* out, hipStream_t s);
+                    int want_index, const float4* tgt, int nt, const uint32_t* seed_idx,
+                    const float* skip_lb /* optional (trimmed): queries with skip_lb[i] > float(skip_u[0]) are left out */, const uint32_t* skip_u, uint32_t* out, hipStream_t s);
+// EXTENSION (trimmed Go-ICP): per query a rigorous bracket [lb, ub] of its nearest squared distance from the LUT (kernels.hip, nn_prep_kernel);
+// box6 = the target's bounding box {minx,maxx,miny,maxy,minz,maxz}
+void launch_nn_prep(const float4* pts, int n, const float* lut, const LutGeom& g, const float* R9, const float* t3, int apply, const float4* tgt, int nt,
+                    const uint32_t* seed_idx, const float* box6, float* ub_out, float* lb_out, hipStream_t s);
 void launch_lut_build_scan(const BvhView& shifted_targets, const LutGeom& g, float* scratch_padded, float* lut_padded, hipStream_t s);
 
 // deterministic double sums: out[k] = sum_i vals[i*stride + k]  (k < width <= 16)

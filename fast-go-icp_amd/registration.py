@@ -74,6 +74,13 @@ class Registration:
         _lib.check(self._lib.fgoicp_lut_read(self._h, _fp(out), out.size), "fgoicp_lut_read")
         return out.reshape(dz, dy, dx)
 
+    def lut_nodes(self, xyz):
+        """Single LUT nodes by index (n, 3) int (x, y, z) — for LUTs too large to read back whole."""
+        q = np.ascontiguousarray(xyz, dtype=np.int32).reshape(-1, 3)
+        out = np.empty(len(q), dtype=np.float32)
+        _lib.check(self._lib.fgoicp_lut_nodes(self._h, q.ctypes.data_as(_lib.c_int_p), len(q), _fp(out)), "fgoicp_lut_nodes")
+        return out
+
     def lut_search(self, queries):
         q = _cloud(queries)
         out = np.empty(len(q), dtype=np.float32)
@@ -134,6 +141,20 @@ class Registration:
     def set_inliers(self, k):
         """EXTENSION (trimmed Go-ICP): every sum over source points runs over the k smallest terms; 0 = off."""
         _lib.check(self._lib.fgoicp_ctx_set_inliers(self._h, int(k)), "fgoicp_ctx_set_inliers")
+
+    def point_distances(self, R, rot_span, tnode, fix_rot):
+        """Trimmed mode, diagnostic: e_i = max(distance_i, 0) of registration.cu:48-52 for one subcube, caller order."""
+        tn = pack_tnodes(np.asarray(tnode, np.float32).reshape(1, 4))
+        out = np.empty(self.ns, dtype=np.float32)
+        _lib.check(self._lib.fgoicp_bounds_point_distances(self._h, _fp(to_glm(R)), float(rot_span), _fp(tn), int(bool(fix_rot)), _fp(out)),
+                   "fgoicp_bounds_point_distances")
+        return out
+
+    def sort_fallbacks(self):
+        """(sorted ticks, ticks repeated after a failed permutation check)"""
+        a = C.c_uint64(); b = C.c_uint64()
+        _lib.check(self._lib.fgoicp_ctx_sort_fallbacks(self._h, C.byref(a), C.byref(b)), "fgoicp_ctx_sort_fallbacks")
+        return a.value, b.value
 
     def set_profile(self, enabled):
         _lib.check(self._lib.fgoicp_ctx_set_profile(self._h, int(bool(enabled))), "fgoicp_ctx_set_profile")

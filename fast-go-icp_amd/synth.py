@@ -91,10 +91,7 @@ def preprocess(tgt, src):
     def center(pc):
         c = np.zeros(3, np.float32)
         for k in range(3):
-            acc = np.float32(0)
-            for v in pc[:, k]:
-                acc = np.float32(acc + v)
-            c[k] = acc
+            c[k] = np.cumsum(pc[:, k], dtype=np.float32)[-1]  # serial fp32 sum, in order (a running sum cannot be re-associated)
         c = (c / np.float32(len(pc))).astype(np.float32)
         return (pc - c[None, :]).astype(np.float32), (-c).astype(np.float32)
     s_c, off_s = center(src.astype(np.float32))

@@ -67,6 +67,9 @@ void fgoicp_ctx_destroy(fgoicp_ctx* ctx);
  * (registration.cu:186-188, :276).  Used by tests and by INTEGRATION.md's façade. */
 int fgoicp_lut_dims(const fgoicp_ctx* ctx, int* dims3);
 int fgoicp_lut_read(fgoicp_ctx* ctx, float* out, size_t capacity_floats);
+/* n single nodes of the LUT: out[i] = node (x, y, z) = xyz[3i..3i+2] (the value buildLUTKernel, registration.cu:258-278, stores at
+ * index (z*dy + y)*dx + x).  For LUTs too large to read back whole (test/bunny.toml: 923 x 906 x 711 nodes). */
+int fgoicp_lut_nodes(fgoicp_ctx* ctx, const int* xyz, size_t n, float* out);
 /* Device evaluation of NearestNeighborLUT::search (registration.cu:320-328; CUDA tex3D linear
  * filtering restated in software) at n query points. */
 int fgoicp_lut_search(fgoicp_ctx* ctx, const float* q_xyz, size_t n, float* out);
@@ -118,7 +121,8 @@ int fgoicp_sse(fgoicp_ctx* ctx, const float* R9, const float* t3, float* sse_out
 int fgoicp_icp(fgoicp_ctx* ctx, const float* R0_9, const float* t0_3, size_t max_iter, float conv_thr, float* sse_out,
                float* R_out9, float* t_out3, int* iters_out);
 /* One IterativeClosestPoint3D::procrustes() step (icp3d.cu:140-172) on an explicit working cloud
- * (ns x xyz, caller order).  Test hook: optional outputs may be NULL. */
+ * (ns x xyz, caller order).  Test hook: optional outputs may be NULL.  In trimmed mode corr_idx is 0x7fffffff for points
+ * that provably lie outside the inlier set (they take no part in the step and their exact neighbour is not searched). */
 int fgoicp_procrustes(fgoicp_ctx* ctx, const float* working_xyz, float* R_out9, float* t_out3, float* centroids6,
                       float* ABt9, int* corr_idx);
 
@@ -128,6 +132,17 @@ int fgoicp_procrustes(fgoicp_ctx* ctx, const float* working_xyz, float* R_out9, 
  * points (bounds, SSE, the Procrustes means) runs over the k smallest per-point terms.  k = 0 or k >= ns: off.
  */
 int fgoicp_ctx_set_inliers(fgoicp_ctx* ctx, size_t k);
+
+/*
+ * Trimmed mode only (diagnostic): the per-point quantity behind one subcube's bounds, in caller order —
+ * e_i = max(d_i, 0) with d_i the value of `distance` at registration.cu:48-52 (after the rotation-uncertainty term when
+ * fix_rot == 0); the reference's per-point outputs are ub_i = e_i^2 (:54) and lb_i = max(e_i - sqrt3*span, 0)^2 (:57-58).
+ */
+int fgoicp_bounds_point_distances(fgoicp_ctx* ctx, const float* R9, float rot_span, const float* tnode4, int fix_rot, float* e_out);
+
+/* Sorted ticks so far and how many of them had to be repeated because the on-device check found that the locality sort had not
+ * produced a permutation of the work items (then the context switches to device-scope atomics for good). */
+int fgoicp_ctx_sort_fallbacks(const fgoicp_ctx* ctx, uint64_t* sorted_ticks, uint64_t* fallbacks);
 
 /* Accumulated HIP-event timing of the bounds kernel since the last reset (FGOICP_FLAG_PROFILE):
  * kernel_ms = sum of launch durations, launches = kernel launches, subcubes = (rot, trans) pairs. */

@@ -97,6 +97,22 @@ def bounds(lut, lut_bounds, res, src, R, rot_span, tnodes4, fix_rot, quant=True,
     return np.array(lbs, f32), np.array(ubs, f32)
 
 
+def point_distances(lut, lut_bounds, res, src, R, rot_span, tnode4, fix_rot, quant=True):
+    """e_i = max(distance_i, 0) with `distance` of registration.cu:48-52 (the per-point quantity both bounds are functions of:
+    ub_i = e_i^2, lb_i = max(e_i - sqrt3 * span, 0)^2) for ONE translation node."""
+    src = np.asarray(src, f32)
+    rp = rot_apply(R, src)
+    tx, ty, tz, _ = np.asarray(tnode4, f32)
+    q = (rp + np.array([tx, ty, tz], f32)[None, :]).astype(f32)
+    d = np.sqrt(lut_search(lut, lut_bounds, res, q, quant)).astype(f32)
+    if not fix_rot:
+        half_angle = f32(f32(f32(f32(rot_span) * SQRT3) * PI) / f32(2.0))
+        sin_half = f32(np.sin(half_angle, dtype=np.float32))
+        radius = fma(src[:, 2], src[:, 2], fma(src[:, 1], src[:, 1], (src[:, 0] * src[:, 0]).astype(f32)))
+        d = (d - ((f32(2.0) * radius).astype(f32) * sin_half).astype(f32)).astype(f32)
+    return np.where(d > 0, d, f32(0)).astype(f32)
+
+
 def rotation(x, y, z):
     """common.hpp:37-57 → (math-convention R, r, in_SO3)"""
     x, y, z = f32(x), f32(y), f32(z)

@@ -515,21 +515,3 @@ def test_submit_collect_two_slots_equal_synchronous_call(fg, tiny_case, gpu_requ
         for g, (lbr, ubr) in enumerate(ref):
             assert np.array_equal(lb[offs[g]:offs[g + 1]], lbr) and np.array_equal(ub[offs[g]:offs[g + 1]], ubr)
     reg.close()
-
-
-def test_dragon_size_scan_equals_brute_force(fg, gpu_required):
-    """437k x 437k: the exact box scan against the brute-force kernels (both HIP) — SSE bits and correspondences."""
-    tgt, src, _, _ = fg.synth.workload("dragon", angle_deg=40.0)
-    pct, pcs, *_, bounds = fg.synth.preprocess(tgt[:200000], src[:150000])
-    scan = fg.Registration(pct, pcs, bounds, 0.02)
-    brute = fg.Registration(pct, pcs, bounds, 0.02, flags=fg.FLAG_BRUTE_FORCE_NN)
-    assert np.array_equal(scan.lut_read().view(np.uint32), brute.lut_read().view(np.uint32))
-    rng = np.random.default_rng(1)
-    R = fg.synth.random_rotation(rng, 20.0).astype(np.float32)
-    t = rng.uniform(-0.05, 0.05, 3).astype(np.float32)
-    assert scan.compute_sse_error(R, t).view(np.uint32) == brute.compute_sse_error(R, t).view(np.uint32)
-    w = (pcs @ R.T + t).astype(np.float32)
-    *_, idx_a = scan.procrustes(w)
-    *_, idx_b = brute.procrustes(w)
-    assert np.array_equal(idx_a, idx_b)
-    scan.close(); brute.close()

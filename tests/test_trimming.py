@@ -116,7 +116,12 @@ def test_hip_trimmed_operators_match_oracle(fg, oracle, tiny_case, gpu_required,
     w = (c["pcs"] @ R.T + t).astype(f32)
     Rh, th, cen, ABt, idx = hip.procrustes(w)
     Ro, to, ceno, ABto, idxo = orc.procrustes(w)
-    assert np.array_equal(idx, idxo) and np.allclose(cen, ceno, rtol=1e-6, atol=1e-7)
+    # points that provably cannot be among the k closest get no correspondence (index 0x7fffffff, nn_prep_kernel); every other
+    # index is the reference's, and the points left out really lie beyond the k-th smallest correspondence distance
+    found = idx != 0x7fffffff
+    d2o = ((w - c["pct"][idxo]).astype(np.float64) ** 2).sum(1)
+    assert np.array_equal(idx[found], idxo[found]) and found.sum() >= k and (found.all() or d2o[~found].min() > np.sort(d2o)[k - 1])
+    assert np.allclose(cen, ceno, rtol=1e-6, atol=1e-7)
     assert np.allclose(ABt, ABto, rtol=1e-5, atol=1e-5) and np.allclose(Rh, Ro, atol=2e-6) and np.allclose(th, to, atol=2e-6)
     sse, Ri, ti = fg.IterativeClosestPoint3D(hip, None, None, 100, 0.005, R, t).run()
     sse_o, Ri_o, ti_o, it_o = orc.icp(R, t, 100, 0.005)
