@@ -17,18 +17,27 @@ expansion round (8 rotation cubes, 16.5k subcubes): sse_threshold = ns*mse = 40 
 optimum's residual (3.4), so the first good ICP ends the search and the step measures 5 ICP runs, not
 the branch-and-bound.  The reference's own example (test/bunny.toml: ~3k source points, ns*mse ~ 3,
 below the residual of the shipped clouds) is in the opposite regime: the search has to CERTIFY the
-optimum (every remaining cube's lower bound within the threshold of the incumbent).  The headline
-step therefore uses mse_threshold = 5e-5 (ns*mse = 2.0 < residual), same clouds, same LUT, same
-optimum — ~100x more branch-and-bound work — and the default-threshold run is reported next to it
-under "reference_default_threshold".
+optimum.  The headline step therefore uses mse_threshold = 5e-5 (ns*mse = 2.0 < residual), same
+clouds, same LUT, same optimum — ~100x more branch-and-bound work — and the default-threshold run is
+reported next to it ("default_threshold_*" keys and "reference_default_threshold").
+
+Legs (every one is a full run() on its own workload; --only LEG runs one alone, e.g. under rocprofv3):
+  headline            bunny shape, mse 5e-5, schedule ROUND (adaptive width), K timed steps
+  default_threshold   same clouds, mse 1e-3 (BASELINE.md's parameters)
+  serial              same clouds, mse 5e-5, the reference's exploration order (SERIAL schedule), one step
+  dragon              dragon shape 437 645^2 (configs[2]), mse 5e-6 (certify), one step
+  trimmed             1M points, 20 % outliers, trim_fraction 0.2 (configs[4]), mse 1e-3, one step
+  cpu_baseline        N = 1 only: the oracle-backed driver (tests/host_harness) on this host's cores
 
 For N > 1 the rotation cubes of every expansion round are sharded over the ranks (one process per
 GPU) with one RCCL all-reduce(MIN) of the best error + one small all-gather per round: the total
 work is fixed, so "scaling" is "strong".
 
-Extra keys: "roofline" (bounds kernel, HIP events on its own stream, algorithmic bytes vs the
-8 TB/s HBM peak) and, at N = 1, "cpu_baseline" (the CPU oracle's bounds operator timed on this
-host, bounded sample)."""
+"roofline" (one object per workload): HIP events around every launch of the bounds kernel on the stream
+it runs on (fgoicp_ctx_profile).  `achieved` = algorithmic bytes of the EVALUATIONS the launches did
+(ns * (32 + 12/32) B each; a twin pair is two subcubes and one evaluation) / the launches'
+duration; `traffic` = HBM bytes per launch from separate rocprofv3 --pmc passes of `--only LEG`
+(profiles/bench_pmc.json, see tools/gpu_profile.sh); `hbm_actual_GBps` = traffic / duration."""
 import argparse
 import json
 import os
@@ -42,6 +51,8 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy rate)
+HBM_COPY_GBS = 6290.0
+LEGS = ("headline", "default_threshold", "serial", "dragon", "trimmed", "cpu_baseline")
 
 
 def parse():
@@ -54,41 +65,195 @@ def parse():
     ap.add_argument("--mse-threshold", type=float, default=5e-5, help="headline threshold (see module docstring); the reference default 1e-3 is measured as well")
     ap.add_argument("--schedule", default="round", choices=["round", "serial"])
     ap.add_argument("--round-width", type=int, default=0, help="rotation cubes popped per round (0 = adaptive)")
+    ap.add_argument("--only", default=None, choices=LEGS, help="run ONE leg (profiling); the headline keys then describe that leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-default-threshold-run", action="store_true")
+    ap.add_argument("--no-serial", action="store_true")
     ap.add_argument("--no-dragon", action="store_true", help="skip the secondary dragon-shape (437k points) measurement")
     ap.add_argument("--no-trimmed", action="store_true", help="skip the secondary 1M-point trimmed Go-ICP measurement (20 %% outliers)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=6.0, help="time budget of the one-core operator sample of cpu_baseline")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 rehearsal on a one-GPU box: every rank uses device 0 and the exchange runs on gloo (timings are meaningless)")
     return ap.parse_args()
 
 
-def cpu_baseline(fg, reg, pct, pcs, bounds, res, seconds):
-    """Times the CPU oracle's bounds operator (oracle/, kind "port") on batches of 32 subcubes of the
-    SAME workload.  The oracle's LUT is filled from the device LUT (bit-identical to its own build,
-    tests/test_gpu_ops.py::test_lut_nodes_bit_exact — the brute-force CPU build is O(nodes*nt))."""
+def rot_err_deg(R, R_gt):
+    return float(np.degrees(np.arccos(np.clip((np.trace(np.asarray(R, np.float64).T @ R_gt) - 1) / 2, -1, 1))))
+
+
+class Env:
+    """Process-group plumbing shared by the legs."""
+
+    def __init__(self, a):
+        import torch
+        self.torch = torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != a.gpus:
+            if self.world == 1 and a.gpus > 1:
+                raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+            a.gpus = self.world
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: no GPU visible (fgoicp_amd has no CPU path)")
+        if a.rehearse_on_one_gpu:
+            self.local_rank = 0
+        torch.cuda.set_device(self.local_rank)
+        self.dist = None
+        self.red_dev = "cuda"
+        self.ex = None
+        if self.world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            if a.rehearse_on_one_gpu:
+                dist.init_process_group("gloo")
+                self.red_dev = "cpu"
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            from fgoicp_amd.dist import TorchExchange
+            self.ex = TorchExchange()
+            self.ex.warmup()  # communicator setup is not part of a registration run
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def sum_max(self, values):
+        """-> (sum over ranks, max over ranks) of a list of floats"""
+        t = self.torch.tensor([float(v) for v in values], dtype=self.torch.float64, device=self.red_dev)
+        if self.dist is None:
+            return t.tolist(), t.tolist()
+        m = t.clone()
+        self.dist.all_reduce(m, op=self.dist.ReduceOp.MAX)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.tolist(), m.tolist()
+
+
+def run_leg(env, fg, tgt, src, res, mse, sched, K, steps, warmup, trim=0.0):
+    """W warm-up + exactly `steps` timed run()s bracketed by barrier + synchronize; wall = max over ranks, subcubes = sum."""
+    t0 = time.perf_counter()
+    solver = fg.FastGoICP(tgt, src, res, mse, schedule=sched, round_width=K, device=env.local_rank, trim_fraction=trim)
+    env.torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t0
+    if env.ex is not None:
+        solver.set_exchange(env.ex)
+    reg = solver.registration
+    for _ in range(warmup):
+        solver.run()
+    reg.set_profile(True)  # HIP events around every bounds kernel of the timed region (~2 % of a step)
+    reg.profile(reset=True)
+    sub, stats, R, t = 0, None, None, None
+    env.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        R, t = solver.run()
+        stats = solver.stats()
+        sub += stats["trans_cubes"]
+    env.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = reg.profile(reset=True)
+    reg.set_profile(False)
+    sums, maxes = env.sum_max([sub, elapsed])
+    out = dict(solver=solver, reg=reg, R=R, t=t, stats=stats, prof=prof, elapsed=maxes[1], subcubes=sums[0], subcubes_rank=sub, steps=steps, setup_s=setup_s,
+               best_sse=float(solver.get_best_error()), ns=reg.ns, nt=reg.nt, lut_dims=list(reg.lut_dims()))
+    return out
+
+
+def unit_bytes(ns):
+    return ns * (32.0 + 12.0 / 32.0)  # SURVEY 8d: per subcube, batches of B = 32 sharing one rotated source
+
+
+def roofline(leg, pmc, extra=None):
+    """The bounds kernel of one leg (rank 0's launches) against the HBM roof."""
+    p, ns = leg["prof"], leg["ns"]
+    launches, kms = p["launches"], p["kernel_ms"]
+    if not launches or kms <= 0:
+        return None
+    ub = unit_bytes(ns)
+    ach = p["evaluations"] * ub / (kms * 1e-3) / 1e9
+    served = p["subcubes"] * ub / (kms * 1e-3) / 1e9
+    r = {"bound": "hbm", "kernel": "bounds_sorted_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+         "traffic": None, "frac_of_measured_copy_rate": ach / HBM_COPY_GBS,
+         "avg_launch_us": kms * 1e3 / launches, "launches": int(launches), "evaluations_per_launch": p["evaluations"] / launches,
+         "subcubes_per_launch": p["subcubes"] / launches, "algorithmic_bytes_per_evaluation": ub,
+         "algorithmic_bytes_per_launch": p["evaluations"] * ub / launches,
+         "achieved_per_subcube_served": served, "frac_per_subcube_served": served / HBM_PEAK_GBS,
+         "every_counted_subcube_profiled": bool(p["subcubes"] == leg["subcubes_rank"]),
+         "note": "achieved = algorithmic bytes of the EVALUATIONS (SURVEY 8d unit x evaluations per launch) / launch duration, HIP events on the kernel's own stream; a "
+                 "translation node held by both the UB and the LB task of a rotation cube in one tick is two subcubes served by one evaluation (achieved_per_subcube_served)"}
+    if pmc:
+        r["traffic"] = pmc.get("hbm_bytes_per_launch")
+        r["traffic_source"] = pmc.get("source")
+        r["traffic_read_bytes_per_launch"] = pmc.get("read_bytes_per_launch")
+        r["traffic_write_bytes_per_launch"] = pmc.get("write_bytes_per_launch")
+        r["l2_hit_rate"] = pmc.get("l2_hit_rate")
+        if pmc.get("hbm_bytes_per_launch"):  # the passes run the same deterministic step: bytes per launch carry over, durations are this run's
+            act = pmc["hbm_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9
+            r["hbm_actual_GBps"] = act
+            r["hbm_actual_frac"] = act / HBM_PEAK_GBS
+            r["traffic_over_algorithmic"] = pmc["hbm_bytes_per_launch"] / r["algorithmic_bytes_per_launch"]
+        if pmc.get("limited_by"):
+            r["limited_by"] = pmc["limited_by"]
+    if extra:
+        r.update(extra)
+    return r
+
+
+def unique_line_model(fg, tgt, src, res, layout_bytes, samples=6, seed=0):
+    """Dense clouds: neighbouring points share LUT texels, so 8 private texels per point over-count what a subcube needs.
+    Counts, for sampled rigid motions, the distinct 128-byte lines of the packed LUT (z-pair: 8 B per node, rows y0 and y0+1;
+    yz-quad: 16 B per node) one evaluation touches — the compulsory traffic of a subcube with perfect re-use inside it and
+    none across subcubes.  numpy restatement of lut_address (kernels.hip) on the pre-processed clouds."""
+    pct, pcs, *_, bounds = fg.synth.preprocess(tgt, src)
+    b = np.asarray(bounds, np.float64)
+    d = [int(np.ceil(np.float32(np.float32(b[a, 1] - b[a, 0]) / np.float32(res)))) for a in range(3)]
+    px, py = d[0] + 2, d[1] + 2
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(samples):
+        R = fg.synth.random_rotation(rng)
+        t = rng.uniform(-0.25, 0.25, 3)
+        q = pcs.astype(np.float64) @ R.T + t
+        idx = []
+        for a in range(3):
+            u = (q[:, a] - b[a, 0]) / res - 0.5
+            idx.append(np.clip(np.floor(u), -1, d[a] - 1).astype(np.int64) + 1)
+        o = (idx[2] * py + idx[1]) * px + idx[0]
+        if layout_bytes == 8:   # z-pair: two 16-byte gathers, rows y0 and y0 + 1
+            addr = np.concatenate([o * 8, o * 8 + 15, (o + px) * 8, (o + px) * 8 + 15])
+        else:                   # yz-quad: 32 contiguous bytes
+            addr = np.concatenate([o * 16, o * 16 + 31])
+        out.append(len(np.unique(addr >> 7)) * 128.0 + len(pcs) * 16.0 / 32.0)
+    return float(np.mean(out))
+
+
+def cpu_baseline(fg, reg, tgt, src, res, mse, sched_id, K, seconds, gpu_leg):
+    """The reference has no CPU path, so the baseline is the product's host driver over the CPU oracle's operators
+    (tests/host_harness: same driver template, thresholds and LUT semantics) with a uniform-grid exact nearest-neighbour search
+    standing in for the nanoflann kd-tree the reference's README names.  A full run() to the optimum at the reference's default
+    threshold on the host's cores (kind "port"); its LUT is filled from the device LUT (bit-identical; the O(nodes * nt) CPU
+    build would take hours and is outside the timed span on the GPU side as well).  Plus the bounds operator on ONE core for a
+    bounded sample."""
     from oracle import pyoracle
+    from tests import host_harness as hh
     pyoracle.build()
+    cores = int(pyoracle.lib().orc_num_threads())
+    h = hh.HostDriver(tgt, src, res, mse, schedule=sched_id, round_width=K, build_lut=False, use_grid=True)
+    assert h.lut_dims() == tuple(reg.lut_dims())
+    h.lut_set(reg.lut_read())
+    t0 = time.perf_counter()
+    r = h.run()
+    wall = time.perf_counter() - t0
+    secs = h.seconds()
+    same = bool(abs(float(r["best_sse"]) - gpu_leg["best_sse"]) <= 1e-5 * gpu_leg["best_sse"] and np.allclose(r["R"], gpu_leg["R"], atol=1e-5))
+    # the bounds operator on ONE core, bounded sample of the same workload
+    pct, pcs, *_, bounds = fg.synth.preprocess(tgt, src)
     orc = pyoracle.Registration(pct, pcs, bounds, res, build_lut=False)
-    assert orc.lut_dims() == reg.lut_dims()
     orc.lut_set(reg.lut_read())
     rng = np.random.default_rng(0)
     rn = fg.RotNode(0.25, -0.125, 0.375, 0.125)
-    done, t0 = 0, time.perf_counter()
-    check = None
-    while True:
-        tn = np.concatenate([rng.uniform(-0.5, 0.5, (32, 3)), np.full((32, 1), 0.125)], axis=1).astype(np.float32)
-        lb, ub = orc.compute_bounds(rn.q.R, rn.span, tn, False)
-        if check is None:  # the checker checks: same batch on the GPU
-            lbg, ubg = reg.compute_sse_error(rn, tn, False)
-            check = bool(np.allclose(ub, ubg, rtol=1e-6) and np.allclose(lb, lbg, rtol=1e-6, atol=1e-6 * float(ub.max())))
-        done += 32
-        dt = time.perf_counter() - t0
-        if dt >= seconds:
-            break
-    cores = pyoracle.lib().orc_num_threads()
-    # the same operator on ONE core (a quarter of the time budget)
     pyoracle.lib().orc_set_num_threads(1)
     done1, t1 = 0, time.perf_counter()
     while True:
@@ -96,238 +261,144 @@ def cpu_baseline(fg, reg, pct, pcs, bounds, res, seconds):
         orc.compute_bounds(rn.q.R, rn.span, tn, False)
         done1 += 32
         dt1 = time.perf_counter() - t1
-        if dt1 >= seconds / 4:
+        if dt1 >= seconds:
             break
-    pyoracle.lib().orc_set_num_threads(int(cores))
-    return {"value": done / dt, "unit": "subcubes/s", "cores": int(cores), "kind": "port", "value_1_core": done1 / dt1,
-            "sample": f"{done} subcubes (batches of 32, fix_rot=0, ns={len(pcs)}) of the same workload in {dt:.1f}s, OpenMP over points",
-            "matches_gpu": check}
+    pyoracle.lib().orc_set_num_threads(cores)
+    sub = r["stats"]["trans_cubes"]
+    return {"value": sub / wall, "unit": "subcubes/s", "cores": cores, "kind": "port",
+            "sample": f"one full run() to the optimum: bunny-shape pair, mse_threshold={mse} (the reference's default), {sub} subcubes, "
+                      f"{r['stats']['icp_runs']} ICP runs ({r['stats']['icp_iters']} iterations), OpenMP over points/queries on {cores} threads",
+            "wall_clock_to_optimum_s": wall, "seconds_bnb": secs["bnb"], "seconds_icp": secs["icp"], "subcubes": int(sub),
+            "same_optimum_as_gpu": same, "best_sse": float(r["best_sse"]),
+            "gpu_wall_clock_to_optimum_s_same_run": gpu_leg["elapsed"] / gpu_leg["steps"],
+            "value_1_core": done1 / dt1, "sample_1_core": f"bounds operator only, {done1} subcubes (batches of 32, fix_rot=0) in {dt1:.1f}s on one thread",
+            "nearest_neighbour": "uniform grid over the target (oracle/goicp_oracle.cpp GridNN; exact, identical to the O(n*m) loops)"}
+
+
+def leg_summary(leg, R_gt, t_gt, what):
+    st = leg["stats"]
+    return {"workload": what, "subcubes_per_s": leg["subcubes"] / leg["elapsed"], "wall_clock_to_optimum_s": leg["elapsed"] / leg["steps"],
+            "subcubes_per_step": leg["subcubes"] / leg["steps"], "rot_cubes_rank0": st["rot_cubes"], "icp_runs_rank0": st["icp_runs"], "rounds": st["rounds"],
+            "seconds_bnb_rank0": st["seconds_bnb"], "seconds_icp_rank0": st["seconds_icp"], "best_sse": leg["best_sse"],
+            "bnb_without_icp_subcubes_per_s_rank0": st["trans_cubes"] / (st["seconds_total"] - st["seconds_icp"]) if st["seconds_total"] > st["seconds_icp"] else None,
+            "rotation_error_deg_vs_ground_truth": rot_err_deg(leg["R"], R_gt), "translation_error_vs_ground_truth": float(np.linalg.norm(leg["t"] - t_gt)),
+            "setup_s_upload_plus_lut_build": leg["setup_s"], "lut_dims": leg["lut_dims"]}
 
 
 def main():
     a = parse()
-    import torch
     import fgoicp_amd as fg
+    env = Env(a)
+    world, rank = env.world, env.rank
+    want = lambda name: (a.only is None or a.only == name)
+    pmc_all = {}
+    try:
+        pmc_all = json.load(open(os.path.join(REPO, "profiles", "bench_pmc.json")))
+    except Exception:
+        pass
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        a.gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no GPU visible (fgoicp_amd has no CPU path)")
-    if a.rehearse_on_one_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dist = None
-    red_dev = "cuda"  # where the few scalars of the final reduction live
-    if world > 1:
-        import torch.distributed as dist
-        if a.rehearse_on_one_gpu:
-            dist.init_process_group("gloo")
-            red_dev = "cpu"
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    # synthetic pair: rotation far outside the ICP basin, so the search has real work to do
-    tgt, src, R_gt, t_gt = fg.synth.workload(a.workload, angle_deg=150.0, min_angle_deg=110.0)
-    K = a.round_width  # rotation cubes popped per round; 0 = the solver's adaptive width (32 per rank, doubling while the incumbent stands)
+    K = a.round_width
     sched = fg.SCHEDULE_ROUND if a.schedule == "round" else fg.SCHEDULE_SERIAL
-    t0 = time.perf_counter()
-    solver = fg.FastGoICP(tgt, src, a.lut_resolution, a.mse_threshold, schedule=sched, round_width=K, device=local_rank)
-    torch.cuda.synchronize()
-    setup_s = time.perf_counter() - t0
-    reg = solver.registration
-    if world > 1:
-        from fgoicp_amd.dist import TorchExchange
-        ex = TorchExchange()
-        ex.warmup()  # communicator setup is not part of a registration run
-        solver.set_exchange(ex)
+    tgt, src, R_gt, t_gt = fg.synth.workload(a.workload, angle_deg=150.0, min_angle_deg=110.0)  # rotation far outside the ICP basin
+    line = {"metric": "BnB subcubes/sec + wall-clock to global optimum, bunny 40k pts, 1/2/4/8 GPU", "value": None, "unit": "subcubes/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic"}
+    head = None
+    if want("headline"):
+        head = run_leg(env, fg, tgt, src, a.lut_resolution, a.mse_threshold, sched, K, a.steps, a.warmup)
+        line.update({"value": head["subcubes"] / head["elapsed"], "ms_per_step": head["elapsed"] / a.steps * 1e3,
+                     "config": {"workload": f"{a.workload}-shape synthetic pair (nt={len(tgt)}, ns={len(src)}), lut_resolution={a.lut_resolution}, "
+                                            f"mse_threshold={a.mse_threshold}, full FastGoICP::run() per step",
+                                "schedule": a.schedule, "round_width": K if K > 0 else "adaptive (32 per rank, doubled after each round that leaves the incumbent standing)",
+                                "lut_dims": head["lut_dims"], "parallelism": f"rotation cubes sharded over {world} rank(s), allreduce(min)+allgather per round"},
+                     "wall_clock_to_optimum_s": head["elapsed"] / a.steps, "subcubes_per_step": head["subcubes"] / a.steps})
+        s = leg_summary(head, R_gt, t_gt, "headline")
+        line.update({k: s[k] for k in ("rot_cubes_rank0", "icp_runs_rank0", "rounds", "seconds_bnb_rank0", "seconds_icp_rank0", "setup_s_upload_plus_lut_build")})
+        line["result"] = {"best_sse": head["best_sse"], "rotation_error_deg_vs_ground_truth": s["rotation_error_deg_vs_ground_truth"],
+                          "translation_error_vs_ground_truth": s["translation_error_vs_ground_truth"]}
+        line["roofline"] = roofline(head, pmc_all.get("headline"))
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    # BASELINE.md's parameters (mse_threshold 1e-3) on the same clouds
+    dflt = None
+    if want("default_threshold") and not a.no_default_threshold_run:
+        dflt = run_leg(env, fg, tgt, src, a.lut_resolution, 1e-3, sched, K, 3, 1)
+        s = leg_summary(dflt, R_gt, t_gt, f"{a.workload}-shape pair, mse_threshold=0.001 (BASELINE.md's parameters), 3 steps after 1 warm-up")
+        s["mse_threshold"] = 1e-3
+        if head is not None:
+            s["same_optimum_as_headline"] = bool(np.allclose(dflt["R"], head["R"], atol=1e-5) and np.allclose(dflt["t"], head["t"], atol=1e-5 * max(1.0, float(np.abs(head["t"]).max()))))
+        line["reference_default_threshold"] = s
+        line["default_threshold_ms_per_step"] = s["wall_clock_to_optimum_s"] * 1e3
+        line["default_threshold_subcubes_per_s"] = s["subcubes_per_s"]
+        line["default_threshold_subcubes_per_step"] = s["subcubes_per_step"]
 
-    for _ in range(a.warmup):
-        solver.run()
-    reg.set_profile(True)  # HIP events around every bounds kernel of the timed region (costs ~2 % of the step)
-    reg.profile(reset=True)
-    sub = 0
-    stats = None
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        R, t = solver.run()
-        stats = solver.stats()
-        sub += stats["trans_cubes"]
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = reg.profile(reset=True)
-    reg.set_profile(False)
+    # the reference's own exploration order (the drop-in classes' default schedule)
+    if want("serial") and not a.no_serial and world == 1:
+        ser = run_leg(env, fg, tgt, src, a.lut_resolution, a.mse_threshold, fg.SCHEDULE_SERIAL, 1, 1, 1)
+        s = leg_summary(ser, R_gt, t_gt, f"{a.workload}-shape pair, mse_threshold={a.mse_threshold}, SERIAL schedule (the reference's pops, pushes and counters — "
+                                          "checked against the oracle's literal driver in tests), one step after 1 warm-up")
+        if head is not None:
+            s["same_optimum_as_headline"] = bool(np.allclose(ser["R"], head["R"], atol=1e-5) and abs(ser["best_sse"] - head["best_sse"]) <= 1e-5 * head["best_sse"])
+        s["roofline"] = roofline(ser, None)
+        line["serial_reference_order"] = s
+        ser["solver"].close()
 
-    tot = torch.tensor([float(sub), elapsed, prof["kernel_ms"], float(prof["launches"]), float(prof["subcubes"])], dtype=torch.float64, device=red_dev)
-    profiled_all = bool(prof["subcubes"] == sub)  # every counted subcube went through the profiled kernel
-    if dist is not None:
-        mx = tot.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        elapsed = float(mx[1])
-    total_sub = float(tot[0])
-
-    # the reference's default threshold on the same clouds (own solver: the threshold is a constructor argument)
-    ref_default = None
-    if not a.no_default_threshold_run:
-        s2 = fg.FastGoICP(tgt, src, a.lut_resolution, 1e-3, schedule=sched, round_width=K, device=local_rank)
-        if world > 1:
-            s2.set_exchange(ex)
-        s2.run()
-        barrier()
-        t1 = time.perf_counter()
-        n2 = 3
-        sub2 = 0
-        for _ in range(n2):
-            R2, t2 = s2.run()
-            sub2 += s2.stats()["trans_cubes"]
-        barrier()
-        e2 = time.perf_counter() - t1
-        tt = torch.tensor([float(sub2), e2], dtype=torch.float64, device=red_dev)
-        if dist is not None:
-            m2 = tt.clone()
-            dist.all_reduce(m2, op=dist.ReduceOp.MAX)
-            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-            e2 = float(m2[1])
-        st2 = s2.stats()
-        ref_default = {"mse_threshold": 1e-3, "wall_clock_to_optimum_s": e2 / n2, "subcubes_per_step": float(tt[0]) / n2,
-                       "subcubes_per_s": float(tt[0]) / e2, "rot_cubes_rank0": st2["rot_cubes"], "icp_runs_rank0": st2["icp_runs"],
-                       "seconds_icp_rank0": st2["seconds_icp"], "best_sse": float(s2.get_best_error()),
-                       "same_optimum_as_headline": bool(np.allclose(R2, R, atol=1e-5) and np.allclose(t2, t, atol=1e-5 * max(1.0, float(np.abs(t).max()))))}
-        s2.close()
-
-    # secondary measurement: the dragon-shape pair (BASELINE configs[2]/[3]; nt = ns = 437 645), certify regime, one step
-    dragon = None
-    if not a.no_dragon and a.workload == "bunny":
+    # dragon shape (BASELINE configs[2]/[3]; nt = ns = 437 645), certify regime, one step
+    if want("dragon") and not a.no_dragon and a.workload == "bunny":
         tgt_d, src_d, R_gt_d, t_gt_d = fg.synth.workload("dragon", angle_deg=150.0, min_angle_deg=110.0)
-        s3 = fg.FastGoICP(tgt_d, src_d, a.lut_resolution, 5e-6, schedule=sched, round_width=K, device=local_rank)  # ns*mse = 2.2 < residual 3.0
-        if world > 1:
-            s3.set_exchange(ex)
-        reg3 = s3.registration
-        reg3.set_profile(True)
-        reg3.profile(reset=True)
-        barrier()
-        t1 = time.perf_counter()
-        R3, t3 = s3.run()
-        barrier()
-        e3 = time.perf_counter() - t1
-        p3 = reg3.profile(reset=True)
-        st3 = s3.stats()
-        tt = torch.tensor([float(st3["trans_cubes"]), e3], dtype=torch.float64, device=red_dev)
-        if dist is not None:
-            m3 = tt.clone()
-            dist.all_reduce(m3, op=dist.ReduceOp.MAX)
-            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-            e3 = float(m3[1])
-        ach3 = (p3["subcubes"] * reg3.ns * 32.0 + p3["launches"] * reg3.ns * 12.0) / (p3["kernel_ms"] * 1e-3) / 1e9 if p3["kernel_ms"] > 0 else 0.0
-        dragon = {"workload": f"dragon-shape synthetic pair (nt={len(tgt_d)}, ns={len(src_d)}), mse_threshold=5e-06, one step, no warm-up",
-                  "subcubes_per_s": float(tt[0]) / e3, "wall_clock_to_optimum_s": e3, "subcubes": float(tt[0]), "rot_cubes_rank0": st3["rot_cubes"],
-                  "best_sse": float(s3.get_best_error()),
-                  "rotation_error_deg_vs_ground_truth": float(np.degrees(np.arccos(np.clip((np.trace(R3.astype(np.float64).T @ R_gt_d) - 1) / 2, -1, 1)))),
-                  "bounds_kernel_algorithmic_GBps_rank0": ach3,
-                  "note": "algorithmic bytes/s of the bounds kernel can exceed the HBM peak here: the dense cloud re-uses LUT lines out of L2 / Infinity Cache"}
-        s3.close()
+        dr = run_leg(env, fg, tgt_d, src_d, a.lut_resolution, 5e-6, sched, K, 1, 0)  # ns*mse = 2.2 < residual 3.0
+        s = leg_summary(dr, R_gt_d, t_gt_d, f"dragon-shape synthetic pair (nt={len(tgt_d)}, ns={len(src_d)}), mse_threshold=5e-06, one step, no warm-up")
+        extra = None
+        if rank == 0:
+            uniq = unique_line_model(fg, tgt_d, src_d, a.lut_resolution, 8)
+            p = dr["prof"]
+            ach_u = p["evaluations"] * uniq / (p["kernel_ms"] * 1e-3) / 1e9 if p["kernel_ms"] > 0 else 0.0
+            extra = {"private_texel_model_GBps": None, "unique_line_bytes_per_evaluation": uniq,
+                     "model": "dense cloud (>= 1 source point per LUT voxel face): neighbouring points share texels, so the byte model counts the distinct 128-B lines of the "
+                              "z-pair LUT one evaluation touches (sampled rigid motions, numpy) + the source read; 8 private texels per point (SURVEY 8d) is reported as "
+                              "private_texel_model_GBps and is NOT a roof here"}
+            r = roofline(dr, pmc_all.get("dragon"), extra)
+            if r:
+                r["private_texel_model_GBps"] = r["achieved"]
+                r["achieved"] = ach_u
+                r["frac"] = ach_u / HBM_PEAK_GBS
+                r["frac_of_measured_copy_rate"] = ach_u / HBM_COPY_GBS
+                r["algorithmic_bytes_per_evaluation"] = uniq
+                r["algorithmic_bytes_per_launch"] = p["evaluations"] * uniq / p["launches"]
+            s["roofline"] = r
+        line["dragon_shape"] = s
+        dr["solver"].close()
 
-    # secondary measurement: BASELINE configs[4] — 1M points, 20 % uniform outliers, trimmed Go-ICP (an extension: the reference
-    # parses `trim` and ignores it), the reference's default threshold, one step
-    trimmed = None
-    if not a.no_trimmed and a.workload == "bunny":
+    # BASELINE configs[4] — 1M points, 20 % uniform outliers, trimmed Go-ICP (an extension: the reference parses `trim` and ignores it)
+    if want("trimmed") and not a.no_trimmed and a.workload == "bunny":
         tgt_m, src_m, R_gt_m, t_gt_m = fg.synth.workload("synthetic1m_outliers", angle_deg=150.0, min_angle_deg=110.0)
-        s4 = fg.FastGoICP(tgt_m, src_m, a.lut_resolution, 1e-3, schedule=sched, round_width=K, device=local_rank, trim_fraction=0.2)
-        if world > 1:
-            s4.set_exchange(ex)
-        reg4 = s4.registration
-        reg4.set_profile(True)
-        reg4.profile(reset=True)
-        barrier()
-        t1 = time.perf_counter()
-        R4, t4 = s4.run()
-        barrier()
-        e4 = time.perf_counter() - t1
-        p4 = reg4.profile(reset=True)
-        st4 = s4.stats()
-        tt = torch.tensor([float(st4["trans_cubes"]), e4], dtype=torch.float64, device=red_dev)
-        if dist is not None:
-            m4 = tt.clone()
-            dist.all_reduce(m4, op=dist.ReduceOp.MAX)
-            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-            e4 = float(m4[1])
-        trimmed = {"workload": f"1M-point synthetic pair, 20 % of the source replaced by uniform outliers (nt={len(tgt_m)}, ns={len(src_m)}), trim_fraction=0.2, "
-                               "mse_threshold=0.001, one step, no warm-up",
-                   "subcubes_per_s": float(tt[0]) / e4, "wall_clock_to_optimum_s": e4, "subcubes": float(tt[0]), "rot_cubes_rank0": st4["rot_cubes"],
-                   "icp_runs_rank0": st4["icp_runs"], "seconds_icp_rank0": st4["seconds_icp"], "best_sse": float(s4.get_best_error()),
-                   "bounds_kernel_algorithmic_GBps_rank0": ((p4["subcubes"] * reg4.ns * 32.0 + p4["launches"] * reg4.ns * 12.0) / (p4["kernel_ms"] * 1e-3) / 1e9) if p4["kernel_ms"] > 0 else 0.0,
-                   "bounds_kernel_frac_of_hbm_peak_rank0": ((p4["subcubes"] * reg4.ns * 32.0 + p4["launches"] * reg4.ns * 12.0) / (p4["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if p4["kernel_ms"] > 0 else 0.0,
-                   "note": "the trimmed bounds kernel also writes 8 B per point-subcube (the per-point terms the selection kernel reads back); ICP on 1M points with 20 % "
-                           "far outliers is the larger part of the run",
-                   "rotation_error_deg_vs_ground_truth": float(np.degrees(np.arccos(np.clip((np.trace(R4.astype(np.float64).T @ R_gt_m) - 1) / 2, -1, 1))))}
-        s4.close()
+        tr = run_leg(env, fg, tgt_m, src_m, a.lut_resolution, 1e-3, sched, K, 1, 0, trim=0.2)
+        s = leg_summary(tr, R_gt_m, t_gt_m, f"1M-point synthetic pair, 20 % of the source replaced by uniform outliers (nt={len(tgt_m)}, ns={len(src_m)}), trim_fraction=0.2, "
+                                             "mse_threshold=0.001, one step, no warm-up")
+        p = tr["prof"]
+        extra = {"select_kernel": "trim_rows_kernel", "select_kernel_ms": p["select_ms"], "bounds_kernel_ms": p["kernel_ms"],
+                 "select_bytes_per_row": 2 * 4.0 * tr["ns"], "bounds_write_bytes_per_row": 4.0 * tr["ns"],
+                 "bnb_without_icp_GBps_algorithmic_rank0": tr["stats"]["trans_cubes"] * unit_bytes(tr["ns"]) / (tr["stats"]["seconds_total"] - tr["stats"]["seconds_icp"]) / 1e9,
+                 "model": "algorithmic bytes as for the untrimmed operator (SURVEY 8d); on top of them the trimmed path writes 4 B per point-row (e = max(d, 0)) and the "
+                          "selection kernel, which runs NEXT TO the bounds kernel on a side stream, reads each row twice"}
+        s["roofline"] = roofline(tr, pmc_all.get("trimmed"), extra)
+        line["trimmed_1m_outliers"] = s
+        tr["solver"].close()
 
     if rank == 0:
-        ns = reg.ns
-        launches, ksub, kms = prof["launches"], prof["subcubes"], prof["kernel_ms"]
-        alg_bytes = ksub * ns * 32.0 + launches * ns * 12.0  # ns*(32 + 12/B) per subcube
-        ach = alg_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-        err_R = float(np.degrees(np.arccos(np.clip((np.trace(R.astype(np.float64).T @ R_gt) - 1) / 2, -1, 1))))
-        line = {
-            "metric": "BnB subcubes/sec + wall-clock to global optimum, bunny 40k pts, 1/2/4/8 GPU",
-            "value": total_sub / elapsed, "unit": "subcubes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{a.workload}-shape synthetic pair (nt={len(tgt)}, ns={len(src)}), lut_resolution={a.lut_resolution}, "
-                                   f"mse_threshold={a.mse_threshold}, full FastGoICP::run() per step",
-                       "schedule": a.schedule, "round_width": K if K > 0 else "adaptive (32 per rank, doubled after each round that leaves the incumbent standing)", "lut_dims": list(reg.lut_dims()),
-                       "parallelism": f"rotation cubes sharded over {world} rank(s), allreduce(min)+allgather per round"},
-            "wall_clock_to_optimum_s": elapsed / a.steps,
-            "subcubes_per_step": total_sub / a.steps,
-            "rot_cubes_rank0": stats["rot_cubes"], "icp_runs_rank0": stats["icp_runs"], "rounds": stats["rounds"],
-            "seconds_bnb_rank0": stats["seconds_bnb"], "seconds_icp_rank0": stats["seconds_icp"],
-            "setup_s_upload_plus_lut_build": setup_s,
-            "result": {"best_sse": float(solver.get_best_error()), "rotation_error_deg_vs_ground_truth": err_R,
-                       "translation_error_vs_ground_truth": float(np.linalg.norm(t - t_gt))},
-            "reference_default_threshold": ref_default,
-            "dragon_shape": dragon,
-            "trimmed_1m_outliers": trimmed,
-            "roofline": {"bound": "hbm", "kernel": "bounds_sorted_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                         "avg_launch_us": kms * 1e3 / launches if launches else None, "launches": int(launches),
-                         "subcubes_per_launch": ksub / launches if launches else None,
-                         "evaluations_per_launch": prof["evaluations"] / launches if launches else None,
-                         "every_counted_subcube_profiled": profiled_all,
-                         "note": "achieved = algorithmic bytes of the SUBCUBES a launch serves (SURVEY 8d) / its duration; a translation node held by both the "
-                                 "UB and the LB task of a rotation cube in the same tick is two subcubes and one evaluation (one lookup per point, both variants)",
-                         "algorithmic_bytes_per_subcube": ns * 32.0 + ns * 12.0 * launches / max(ksub, 1)},
-        }
-        pmc = os.path.join(REPO, "profiles", "bench_pmc.json")  # written from separate rocprofv3 --pmc passes of this same command
-        if world == 1 and os.path.exists(pmc):
-            try:
-                pj = json.load(open(pmc))
-                line["roofline"]["traffic"] = pj["hbm_bytes_per_launch"]
-                line["roofline"]["traffic_source"] = pj.get("source", "profiles/bench_pmc.json")
-                line["roofline"]["algorithmic_bytes_per_launch"] = alg_bytes / launches if launches else None
-            except Exception:
-                pass
-        if world == 1 and not a.no_cpu_baseline:
-            pct, pcs, *_, bounds = fg.synth.preprocess(tgt, src)
-            pp = solver.preproc()
-            assert np.array_equal(pp["bounds"], bounds)
-            line["cpu_baseline"] = cpu_baseline(fg, reg, pct, pcs, bounds, a.lut_resolution, a.cpu_seconds)
+        if world == 1 and want("cpu_baseline") and not a.no_cpu_baseline and a.only in (None, "cpu_baseline"):
+            gleg = dflt
+            if gleg is None:  # --only cpu_baseline: the GPU run it is compared with
+                gleg = run_leg(env, fg, tgt, src, a.lut_resolution, 1e-3, sched, K, 1, 1)
+            line["cpu_baseline"] = cpu_baseline(fg, gleg["reg"], tgt, src, a.lut_resolution, 1e-3, 1 if a.schedule == "round" else 0, K, a.cpu_seconds, gleg)
+        if a.only and a.only != "headline":
+            line["only"] = a.only
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    solver.close()
+    if env.dist is not None:
+        env.dist.barrier()
+        env.dist.destroy_process_group()
+    for leg in (head, dflt):
+        if leg is not None:
+            leg["solver"].close()
 
 
 if __name__ == "__main__":

@@ -38,6 +38,12 @@ int ctx_flush_profile(fgoicp_ctx* c) {
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, c->ev_start[i], c->ev_stop[i]));
         c->prof_ms += ms;
+        if (c->ev_has_sel[i]) {  // trimmed mode: the selection kernel of the same window (side stream)
+            HIPCHK(hipEventSynchronize(c->ev_sel_stop[i]));
+            HIPCHK(hipEventElapsedTime(&ms, c->ev_sel_start[i], c->ev_sel_stop[i]));
+            c->prof_sel_ms += ms;
+            c->ev_has_sel[i] = 0;
+        }
     }
     c->ev_used = 0;
     return FGOICP_OK;
@@ -103,9 +109,12 @@ static int tick_launch_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
         HIPCHK(hipEventRecord(sl.bounds_ev, sl.stream));
         HIPCHK(hipStreamWaitEvent(fin, sl.bounds_ev, 0));
     }
-    if (c->inliers)  // trimmed: per row one selection of the k smallest e, both sums from it
+    if (c->inliers) {  // trimmed: per row one selection of the k smallest e, both sums from it
+        const int pi = e0 ? c->ev_used - 1 : -1;
+        if (pi >= 0) { HIPCHK(hipEventRecord(c->ev_sel_start[pi], fin)); c->ev_has_sel[pi] = 1; }
         launch_trim_rows(sl.d_evals, c->erow, (int)c->ns, (int)c->inliers, rows, sl.hd_row_span, sl.hd_ub, sl.hd_lb, fin);
-    else
+        if (pi >= 0) HIPCHK(hipEventRecord(c->ev_sel_stop[pi], fin));
+    } else
         launch_bounds_finalize(sl.d_partials, c->nchunk1, rows, sl.hd_lb, sl.hd_ub, fin);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(sl.done, fin));
@@ -829,6 +838,8 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& e : c->ev_start) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_stop) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_sel_start) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_sel_stop) if (e) (void)hipEventDestroy(e);
     (void)hipFree(c->d_src); (void)hipFree(c->d_work); (void)hipFree(c->d_tgt); (void)hipFree(c->d_lut); (void)hipFree(c->d_lut_zp);
     (void)hipFree(c->d_partials); (void)hipFree(c->d_min_bits); (void)hipFree(c->d_thr_bits); (void)hipFree(c->d_first_idx);
     (void)hipFree(c->d_bp); (void)hipFree(c->d_bp2); (void)hipFree(c->d_bp3); (void)hipFree(c->d_cen); (void)hipFree(c->d_first_idx2);
@@ -1026,7 +1037,18 @@ int fgoicp_ctx_profile(fgoicp_ctx* c, double* kernel_ms, uint64_t* launches, uin
     if (kernel_ms) *kernel_ms = c->prof_ms;
     if (launches) *launches = c->prof_launches;
     if (subcubes) *subcubes = c->prof_subcubes;
-    if (reset) { c->prof_ms = 0; c->prof_launches = 0; c->prof_subcubes = 0; c->prof_evals = 0; }
+    if (reset) { c->prof_ms = 0; c->prof_launches = 0; c->prof_subcubes = 0; c->prof_evals = 0; c->prof_sel_ms_last = c->prof_sel_ms; c->prof_sel_ms = 0; }
+    return FGOICP_OK;
+}
+
+int fgoicp_ctx_profile_select_ms(fgoicp_ctx* c, double* select_ms) {
+    if (!c || !select_ms) return FGOICP_ERR_INVALID_ARG;
+    if (c->ev_used) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        int rc = ctx_flush_profile(c);
+        if (rc) return rc;
+    }
+    *select_ms = c->prof_sel_ms;
     return FGOICP_OK;
 }
 
@@ -1042,9 +1064,14 @@ int fgoicp_ctx_set_profile(fgoicp_ctx* c, int enabled) {
     if (enabled && c->ev_start.empty()) {
         c->ev_start.assign(1024, nullptr);
         c->ev_stop.assign(1024, nullptr);
+        c->ev_sel_start.assign(1024, nullptr);
+        c->ev_sel_stop.assign(1024, nullptr);
+        c->ev_has_sel.assign(1024, 0);
         for (size_t i = 0; i < c->ev_start.size(); ++i) {
             HIPCHK(hipEventCreate(&c->ev_start[i]));
             HIPCHK(hipEventCreate(&c->ev_stop[i]));
+            HIPCHK(hipEventCreate(&c->ev_sel_start[i]));
+            HIPCHK(hipEventCreate(&c->ev_sel_stop[i]));
         }
     }
     if (!enabled && c->ev_used) {

@@ -101,7 +101,9 @@ struct fgoicp_ctx {
     float *h_cen = nullptr, *hd_cen = nullptr;  // ... and their pinned host copy
 
     // HIP-event profile of the bounds kernel
-    std::vector<hipEvent_t> ev_start, ev_stop;
+    std::vector<hipEvent_t> ev_start, ev_stop, ev_sel_start, ev_sel_stop;   // bounds kernel / trimmed selection kernel of the same window
+    std::vector<char> ev_has_sel;
+    double prof_sel_ms = 0.0, prof_sel_ms_last = 0.0;
     int ev_used = 0;
     double prof_ms = 0.0;
     uint64_t prof_launches = 0, prof_subcubes = 0, prof_evals = 0;

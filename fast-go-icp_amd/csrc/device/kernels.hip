@@ -435,6 +435,14 @@ __global__ __launch_bounds__(64) void tick_check_kernel(const unsigned* __restri
     for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < nitems; i += (size_t)gridDim.x * 64) bad = bad || sorted[i] >= nitems;
     if (__any(bad) && threadIdx.x == 0) *err = 1u;
 }
+// one-wave workgroups like the rest of the sort (a runtime memset uses wide workgroups, which wait for several free wave slots
+// on ONE CU while the other slot's bounds kernel keeps them all taken: measured 390 us per call instead of a few)
+__global__ __launch_bounds__(64) void tick_prefill_kernel(unsigned* __restrict__ sorted, size_t nitems) {
+    uint4* s4 = reinterpret_cast<uint4*>(sorted);
+    const size_t n4 = nitems >> 2;
+    for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 64) s4[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    if (blockIdx.x == 0 && threadIdx.x < (nitems & 3)) sorted[(n4 << 2) + threadIdx.x] = ~0u;
+}
 __global__ void tick_fault_kernel(unsigned* sorted) { sorted[0] = 0xFFFFFFFFu; }  // test hook (FGOICP_SORT_FAULT_TICK): a slot no item was scattered to
 // A/B only (FGOICP_SORT_RANKS=0): the classic scatter with its own atomic per item
 __global__ __launch_bounds__(64) void tick_scatter_atomic_kernel(const unsigned short* __restrict__ keys, size_t nitems, unsigned* __restrict__ cursor,
@@ -911,8 +919,9 @@ __global__ __launch_bounds__(64) void select_wide_final_kernel(uint32_t* __restr
 
 // ICP with trimming: squared distance of every working point to its correspondence ...
 __global__ __launch_bounds__(kBlock) void icp_corr_d2_kernel(const float4* __restrict__ work, const float4* __restrict__ tgt, const uint32_t* __restrict__ idx,
-                                                             int n, int nt, float* __restrict__ d2) {
+                                                             int n, int nt, float* __restrict__ d2, uint32_t* __restrict__ equal_count) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i == 0) *equal_count = 0u;  // counted by icp_inlier_mask_kernel, two launches later on the same stream
     if (i >= n) return;
     const float4 a = work[i];
     const uint32_t j = idx[i];
@@ -1682,7 +1691,7 @@ void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, con
     static const int hilbert = [] { const char* e = std::getenv("FGOICP_SORT_CURVE"); return e ? std::atoi(e) : 1; }();  // tuning knob: 1 = Hilbert (default), 0 = Z-order
     static const int use_ranks = [] { const char* e = std::getenv("FGOICP_SORT_RANKS"); return e ? std::atoi(e) : 1; }();  // tuning knob
     const bool xcd = allow_xcd && use_ranks && hist_xcd && xoff;  // allow_xcd: FGOICP_SORT_XCD per context, cleared by a failed permutation check
-    if (check_err) (void)hipMemsetAsync(sorted, 0xFF, sizeof(unsigned) * nitems, s);
+    if (check_err) hipLaunchKernelGGL(tick_prefill_kernel, dim3((unsigned)std::min<size_t>((nitems / 4 + 63) / 64 + 1, 4096)), dim3(64), 0, s, sorted, nitems);
     if (xcd) {
         if (hilbert) hipLaunchKernelGGL((tick_keys_kernel<1, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd);
         else hipLaunchKernelGGL((tick_keys_kernel<0, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd);
@@ -1877,9 +1886,8 @@ void launch_trim_select(const float* vals, int n, int k, float* out, uint32_t* s
 void launch_icp_inliers(const float4* work, const float4* tgt, const uint32_t* idx, int n, int nt, int k, float* d2, uint32_t* sel_info,
                         uint32_t* equal_count, const uint32_t* orig_of_slot, unsigned char* use, uint32_t* wide_scratch, hipStream_t s) {
     const int nb = (n + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(icp_corr_d2_kernel, dim3(nb), dim3(kBlock), 0, s, work, tgt, idx, n, nt, d2);
+    hipLaunchKernelGGL(icp_corr_d2_kernel, dim3(nb), dim3(kBlock), 0, s, work, tgt, idx, n, nt, d2, equal_count);
     launch_trim_select(d2, n, k, nullptr, sel_info, wide_scratch, s);
-    (void)hipMemsetAsync(equal_count, 0, sizeof(uint32_t), s);
     hipLaunchKernelGGL(icp_inlier_mask_kernel, dim3(nb), dim3(kBlock), 0, s, d2, n, sel_info, use, equal_count);
     hipLaunchKernelGGL(icp_inlier_ties_kernel, dim3(std::max(1, std::min(256, (n + 1023) / 1024))), dim3(1024), 0, s, n, sel_info, equal_count, orig_of_slot, use);
 }

@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <array>
 #include <functional>
+#include <iterator>
 #include <map>
 #include <thread>
 #include <cstdint>
@@ -187,6 +188,7 @@ struct InnerTask {
 };
 
 struct Task : InnerTask {
+    std::vector<std::array<uint32_t, 4>> seen;  // FGOICP_OVERLAP_STATS only: every node this task had evaluated
     bool done = false;
     bool has_batch = false;
     uint64_t batches = 0;  // operator calls this task took part in (= compute_sse_error calls of the reference for it)
@@ -321,6 +323,11 @@ public:
             std::fprintf(stderr, "[fgoicp timing] run %.3f s: pop+pack %.3f s, operator %.3f s, push %.3f s, icp %.3f s, calls %llu\n", stats_.seconds_total, t_pop_, t_ops_,
                          t_push_, stats_.seconds_icp, (unsigned long long)stats_.bounds_calls);
         t_pop_ = t_ops_ = t_push_ = 0;
+        if (overlap_stats_) {
+            std::fprintf(stderr, "[fgoicp overlap] UB-task nodes %llu, LB-task nodes %llu, in both %llu (%.1f %% of all subcubes could be served from the twin's evaluation)\n",
+                         (unsigned long long)ov_ub_, (unsigned long long)ov_lb_, (unsigned long long)ov_both_, 100.0 * ov_both_ / std::max<double>(1.0, (double)(ov_ub_ + ov_lb_)));
+            ov_ub_ = ov_lb_ = ov_both_ = 0;
+        }
         return kDriverOk;
     }
 
@@ -640,6 +647,8 @@ private:
             if (!tk.next_batch(sse_threshold_)) { tk.done = true; return; }
             tk.has_batch = true;
             tk.batches++;
+            if (overlap_stats_)
+                for (const TransCube& c : tk.batch) { std::array<uint32_t, 4> k; std::memcpy(k.data(), &c.t.x, 12); std::memcpy(&k[3], &c.span, 4); tk.seen.push_back(k); }
         };
         if (par) pool_->parallel_for(h.members.size(), pop_fn);
         else for (size_t k = 0; k < h.members.size(); ++k) pop_fn(k);
@@ -747,7 +756,22 @@ private:
     // split into two halves on two slots: while the device evaluates one half, the host consumes the
     // results of the other and pops its next batches.  A task's own sequence of batches is the same
     // either way, so results do not depend on the mode.
+    void overlap_report(std::vector<Task*>& tasks, const std::vector<const RotCube*>& cubes) {
+        for (size_t i = 0; i + 1 < tasks.size(); i += 2) {
+            if (cubes[i] != cubes[i + 1]) continue;
+            auto &a = tasks[i]->seen, &b = tasks[i + 1]->seen;
+            std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
+            std::vector<std::array<uint32_t, 4>> both;
+            std::set_intersection(a.begin(), a.end(), b.begin(), b.end(), std::back_inserter(both));
+            ov_ub_ += a.size(); ov_lb_ += b.size(); ov_both_ += both.size();
+        }
+    }
     int run_task_list(std::vector<Task*>& tasks, const std::vector<const RotCube*>& cubes) {
+        const int rc_ = run_task_list_impl(tasks, cubes);
+        if (overlap_stats_) overlap_report(tasks, cubes);
+        return rc_;
+    }
+    int run_task_list_impl(std::vector<Task*>& tasks, const std::vector<const RotCube*>& cubes) {
         const bool par = tasks.size() >= 8 && pool_->size() > 1;
         const bool timing = timing_;
         if (tasks.size() >= 4 && ops_.async()) {
@@ -805,6 +829,8 @@ private:
     double t_pop_ = 0, t_ops_ = 0, t_push_ = 0;
     const bool timing_ = std::getenv("FGOICP_TIMING") != nullptr;  // host-side timing lines on stderr
     bool use_twins_ = [] { const char* e = std::getenv("FGOICP_TWINS"); return !e || std::atoi(e) != 0; }();  // tuning knob
+    const bool overlap_stats_ = std::getenv("FGOICP_OVERLAP_STATS") != nullptr;  // diagnostic: how many nodes both tasks of a rotation cube evaluate
+    uint64_t ov_ub_ = 0, ov_lb_ = 0, ov_both_ = 0;
     bool account_submissions_ = true;   // false while SERIAL speculates: work is accounted per committed task instead
     std::unique_ptr<WorkerPool> pool_;
     float sse_threshold_;

@@ -160,10 +160,11 @@ class Registration:
         _lib.check(self._lib.fgoicp_ctx_set_profile(self._h, int(bool(enabled))), "fgoicp_ctx_set_profile")
 
     def profile(self, reset=False):
-        ms = C.c_double(); launches = C.c_uint64(); sub = C.c_uint64(); ev = C.c_uint64()
+        ms = C.c_double(); launches = C.c_uint64(); sub = C.c_uint64(); ev = C.c_uint64(); sel = C.c_double()
         _lib.check(self._lib.fgoicp_ctx_profile_evaluations(self._h, C.byref(ev)), "fgoicp_ctx_profile_evaluations")
+        _lib.check(self._lib.fgoicp_ctx_profile_select_ms(self._h, C.byref(sel)), "fgoicp_ctx_profile_select_ms")
         _lib.check(self._lib.fgoicp_ctx_profile(self._h, C.byref(ms), C.byref(launches), C.byref(sub), int(reset)), "fgoicp_ctx_profile")
-        return {"kernel_ms": ms.value, "launches": launches.value, "subcubes": sub.value, "evaluations": ev.value}
+        return {"kernel_ms": ms.value, "launches": launches.value, "subcubes": sub.value, "evaluations": ev.value, "select_ms": sel.value}
 
 
 class IterativeClosestPoint3D:

@@ -150,6 +150,9 @@ int fgoicp_ctx_profile(fgoicp_ctx* ctx, double* kernel_ms, uint64_t* launches, u
 /* Evaluations behind those subcubes since the last reset: a twin pair (fgoicp_bounds_submit_twins) is two subcubes and one
  * evaluation.  Read it before the fgoicp_ctx_profile call that resets. */
 int fgoicp_ctx_profile_evaluations(fgoicp_ctx* ctx, uint64_t* evaluations);
+/* Trimmed mode: accumulated duration of the selection kernel (one launch per window, next to the bounds kernel) since the last
+ * reset by fgoicp_ctx_profile — read it before that call. */
+int fgoicp_ctx_profile_select_ms(fgoicp_ctx* ctx, double* select_ms);
 /* Turns the HIP-event bracketing on or off at run time (events are created on first use). */
 int fgoicp_ctx_set_profile(fgoicp_ctx* ctx, int enabled);
 size_t fgoicp_ctx_ns(const fgoicp_ctx* ctx);

@@ -82,6 +82,7 @@ void* orc_reg_create(const float* tgt, size_t nt, const float* src, size_t ns, c
 }
 void orc_reg_destroy(void* p) { delete static_cast<RegHandle*>(p); }
 void orc_reg_set_inliers(void* p, size_t k) { static_cast<RegHandle*>(p)->reg->inliers = k; }
+void orc_reg_use_grid(void* p, int on) { static_cast<RegHandle*>(p)->reg->use_grid(on != 0); }  // CPU baseline only
 void orc_reg_lut_dims(void* p, int* dims3) {
     auto* h = static_cast<RegHandle*>(p);
     for (int i = 0; i < 3; ++i) dims3[i] = h->reg->nnlut.dims[i];

@@ -163,6 +163,140 @@ float brute_force_find_nearest_neighbor(const Vec3& q, const PointCloud& pct) { 
     return best;
 }
 
+// ---------------------------------------------------------------------------------------------
+// GridNN — CPU baseline only (see header).  Cells of side h hold the target indices (counting sort, ascending inside a cell);
+// a query walks Chebyshev shells around its (clamped) cell until everything outside the walked block is provably farther.
+// ---------------------------------------------------------------------------------------------
+void GridNN::build(const PointCloud& cloud) {
+    pc = &cloud;
+    const size_t nt = cloud.size();
+    lo = hi = cloud[0];
+    for (const Vec3& p : cloud) {
+        lo.x = std::min(lo.x, p.x); lo.y = std::min(lo.y, p.y); lo.z = std::min(lo.z, p.z);
+        hi.x = std::max(hi.x, p.x); hi.y = std::max(hi.y, p.y); hi.z = std::max(hi.z, p.z);
+    }
+    const double ex = std::max(1e-9, (double)hi.x - lo.x), ey = std::max(1e-9, (double)hi.y - lo.y), ez = std::max(1e-9, (double)hi.z - lo.z);
+    // surfaces: ~2 points per occupied cell when the cell side is ~sqrt(2 * area / nt); the box area stands in for the surface's
+    const double area = 2.0 * (ex * ey + ey * ez + ex * ez);
+    h = (float)std::max(std::sqrt(2.0 * area / (double)nt), std::max(ex, std::max(ey, ez)) / 512.0);
+    n[0] = std::max(1, (int)std::ceil(ex / h)); n[1] = std::max(1, (int)std::ceil(ey / h)); n[2] = std::max(1, (int)std::ceil(ez / h));
+    auto cell_of = [&](const Vec3& p, int a) {
+        const float v = a == 0 ? (p.x - lo.x) : a == 1 ? (p.y - lo.y) : (p.z - lo.z);
+        return std::min(n[a] - 1, std::max(0, (int)std::floor(v / h)));
+    };
+    const size_t ncell = (size_t)n[0] * n[1] * n[2];
+    start.assign(ncell + 1, 0);
+    std::vector<int> cid(nt);
+    for (size_t i = 0; i < nt; ++i) {
+        cid[i] = (cell_of(cloud[i], 2) * n[1] + cell_of(cloud[i], 1)) * n[0] + cell_of(cloud[i], 0);
+        start[cid[i] + 1]++;
+    }
+    for (size_t c = 0; c < ncell; ++c) start[c + 1] += start[c];
+    items.resize(nt);
+    std::vector<int> cur(start.begin(), start.end() - 1);
+    for (size_t i = 0; i < nt; ++i) items[cur[cid[i]]++] = (int)i;
+}
+
+// visit(first, last) is called with item ranges; after every shell `done(lb2)` is asked whether points at squared distance >= lb2
+// can still matter (lb2 = squared distance from q to everything outside the walked block of cells, deflated for rounding).
+template <class F>
+void GridNN::rings(const Vec3& q, F& f) const {
+    int c[3];
+    const float qv[3] = {q.x, q.y, q.z}, lov[3] = {lo.x, lo.y, lo.z}, hiv[3] = {hi.x, hi.y, hi.z};
+    for (int a = 0; a < 3; ++a) c[a] = std::min(n[a] - 1, std::max(0, (int)std::floor((qv[a] - lov[a]) / h)));
+    const int rmax = std::max(n[0], std::max(n[1], n[2]));
+    for (int r = 0; r <= rmax; ++r) {
+        const int x0 = std::max(0, c[0] - r), x1 = std::min(n[0] - 1, c[0] + r), y0 = std::max(0, c[1] - r), y1 = std::min(n[1] - 1, c[1] + r);
+        const int z0 = std::max(0, c[2] - r), z1 = std::min(n[2] - 1, c[2] + r);
+        for (int z = z0; z <= z1; ++z)
+            for (int y = y0; y <= y1; ++y) {
+                const bool edge_zy = (z == c[2] - r || z == c[2] + r || y == c[1] - r || y == c[1] + r);
+                if (edge_zy) {
+                    const size_t row = ((size_t)z * n[1] + y) * n[0];
+                    f.visit(start[row + x0], start[row + x1 + 1]);
+                } else {  // only the two end cells of the row lie on the shell
+                    const size_t row = ((size_t)z * n[1] + y) * n[0];
+                    if (c[0] - r >= 0) f.visit(start[row + c[0] - r], start[row + c[0] - r + 1]);
+                    if (r > 0 && c[0] + r < n[0]) f.visit(start[row + c[0] + r], start[row + c[0] + r + 1]);
+                }
+            }
+        // everything not walked yet lies in one of up to six slabs of the grid's box outside the block [x0..x1] x [y0..y1] x [z0..z1]
+        const int b0[3] = {x0, y0, z0}, b1[3] = {x1, y1, z1};
+        double lb2 = -1.0;
+        for (int a = 0; a < 3; ++a)
+            for (int side = 0; side < 2; ++side) {
+                if (side == 0 ? b0[a] == 0 : b1[a] == n[a] - 1) continue;
+                double d2 = 0.0;
+                for (int k = 0; k < 3; ++k) {
+                    double slo = lov[k], shi = hiv[k];
+                    if (k == a) {  // the slab, widened by a hair towards the block (points are binned with fp32 arithmetic)
+                        if (side == 0) shi = (double)lov[k] + (double)b0[k] * h + 1e-3 * h;
+                        else slo = (double)lov[k] + (double)(b1[k] + 1) * h - 1e-3 * h;
+                    }
+                    const double d = std::max(std::max(slo - qv[k], qv[k] - shi), 0.0);
+                    d2 += d * d;
+                }
+                lb2 = lb2 < 0.0 || d2 < lb2 ? d2 : lb2;
+            }
+        if (lb2 < 0.0) return;                       // the block is the whole grid
+        if (f.done((float)(lb2 * 0.9999))) return;
+    }
+}
+
+float GridNN::min_d2(const Vec3& q) const {
+    struct V {
+        const GridNN& g; const Vec3& q; float best;
+        void visit(int a, int b) {
+            for (int k = a; k < b; ++k) {
+                const Vec3& p = (*g.pc)[g.items[k]];
+                const float d = dev_dist_sq(q.x, q.y, q.z, p.x, p.y, p.z);
+                if (d < best) best = d;
+            }
+        }
+        bool done(float lb2) const { return lb2 > best; }
+    } v{*this, q, kInf};
+    rings(q, v);
+    return v.best;
+}
+
+static float sqrt_tie_threshold(float best) {  // largest float whose correctly rounded sqrt equals sqrt(best)
+    uint32_t b;
+    std::memcpy(&b, &best, 4);
+    const float s = std::sqrt(best);
+    for (int it = 0; it < 8; ++it) {
+        const uint32_t nb = b + 1;
+        float x;
+        std::memcpy(&x, &nb, 4);
+        if (std::sqrt(x) == s) b = nb; else break;
+    }
+    float out;
+    std::memcpy(&out, &b, 4);
+    return out;
+}
+
+int GridNN::first_min_sqrt_index(const Vec3& q) const {
+    const float thr = sqrt_tie_threshold(min_d2(q));  // icp3d.cu:20-25 compares sqrt distances with a strict '>': the first index of the tie set wins
+    struct V {
+        const GridNN& g; const Vec3& q; float thr; int idx;
+        void visit(int a, int b) {
+            for (int k = a; k < b; ++k) {
+                const int j = g.items[k];
+                const Vec3& p = (*g.pc)[j];
+                if (dev_dist_sq(p.x, p.y, p.z, q.x, q.y, q.z) <= thr && j < idx) idx = j;
+            }
+        }
+        bool done(float lb2) const { return lb2 > thr; }
+    } v{*this, q, thr, 0x7fffffff};
+    rings(q, v);
+    return v.idx;
+}
+
+void Registration::use_grid(bool on) {
+    if (!on) { grid.reset(); return; }
+    grid = std::make_shared<GridNN>();
+    grid->build(pct);
+}
+
 // EXTENSION: trimmed sums (see header).  The k smallest terms, added in ascending order in fp64.
 float trimmed_sum(std::vector<float>& v, size_t k) {
     if (k == 0 || k >= v.size()) {
@@ -188,7 +322,8 @@ float Registration::compute_sse_error(const Mat3& R, const Vec3& t) const {  // 
 #pragma omp parallel for schedule(static)
         for (long i = 0; i < ns; ++i) {
             Vec3 rp = dev_mul(R, pcs[i]);
-            e[i] = brute_force_find_nearest_neighbor(Vec3{rp.x + t.x, rp.y + t.y, rp.z + t.z}, pct);
+            const Vec3 q{rp.x + t.x, rp.y + t.y, rp.z + t.z};
+            e[i] = grid ? grid->min_d2(q) : brute_force_find_nearest_neighbor(q, pct);
         }
         return trimmed_sum(e, inliers);
     }
@@ -200,7 +335,7 @@ float Registration::compute_sse_error(const Mat3& R, const Vec3& t) const {  // 
         for (long i = c * kChunk; i < std::min(ns, (c + 1) * kChunk); ++i) {
             Vec3 rp = dev_mul(R, pcs[i]);
             Vec3 q{rp.x + t.x, rp.y + t.y, rp.z + t.z};
-            s += (double)brute_force_find_nearest_neighbor(q, pct);
+            s += (double)(grid ? grid->min_d2(q) : brute_force_find_nearest_neighbor(q, pct));
         }
         part[c] = s;
     }
@@ -432,6 +567,12 @@ std::tuple<Mat3, Vec3> IterativeClosestPoint3D::procrustes(ProcrustesDebug* dbg)
         Vec3 corr{0.f, 0.f, 0.f};
         int best = -1;
         const Vec3 s = pcs_buf_[i];
+        if (reg_.grid) {  // CPU baseline only: the same index through the grid
+            best = reg_.grid->first_min_sqrt_index(s);
+            corrs[i] = pct_[best];
+            corr_idx_[i] = best;
+            continue;
+        }
         for (long j = 0; j < nt; ++j) {
             float dist = std::sqrt(dev_dist_sq(pct_[j].x, pct_[j].y, pct_[j].z, s.x, s.y, s.z));
             if (dist_min > dist) { dist_min = dist; corr = pct_[j]; best = (int)j; }

@@ -29,6 +29,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <memory>
 #include <tuple>
 #include <utility>
 #include <vector>
@@ -102,6 +103,24 @@ struct NearestNeighborLUT {
     size_t size() const { return (size_t)dims[0] * dims[1] * dims[2]; }
 };
 
+// CPU-BASELINE ONLY (bench.py's cpu_baseline leg; off by default, the restatement's searches stay the literal O(n*m) loops).
+// The reference's README names a nanoflann kd-tree for the CPU nearest-neighbour queries but its code never calls one
+// (SURVEY fact 2); this uniform grid over the target's bounding box stands in for it.  Results are those of the brute-force
+// loops bit for bit (same fp32 distance expression, min is order-independent, the first-index rule of icp3d.cu:20-25 is
+// applied on the sqrt-tie set) — tests/test_oracle_kat.py checks that.
+struct GridNN {
+    Vec3 lo{0, 0, 0}, hi{0, 0, 0};
+    float h = 1.f;
+    int n[3] = {1, 1, 1};
+    std::vector<int> start, items;
+    const PointCloud* pc = nullptr;
+    void build(const PointCloud& cloud);
+    float min_d2(const Vec3& q) const;            // brute_force_find_nearest_neighbor
+    int first_min_sqrt_index(const Vec3& q) const; // kernFindNearestNeighbor's index
+private:
+    template <class F> void rings(const Vec3& q, F& visit_and_bound) const;
+};
+
 // fgoicp/registration.hpp:49-98, registration.cu:14-174
 class Registration {
 public:
@@ -119,6 +138,8 @@ public:
     // Trimmed Go-ICP as in Yang et al.'s Go-ICP: every sum over source points becomes the sum of the
     // `inliers` smallest per-point terms (0 = no trimming).
     size_t inliers = 0;
+    std::shared_ptr<GridNN> grid;   // CPU baseline only: exact NN through a uniform grid instead of the O(n*m) loops (same results)
+    void use_grid(bool on);
 };
 // sum of the k smallest values (fp64 accumulation in ascending order, rounded once); k = 0 or k >= n: plain sum in index order
 float trimmed_sum(std::vector<float>& values, size_t k);

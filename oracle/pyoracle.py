@@ -63,6 +63,7 @@ def lib():
         L.orc_reg_create.restype = C.c_void_p
         L.orc_reg_destroy.argtypes = [C.c_void_p]
         L.orc_reg_set_inliers.argtypes = [C.c_void_p, C.c_size_t]
+        L.orc_reg_use_grid.argtypes = [C.c_void_p, C.c_int]
         L.orc_goicp_create_trim.argtypes = [_fp, C.c_size_t, _fp, C.c_size_t, C.c_float, C.c_float, C.c_float]
         L.orc_goicp_create_trim.restype = C.c_void_p
         L.orc_reg_lut_dims.argtypes = [C.c_void_p, _ip]
@@ -145,6 +146,10 @@ class Registration:
     def set_inliers(self, k):
         """EXTENSION: trimmed sums over the k smallest per-point terms (0 = off)."""
         lib().orc_reg_set_inliers(self._h, int(k))
+
+    def use_grid(self, on=True):
+        """CPU baseline only: exact nearest neighbours through a uniform grid instead of the O(n*m) loops (same results)."""
+        lib().orc_reg_use_grid(self._h, int(bool(on)))
 
     def lut_dims(self):
         d = (C.c_int * 3)()

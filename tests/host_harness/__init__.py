@@ -39,6 +39,12 @@ def lib():
         L.harness_create.restype = C.c_void_p
         L.harness_create_trim.argtypes = [_fp, C.c_size_t, _fp, C.c_size_t, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float]
         L.harness_create_trim.restype = C.c_void_p
+        L.harness_create_ex.argtypes = [_fp, C.c_size_t, _fp, C.c_size_t, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int]
+        L.harness_create_ex.restype = C.c_void_p
+        L.harness_lut_dims.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.harness_lut_set.argtypes = [C.c_void_p, _fp, C.c_size_t]
+        L.harness_seconds.argtypes = [C.c_void_p, C.c_int]
+        L.harness_seconds.restype = C.c_double
         L.harness_destroy.argtypes = [C.c_void_p]
         L.harness_set_exchange.argtypes = [C.c_void_p, C.c_int, C.c_int, AR, AG]
         L.harness_preproc.argtypes = [C.c_void_p, _fp, _fp, _fp]
@@ -58,10 +64,24 @@ def _f(a):
 class HostDriver:
     """Product driver template over oracle operators."""
 
-    def __init__(self, pct, pcs, lut_res, mse_thr, schedule=0, round_width=1, trim_fraction=0.0):
+    def __init__(self, pct, pcs, lut_res, mse_thr, schedule=0, round_width=1, trim_fraction=0.0, build_lut=True, use_grid=False):
         pct = np.ascontiguousarray(pct, np.float32); pcs = np.ascontiguousarray(pcs, np.float32)
-        self._h = C.c_void_p(lib().harness_create_trim(_f(pct), len(pct), _f(pcs), len(pcs), lut_res, mse_thr, schedule, round_width, trim_fraction))
+        self._h = C.c_void_p(lib().harness_create_ex(_f(pct), len(pct), _f(pcs), len(pcs), lut_res, mse_thr, schedule, round_width, trim_fraction,
+                                                     int(build_lut), int(use_grid)))
         self._cbs = None
+
+    def lut_dims(self):
+        d = (C.c_int * 3)()
+        lib().harness_lut_dims(self._h, d)
+        return tuple(d)
+
+    def lut_set(self, data):
+        a = np.ascontiguousarray(data, np.float32).reshape(-1)
+        if lib().harness_lut_set(self._h, _f(a), a.size):
+            raise ValueError("LUT size mismatch")
+
+    def seconds(self):
+        return {k: lib().harness_seconds(self._h, i) for i, k in enumerate(("total", "bnb", "icp"))}
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -74,8 +74,10 @@ extern "C" {
 typedef int (*ar_fn)(float*, size_t, void*);
 typedef int (*ag_fn)(const float*, float*, size_t, void*);
 
-void* harness_create_trim(const float* tgt, size_t nt, const float* src, size_t ns, float lut_res, float mse_thr, int schedule, int round_width,
-                          float trim_fraction) {
+// build_lut = 0: the LUT is left empty and must be filled with harness_lut_set (bench.py's cpu_baseline: the O(nodes * nt) CPU build of
+// a 5e7-node LUT would take hours; the device LUT is bit-identical, tests/test_gpu_ops.py::test_lut_nodes_bit_exact)
+void* harness_create_ex(const float* tgt, size_t nt, const float* src, size_t ns, float lut_res, float mse_thr, int schedule, int round_width,
+                        float trim_fraction, int build_lut, int use_grid) {
     auto* h = new Harness;
     h->pcs.resize(ns); h->pct.resize(nt);
     std::memcpy(h->pcs.data(), src, sizeof(Vec3f) * ns);
@@ -88,7 +90,8 @@ void* harness_create_trim(const float* tgt, size_t nt, const float* src, size_t 
     std::memcpy(h->opct.data(), h->pct.data(), sizeof(Vec3f) * nt);
     std::memcpy(h->opcs.data(), h->pcs.data(), sizeof(Vec3f) * ns);
     orc::Bounds b{std::make_pair(h->bounds6[0], h->bounds6[1]), std::make_pair(h->bounds6[2], h->bounds6[3]), std::make_pair(h->bounds6[4], h->bounds6[5])};
-    h->reg.reset(new orc::Registration(h->opct, h->opcs, b, lut_res));
+    h->reg.reset(new orc::Registration(h->opct, h->opcs, b, lut_res, build_lut != 0));
+    if (use_grid) h->reg->use_grid(true);
     h->ops.reg = h->reg.get(); h->ops.pct = &h->opct; h->ops.pcs = &h->opcs;
     h->ops.use_async = schedule >= 2;  // schedule 2 = ROUND, 3 = SERIAL, both with the two-slot pipelined task loop
     schedule = schedule == 2 ? 1 : schedule == 3 ? 0 : schedule;
@@ -100,6 +103,21 @@ void* harness_create_trim(const float* tgt, size_t nt, const float* src, size_t 
     }
     h->drv.reset(new GoIcpDriver<OracleOps>(h->ops, n_thr, mse_thr, schedule, round_width));
     return h;
+}
+void* harness_create_trim(const float* tgt, size_t nt, const float* src, size_t ns, float lut_res, float mse_thr, int schedule, int round_width,
+                          float trim_fraction) {
+    return harness_create_ex(tgt, nt, src, ns, lut_res, mse_thr, schedule, round_width, trim_fraction, 1, 0);
+}
+void harness_lut_dims(void* p, int* dims3) { for (int a = 0; a < 3; ++a) dims3[a] = static_cast<Harness*>(p)->reg->nnlut.dims[a]; }
+int harness_lut_set(void* p, const float* data, size_t count) {
+    auto& lut = static_cast<Harness*>(p)->reg->nnlut;
+    if (count != lut.size()) return 1;
+    lut.data.assign(data, data + count);
+    return 0;
+}
+double harness_seconds(void* p, int which) {
+    const DriverStats& s = static_cast<Harness*>(p)->drv->stats();
+    return which == 0 ? s.seconds_total : which == 1 ? s.seconds_bnb : s.seconds_icp;
 }
 void* harness_create(const float* tgt, size_t nt, const float* src, size_t ns, float lut_res, float mse_thr, int schedule, int round_width) {
     return harness_create_trim(tgt, nt, src, ns, lut_res, mse_thr, schedule, round_width, 0.0f);

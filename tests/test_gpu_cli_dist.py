@@ -44,6 +44,27 @@ def test_cli_runs_and_matches_library(fg, gpu_required, tmp_path):
     assert sse == pytest.approx(best, rel=1e-4)
     viz = (tmp_path / "viz.ply").read_text().splitlines()
     assert viz[0] == "ply" and f"element vertex {700 + ns}" in viz
+    # the CLI's result against the oracle on the SAME clouds: the loader of the CLI (same file, subsample and seed — the source
+    # stream is seeded with seed + 1, main.cpp) through the test harness, then the oracle's FastGoICP (src/main.cpp:41-55)
+    import ctypes as C
+    from tests.test_cli_host import load as cli_load
+    here = os.path.join(REPO, "tests", "host_harness")
+    so = os.path.join(here, "libcli_harness.so")
+    if not os.path.exists(so):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(here, "cli_harness.cpp")], check=True)
+    L = C.CDLL(so)
+    L.cli_load_cloud.argtypes = [C.c_char_p, C.c_float, C.c_longlong, C.POINTER(C.c_float), C.c_long, C.c_char_p, C.c_int]
+    L.cli_load_cloud.restype = C.c_long
+    tgt_l = cli_load(L, tmp_path / "tgt.txt", 1.0, 3)
+    src_l = cli_load(L, tmp_path / "src.txt", 0.5, 4)
+    assert len(tgt_l) == 700 and len(src_l) == ns
+    from oracle import pyoracle
+    o = pyoracle.FastGoICP(tgt_l, src_l, float(G["runsyn_res"]), float(G["runsyn_mse"])).run()
+    rot = np.array([[float(v) for v in re.findall(r"[-+0-9.eE]+", line)] for line in re.search(r"rotation = \[\n(.*?)\n\]", txt, re.S).group(1).splitlines()], np.float64)
+    tr = np.array([float(v) for v in re.findall(r"[-+0-9.eE]+", re.search(r"^translation = \[(.*)\]$", txt, re.M).group(1))])
+    assert sse == pytest.approx(float(o["best_sse"]), rel=1e-5) and np.allclose(rot, o["R"], atol=1e-5) and np.allclose(tr, o["t"], atol=1e-5)
+    st_sub = int(re.search(r"^subcubes = (\d+)$", txt, re.M).group(1))
+    assert st_sub == o["stats"]["trans_cubes"]  # the CLI's default schedule follows the reference's exploration order
     # missing config -> usage + non-zero exit; bad extension -> runtime_error (uncaught upstream too)
     assert subprocess.run([exe], capture_output=True).returncode != 0
     # full-cloud run through the CLI equals the library result (same solver underneath)

@@ -259,3 +259,30 @@ def test_full_run_recovers_known_se3(oracle, fg):
     ang = np.degrees(np.arccos(np.clip((np.trace(out["R"].astype(np.float64).T @ R_gt) - 1) / 2, -1, 1)))
     assert ang < 0.05 and np.linalg.norm(out["t"] - t_gt) < 1e-4
     assert float(out["best_sse"]) < 1e-6
+
+
+@pytest.mark.parametrize("case", ["plain", "duplicates", "far_queries", "lattice_ties"])
+def test_grid_nn_of_the_cpu_baseline_equals_the_brute_force_loops(oracle, fg, case):
+    """bench.py's cpu_baseline leg searches nearest neighbours through a uniform grid (the stand-in for the nanoflann kd-tree the
+    reference's README names): minimum squared distances and first-index correspondences are those of the restated O(n*m)
+    loops (registration.cu:162-174, icp3d.cu:11-28), bit for bit — duplicates, queries far outside the target's box and exact
+    ties on a lattice included."""
+    tgt, src, *_ = fg.synth.make_pair(2500, 1500, (0.156, 0.152, 0.118), seed=3)
+    pct, pcs, *_, bounds = fg.synth.preprocess(tgt, src)
+    R = fg.synth.random_rotation(np.random.default_rng(1), 40.0).astype(np.float32)
+    t = np.array([0.05, -0.08, 0.02], np.float32)
+    if case == "duplicates":
+        pct = np.concatenate([pct, pct[:300]])
+    elif case == "far_queries":
+        pcs = (pcs * 3).astype(np.float32)
+    elif case == "lattice_ties":
+        pct = (np.round(pct * 8) / 8).astype(np.float32); pcs = (np.round(pcs * 8) / 8).astype(np.float32)
+        R = np.eye(3, dtype=np.float32); t = np.zeros(3, np.float32)
+    brute = oracle.Registration(pct, pcs, bounds, 0.1, build_lut=False)
+    grid = oracle.Registration(pct, pcs, bounds, 0.1, build_lut=False)
+    grid.use_grid(True)
+    assert brute.compute_sse_error(R, t).view(np.uint32) == grid.compute_sse_error(R, t).view(np.uint32)
+    w = (pcs @ R.T + t).astype(np.float32)
+    assert np.array_equal(brute.procrustes(w)[-1], grid.procrustes(w)[-1])
+    grid.set_inliers(len(pcs) // 2); brute.set_inliers(len(pcs) // 2)
+    assert brute.compute_sse_error(R, t).view(np.uint32) == grid.compute_sse_error(R, t).view(np.uint32)
