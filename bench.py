@@ -110,8 +110,16 @@ class Env:
                 self.red_dev = "cpu"
             else:
                 dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
-            from fgoicp_amd.dist import TorchExchange
-            self.ex = TorchExchange()
+            if a.rehearse_on_one_gpu:
+                from fgoicp_amd.dist import TorchExchange
+                self.ex = TorchExchange()
+            else:  # the library's own RCCL transport (no Python in the per-round collectives); the id travels over torch.distributed
+                import fgoicp_amd as fg
+                ident = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                if self.rank == 0:
+                    ident.copy_(torch.frombuffer(bytearray(fg.rccl_unique_id()), dtype=torch.uint8))
+                dist.broadcast(ident, 0)
+                self.ex = fg.RcclExchange(self.rank, self.world, bytes(ident.cpu().numpy().tobytes()), self.local_rank)
             self.ex.warmup()  # communicator setup is not part of a registration run
 
     def barrier(self):
@@ -310,7 +318,7 @@ def main():
                      "config": {"workload": f"{a.workload}-shape synthetic pair (nt={len(tgt)}, ns={len(src)}), lut_resolution={a.lut_resolution}, "
                                             f"mse_threshold={a.mse_threshold}, full FastGoICP::run() per step",
                                 "schedule": a.schedule, "round_width": K if K > 0 else "adaptive (32 per rank, doubled after each round that leaves the incumbent standing)",
-                                "lut_dims": head["lut_dims"], "parallelism": f"rotation cubes sharded over {world} rank(s), allreduce(min)+allgather per round"},
+                                "lut_dims": head["lut_dims"], "parallelism": f"rotation cubes sharded over {world} rank(s), one RCCL allreduce(min) + one allgather per round inside libfgoicp_amd.so"},
                      "wall_clock_to_optimum_s": head["elapsed"] / a.steps, "subcubes_per_step": head["subcubes"] / a.steps})
         s = leg_summary(head, R_gt, t_gt, "headline")
         line.update({k: s[k] for k in ("rot_cubes_rank0", "icp_runs_rank0", "rounds", "seconds_bnb_rank0", "seconds_icp_rank0", "setup_s_upload_plus_lut_build")})

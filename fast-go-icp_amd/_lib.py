@@ -76,7 +76,23 @@ _SIGS = {
     "fgoicp_solver_stats": (C.c_int, [C.c_void_p, C.POINTER(RunStats)]),
     "fgoicp_solver_preproc": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_float_p]),
     "fgoicp_solver_ctx": (C.c_void_p, [C.c_void_p]),
+    "fgoicp_rccl_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
+    "fgoicp_rccl_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.POINTER(C.c_void_p)]),
+    "fgoicp_rccl_exchange": (C.c_int, [C.c_void_p, C.POINTER(Exchange)]),
+    "fgoicp_rccl_calls": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "fgoicp_rccl_destroy": (None, [C.c_void_p]),
+    "fgoicp_multi_create": (C.c_int, [c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_float, C.c_float, C.POINTER(SolverOpts), c_int_p, C.c_int, C.c_int,
+                                      C.POINTER(C.c_void_p)]),
+    "fgoicp_multi_destroy": (None, [C.c_void_p]),
+    "fgoicp_multi_run": (C.c_int, [C.c_void_p, c_float_p, c_float_p]),
+    "fgoicp_multi_world": (C.c_int, [C.c_void_p]),
+    "fgoicp_multi_solver": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "fgoicp_multi_seconds": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
+    "fgoicp_multi_set_record": (C.c_int, [C.c_void_p, C.c_int]),
+    "fgoicp_multi_replay_rank": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
 }
+TRANSPORT_RCCL = 0
+TRANSPORT_IN_PROCESS = 1
 
 _lib = None
 

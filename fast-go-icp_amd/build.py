@@ -20,6 +20,7 @@ SOURCES = [
     os.path.join(CSRC, "device", "ctx.hip"),
     os.path.join(CSRC, "device", "bvh.hip"),
     os.path.join(CSRC, "host", "solver.cpp"),
+    os.path.join(CSRC, "host", "multi.cpp"),
 ]
 CLI_SOURCES = [os.path.join(CSRC, "cli", "main.cpp")]
 
@@ -53,7 +54,7 @@ def build(force=False, verbose=False):
     deps = [CSRC, os.path.join(REPO, "include")]
     srcs = [s for s in SOURCES if os.path.exists(s)]
     if force or not _newer(LIB_PATH, deps):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-x", "hip", *COMMON_FLAGS, "-shared", "-o", LIB_PATH, *srcs]
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-x", "hip", *COMMON_FLAGS, "-shared", "-o", LIB_PATH, *srcs, "-lrccl"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)

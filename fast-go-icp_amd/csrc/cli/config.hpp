@@ -118,6 +118,7 @@ struct Config {
         std::string schedule = "serial";
         int round_width = 1;
         float trim_fraction = 0.0f;  // EXTENSION: > 0 enables trimmed Go-ICP; `trim` itself stays parsed-and-ignored as upstream
+        int gpus = 1;                // EXTENSION: > 1 shards the outer BnB over that many GPUs of this node (one host thread each, RCCL)
     } params;
 
     explicit Config(const std::string& toml_filepath) {
@@ -163,6 +164,7 @@ struct Config {
             params.schedule = str("params", "schedule", "serial");
             params.round_width = (int)num("params", "round_width", 1);
             params.trim_fraction = clampf0((float)num("params", "trim_fraction", 0.0));
+            params.gpus = std::max(1, (int)num("params", "gpus", 1));
             auto clampf = [](float x, float lo, float hi) { return x < hi ? (x > lo ? x : lo) : hi; };
             params.target_subsample = clampf(params.target_subsample, 1e-5f, 1.0f);  // utilities.hpp:101-104
             params.source_subsample = clampf(params.source_subsample, 1e-5f, 1.0f);

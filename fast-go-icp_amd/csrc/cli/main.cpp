@@ -13,12 +13,14 @@ static std::string usage(const std::string& exe) {
     return "Fast Go-ICP: an MI355X (HIP) implementation of Go-ICP\nUsage: " + exe + " [OPTIONS]\n\nOptions:\n"
            "  -h,--help                   Print this help message and exit\n"
            "  -c,--config TEXT REQUIRED   Path to the TOML configuration file\n"
-           "  -v,--verbose                Enable verbose logging\n\nExample Usage:\n  " + exe + " -c config.toml --verbose\n  " + exe + " --config=config.toml\n";
+           "  -v,--verbose                Enable verbose logging\n"
+           "  -g,--gpus N                 Shard the search over N GPUs of this node (default: params.gpus, 1)\n\nExample Usage:\n  " + exe + " -c config.toml --verbose\n  " + exe + " --config=config.toml\n";
 }
 
 int main(int argc, char* argv[]) {
     std::string config_file;
     bool verbose = false;
+    int gpus_flag = 0;
     const std::string exe = std::filesystem::path(argv[0]).filename().string();
     auto fail = [&](const std::string& what, int code) {
         icp::Logger(icp::LogLevel::Error) << what;
@@ -29,6 +31,8 @@ int main(int argc, char* argv[]) {
         const std::string a = argv[i];
         if (a == "-h" || a == "--help") { std::cout << usage(exe); return 0; }
         else if (a == "-v" || a == "--verbose") verbose = true;
+        else if (a == "-g" || a == "--gpus") { if (i + 1 >= argc) fail("--gpus: 1 required INT missing", 114); gpus_flag = std::atoi(argv[++i]); }
+        else if (a.rfind("--gpus=", 0) == 0) gpus_flag = std::atoi(a.substr(7).c_str());
         else if (a == "-c" || a == "--config") { if (i + 1 >= argc) fail("--config: 1 required TEXT missing", 114); config_file = argv[++i]; }
         else if (a.rfind("--config=", 0) == 0) config_file = a.substr(9);
         else if (a.rfind("-c", 0) == 0 && a.size() > 2) config_file = a.substr(2);
@@ -46,19 +50,54 @@ int main(int argc, char* argv[]) {
     const std::vector<icp::vec3> pct_in = pct, pcs_in = pcs;
 
     const int schedule = config.params.schedule == "round" ? FGOICP_SCHEDULE_ROUND : FGOICP_SCHEDULE_SERIAL;
-    icp::FastGoICP fgoicp(std::move(pct), std::move(pcs), config.params.lut_resolution, config.params.mse_threshold, schedule,
-                          config.params.round_width, 0, config.params.trim_fraction);
-
-    auto start = std::chrono::high_resolution_clock::now();
-    auto [R, t] = fgoicp.run();
-    auto end = std::chrono::high_resolution_clock::now();
-    std::chrono::duration<double> elapsed_seconds = end - start;
-    const fgoicp_run_stats st = fgoicp.stats();
+    const int gpus = gpus_flag > 0 ? gpus_flag : config.params.gpus;
+    icp::mat3 R;
+    icp::vec3 t;
+    fgoicp_run_stats st{};
+    float best_error = 0.f;
+    std::chrono::duration<double> elapsed_seconds{};
+    if (gpus > 1) {
+        // EXTENSION: one host thread + one solver per GPU, children of every expansion round dealt round-robin, one RCCL
+        // all-reduce(min) + one all-gather per round (include/fgoicp_amd.h, fgoicp_multi_*).  Always the ROUND schedule.
+        std::vector<int> devices;
+        for (int d = 0; d < gpus; ++d) devices.push_back(d);
+        int transport = FGOICP_TRANSPORT_RCCL;
+        if (const char* e = std::getenv("FGOICP_MULTI_DEVICES")) {  // e.g. "0,0": rehearse two ranks on one GPU (in-process transport)
+            devices.clear();
+            for (const char* p = e; *p;) { devices.push_back(std::atoi(p)); while (*p && *p != ',') ++p; if (*p) ++p; }
+            transport = FGOICP_TRANSPORT_IN_PROCESS;
+        }
+        icp::Logger(icp::LogLevel::Info) << "Sharding the search over " << devices.size() << " GPUs (schedule: expansion rounds)";
+        fgoicp_solver_opts o{FGOICP_SCHEDULE_ROUND, schedule == FGOICP_SCHEDULE_ROUND ? config.params.round_width : 0, 0u, 0, config.params.trim_fraction};
+        fgoicp_multi* m = nullptr;
+        icp::check_status(fgoicp_multi_create(&pct.data()->x, pct.size(), &pcs.data()->x, pcs.size(), config.params.lut_resolution, config.params.mse_threshold, &o,
+                                              devices.data(), (int)devices.size(), transport, &m), "fgoicp_multi_create");
+        auto start = std::chrono::high_resolution_clock::now();
+        icp::check_status(fgoicp_multi_run(m, R.data(), &t.x), "fgoicp_multi_run");
+        elapsed_seconds = std::chrono::high_resolution_clock::now() - start;
+        for (int r = 0; r < (int)devices.size(); ++r) {  // counters summed over the ranks; rank 0's incumbent is every rank's
+            fgoicp_run_stats s1{};
+            icp::check_status(fgoicp_solver_stats(fgoicp_multi_solver(m, r), &s1), "fgoicp_solver_stats");
+            st.trans_cubes += s1.trans_cubes; st.rot_cubes += s1.rot_cubes; st.icp_runs += s1.icp_runs; st.icp_iters += s1.icp_iters;
+            st.bounds_calls += s1.bounds_calls; st.inner_bnb += s1.inner_bnb;
+            if (r == 0) { st.rounds = s1.rounds; st.initial_icp_sse = s1.initial_icp_sse; }
+        }
+        icp::check_status(fgoicp_solver_best_error(fgoicp_multi_solver(m, 0), &best_error), "fgoicp_solver_best_error");
+        fgoicp_multi_destroy(m);
+    } else {
+        icp::FastGoICP fgoicp(std::move(pct), std::move(pcs), config.params.lut_resolution, config.params.mse_threshold, schedule,
+                              config.params.round_width, 0, config.params.trim_fraction);
+        auto start = std::chrono::high_resolution_clock::now();
+        std::tie(R, t) = fgoicp.run();
+        elapsed_seconds = std::chrono::high_resolution_clock::now() - start;
+        st = fgoicp.stats();
+        best_error = fgoicp.get_best_error();
+    }
     icp::Logger(icp::LogLevel::Info) << "Initial ICP best error: " << st.initial_icp_sse;
-    icp::Logger(icp::LogLevel::Info) << "Searching over! Best Error: " << fgoicp.get_best_error() << "\n\tRotation:\n" << R << "\n\tTranslation: " << t;
+    icp::Logger(icp::LogLevel::Info) << "Searching over! Best Error: " << best_error << "\n\tRotation:\n" << R << "\n\tTranslation: " << t;
     icp::Logger(icp::LogLevel::Debug) << "Subcubes: " << st.trans_cubes << ", rotation cubes: " << st.rot_cubes << ", ICP runs: " << st.icp_runs;
     icp::Logger(icp::LogLevel::Info) << "Fast Go-ICP finished, time elapsed: " << std::fixed << std::setprecision(3) << elapsed_seconds.count() << " seconds";
-    if (!config.io.output.empty()) cli::write_result_toml(config.io.output, R, t, fgoicp.get_best_error(), pcs_in.size(), elapsed_seconds.count(), st);
+    if (!config.io.output.empty()) cli::write_result_toml(config.io.output, R, t, best_error, pcs_in.size(), elapsed_seconds.count(), st);
     if (!config.io.visualization.empty()) cli::write_visualization_ply(config.io.visualization, pct_in, pcs_in, R, t);
     return 0;
 }

@@ -460,17 +460,25 @@ __global__ __launch_bounds__(64) void tick_scatter_kernel(const unsigned short* 
 // 64x4 (default: one wave per item, no block-level reduction) 2.94 M subcubes/s, 128x2 2.81, 256x1 2.54; 128- and 64-point
 // items (64x2, 64x1) 2.77 / 2.26 — smaller items do not buy locality, they only add items.  Dragon shape: 64x4 = 128x2.
 // Fewer resident blocks per CU (LDS padding) only hurts — the kernel wants every wave slot and many gathers in flight.
-template <int THREADS, int P, int ZPAIR, int TRIM>
-__global__ __launch_bounds__(THREADS) void bounds_sorted_kernel(const float4* __restrict__ src, int ns, const float* __restrict__ lut,
+// WPG > 1 (THREADS == 64 only): a workgroup is WPG independent one-wave items that are NEIGHBOURS in the sorted order, so they run
+// on one CU at the same time and share its L1 (the XCD remap alone spreads neighbours over the 32 CUs of an XCD: they share
+// the L2 only).  NT = 1: the source points are loaded non-temporally (they stream through once per item; kept out of the L1
+// they leave it to the LUT lines).
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <int THREADS, int P, int ZPAIR, int TRIM, int WPG = 1, int NT = 0>
+__global__ __launch_bounds__(THREADS * WPG) void bounds_sorted_kernel(const float4* __restrict__ src, int ns, const float* __restrict__ lut,
                                                                 const float2* __restrict__ zp, LutGeom g,
                                                                 const TickGroup* __restrict__ groups, const TickSub* __restrict__ subs,
                                                                 const unsigned* __restrict__ sorted, int nchunk, int chunk_pts,
-                                                                double2* __restrict__ partials, float* __restrict__ evals, size_t erow) {
+                                                                double2* __restrict__ partials, float* __restrict__ evals, size_t erow, unsigned nitems) {
     static_assert(THREADS % 64 == 0 && THREADS * P <= kBlock, "one pass covers THREADS * P points");
+    static_assert(WPG == 1 || THREADS == 64, "several items per workgroup: one wave each");
     __shared__ double red[4 * (THREADS / 64)];
-    const unsigned slot = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned slot = xcd_remap(blockIdx.x, gridDim.x) * WPG + (WPG > 1 ? threadIdx.x >> 6 : 0);
+    if (WPG > 1 && slot >= nitems) return;
     const unsigned item = sorted ? sorted[slot] : slot;  // small ticks come unsorted
-    if (item >= gridDim.x) return;  // never taken when `sorted` is a permutation (tick_check_kernel verifies that on the device)
+    if (item >= nitems) return;  // never taken when `sorted` is a permutation (tick_check_kernel verifies that on the device)
+    const unsigned tix = WPG > 1 ? (threadIdx.x & 63u) : threadIdx.x;  // thread index inside the item
     const int s = (int)(item / (unsigned)nchunk);
     const int chunk = (int)(item - (unsigned)s * (unsigned)nchunk);
     const TickSub sb = subs[s];
@@ -485,17 +493,22 @@ __global__ __launch_bounds__(THREADS) void bounds_sorted_kernel(const float4* __
         float4 p[P];
         TexAddr ta[P];
         float2u v00[P], v10[P], v01[P], v11[P];
-        const int first = chunk * chunk_pts + pass + (int)threadIdx.x;
+        const int first = chunk * chunk_pts + pass + (int)tix;
 #pragma unroll
         for (int k = 0; k < P; ++k) {
             const int i = first + k * THREADS;
-            p[k] = src[i < ns ? i : ns - 1];
+            if (NT) {
+                const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + (i < ns ? i : ns - 1)));
+                p[k] = make_float4(v.x, v.y, v.z, v.w);
+            } else {
+                p[k] = src[i < ns ? i : ns - 1];
+            }
             float rx, ry, rz;
             rotate(gr.R, p[k].x, p[k].y, p[k].z, rx, ry, rz);
             ta[k] = lut_address(g, rx + sb.tx, ry + sb.ty, rz + sb.tz);  // :34, :323-325
         }
         QuadPairLoads qp[ZPAIR == 3 ? P : 1];
-        const int odd = (int)threadIdx.x & 1;
+        const int odd = (int)tix & 1;
         if (ZPAIR == 3) {
 #pragma unroll
             for (int k = 0; k < P; ++k) qp[k] = quad_pair_issue(reinterpret_cast<const float4*>(zp), ta[k], odd);
@@ -560,7 +573,18 @@ __global__ __launch_bounds__(THREADS) void bounds_sorted_kernel(const float4* __
             acc[1] += valid ? (double)lbv : 0.0;
         }
     }
-    if (!TRIM) {
+    if (!TRIM && WPG > 1) {  // one wave per item, several items per workgroup: the wave tree only (= block_sum with one wave), no barrier
+        const double r0 = wave_sum(acc[0]), r1 = wave_sum(acc[1]);
+        if (dual) {
+            const double r2 = wave_sum(acc[2]), r3 = wave_sum(acc[3]);
+            if (tix == 0) {
+                partials[(size_t)sb.out0 * nchunk + chunk] = make_double2(r0, r1);
+                partials[(size_t)sb.out1 * nchunk + chunk] = make_double2(r2, r3);
+            }
+        } else if (tix == 0) {
+            partials[(size_t)sb.out0 * nchunk + chunk] = make_double2(r0, r1);
+        }
+    } else if (!TRIM) {
         // sums 0, 1 land in threads 0, 1 (dual: sums 2, 3 in threads 2, 3); same reduction tree per sum either way
         if (dual) {
             const double r = block_sum<4, THREADS / 64>(acc, red);
@@ -1718,8 +1742,20 @@ void launch_bounds_sorted(const float4* src, int ns, const float* lut, const flo
     if (ev_start) (void)hipEventRecord(ev_start, s);
     static const int variant = [] { const char* e = std::getenv("FGOICP_BOUNDS_VARIANT"); return e ? std::atoi(e) : 2; }();  // tuning knob (2 = default: one wave, 4 points per lane)
     const dim3 grid((unsigned)nitems);
+    static const int wpg = [] { const char* e = std::getenv("FGOICP_ITEMS_PER_WG"); return e ? std::atoi(e) : 1; }();   // tuning knob: 1, 2 or 4 one-wave items per workgroup
+    static const int nt_src = [] { const char* e = std::getenv("FGOICP_NT_SOURCE"); return e ? std::atoi(e) : 0; }();   // tuning knob: non-temporal source loads
 #define FGOICP_LAUNCH_SORTED(T, PP, Z, TR) \
-    hipLaunchKernelGGL((bounds_sorted_kernel<T, PP, Z, TR>), grid, dim3(T), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, chunk_pts, partials, evals, erow)
+    hipLaunchKernelGGL((bounds_sorted_kernel<T, PP, Z, TR>), grid, dim3(T), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, chunk_pts, partials, evals, erow, (unsigned)nitems)
+#define FGOICP_LAUNCH_WPG(Z, W, N) \
+    hipLaunchKernelGGL((bounds_sorted_kernel<64, 4, Z, 0, W, N>), dim3((unsigned)((nitems + W - 1) / W)), dim3(64 * W), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, chunk_pts, partials, evals, erow, (unsigned)nitems)
+    if (!evals && variant == 2 && (wpg > 1 || nt_src)) {  // experimental variants of the default 64 x 4 kernel
+        const int z = (zp && layout == 2) ? 3 : zp ? 1 : 0;
+        bool done = true;
+        if (z == 3) { if (wpg == 4 && nt_src) FGOICP_LAUNCH_WPG(3, 4, 1); else if (wpg == 4) FGOICP_LAUNCH_WPG(3, 4, 0); else if (wpg == 2 && nt_src) FGOICP_LAUNCH_WPG(3, 2, 1); else if (wpg == 2) FGOICP_LAUNCH_WPG(3, 2, 0); else if (nt_src) FGOICP_LAUNCH_WPG(3, 1, 1); else done = false; }
+        else if (z == 1) { if (wpg == 4 && nt_src) FGOICP_LAUNCH_WPG(1, 4, 1); else if (wpg == 4) FGOICP_LAUNCH_WPG(1, 4, 0); else if (wpg == 2 && nt_src) FGOICP_LAUNCH_WPG(1, 2, 1); else if (wpg == 2) FGOICP_LAUNCH_WPG(1, 2, 0); else if (nt_src) FGOICP_LAUNCH_WPG(1, 1, 1); else done = false; }
+        else done = false;
+        if (done) { if (ev_stop) (void)hipEventRecord(ev_stop, s); return; }
+    }
     if (evals) {
         static const int trim_variant = [] { const char* e = std::getenv("FGOICP_TRIM_VARIANT"); return e ? std::atoi(e) : 2; }();  // tuning knob (2 = 64x4, default)
         if (trim_variant == 2) {
@@ -1737,6 +1773,7 @@ void launch_bounds_sorted(const float4* src, int ns, const float* lut, const flo
         if (variant == 0) FGOICP_LAUNCH_SORTED(256, 1, 0, 0); else if (variant == 2) FGOICP_LAUNCH_SORTED(64, 4, 0, 0); else FGOICP_LAUNCH_SORTED(128, 2, 0, 0);
     }
 #undef FGOICP_LAUNCH_SORTED
+#undef FGOICP_LAUNCH_WPG
     if (ev_stop) (void)hipEventRecord(ev_stop, s);
 }
 

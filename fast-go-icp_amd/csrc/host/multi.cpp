@@ -1,0 +1,398 @@
+// Multi-GPU part of the C ABI (include/fgoicp_amd.h): the exchange of the sharded outer branch-and-bound inside the library.
+//
+//   fgoicp_rccl_*    one communicator per rank (ncclCommInitRank: one process per GPU, the id comes from rank 0 by whatever
+//                    channel the launcher has; or one host thread per GPU in one process) — per expansion round ONE
+//                    ncclAllReduce(ncclMin) of the best error and ONE small ncclAllGather on device buffers, over xGMI.
+//   fgoicp_multi_*   one process, one host thread + one solver per device: what `fast-go-icp --gpus N` runs.
+//                    Transport RCCL (distinct devices) or an in-process rendezvous (any device list, e.g. {0, 0, 0, 0} to
+//                    rehearse four ranks on one GPU); optional recording of what every exchange returned and replay of ONE
+//                    rank alone against the recording (tools/scale_replay.py: strong-scaling estimate on one GPU).
+//
+// The reference is single-GPU (no NCCL/MPI call sites); nothing here replaces reference code.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../../include/fgoicp_amd.h"
+
+namespace fgoicp {
+void set_error(const std::string& s);
+}
+using fgoicp::set_error;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// RCCL transport
+// ---------------------------------------------------------------------------------------------------------------------
+struct fgoicp_rccl {
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    float *d_send = nullptr, *d_recv = nullptr;   // device buffers of the collectives
+    float* h_pin = nullptr;                       // pinned staging (send | recv)
+    size_t cap = 0;                               // floats per rank the buffers hold
+    int rank = 0, world = 1, device = 0;
+    uint64_t calls = 0;
+};
+
+namespace {
+
+#define RCCL_HIP(expr)                                                                                     \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) { set_error(std::string(#expr) + " failed: " + hipGetErrorString(e_)); return 1; } \
+    } while (0)
+#define RCCL_NCCL(expr)                                                                                    \
+    do {                                                                                                   \
+        ncclResult_t r_ = (expr);                                                                          \
+        if (r_ != ncclSuccess) { set_error(std::string(#expr) + " failed: " + ncclGetErrorString(r_)); return 1; } \
+    } while (0)
+
+int rccl_reserve(fgoicp_rccl* x, size_t n) {
+    if (n <= x->cap) return 0;
+    size_t cap = x->cap ? x->cap : 64;
+    while (cap < n) cap *= 2;
+    (void)hipFree(x->d_send); (void)hipFree(x->d_recv);
+    if (x->h_pin) (void)hipHostFree(x->h_pin);
+    x->d_send = x->d_recv = x->h_pin = nullptr;
+    x->cap = 0;
+    RCCL_HIP(hipMalloc(&x->d_send, sizeof(float) * cap));
+    RCCL_HIP(hipMalloc(&x->d_recv, sizeof(float) * cap * x->world));
+    RCCL_HIP(hipHostMalloc((void**)&x->h_pin, sizeof(float) * cap * (x->world + 1), hipHostMallocDefault));
+    x->cap = cap;
+    return 0;
+}
+
+int rccl_allreduce_min(float* buf, size_t n, void* user) {
+    fgoicp_rccl* x = static_cast<fgoicp_rccl*>(user);
+    RCCL_HIP(hipSetDevice(x->device));
+    if (rccl_reserve(x, n)) return 1;
+    std::memcpy(x->h_pin, buf, sizeof(float) * n);
+    RCCL_HIP(hipMemcpyAsync(x->d_send, x->h_pin, sizeof(float) * n, hipMemcpyHostToDevice, x->stream));
+    RCCL_NCCL(ncclAllReduce(x->d_send, x->d_recv, n, ncclFloat, ncclMin, x->comm, x->stream));
+    RCCL_HIP(hipMemcpyAsync(x->h_pin, x->d_recv, sizeof(float) * n, hipMemcpyDeviceToHost, x->stream));
+    RCCL_HIP(hipStreamSynchronize(x->stream));
+    std::memcpy(buf, x->h_pin, sizeof(float) * n);
+    x->calls++;
+    return 0;
+}
+
+int rccl_allgather(const float* send, float* recv, size_t n, void* user) {
+    fgoicp_rccl* x = static_cast<fgoicp_rccl*>(user);
+    RCCL_HIP(hipSetDevice(x->device));
+    if (rccl_reserve(x, n)) return 1;
+    std::memcpy(x->h_pin, send, sizeof(float) * n);
+    RCCL_HIP(hipMemcpyAsync(x->d_send, x->h_pin, sizeof(float) * n, hipMemcpyHostToDevice, x->stream));
+    RCCL_NCCL(ncclAllGather(x->d_send, x->d_recv, n, ncclFloat, x->comm, x->stream));
+    RCCL_HIP(hipMemcpyAsync(x->h_pin + x->cap, x->d_recv, sizeof(float) * n * x->world, hipMemcpyDeviceToHost, x->stream));
+    RCCL_HIP(hipStreamSynchronize(x->stream));
+    std::memcpy(recv, x->h_pin + x->cap, sizeof(float) * n * x->world);
+    x->calls++;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fgoicp_rccl_unique_id(unsigned char* id128) {
+    if (!id128) return FGOICP_ERR_INVALID_ARG;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) { set_error(std::string("ncclGetUniqueId failed: ") + ncclGetErrorString(r)); return FGOICP_ERR_EXCHANGE; }
+    std::memcpy(id128, &id, 128);
+    return FGOICP_OK;
+}
+
+void fgoicp_rccl_destroy(fgoicp_rccl* x) {
+    if (!x) return;
+    (void)hipSetDevice(x->device);
+    if (x->stream) (void)hipStreamSynchronize(x->stream);
+    if (x->comm) (void)ncclCommDestroy(x->comm);
+    (void)hipFree(x->d_send); (void)hipFree(x->d_recv);
+    if (x->h_pin) (void)hipHostFree(x->h_pin);
+    if (x->stream) (void)hipStreamDestroy(x->stream);
+    delete x;
+}
+
+int fgoicp_rccl_create(int rank, int world, const unsigned char* id128, int device, fgoicp_rccl** out) {
+    if (!out) return FGOICP_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!id128 || world < 1 || rank < 0 || rank >= world) { set_error("fgoicp_rccl_create: invalid argument"); return FGOICP_ERR_INVALID_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { set_error("fgoicp_rccl_create: no such HIP device"); return FGOICP_ERR_NO_DEVICE; }
+    auto x = std::make_unique<fgoicp_rccl>();
+    x->rank = rank; x->world = world; x->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking) != hipSuccess) {
+        set_error("fgoicp_rccl_create: stream creation failed");
+        return FGOICP_ERR_HIP;
+    }
+    ncclUniqueId id;
+    std::memcpy(&id, id128, 128);
+    ncclResult_t r = ncclCommInitRank(&x->comm, world, id, rank);
+    if (r != ncclSuccess) {
+        set_error(std::string("ncclCommInitRank failed: ") + ncclGetErrorString(r));
+        x->comm = nullptr;
+        fgoicp_rccl_destroy(x.release());
+        return FGOICP_ERR_EXCHANGE;
+    }
+    if (rccl_reserve(x.get(), 64)) { fgoicp_rccl_destroy(x.release()); return FGOICP_ERR_HIP; }
+    *out = x.release();
+    return FGOICP_OK;
+}
+
+int fgoicp_rccl_exchange(fgoicp_rccl* x, fgoicp_exchange* out) {
+    if (!x || !out) return FGOICP_ERR_INVALID_ARG;
+    out->rank = x->rank;
+    out->world_size = x->world;
+    out->allreduce_min = rccl_allreduce_min;
+    out->allgather = rccl_allgather;
+    out->user = x;
+    return FGOICP_OK;
+}
+
+int fgoicp_rccl_calls(const fgoicp_rccl* x, uint64_t* calls) {
+    if (!x || !calls) return FGOICP_ERR_INVALID_ARG;
+    *calls = x->calls;
+    return FGOICP_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One process, one host thread and one solver per device
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+// In-process rendezvous of `world` threads: min-all-reduce and all-gather through shared memory (two generations of buffers,
+// so a fast rank may enter the next collective while a slow one still reads the last result).
+struct Rendezvous {
+    std::mutex m;
+    std::condition_variable cv;
+    int world = 1, arrived = 0;
+    uint64_t gen = 0;
+    std::vector<float> acc[2];
+    void run(size_t total, const std::function<void(std::vector<float>&, bool first)>& contribute, const std::function<void(const std::vector<float>&)>& collect) {
+        std::unique_lock<std::mutex> lk(m);
+        const uint64_t g = gen;
+        std::vector<float>& a = acc[g & 1];
+        const bool first = arrived == 0;
+        if (first) a.assign(total, 0.f);
+        contribute(a, first);
+        if (++arrived == world) {
+            arrived = 0;
+            ++gen;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return gen != g; });
+        }
+        collect(a);
+    }
+};
+
+struct RankLink {        // what one rank's exchange callbacks see
+    int rank = 0, world = 1;
+    Rendezvous* rv = nullptr;
+    fgoicp_exchange inner{};                      // transport underneath (RCCL) when rv == nullptr
+    bool record = false;
+    std::vector<std::vector<float>>* log = nullptr;   // results of every exchange, in order
+    size_t replay_pos = 0;
+    bool replay = false;
+};
+
+int link_allreduce_min(float* buf, size_t n, void* user) {
+    RankLink* l = static_cast<RankLink*>(user);
+    if (l->replay) {
+        if (l->replay_pos >= l->log->size() || (*l->log)[l->replay_pos].size() != n) return 1;
+        std::memcpy(buf, (*l->log)[l->replay_pos++].data(), sizeof(float) * n);
+        return 0;
+    }
+    int rc = 0;
+    if (l->rv) {
+        l->rv->run(n,
+                   [&](std::vector<float>& a, bool first) { for (size_t i = 0; i < n; ++i) a[i] = first ? buf[i] : (buf[i] < a[i] ? buf[i] : a[i]); },
+                   [&](const std::vector<float>& a) { std::memcpy(buf, a.data(), sizeof(float) * n); });
+    } else {
+        rc = l->inner.allreduce_min(buf, n, l->inner.user);
+    }
+    if (!rc && l->record) l->log->emplace_back(buf, buf + n);
+    return rc;
+}
+
+int link_allgather(const float* send, float* recv, size_t n, void* user) {
+    RankLink* l = static_cast<RankLink*>(user);
+    if (l->replay) {
+        if (l->replay_pos >= l->log->size() || (*l->log)[l->replay_pos].size() != n * (size_t)l->world) return 1;
+        std::memcpy(recv, (*l->log)[l->replay_pos++].data(), sizeof(float) * n * l->world);
+        return 0;
+    }
+    int rc = 0;
+    if (l->rv) {
+        l->rv->run(n * (size_t)l->world,
+                   [&](std::vector<float>& a, bool) { std::memcpy(a.data() + n * (size_t)l->rank, send, sizeof(float) * n); },
+                   [&](const std::vector<float>& a) { std::memcpy(recv, a.data(), sizeof(float) * n * l->world); });
+    } else {
+        rc = l->inner.allgather(send, recv, n, l->inner.user);
+    }
+    if (!rc && l->record) l->log->emplace_back(recv, recv + n * (size_t)l->world);
+    return rc;
+}
+
+}  // namespace
+
+struct fgoicp_multi {
+    std::vector<int> devices;
+    std::vector<fgoicp_solver*> solvers;
+    std::vector<fgoicp_rccl*> rccl;
+    std::vector<std::unique_ptr<RankLink>> links;
+    std::vector<std::vector<std::vector<float>>> logs;
+    Rendezvous rv;
+    int transport = FGOICP_TRANSPORT_RCCL;
+    std::vector<double> seconds;   // wall-clock of every rank's last run
+};
+
+extern "C" {
+
+void fgoicp_multi_destroy(fgoicp_multi* m) {
+    if (!m) return;
+    for (fgoicp_solver* s : m->solvers) fgoicp_solver_destroy(s);
+    for (fgoicp_rccl* x : m->rccl) fgoicp_rccl_destroy(x);
+    delete m;
+}
+
+int fgoicp_multi_create(const float* tgt_xyz, size_t nt, const float* src_xyz, size_t ns, float lut_resolution, float mse_threshold,
+                        const fgoicp_solver_opts* opts, const int* devices, int ndev, int transport, fgoicp_multi** out) {
+    if (!out) return FGOICP_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!devices || ndev < 1 || (transport != FGOICP_TRANSPORT_RCCL && transport != FGOICP_TRANSPORT_IN_PROCESS)) {
+        set_error("fgoicp_multi_create: invalid argument");
+        return FGOICP_ERR_INVALID_ARG;
+    }
+    auto m = std::make_unique<fgoicp_multi>();
+    m->devices.assign(devices, devices + ndev);
+    m->transport = transport;
+    m->rv.world = ndev;
+    m->logs.resize(ndev);
+    m->seconds.assign(ndev, 0.0);
+    fgoicp_solver_opts o{FGOICP_SCHEDULE_ROUND, 0, 0u, 0, 0.0f};
+    if (opts) o = *opts;
+    o.schedule = FGOICP_SCHEDULE_ROUND;  // only expansion rounds shard (SERIAL is the single-GPU reference order)
+    auto fail = [&](int rc) { fgoicp_multi_destroy(m.release()); return rc; };
+    for (int r = 0; r < ndev; ++r) {
+        o.device = devices[r];
+        fgoicp_solver* s = nullptr;
+        int rc = fgoicp_solver_create(tgt_xyz, nt, src_xyz, ns, lut_resolution, mse_threshold, &o, &s);
+        if (rc) return fail(rc);
+        m->solvers.push_back(s);
+    }
+    if (ndev > 1 && transport == FGOICP_TRANSPORT_RCCL) {
+        for (int a = 0; a < ndev; ++a)
+            for (int b = a + 1; b < ndev; ++b)
+                if (devices[a] == devices[b]) { set_error("fgoicp_multi_create: the RCCL transport needs distinct devices (use FGOICP_TRANSPORT_IN_PROCESS to rehearse)"); return fail(FGOICP_ERR_INVALID_ARG); }
+        unsigned char id[128];
+        int rc = fgoicp_rccl_unique_id(id);
+        if (rc) return fail(rc);
+        m->rccl.assign(ndev, nullptr);
+        std::vector<int> rcs(ndev, 0);
+        std::vector<std::string> errs(ndev);
+        std::vector<std::thread> th;  // ncclCommInitRank blocks until every rank has joined: one thread per rank
+        for (int r = 0; r < ndev; ++r)
+            th.emplace_back([&, r] {
+                rcs[r] = fgoicp_rccl_create(r, ndev, id, devices[r], &m->rccl[r]);
+                if (rcs[r]) errs[r] = fgoicp_last_error();
+            });
+        for (auto& t : th) t.join();
+        for (int r = 0; r < ndev; ++r)
+            if (rcs[r]) { set_error("rank " + std::to_string(r) + ": " + errs[r]); return fail(rcs[r]); }
+    }
+    for (int r = 0; r < ndev; ++r) {
+        auto l = std::make_unique<RankLink>();
+        l->rank = r;
+        l->world = ndev;
+        l->log = &m->logs[r];
+        if (ndev > 1 && transport == FGOICP_TRANSPORT_RCCL) fgoicp_rccl_exchange(m->rccl[r], &l->inner);
+        else l->rv = &m->rv;
+        fgoicp_exchange ex{r, ndev, link_allreduce_min, link_allgather, l.get()};
+        int rc = fgoicp_solver_set_exchange(m->solvers[r], ndev > 1 ? &ex : nullptr);
+        if (rc) return fail(rc);
+        m->links.push_back(std::move(l));
+    }
+    *out = m.release();
+    return FGOICP_OK;
+}
+
+int fgoicp_multi_set_record(fgoicp_multi* m, int on) {
+    if (!m) return FGOICP_ERR_INVALID_ARG;
+    for (size_t r = 0; r < m->links.size(); ++r) {
+        m->links[r]->record = on != 0;
+        m->links[r]->replay = false;
+        if (on) m->logs[r].clear();
+    }
+    return FGOICP_OK;
+}
+
+// Every rank's run() on its own host thread; the result is rank 0's (all ranks hold the same incumbent after the last exchange).
+int fgoicp_multi_run(fgoicp_multi* m, float* R_out9, float* t_out3) {
+    if (!m || !R_out9 || !t_out3) return FGOICP_ERR_INVALID_ARG;
+    const int n = (int)m->solvers.size();
+    std::vector<int> rcs(n, 0);
+    std::vector<std::string> errs(n);
+    std::vector<float> R(9 * (size_t)n), t(3 * (size_t)n);
+    for (auto& l : m->links) { l->replay = false; if (l->record) l->log->clear(); }
+    std::vector<std::thread> th;
+    for (int r = 0; r < n; ++r)
+        th.emplace_back([&, r] {
+            const auto t0 = std::chrono::steady_clock::now();
+            rcs[r] = fgoicp_solver_run(m->solvers[r], &R[9 * (size_t)r], &t[3 * (size_t)r]);
+            if (rcs[r]) errs[r] = fgoicp_last_error();
+            m->seconds[r] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        });
+    for (auto& x : th) x.join();
+    for (int r = 0; r < n; ++r)
+        if (rcs[r]) { set_error("rank " + std::to_string(r) + ": " + errs[r]); return rcs[r]; }
+    for (int r = 1; r < n; ++r)
+        if (std::memcmp(&R[0], &R[9 * (size_t)r], 36) != 0 || std::memcmp(&t[0], &t[3 * (size_t)r], 12) != 0) {
+            set_error("fgoicp_multi_run: ranks ended with different incumbents");
+            return FGOICP_ERR_EXCHANGE;
+        }
+    std::memcpy(R_out9, R.data(), 36);
+    std::memcpy(t_out3, t.data(), 12);
+    return FGOICP_OK;
+}
+
+// ONE rank alone against the recording of the last recorded run: what that rank would do on a GPU of its own (everything but
+// the latency of the collectives).  seconds_out = wall-clock of its run().
+int fgoicp_multi_replay_rank(fgoicp_multi* m, int rank, double* seconds_out) {
+    if (!m || rank < 0 || rank >= (int)m->solvers.size()) return FGOICP_ERR_INVALID_ARG;
+    RankLink* l = m->links[rank].get();
+    if (m->solvers.size() > 1 && l->log->empty()) { set_error("fgoicp_multi_replay_rank: nothing recorded (fgoicp_multi_set_record, then fgoicp_multi_run)"); return FGOICP_ERR_INVALID_ARG; }
+    const bool was_recording = l->record;
+    l->record = false;
+    l->replay = true;
+    l->replay_pos = 0;
+    float R[9], t[3];
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = fgoicp_solver_run(m->solvers[rank], R, t);
+    if (seconds_out) *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    l->replay = false;
+    l->record = was_recording;
+    return rc;
+}
+
+int fgoicp_multi_world(const fgoicp_multi* m) { return m ? (int)m->solvers.size() : 0; }
+fgoicp_solver* fgoicp_multi_solver(fgoicp_multi* m, int rank) { return m && rank >= 0 && rank < (int)m->solvers.size() ? m->solvers[rank] : nullptr; }
+int fgoicp_multi_seconds(const fgoicp_multi* m, int rank, double* seconds) {
+    if (!m || !seconds || rank < 0 || rank >= (int)m->seconds.size()) return FGOICP_ERR_INVALID_ARG;
+    *seconds = m->seconds[rank];
+    return FGOICP_OK;
+}
+
+}  // extern "C"

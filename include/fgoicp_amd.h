@@ -227,6 +227,40 @@ int fgoicp_solver_preproc(const fgoicp_solver* s, float* offs6, float* scale, fl
 /* The operator context the solver drives (borrowed; valid until solver_destroy). */
 fgoicp_ctx* fgoicp_solver_ctx(fgoicp_solver* s);
 
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU inside the library (no reference counterpart: the reference is single-GPU).
+ * The rotation cubes of every expansion round are dealt round-robin to the ranks; per round ONE all-reduce(MIN) of the
+ * best error and ONE small all-gather keep every rank's queue and incumbent identical.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct fgoicp_rccl fgoicp_rccl;
+/* RCCL transport of the exchange, one communicator per rank (one process per GPU, or one thread per GPU): rank 0 draws the
+ * 128-byte id (ncclGetUniqueId) and hands it to the others by whatever channel the launcher has; every rank then calls
+ * fgoicp_rccl_create (ncclCommInitRank — blocks until all ranks have joined) and installs fgoicp_rccl_exchange's struct with
+ * fgoicp_solver_set_exchange.  The collectives run on device buffers over xGMI, on a stream of their own. */
+int fgoicp_rccl_unique_id(unsigned char* id128);
+int fgoicp_rccl_create(int rank, int world_size, const unsigned char* id128, int device, fgoicp_rccl** out);
+int fgoicp_rccl_exchange(fgoicp_rccl* x, fgoicp_exchange* out);   /* `out` borrows x: keep x alive while a solver uses it */
+int fgoicp_rccl_calls(const fgoicp_rccl* x, uint64_t* collectives);
+void fgoicp_rccl_destroy(fgoicp_rccl* x);
+
+/* One process, one host thread + one solver per device — what `fast-go-icp --gpus N` runs.  devices[r] = HIP ordinal of rank r.
+ * FGOICP_TRANSPORT_RCCL needs distinct devices; FGOICP_TRANSPORT_IN_PROCESS (a shared-memory rendezvous of the rank threads)
+ * takes any list, e.g. {0, 0, 0, 0}: four ranks rehearsed on one GPU.  The schedule is always FGOICP_SCHEDULE_ROUND. */
+typedef struct fgoicp_multi fgoicp_multi;
+enum { FGOICP_TRANSPORT_RCCL = 0, FGOICP_TRANSPORT_IN_PROCESS = 1 };
+int fgoicp_multi_create(const float* tgt_xyz, size_t nt, const float* src_xyz, size_t ns, float lut_resolution, float mse_threshold,
+                        const fgoicp_solver_opts* opts, const int* devices, int ndev, int transport, fgoicp_multi** out);
+void fgoicp_multi_destroy(fgoicp_multi* m);
+/* FastGoICP::run() on all ranks at once; R, t as fgoicp_solver_run (every rank ends with the same incumbent — checked). */
+int fgoicp_multi_run(fgoicp_multi* m, float* R_out9, float* t_out3);
+int fgoicp_multi_world(const fgoicp_multi* m);
+fgoicp_solver* fgoicp_multi_solver(fgoicp_multi* m, int rank);     /* borrowed: stats, getters */
+int fgoicp_multi_seconds(const fgoicp_multi* m, int rank, double* seconds);   /* wall-clock of that rank's last run() */
+/* Scaling rehearsal on fewer GPUs than ranks: record what every exchange returned during a run, then run ONE rank alone
+ * against the recording — the time that rank would need on a GPU of its own, without the collectives' latency. */
+int fgoicp_multi_set_record(fgoicp_multi* m, int on);
+int fgoicp_multi_replay_rank(fgoicp_multi* m, int rank, double* seconds_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,87 @@
+"""GPU: the multi-GPU path inside the library (include/fgoicp_amd.h, fgoicp_rccl_* / fgoicp_multi_*) on the one GPU a test box has:
+several ranks on device 0 over the in-process transport, the RCCL transport with one rank, record / replay, and the CLI's --gpus.
+The exchange logic itself (uneven shards, ties between ranks, 8 ranks) is covered on CPU by tests/test_dist_gloo.py."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = np.load(os.path.join(REPO, "tests", "golden", "goicp_golden.npz"))
+
+
+def same(a, b):
+    (Ra, ta, ea), (Rb, tb, eb) = a, b
+    return abs(float(ea) - float(eb)) <= 1e-5 * float(eb) and np.allclose(Ra, Rb, atol=1e-5) and np.allclose(ta, tb, atol=1e-5 * max(1.0, float(np.abs(tb).max())))
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_ranks_on_one_gpu_reach_the_single_gpu_optimum(fg, gpu_required, world):
+    tgt, src, R_gt, t_gt = fg.synth.workload("small", angle_deg=150.0, min_angle_deg=110.0)
+    mse = 2e-4  # ns * mse = 1.0: below the residual, the search has to certify
+    one = fg.FastGoICP(tgt, src, 0.01, mse, schedule=fg.SCHEDULE_ROUND, round_width=0)
+    R1, t1 = one.run()
+    ref = (R1, t1, one.get_best_error())
+    sub1 = one.stats()["trans_cubes"]
+    one.close()
+    m = fg.MultiGoICP(tgt, src, 0.01, mse, devices=[0] * world, transport=fg.TRANSPORT_IN_PROCESS)
+    m.set_record(True)
+    R, t = m.run()
+    assert same((R, t, m.get_best_error()), ref)
+    subs = [m.stats(r)["trans_cubes"] for r in range(world)]
+    assert min(subs) > 0 and 0.5 * sub1 < sum(subs) < 2.5 * sub1  # every rank worked; the total stays in the single-GPU ballpark
+    for r in range(world):
+        assert m.get_best_error(r) == m.get_best_error(0)  # identical incumbents by construction
+    # one rank alone against the recorded exchange: same share of the work, same end state
+    secs = m.replay_rank(world - 1)
+    assert secs > 0 and m.stats(world - 1)["trans_cubes"] == subs[world - 1]
+    assert m.get_best_error(world - 1) == m.get_best_error(0)
+    m.close()
+
+
+def test_rccl_transport_with_one_rank(fg, gpu_required):
+    """ncclCommInitRank + all-reduce(min) + all-gather on device buffers (world size 1 is all a one-GPU box can form)."""
+    ident = fg.rccl_unique_id()
+    assert len(ident) == 128
+    ex = fg.RcclExchange(0, 1, ident, 0)
+    buf = (C.c_float * 3)(3.0, -1.0, 2.5)
+    assert ex.struct.allreduce_min(buf, 3, ex.struct.user) == 0 and list(buf) == [3.0, -1.0, 2.5]
+    send = (C.c_float * 200)(*range(200))  # beyond the initial buffer: the transport re-allocates
+    recv = (C.c_float * 200)()
+    assert ex.struct.allgather(send, recv, 200, ex.struct.user) == 0 and list(recv) == list(map(float, range(200)))
+    assert ex.calls == 2 and ex.warmup() and ex.calls == 4
+    s = fg.FastGoICP(G["runsyn_tgt"], G["runsyn_src"], float(G["runsyn_res"]), float(G["runsyn_mse"]), schedule=fg.SCHEDULE_ROUND, round_width=2)
+    s.set_exchange(ex)
+    R, t = s.run()
+    assert np.allclose(R, G["runsyn_R"], atol=1e-5)
+    s.close()
+    ex.close()
+    m = fg.MultiGoICP(G["runsyn_tgt"], G["runsyn_src"], float(G["runsyn_res"]), float(G["runsyn_mse"]), devices=[0], transport=fg.TRANSPORT_RCCL, round_width=2)
+    R2, t2 = m.run()
+    assert np.allclose(R2, G["runsyn_R"], atol=1e-5)
+    m.close()
+    with pytest.raises(fg.FgoicpError):  # two ranks on one device cannot form an RCCL communicator: refused up front
+        fg.MultiGoICP(G["runsyn_tgt"], G["runsyn_src"], float(G["runsyn_res"]), float(G["runsyn_mse"]), devices=[0, 0], transport=fg.TRANSPORT_RCCL)
+
+
+def test_cli_gpus_flag(fg, gpu_required, tmp_path):
+    from tests.test_gpu_cli_dist import write_txt
+    exe = os.path.join(REPO, "fast-go-icp_amd", "lib", "fast-go-icp")
+    write_txt(tmp_path / "tgt.txt", G["runsyn_tgt"])
+    write_txt(tmp_path / "src.txt", G["runsyn_src"][:250])
+    out = {}
+    for name, extra, env in (("one", [], {}), ("two", ["--gpus", "2"], {"FGOICP_MULTI_DEVICES": "0,0"})):
+        cfg = tmp_path / f"{name}.toml"
+        cfg.write_text(f'[io]\ntarget = "{tmp_path}/tgt.txt"\nsource = "{tmp_path}/src.txt"\noutput = "{tmp_path}/{name}_out.toml"\n'
+                       f'[params]\nsource_subsample = 1.0\nschedule = "round"\nround_width = 4\nlut_resolution = {float(G["runsyn_res"])}\nmse_threshold = {float(G["runsyn_mse"])}\nseed = 3\n')
+        p = subprocess.run([exe, "-c", str(cfg), *extra], capture_output=True, text=True, timeout=300, env={**os.environ, **env})
+        assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+        if extra:
+            assert "Sharding the search over 2 GPUs" in p.stdout
+        txt = (tmp_path / f"{name}_out.toml").read_text()
+        out[name] = float(re.search(r"^sse = (.*)$", txt, re.M).group(1))
+    assert out["two"] == pytest.approx(out["one"], rel=1e-5)
