@@ -57,6 +57,7 @@ _SIGS = {
     "fgoicp_bounds_collect": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p]),
     "fgoicp_sse": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_float_p]),
     "fgoicp_icp": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_size_t, C.c_float, c_float_p, c_float_p, c_float_p, c_int_p]),
+    "fgoicp_icp_batch": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, C.c_size_t, C.c_float, c_float_p, c_float_p, c_float_p, c_int_p]),
     "fgoicp_procrustes": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_int_p]),
     "fgoicp_ctx_set_inliers": (C.c_int, [C.c_void_p, C.c_size_t]),
     "fgoicp_ctx_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),

@@ -12,7 +12,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libfgoicp_amd.so")
+LIB_PATH = os.environ.get("FGOICP_LIB") or os.path.join(LIB_DIR, "libfgoicp_amd.so")  # FGOICP_LIB: a development build elsewhere (tools/ablate.sh)
 CLI_PATH = os.path.join(LIB_DIR, "fast-go-icp")
 
 SOURCES = [

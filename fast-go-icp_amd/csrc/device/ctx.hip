@@ -11,6 +11,7 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/fgoicp_amd.h"
@@ -329,86 +330,89 @@ int ctx_bounds_multi(fgoicp_ctx* c, int G, const float* R9, const float* rot_spa
 
 // float Registration::compute_sse_error(glm::mat3, glm::vec3) — registration.cu:62-86.  Enqueue only: the result lands in
 // pinned memory (sse_result) once `st` has drained.
-static int sse_enqueue(fgoicp_ctx* c, const float* R9, const float* t3, const uint32_t* seed_idx, hipStream_t st) {
+static int sse_enqueue(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R9, const float* t3, const uint32_t* seed_idx, hipStream_t st) {
     const int ns = (int)c->ns;
     if (c->brute_force_nn) {
-        launch_fill_u32(c->d_min_bits, 0x501502F9u /* bits(1e10f) */, c->ns, st);
-        launch_nn_min(c->d_src, ns, c->d_tgt, (int)c->nt, R9, t3, 1, c->d_min_bits, st);
+        launch_fill_u32(L.d_min_bits, 0x501502F9u /* bits(1e10f) */, c->ns, st);
+        launch_nn_min(c->d_src, ns, c->d_tgt, (int)c->nt, R9, t3, 1, L.d_min_bits, st);
     } else {
         const float* skip_lb = nullptr;
         const uint32_t* skip_u = nullptr;
         if (c->inliers && c->trim_skip) {  // trimmed: queries provably beyond the k-th smallest distance are left out of the exact search
-            launch_nn_prep(c->d_src, ns, c->d_lut, c->geom, R9, t3, 1, c->d_tgt, (int)c->nt, seed_idx, c->bounds6, c->d_nn_ub, c->d_nn_lb, st);
-            launch_trim_select(c->d_nn_ub, ns, (int)c->inliers, nullptr, c->d_sel + 8, c->d_sel_wide, st);
-            skip_lb = c->d_nn_lb;
-            skip_u = c->d_sel + 8;
+            launch_nn_prep(c->d_src, ns, c->d_lut, c->geom, R9, t3, 1, c->d_tgt, (int)c->nt, seed_idx, c->bounds6, L.d_nn_ub, L.d_nn_lb, st);
+            launch_trim_select(L.d_nn_ub, ns, (int)c->inliers, nullptr, L.d_sel + 8, L.d_sel_wide, st);
+            skip_lb = L.d_nn_lb;
+            skip_u = L.d_sel + 8;
         }
-        launch_nn_scan(c->d_src, ns, c->bvh_tgt.view(), c->d_lut, c->geom, R9, t3, 1, 0, c->d_tgt, (int)c->nt, seed_idx, skip_lb, skip_u, c->d_min_bits, st);
+        launch_nn_scan(c->d_src, ns, c->bvh_tgt.view(), c->d_lut, c->geom, R9, t3, 1, 0, c->d_tgt, (int)c->nt, seed_idx, skip_lb, skip_u, L.d_min_bits, st);
     }
     if (c->inliers) {  // trimmed SSE: the k smallest nearest-neighbour terms
-        launch_trim_select(reinterpret_cast<const float*>(c->d_min_bits), ns, (int)c->inliers, c->hd_trim, nullptr, c->d_sel_wide, st);
+        launch_trim_select(reinterpret_cast<const float*>(L.d_min_bits), ns, (int)c->inliers, L.hd_trim, nullptr, L.d_sel_wide, st);
     } else {
         const int nb = reduce_blocks_for(ns);
-        launch_sum_f32_as_f64(c->d_min_bits, ns, c->d_bp3, nb, st);
-        launch_sum_partials(c->d_bp3, nb, 1, c->hd_sums + 12, st);
+        launch_sum_f32_as_f64(L.d_min_bits, ns, L.d_bp3, nb, st);
+        launch_sum_partials(L.d_bp3, nb, 1, L.hd_sums + 12, st);
     }
     HIPCHK(hipGetLastError());
     return FGOICP_OK;
 }
-static float sse_result(const fgoicp_ctx* c) { return c->inliers ? c->h_trim[0] : (float)c->h_sums[12]; }
+static float sse_result(const fgoicp_ctx* c, const fgoicp_ctx::IcpLane& L) { return c->inliers ? L.h_trim[0] : (float)L.h_sums[12]; }
 
-int ctx_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out, const uint32_t* seed_idx) {
-    HIPCHK(hipSetDevice(c->device));
-    int rc = sse_enqueue(c, R9, t3, seed_idx, c->stream);
+static int lane_sse(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R9, const float* t3, float* sse_out, const uint32_t* seed_idx) {
+    int rc = sse_enqueue(c, L, R9, t3, seed_idx, L.stream);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    *sse_out = sse_result(c);
+    HIPCHK(hipStreamSynchronize(L.stream));
+    *sse_out = sse_result(c, L);
     return FGOICP_OK;
 }
+int ctx_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out, const uint32_t* seed_idx) {
+    HIPCHK(hipSetDevice(c->device));
+    return lane_sse(c, c->lanes[0], R9, t3, sse_out, seed_idx);
+}
 
-// IterativeClosestPoint3D::procrustes() on c->d_work — icp3d.cu:140-172.  The device half (enqueue only): correspondences
+// IterativeClosestPoint3D::procrustes() on L.d_work — icp3d.cu:140-172.  The device half (enqueue only): correspondences
 // into `idx`, centroids and covariance into pinned memory; `wide` is the selection scratch of the trimmed variant.
-static int procrustes_enqueue(fgoicp_ctx* c, const uint32_t* seed_idx, uint32_t* idx, uint32_t* wide, hipStream_t st) {
+static int procrustes_enqueue(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const uint32_t* seed_idx, uint32_t* idx, uint32_t* wide, hipStream_t st) {
     const int ns = (int)c->ns, nt = (int)c->nt;
     // kernFindNearestNeighbor (icp3d.cu:11-28): min distance, tie set, lowest index
     if (c->brute_force_nn) {
-        launch_fill_u32(c->d_min_bits, 0x501502F9u, c->ns, st);
+        launch_fill_u32(L.d_min_bits, 0x501502F9u, c->ns, st);
         launch_fill_u32(idx, 0x7fffffffu, c->ns, st);
-        launch_nn_min(c->d_work, ns, c->d_tgt, nt, nullptr, nullptr, 0, c->d_min_bits, st);
-        launch_nn_tie_threshold(c->d_min_bits, ns, c->d_thr_bits, st);
-        launch_nn_first_index(c->d_work, ns, c->d_tgt, nt, c->d_thr_bits, idx, st);
+        launch_nn_min(L.d_work, ns, c->d_tgt, nt, nullptr, nullptr, 0, L.d_min_bits, st);
+        launch_nn_tie_threshold(L.d_min_bits, ns, L.d_thr_bits, st);
+        launch_nn_first_index(L.d_work, ns, c->d_tgt, nt, L.d_thr_bits, idx, st);
     } else {
         const float* skip_lb = nullptr;
         const uint32_t* skip_u = nullptr;
         if (c->inliers && c->trim_skip) {  // trimmed: points provably outside the inlier set get no correspondence
-            launch_nn_prep(c->d_work, ns, c->d_lut, c->geom, nullptr, nullptr, 0, c->d_tgt, nt, seed_idx, c->bounds6, c->d_nn_ub2, c->d_nn_lb2, st);
-            launch_trim_select(c->d_nn_ub2, ns, (int)c->inliers, nullptr, c->d_sel + 4, wide, st);
-            skip_lb = c->d_nn_lb2;
-            skip_u = c->d_sel + 4;
+            launch_nn_prep(L.d_work, ns, c->d_lut, c->geom, nullptr, nullptr, 0, c->d_tgt, nt, seed_idx, c->bounds6, L.d_nn_ub2, L.d_nn_lb2, st);
+            launch_trim_select(L.d_nn_ub2, ns, (int)c->inliers, nullptr, L.d_sel + 4, wide, st);
+            skip_lb = L.d_nn_lb2;
+            skip_u = L.d_sel + 4;
         }
-        launch_nn_scan(c->d_work, ns, c->bvh_tgt.view(), c->d_lut, c->geom, nullptr, nullptr, 0, 1, c->d_tgt, nt, seed_idx, skip_lb, skip_u, idx, st);
+        launch_nn_scan(L.d_work, ns, c->bvh_tgt.view(), c->d_lut, c->geom, nullptr, nullptr, 0, 1, c->d_tgt, nt, seed_idx, skip_lb, skip_u, idx, st);
     }
     const int nb = reduce_blocks_for(ns);
     const unsigned char* use = nullptr;
     int ncount = ns;
     if (c->inliers) {  // trimmed ICP: only the k closest correspondences enter the Procrustes sums
-        launch_icp_inliers(c->d_work, c->d_tgt, idx, ns, nt, (int)c->inliers, c->d_d2, c->d_sel, c->d_eq, c->d_orig_of_slot, c->d_use, wide, st);
-        use = c->d_use;
+        launch_icp_inliers(L.d_work, c->d_tgt, idx, ns, nt, (int)c->inliers, L.d_d2, L.d_sel, L.d_eq, c->d_orig_of_slot, L.d_use, wide, st);
+        use = L.d_use;
         ncount = (int)c->inliers;
     }
-    launch_icp_sums(c->d_work, c->d_tgt, idx, ns, nt, use, c->d_bp, nb, st);
-    launch_icp_centroids(c->d_bp, nb, ncount, c->d_cen, c->hd_cen, st);  // icp3d.cu:152-156, no host round trip
-    launch_icp_cov(c->d_work, c->d_tgt, idx, ns, nt, c->d_cen, use, c->d_bp2, nb, st);
-    launch_sum_partials(c->d_bp2, nb, 9, c->hd_sums, st);
+    launch_icp_sums(L.d_work, c->d_tgt, idx, ns, nt, use, L.d_bp, nb, st);
+    launch_icp_centroids(L.d_bp, nb, ncount, L.d_cen, L.hd_cen, st);  // icp3d.cu:152-156, no host round trip
+    launch_icp_cov(L.d_work, c->d_tgt, idx, ns, nt, L.d_cen, use, L.d_bp2, nb, st);
+    launch_sum_partials(L.d_bp2, nb, 9, L.hd_sums, st);
     HIPCHK(hipGetLastError());
     return FGOICP_OK;
 }
 // ... and the host half, once the stream has drained: 3x3 SVD, icp3d.cu:168-169
-static void procrustes_finish(const fgoicp_ctx* c, Mat3f* R_out, Vec3f* t_out, float* centroids6_out, Mat3f* ABt_out) {
+static void procrustes_finish(const fgoicp_ctx::IcpLane& L, Mat3f* R_out, Vec3f* t_out, float* centroids6_out, Mat3f* ABt_out) {
     float cen[6];
-    std::memcpy(cen, c->h_cen, sizeof(cen));
+    std::memcpy(cen, L.h_cen, sizeof(cen));
     Mat3f ABt;
-    for (int k = 0; k < 9; ++k) ABt.m[k] = (float)c->h_sums[k];
+    for (int k = 0; k < 9; ++k) ABt.m[k] = (float)L.h_sums[k];
     const Mat3f Rn = closest_orthogonal_approximation(ABt);  // icp3d.cu:168
     const Vec3f sc{cen[0], cen[1], cen[2]}, cc{cen[3], cen[4], cen[5]};
     *R_out = Rn;
@@ -417,11 +421,11 @@ static void procrustes_finish(const fgoicp_ctx* c, Mat3f* R_out, Vec3f* t_out, f
     if (ABt_out) *ABt_out = ABt;
 }
 
-int ctx_procrustes_device(fgoicp_ctx* c, Mat3f* R_out, Vec3f* t_out, float* centroids6_out, Mat3f* ABt_out, bool seeded) {
-    int rc = procrustes_enqueue(c, seeded ? c->d_first_idx : nullptr, c->d_first_idx, c->d_sel_wide, c->stream);
+int ctx_procrustes_device(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, Mat3f* R_out, Vec3f* t_out, float* centroids6_out, Mat3f* ABt_out, bool seeded) {
+    int rc = procrustes_enqueue(c, L, seeded ? L.d_first_idx : nullptr, L.d_first_idx, L.d_sel_wide, L.stream);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    procrustes_finish(c, R_out, t_out, centroids6_out, ABt_out);
+    HIPCHK(hipStreamSynchronize(L.stream));
+    procrustes_finish(L, R_out, t_out, centroids6_out, ABt_out);
     return FGOICP_OK;
 }
 
@@ -431,17 +435,17 @@ int ctx_procrustes_device(fgoicp_ctx* c, Mat3f* R_out, Vec3f* t_out, float* cent
 // iteration k, so they run next to each other — both are latency chains that fill half the device at 40k points.  The pass of
 // iteration k+1 is speculative (the loop may end on the SSE of iteration k); it is drained before returning.  Same kernels,
 // same arithmetic, same order of every sum as the one-stream loop (FGOICP_ICP_OVERLAP=0).
-int ctx_icp(fgoicp_ctx* c, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3,
-            int* iters_out) {
-    HIPCHK(hipSetDevice(c->device));
+static int lane_icp(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3,
+                    int* iters_out) {
+    HIPCHK(hipSetDevice(c->device));  // per host thread
     const int ns = (int)c->ns;
     const bool overlap = c->icp_overlap && !c->brute_force_nn;
     const bool seeding = c->icp_seeding && !c->brute_force_nn;
-    hipStream_t A = c->stream, B = overlap ? c->icp_stream : c->stream;
-    uint32_t* idx[2] = {c->d_first_idx, overlap ? c->d_first_idx2 : c->d_first_idx};
+    hipStream_t A = L.stream, B = overlap ? L.icp_stream : L.stream;
+    uint32_t* idx[2] = {L.d_first_idx, overlap ? L.d_first_idx2 : L.d_first_idx};
     int cur = 0;
-    HIPCHK(hipMemcpyAsync(c->d_work, c->d_src, sizeof(float4) * c->ns, hipMemcpyDeviceToDevice, A));
-    launch_transform_inplace(c->d_work, ns, R0, t0, A);  // icp3d.cu:85
+    HIPCHK(hipMemcpyAsync(L.d_work, c->d_src, sizeof(float4) * c->ns, hipMemcpyDeviceToDevice, A));
+    launch_transform_inplace(L.d_work, ns, R0, t0, A);  // icp3d.cu:85
     Mat3f R = Mat3f::from(R0);
     Vec3f t{t0[0], t0[1], t0[2]};
     size_t iter = 0;
@@ -451,11 +455,11 @@ int ctx_icp(fgoicp_ctx* c, const float* R0, const float* t0, size_t max_iter, fl
     int iters = 0;
     bool chain_pending = false;  // a correspondence pass is in flight on B
     if (overlap && max_iter > 0) {
-        HIPCHK(hipEventRecord(c->icp_ev_w, A));
-        HIPCHK(hipStreamWaitEvent(B, c->icp_ev_w, 0));
-        int rc = procrustes_enqueue(c, nullptr, idx[0], c->d_sel_wide2, B);
+        HIPCHK(hipEventRecord(L.icp_ev_w, A));
+        HIPCHK(hipStreamWaitEvent(B, L.icp_ev_w, 0));
+        int rc = procrustes_enqueue(c, L, nullptr, idx[0], L.d_sel_wide2, B);
         if (rc) return rc;
-        HIPCHK(hipEventRecord(c->icp_ev_b, B));
+        HIPCHK(hipEventRecord(L.icp_ev_b, B));
         chain_pending = true;
     }
     while (iter++ < max_iter && (last_sse - sse) > thr * last_sse) {  // icp3d.cu:94
@@ -465,40 +469,40 @@ int ctx_icp(fgoicp_ctx* c, const float* R0, const float* t0, size_t max_iter, fl
         Mat3f Rn;
         Vec3f tn;
         if (overlap) {
-            HIPCHK(hipEventSynchronize(c->icp_ev_b));
+            HIPCHK(hipEventSynchronize(L.icp_ev_b));
             chain_pending = false;
-            procrustes_finish(c, &Rn, &tn, nullptr, nullptr);
+            procrustes_finish(L, &Rn, &tn, nullptr, nullptr);
         } else {
             // every pass after the first seeds its exact search with the correspondences of the pass before it
-            int rc = ctx_procrustes_device(c, &Rn, &tn, nullptr, nullptr, iters > 0 && seeding);
+            int rc = ctx_procrustes_device(c, L, &Rn, &tn, nullptr, nullptr, iters > 0 && seeding);
             if (rc) return rc;
         }
         const float tn3[3] = {tn.x, tn.y, tn.z};
-        launch_transform_inplace(c->d_work, ns, Rn.m, tn3, A);  // :100
+        launch_transform_inplace(L.d_work, ns, Rn.m, tn3, A);  // :100
         R = Rn * R;                                              // :101
         t = Rn * t + tn;                                         // :102
         const float t3[3] = {t.x, t.y, t.z};
         if (overlap) {
-            HIPCHK(hipEventRecord(c->icp_ev_w, A));
-            int rc = sse_enqueue(c, R.m, t3, seeding ? idx[cur] : nullptr, A);  // :103
+            HIPCHK(hipEventRecord(L.icp_ev_w, A));
+            int rc = sse_enqueue(c, L, R.m, t3, seeding ? idx[cur] : nullptr, A);  // :103
             if (rc) return rc;
             if (iter < max_iter) {  // the next iteration's pass, next to this iteration's SSE
-                HIPCHK(hipStreamWaitEvent(B, c->icp_ev_w, 0));
-                rc = procrustes_enqueue(c, seeding ? idx[cur] : nullptr, idx[cur ^ 1], c->d_sel_wide2, B);
+                HIPCHK(hipStreamWaitEvent(B, L.icp_ev_w, 0));
+                rc = procrustes_enqueue(c, L, seeding ? idx[cur] : nullptr, idx[cur ^ 1], L.d_sel_wide2, B);
                 if (rc) return rc;
-                HIPCHK(hipEventRecord(c->icp_ev_b, B));
+                HIPCHK(hipEventRecord(L.icp_ev_b, B));
                 chain_pending = true;
                 cur ^= 1;
             }
             HIPCHK(hipStreamSynchronize(A));
-            sse = sse_result(c);
+            sse = sse_result(c, L);
         } else {
-            int rc = ctx_sse(c, R.m, t3, &sse, seeding ? c->d_first_idx : nullptr);  // :103
+            int rc = lane_sse(c, L, R.m, t3, &sse, seeding ? L.d_first_idx : nullptr);  // :103
             if (rc) return rc;
         }
         ++iters;
     }
-    if (chain_pending) HIPCHK(hipEventSynchronize(c->icp_ev_b));  // the speculative pass: drained, not used
+    if (chain_pending) HIPCHK(hipEventSynchronize(L.icp_ev_b));  // the speculative pass: drained, not used
     const bool cur_best = sse < last_sse;  // :106-107
     *sse_out = cur_best ? sse : last_sse;
     const Mat3f& Ro = cur_best ? R : last_R;
@@ -506,6 +510,38 @@ int ctx_icp(fgoicp_ctx* c, const float* R0, const float* t0, size_t max_iter, fl
     std::memcpy(R_out9, Ro.m, sizeof(Ro.m));
     t_out3[0] = to.x; t_out3[1] = to.y; t_out3[2] = to.z;
     if (iters_out) *iters_out = iters;
+    return FGOICP_OK;
+}
+
+int ctx_icp(fgoicp_ctx* c, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3, int* iters_out) {
+    return lane_icp(c, c->lanes[0], R0, t0, max_iter, thr, sse_out, R_out9, t_out3, iters_out);
+}
+
+// Several ICP runs at once (the triggers of one expansion round, driver.hpp): run i goes to lane i % lanes, every lane has its
+// own scratch and streams and a host thread of its own (an ICP iteration is a chain of small kernels with two host syncs — at
+// 40k points one run fills a fraction of the device).  Each run is exactly the run ctx_icp would do: same kernels, same sums.
+int ctx_icp_batch(fgoicp_ctx* c, int n, const float* R0s, const float* t0s, size_t max_iter, float thr, float* sse_out, float* R_out9s, float* t_out3s, int* iters_out) {
+    const int nl = std::min<int>(n, (int)c->lanes.size());
+    if (n <= 0) return FGOICP_OK;
+    if (nl <= 1 || c->brute_force_nn) {
+        for (int i = 0; i < n; ++i) {
+            int rc = lane_icp(c, c->lanes[0], R0s + 9 * i, t0s + 3 * i, max_iter, thr, sse_out + i, R_out9s + 9 * i, t_out3s + 3 * i, iters_out ? iters_out + i : nullptr);
+            if (rc) return rc;
+        }
+        return FGOICP_OK;
+    }
+    std::vector<int> rcs(nl, FGOICP_OK);
+    std::vector<std::string> errs(nl);
+    std::vector<std::thread> th;
+    for (int l = 0; l < nl; ++l)
+        th.emplace_back([&, l] {
+            for (int i = l; i < n && rcs[l] == FGOICP_OK; i += nl)
+                rcs[l] = lane_icp(c, c->lanes[l], R0s + 9 * i, t0s + 3 * i, max_iter, thr, sse_out + i, R_out9s + 9 * i, t_out3s + 3 * i, iters_out ? iters_out + i : nullptr);
+            if (rcs[l]) errs[l] = g_last_error;
+        });
+    for (auto& t : th) t.join();
+    for (int l = 0; l < nl; ++l)
+        if (rcs[l]) { set_error(errs[l]); return rcs[l]; }
     return FGOICP_OK;
 }
 
@@ -527,28 +563,28 @@ int ctx_set_inliers(fgoicp_ctx* c, size_t k) {
         c->vals_rows = (int)rows;
         // every pointer is guarded on its own: a call that failed half-way (out of memory) can be repeated without leaking
         for (auto& sl : c->slots) if (!sl.d_evals) HIPCHK(hipMalloc(&sl.d_evals, sizeof(float) * c->erow * rows));
-        if (!c->d_d2) HIPCHK(hipMalloc(&c->d_d2, sizeof(float) * c->ns));
-        if (!c->d_nn_lb) HIPCHK(hipMalloc(&c->d_nn_lb, sizeof(float) * c->ns));
-        if (!c->d_nn_ub) HIPCHK(hipMalloc(&c->d_nn_ub, sizeof(float) * c->ns));
-        if (!c->d_nn_lb2) HIPCHK(hipMalloc(&c->d_nn_lb2, sizeof(float) * c->ns));
-        if (!c->d_nn_ub2) HIPCHK(hipMalloc(&c->d_nn_ub2, sizeof(float) * c->ns));
-        if (!c->d_sel) HIPCHK(hipMalloc(&c->d_sel, sizeof(uint32_t) * 16));
-        if (!c->d_eq) HIPCHK(hipMalloc(&c->d_eq, sizeof(uint32_t)));
-        {
+        for (auto& L : c->lanes) {
+            if (!L.d_d2) HIPCHK(hipMalloc(&L.d_d2, sizeof(float) * c->ns));
+            if (!L.d_nn_lb) HIPCHK(hipMalloc(&L.d_nn_lb, sizeof(float) * c->ns));
+            if (!L.d_nn_ub) HIPCHK(hipMalloc(&L.d_nn_ub, sizeof(float) * c->ns));
+            if (!L.d_nn_lb2) HIPCHK(hipMalloc(&L.d_nn_lb2, sizeof(float) * c->ns));
+            if (!L.d_nn_ub2) HIPCHK(hipMalloc(&L.d_nn_ub2, sizeof(float) * c->ns));
+            if (!L.d_sel) HIPCHK(hipMalloc(&L.d_sel, sizeof(uint32_t) * 16));
+            if (!L.d_eq) HIPCHK(hipMalloc(&L.d_eq, sizeof(uint32_t)));
             const char* e = std::getenv("FGOICP_SELECT_WIDE");  // tuning knob: 0 = always the one-block selection for single rows
             if (!(e && std::atoi(e) == 0)) {
-                if (!c->d_sel_wide) HIPCHK(hipMalloc(&c->d_sel_wide, 65536));
-                if (!c->d_sel_wide2) HIPCHK(hipMalloc(&c->d_sel_wide2, 65536));
+                if (!L.d_sel_wide) HIPCHK(hipMalloc(&L.d_sel_wide, 65536));
+                if (!L.d_sel_wide2) HIPCHK(hipMalloc(&L.d_sel_wide2, 65536));
+            }
+            if (!L.d_use) HIPCHK(hipMalloc(&L.d_use, c->ns));
+            if (!L.h_trim) {
+                HIPCHK(hipHostMalloc((void**)&L.h_trim, sizeof(float) * 4, hipHostMallocMapped));
+                HIPCHK(hipHostGetDevicePointer((void**)&L.hd_trim, L.h_trim, 0));
             }
         }
-        if (!c->d_use) HIPCHK(hipMalloc(&c->d_use, c->ns));
         if (!c->d_orig_of_slot) {
             HIPCHK(hipMalloc(&c->d_orig_of_slot, sizeof(uint32_t) * c->ns));
             HIPCHK(hipMemcpy(c->d_orig_of_slot, c->perm.data(), sizeof(uint32_t) * c->ns, hipMemcpyHostToDevice));
-        }
-        if (!c->h_trim) {
-            HIPCHK(hipHostMalloc((void**)&c->h_trim, sizeof(float) * 4, hipHostMallocMapped));
-            HIPCHK(hipHostGetDevicePointer((void**)&c->hd_trim, c->h_trim, 0));
         }
         c->trim_ready = true;
     }
@@ -628,7 +664,6 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
         }
         CHK(hipMalloc(&c->d_src, sizeof(float4) * ns));
         CHK(hipMemcpy(c->d_src, h.data(), sizeof(float4) * ns, hipMemcpyHostToDevice));
-        CHK(hipMalloc(&c->d_work, sizeof(float4) * ns));
     }
     // target on the device (caller order) + exact-NN tree; LUT build — buildLUTKernel, registration.cu:258-318
     {
@@ -801,22 +836,33 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
         }
     }
     // exact-NN / ICP scratch
-    CHK(hipMalloc(&c->d_min_bits, sizeof(uint32_t) * ns));
-    CHK(hipMalloc(&c->d_thr_bits, sizeof(uint32_t) * ns));
-    CHK(hipMalloc(&c->d_first_idx, sizeof(uint32_t) * ns));
-    CHK(hipMalloc(&c->d_bp, sizeof(double) * 1024 * 16));
-    CHK(hipMalloc(&c->d_bp2, sizeof(double) * 1024 * 16));
-    CHK(hipMalloc(&c->d_bp3, sizeof(double) * 1024 * 16));
-    CHK(hipMalloc(&c->d_first_idx2, sizeof(uint32_t) * ns));
-    CHK(hipStreamCreateWithFlags(&c->icp_stream, hipStreamNonBlocking));
-    CHK(hipEventCreateWithFlags(&c->icp_ev_w, hipEventDisableTiming));
-    CHK(hipEventCreateWithFlags(&c->icp_ev_b, hipEventDisableTiming));
-    if (const char* e = std::getenv("FGOICP_ICP_OVERLAP")) c->icp_overlap = std::atoi(e) != 0;  // tuning knob
-    CHK(hipMalloc(&c->d_cen, sizeof(float) * 8));
-    CHK(hipHostMalloc((void**)&c->h_cen, sizeof(float) * 8, hipHostMallocMapped));
-    CHK(hipHostGetDevicePointer((void**)&c->hd_cen, c->h_cen, 0));
-    CHK(hipHostMalloc((void**)&c->h_sums, sizeof(double) * 16, hipHostMallocMapped));
-    CHK(hipHostGetDevicePointer((void**)&c->hd_sums, c->h_sums, 0));
+    {
+        int nl = 4;  // concurrent ICP runs (ctx_icp_batch); lane 0 shares the context's main stream
+        if (const char* e = std::getenv("FGOICP_ICP_LANES")) nl = std::max(1, std::min(16, std::atoi(e)));  // tuning knob
+        if (const char* e = std::getenv("FGOICP_ICP_OVERLAP")) c->icp_overlap = std::atoi(e) != 0;       // tuning knob
+        c->lanes.resize((size_t)nl);
+        for (int l = 0; l < nl; ++l) {
+            fgoicp_ctx::IcpLane& L = c->lanes[(size_t)l];
+            if (l == 0) L.stream = c->stream;
+            else CHK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+            CHK(hipMalloc(&L.d_work, sizeof(float4) * ns));
+            CHK(hipMalloc(&L.d_min_bits, sizeof(uint32_t) * ns));
+            if (l == 0) CHK(hipMalloc(&L.d_thr_bits, sizeof(uint32_t) * ns));  // brute-force kernels only, which run on lane 0
+            CHK(hipMalloc(&L.d_first_idx, sizeof(uint32_t) * ns));
+            CHK(hipMalloc(&L.d_first_idx2, sizeof(uint32_t) * ns));
+            CHK(hipMalloc(&L.d_bp, sizeof(double) * 1024 * 16));
+            CHK(hipMalloc(&L.d_bp2, sizeof(double) * 1024 * 16));
+            CHK(hipMalloc(&L.d_bp3, sizeof(double) * 1024 * 16));
+            CHK(hipStreamCreateWithFlags(&L.icp_stream, hipStreamNonBlocking));
+            CHK(hipEventCreateWithFlags(&L.icp_ev_w, hipEventDisableTiming));
+            CHK(hipEventCreateWithFlags(&L.icp_ev_b, hipEventDisableTiming));
+            CHK(hipMalloc(&L.d_cen, sizeof(float) * 8));
+            CHK(hipHostMalloc((void**)&L.h_cen, sizeof(float) * 8, hipHostMallocMapped));
+            CHK(hipHostGetDevicePointer((void**)&L.hd_cen, L.h_cen, 0));
+            CHK(hipHostMalloc((void**)&L.h_sums, sizeof(double) * 16, hipHostMallocMapped));
+            CHK(hipHostGetDevicePointer((void**)&L.hd_sums, L.h_sums, 0));
+        }
+    }
 #undef CHK
     if (c->profile) {
         c->profile = false;
@@ -840,17 +886,24 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
     for (auto& e : c->ev_stop) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_sel_start) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_sel_stop) if (e) (void)hipEventDestroy(e);
-    (void)hipFree(c->d_src); (void)hipFree(c->d_work); (void)hipFree(c->d_tgt); (void)hipFree(c->d_lut); (void)hipFree(c->d_lut_zp);
-    (void)hipFree(c->d_partials); (void)hipFree(c->d_min_bits); (void)hipFree(c->d_thr_bits); (void)hipFree(c->d_first_idx);
-    (void)hipFree(c->d_bp); (void)hipFree(c->d_bp2); (void)hipFree(c->d_bp3); (void)hipFree(c->d_cen); (void)hipFree(c->d_first_idx2);
-    if (c->icp_stream) { (void)hipStreamSynchronize(c->icp_stream); (void)hipStreamDestroy(c->icp_stream); }
-    if (c->icp_ev_w) (void)hipEventDestroy(c->icp_ev_w);
-    if (c->icp_ev_b) (void)hipEventDestroy(c->icp_ev_b);
-    if (c->h_cen) (void)hipHostFree(c->h_cen);
+    (void)hipFree(c->d_src); (void)hipFree(c->d_tgt); (void)hipFree(c->d_lut); (void)hipFree(c->d_lut_zp);
+    (void)hipFree(c->d_partials);
+    for (auto& L : c->lanes) {
+        if (L.stream && L.stream != c->stream) { (void)hipStreamSynchronize(L.stream); (void)hipStreamDestroy(L.stream); }
+        if (L.icp_stream) { (void)hipStreamSynchronize(L.icp_stream); (void)hipStreamDestroy(L.icp_stream); }
+        if (L.icp_ev_w) (void)hipEventDestroy(L.icp_ev_w);
+        if (L.icp_ev_b) (void)hipEventDestroy(L.icp_ev_b);
+        (void)hipFree(L.d_work); (void)hipFree(L.d_min_bits); (void)hipFree(L.d_thr_bits); (void)hipFree(L.d_first_idx); (void)hipFree(L.d_first_idx2);
+        (void)hipFree(L.d_bp); (void)hipFree(L.d_bp2); (void)hipFree(L.d_bp3); (void)hipFree(L.d_cen);
+        (void)hipFree(L.d_d2); (void)hipFree(L.d_nn_lb); (void)hipFree(L.d_nn_ub); (void)hipFree(L.d_nn_lb2); (void)hipFree(L.d_nn_ub2);
+        (void)hipFree(L.d_sel); (void)hipFree(L.d_eq); (void)hipFree(L.d_use); (void)hipFree(L.d_sel_wide); (void)hipFree(L.d_sel_wide2);
+        if (L.h_cen) (void)hipHostFree(L.h_cen);
+        if (L.h_sums) (void)hipHostFree(L.h_sums);
+        if (L.h_trim) (void)hipHostFree(L.h_trim);
+    }
     bvh_free(&c->bvh_tgt);
     (void)hipFree(c->d_chunk_cen);
-    (void)hipFree(c->d_d2); (void)hipFree(c->d_sel); (void)hipFree(c->d_eq); (void)hipFree(c->d_use); (void)hipFree(c->d_orig_of_slot); (void)hipFree(c->d_nn_lb); (void)hipFree(c->d_nn_ub); (void)hipFree(c->d_nn_lb2); (void)hipFree(c->d_nn_ub2); (void)hipFree(c->d_sel_wide); (void)hipFree(c->d_sel_wide2);
-    if (c->h_trim) (void)hipHostFree(c->h_trim);
+    (void)hipFree(c->d_orig_of_slot);
     for (int k = 0; k < 2; ++k) {
         fgoicp_ctx::TickSlot& sl = c->slots[k];
         if (sl.done) (void)hipEventDestroy(sl.done);
@@ -869,7 +922,6 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
     }
     if (c->h_lb) (void)hipHostFree(c->h_lb);
     if (c->h_ub) (void)hipHostFree(c->h_ub);
-    if (c->h_sums) (void)hipHostFree(c->h_sums);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -998,6 +1050,13 @@ int fgoicp_icp(fgoicp_ctx* c, const float* R0, const float* t0, size_t max_iter,
     return ctx_icp(c, R0, t0, max_iter, thr, sse_out, R_out9, t_out3, iters_out);
 }
 
+int fgoicp_icp_batch(fgoicp_ctx* c, int n, const float* R0s_9, const float* t0s_3, size_t max_iter, float thr, float* sse_out, float* R_out9s, float* t_out3s,
+                     int* iters_out) {
+    if (!c || n < 0 || (n > 0 && (!R0s_9 || !t0s_3 || !sse_out || !R_out9s || !t_out3s))) return FGOICP_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    return ctx_icp_batch(c, n, R0s_9, t0s_3, max_iter, thr, sse_out, R_out9s, t_out3s, iters_out);
+}
+
 int fgoicp_procrustes(fgoicp_ctx* c, const float* working_xyz, float* R_out9, float* t_out3, float* centroids6, float* ABt9, int* corr_idx) {
     if (!c || !working_xyz || !R_out9 || !t_out3) return FGOICP_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(c->device));
@@ -1006,17 +1065,17 @@ int fgoicp_procrustes(fgoicp_ctx* c, const float* working_xyz, float* R_out9, fl
         const float* p = working_xyz + 3 * (size_t)c->perm[i];
         h[i] = make_float4(p[0], p[1], p[2], 0.f);
     }
-    HIPCHK(hipMemcpy(c->d_work, h.data(), sizeof(float4) * c->ns, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->lanes[0].d_work, h.data(), sizeof(float4) * c->ns, hipMemcpyHostToDevice));
     Mat3f R, ABt;
     Vec3f t;
-    int rc = ctx_procrustes_device(c, &R, &t, centroids6, &ABt, false);
+    int rc = ctx_procrustes_device(c, c->lanes[0], &R, &t, centroids6, &ABt, false);
     if (rc) return rc;
     std::memcpy(R_out9, R.m, sizeof(R.m));
     t_out3[0] = t.x; t_out3[1] = t.y; t_out3[2] = t.z;
     if (ABt9) std::memcpy(ABt9, ABt.m, sizeof(ABt.m));
     if (corr_idx) {
         std::vector<uint32_t> idx(c->ns);
-        HIPCHK(hipMemcpy(idx.data(), c->d_first_idx, sizeof(uint32_t) * c->ns, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(idx.data(), c->lanes[0].d_first_idx, sizeof(uint32_t) * c->ns, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < c->ns; ++i) corr_idx[c->perm[i]] = (int)idx[i];
     }
     return FGOICP_OK;

@@ -19,7 +19,6 @@ struct fgoicp_ctx {
 
     // HBM-resident state
     float4* d_src = nullptr;     // ns  x {x,y,z,|p|^2}, Morton order (pristine source, registration.hpp:63)
-    float4* d_work = nullptr;    // ns  x {x,y,z,-}: ICP working copy (icp3d.hpp:24)
     float4* d_tgt = nullptr;     // nt  x {x,y,z,0}, caller order (registration.hpp:61)
     float* d_lut = nullptr;      // (dx+2)(dy+2)(dz+2) floats, x fastest, replicated border
     int lut_layout = 1;          // 1: d_lut_zp is the z-paired copy (float2), 2: it is the yz-quad copy (float4)
@@ -82,23 +81,29 @@ struct fgoicp_ctx {
     bool trim_ready = false;                 // trimmed-mode buffers allocated
     bool trim_skip = true;                   // exact NN only for queries that can be among the k smallest (nn_prep_kernel)
     float bounds6[6] = {0, 0, 0, 0, 0, 0};   // the target's bounding box as passed to fgoicp_ctx_create
-    float* d_d2 = nullptr;                   // squared correspondence distances
-    float *d_nn_lb = nullptr, *d_nn_ub = nullptr, *d_nn_lb2 = nullptr, *d_nn_ub2 = nullptr;  // LUT brackets of the nearest distance (SSE pass / correspondence pass)
-    uint32_t *d_sel = nullptr, *d_eq = nullptr, *d_orig_of_slot = nullptr, *d_sel_wide = nullptr, *d_sel_wide2 = nullptr;
-    unsigned char* d_use = nullptr;          // inlier mask of the current Procrustes step
-    float *h_trim = nullptr, *hd_trim = nullptr;   // pinned trimmed SSE
+    uint32_t* d_orig_of_slot = nullptr;      // caller index of every device slot (ties at the inlier cut)
 
-    // exact-NN / ICP scratch
-    uint32_t *d_min_bits = nullptr, *d_thr_bits = nullptr, *d_first_idx = nullptr, *d_first_idx2 = nullptr;
-    double* d_bp = nullptr;      // per-block partial sums
-    double *h_sums = nullptr, *hd_sums = nullptr;  // pinned result of the last reduction (<= 16 doubles)
-    double* d_bp2 = nullptr;     // second partial buffer (covariance), so both reductions of a Procrustes step queue back to back
-    double* d_bp3 = nullptr;     // third one: the exact SSE runs next to the Procrustes pass of the following ICP iteration
-    hipStream_t icp_stream = nullptr;        // side stream of the ICP loop (correspondence + covariance pass)
-    hipEvent_t icp_ev_w = nullptr, icp_ev_b = nullptr;  // working cloud transformed / side-stream pass finished
+    // exact-NN / ICP scratch, one set per lane: ICP runs on different lanes may be in flight together (ctx_icp_batch).  Lane 0 is
+    // the lane of fgoicp_sse / fgoicp_icp / fgoicp_procrustes and queues on the context's main stream.
+    struct IcpLane {
+        hipStream_t stream = nullptr;            // main stream of the lane (SSE pass, working-cloud transforms)
+        hipStream_t icp_stream = nullptr;        // side stream (correspondence + covariance pass of the NEXT iteration)
+        hipEvent_t icp_ev_w = nullptr, icp_ev_b = nullptr;  // working cloud transformed / side-stream pass finished
+        float4* d_work = nullptr;                // ns x {x,y,z,-}: ICP working copy (icp3d.hpp:24)
+        uint32_t *d_min_bits = nullptr, *d_thr_bits = nullptr, *d_first_idx = nullptr, *d_first_idx2 = nullptr;
+        double *d_bp = nullptr, *d_bp2 = nullptr, *d_bp3 = nullptr;   // per-block partial sums (sums / covariance / SSE)
+        double *h_sums = nullptr, *hd_sums = nullptr;                 // pinned result of the last reduction (<= 16 doubles)
+        float* d_cen = nullptr;                  // centroids {src, corr} on the device
+        float *h_cen = nullptr, *hd_cen = nullptr;  // ... and their pinned host copy
+        // trimmed mode
+        float* d_d2 = nullptr;                   // squared correspondence distances
+        float *d_nn_lb = nullptr, *d_nn_ub = nullptr, *d_nn_lb2 = nullptr, *d_nn_ub2 = nullptr;  // LUT brackets of the nearest distance (SSE pass / correspondence pass)
+        uint32_t *d_sel = nullptr, *d_eq = nullptr, *d_sel_wide = nullptr, *d_sel_wide2 = nullptr;
+        unsigned char* d_use = nullptr;          // inlier mask of the current Procrustes step
+        float *h_trim = nullptr, *hd_trim = nullptr;   // pinned trimmed SSE
+    };
+    std::vector<IcpLane> lanes;
     bool icp_overlap = true;
-    float* d_cen = nullptr;      // centroids {src, corr} on the device
-    float *h_cen = nullptr, *hd_cen = nullptr;  // ... and their pinned host copy
 
     // HIP-event profile of the bounds kernel
     std::vector<hipEvent_t> ev_start, ev_stop, ev_sel_start, ev_sel_stop;   // bounds kernel / trimmed selection kernel of the same window
@@ -120,4 +125,6 @@ int ctx_set_inliers(fgoicp_ctx* c, size_t k);
 int ctx_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out, const uint32_t* seed_idx = nullptr);
 int ctx_icp(fgoicp_ctx* c, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3,
             int* iters_out);
+int ctx_icp_batch(fgoicp_ctx* c, int n, const float* R0s, const float* t0s, size_t max_iter, float thr, float* sse_out, float* R_out9s, float* t_out3s,
+                  int* iters_out);
 }  // namespace fgoicp

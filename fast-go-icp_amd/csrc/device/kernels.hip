@@ -504,8 +504,15 @@ __global__ __launch_bounds__(THREADS * WPG) void bounds_sorted_kernel(const floa
                 p[k] = src[i < ns ? i : ns - 1];
             }
             float rx, ry, rz;
+#if defined(FGOICP_ABLATE) && (FGOICP_ABLATE & 1)   // timing-only build (tools/ablate.sh): what the per-evaluation rotation costs
+            rx = p[k].x; ry = p[k].y; rz = p[k].z;
+#else
             rotate(gr.R, p[k].x, p[k].y, p[k].z, rx, ry, rz);
+#endif
             ta[k] = lut_address(g, rx + sb.tx, ry + sb.ty, rz + sb.tz);  // :34, :323-325
+#if defined(FGOICP_ABLATE) && (FGOICP_ABLATE & 4)   // timing-only build: every gather hits a 64 KiB corner of the LUT (address unit + VALU, no misses)
+            ta[k].o &= (size_t)4095;
+#endif
         }
         QuadPairLoads qp[ZPAIR == 3 ? P : 1];
         const int odd = (int)tix & 1;

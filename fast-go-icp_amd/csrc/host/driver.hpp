@@ -441,6 +441,10 @@ private:
                     mine.epoch = epoch;
                     batch.push_back(&mine);
                     if (mode >= 2 && width > 1) {  // the nodes the reference pops next if nothing changes: the tops of the queue
+                        // A COPY of the queue is popped, on purpose: popping the real queue and pushing the nodes back would re-seat nodes
+                        // with equal (lb, span) — unevaluated children inherit their parent's bounds, so such ties are common — and change
+                        // the order in which the reference's heap pops them.  The copy is one memcpy of the heap's vector per cache miss
+                        // (a miss every `width` pops; 1e5 nodes = 7.6 MB, ~1 ms), not a per-pop cost.
                         std::priority_queue<RotCube> peek = rcand;
                         while ((int)batch.size() < width && !peek.empty()) {
                             const RotCube n = peek.top();
@@ -555,7 +559,11 @@ private:
             if (rc) return rc;
             const double s_tasks = seconds_since(t_round), icp_before = stats_.seconds_icp;
 
-            // ICP triggers in child order against the running local best (fgoicp.cpp:74-88)
+            // ICP triggers in child order against the running local best (fgoicp.cpp:74-88), one run after another: a successful run
+            // tightens the trigger of the next child, and after the first success most children no longer qualify.  (Refining every
+            // child that COULD trigger in one concurrent batch — fgoicp_icp_batch — and replaying the rule over the results was
+            // measured and lost: the default-threshold bunny step 38.1 -> 40.5 ms, ICP 17.5 -> 24.3 ms; the batch runs the
+            // candidates the rule would have skipped, and its length is that of its longest run.)
             float loc_sse; Mat3f loc_R; Vec3f loc_t;
             { std::lock_guard<std::mutex> g(mu_); loc_sse = best_sse_; loc_R = best_R_; loc_t = best_t_; }
             for (size_t k = 0; k < mine.size(); ++k) {

@@ -167,6 +167,17 @@ class Registration:
         return {"kernel_ms": ms.value, "launches": launches.value, "subcubes": sub.value, "evaluations": ev.value, "select_ms": sel.value}
 
 
+def icp_batch(reg, Rs, ts, max_iter=100, convergence_threshold=0.005):
+    """n IterativeClosestPoint3D runs at once (fgoicp_icp_batch): -> (sse (n,), R (n,3,3), t (n,3), iterations (n,))"""
+    n = len(Rs)
+    R0 = np.concatenate([to_glm(R) for R in Rs]).astype(np.float32) if n else np.zeros(0, np.float32)
+    t0 = np.ascontiguousarray(np.asarray(ts, np.float32).reshape(-1))
+    sse = np.empty(n, np.float32); Ro = np.empty(9 * n, np.float32); to = np.empty(3 * n, np.float32); it = np.empty(n, np.int32)
+    _lib.check(reg._lib.fgoicp_icp_batch(reg._h, n, _fp(R0), _fp(t0), int(max_iter), float(convergence_threshold), _fp(sse), _fp(Ro), _fp(to),
+                                         it.ctypes.data_as(_lib.c_int_p)), "fgoicp_icp_batch")
+    return sse, np.stack([from_glm(Ro[9 * i:9 * i + 9]) for i in range(n)]) if n else np.zeros((0, 3, 3), np.float32), to.reshape(n, 3), it
+
+
 class IterativeClosestPoint3D:
     """icp::IterativeClosestPoint3D (fgoicp/icp3d.hpp:9-41): ctor arguments as the reference's
     (the clouds live in `reg`), run() -> (sse, R, t)."""

@@ -120,6 +120,11 @@ int fgoicp_sse(fgoicp_ctx* ctx, const float* R9, const float* t3, float* sse_out
  * plus the number of loop iterations executed. */
 int fgoicp_icp(fgoicp_ctx* ctx, const float* R0_9, const float* t0_3, size_t max_iter, float conv_thr, float* sse_out,
                float* R_out9, float* t_out3, int* iters_out);
+/* n IterativeClosestPoint3D objects (fgoicp.cpp:76-77 creates and runs one per promising rotation cube) run at once.  Run i starts from R0s_9[9i..], t0s_3[3i..] and is exactly the run
+ * fgoicp_icp would do; runs share the device through per-run scratch and streams (an ICP iteration is a chain of small
+ * kernels: below ~100k points one run fills a fraction of the device). */
+int fgoicp_icp_batch(fgoicp_ctx* ctx, int n, const float* R0s_9, const float* t0s_3, size_t max_iter, float conv_thr, float* sse_out,
+                     float* R_out9s, float* t_out3s, int* iters_out);
 /* One IterativeClosestPoint3D::procrustes() step (icp3d.cu:140-172) on an explicit working cloud
  * (ns x xyz, caller order).  Test hook: optional outputs may be NULL.  In trimmed mode corr_idx is 0x7fffffff for points
  * that provably lie outside the inlier set (they take no part in the step and their exact neighbour is not searched). */

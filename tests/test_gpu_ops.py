@@ -515,3 +515,26 @@ def test_submit_collect_two_slots_equal_synchronous_call(fg, tiny_case, gpu_requ
         for g, (lbr, ubr) in enumerate(ref):
             assert np.array_equal(lb[offs[g]:offs[g + 1]], lbr) and np.array_equal(ub[offs[g]:offs[g + 1]], ubr)
     reg.close()
+
+
+@pytest.mark.parametrize("trim", [0.0, 0.25])
+def test_icp_batch_equals_single_runs(fg, gpu_required, trim):
+    """fgoicp_icp_batch: several ICP runs share the device on their own lanes (scratch, streams, host thread); every run is bit
+    for bit the run fgoicp_icp does alone — more runs than lanes, trimmed and untrimmed."""
+    tgt, src, R_gt, t_gt = fg.synth.workload("small", angle_deg=40.0)
+    pct, pcs, *_, bounds = fg.synth.preprocess(tgt, src)
+    reg = fg.Registration(pct, pcs, bounds, 0.02)
+    if trim:
+        reg.set_inliers(int(len(pcs) * (1 - trim)))
+    rng = np.random.default_rng(4)
+    Rs = [fg.synth.random_rotation(rng, 50.0).astype(np.float32) for _ in range(7)]
+    ts = rng.uniform(-0.2, 0.2, (7, 3)).astype(np.float32)
+    sse, Ro, to, it = fg.icp_batch(reg, Rs, ts, 100, 0.005)
+    for i in range(7):
+        icp = fg.IterativeClosestPoint3D(reg, None, None, 100, 0.005, Rs[i], ts[i])
+        e, R, t = icp.run()
+        assert e.view(np.uint32) == sse[i].view(np.uint32) and np.array_equal(R, Ro[i]) and np.array_equal(t, to[i]) and icp.iterations == it[i]
+    assert len(set(it.tolist())) > 1  # runs of different length were in flight together
+    e0, *_ = fg.icp_batch(reg, [], np.zeros((0, 3), np.float32))
+    assert e0.size == 0
+    reg.close()
