@@ -710,8 +710,13 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
         const double face_voxels = (double)g.dx * g.dy + (double)g.dy * g.dz + (double)g.dx * g.dz;
         int layout = ((double)ns / face_voxels < 0.5 && total * sizeof(float4) <= ((size_t)16 << 30)) ? 2 : 1;
         if (const char* e = std::getenv("FGOICP_LUT_ZPAIR")) layout = std::atoi(e);  // tuning knob
+        if (layout == 3 && (g.px > 1023 || g.py > 1023 || g.pz > 1023 || c->inliers)) layout = 2;  // the bricked copy packs indices in 10 bits
         c->lut_layout = layout;
-        if (layout == 2) {
+        if (layout == 3) {
+            const size_t bricks = (size_t)((g.px + 3) / 4) * ((g.py + 3) / 4) * ((g.pz + 3) / 4);
+            CHK(hipMalloc(&c->d_lut_zp, bricks * 64 * sizeof(float4)));
+            launch_lut_quad_bricked(c->d_lut, g, reinterpret_cast<float4*>(c->d_lut_zp), c->stream);
+        } else if (layout == 2) {
             CHK(hipMalloc(&c->d_lut_zp, total * sizeof(float4)));
             launch_lut_quad(c->d_lut, g, reinterpret_cast<float4*>(c->d_lut_zp), c->stream);
         } else if (layout == 1) {

@@ -111,6 +111,7 @@ __device__ __forceinline__ float lerp(float p, float q, float w) { return fma_(w
 struct TexAddr {
     size_t o;         // element offset of the first texel (x0, y0, z0) in the padded LUT
     float a, b, c;    // interpolation weights
+    unsigned pk;      // the same texel as packed padded indices x | y << 10 | z << 20 (bricked layout; dims <= 1023)
 };
 __device__ __forceinline__ TexAddr lut_address(const LutGeom& g, float qx, float qy, float qz) {
     const float x = (qx + g.off_x) * g.scale;
@@ -122,6 +123,7 @@ __device__ __forceinline__ TexAddr lut_address(const LutGeom& g, float qx, float
     tex_axis(y, g.dy, g.quantize, iy, t.b);
     tex_axis(z, g.dz, g.quantize, iz, t.c);
     t.o = ((size_t)iz * g.py + iy) * (size_t)g.px + ix;
+    t.pk = (unsigned)ix | ((unsigned)iy << 10) | ((unsigned)iz << 20);
     return t;
 }
 __device__ __forceinline__ float lut_blend(const TexAddr& t, float2u v00, float2u v10, float2u v01, float2u v11) {
@@ -191,6 +193,32 @@ __device__ __forceinline__ void quad_pair_finish(const QuadPairLoads& q, int odd
     v10 = float2u{a.z, b.z};
     v11 = float2u{a.w, b.w};
 }
+// Bricked yz-quad copy (experimental, FGOICP_LUT_ZPAIR=3): the quads of a 4 x 4 x 4 block of nodes are contiguous (1 KiB) and
+// Morton-ordered inside it, so a 128-byte line holds a 2 x 2 x 2 block of quads instead of a run of 8 along x: a surface patch of
+// any orientation then uses ~4 of the 8 quads of a line it touches, an x-run ~3 on average (1 + ln 8).
+__device__ __forceinline__ unsigned spread2(unsigned v) { return (v & 1u) | ((v & 2u) << 2); }
+__device__ __forceinline__ size_t brick_index(unsigned x, unsigned y, unsigned z, unsigned nbx, unsigned nby) {
+    const size_t b = ((size_t)(z >> 2) * nby + (y >> 2)) * nbx + (x >> 2);
+    return b * 64 + (spread2(x & 3u) | (spread2(y & 3u) << 1) | (spread2(z & 3u) << 2));
+}
+__device__ __forceinline__ QuadPairLoads quad_pair_issue_bricked(const float4* __restrict__ qd, const TexAddr& t, int odd, unsigned nbx, unsigned nby) {
+    const int own = (int)t.pk, other = swap_lane_pair(own);
+    const unsigned p_even = (unsigned)(odd ? other : own), p_odd = (unsigned)(odd ? own : other);
+    QuadPairLoads q;
+    q.r1 = *(const float4a*)(qd + brick_index((p_even & 1023u) + odd, (p_even >> 10) & 1023u, p_even >> 20, nbx, nby));
+    q.r2 = *(const float4a*)(qd + brick_index((p_odd & 1023u) + odd, (p_odd >> 10) & 1023u, p_odd >> 20, nbx, nby));
+    return q;
+}
+__global__ __launch_bounds__(kBlock) void lut_quad_bricked_kernel(const float* __restrict__ lut, LutGeom g, float4* __restrict__ qd) {
+    const unsigned nbx = (unsigned)(g.px + 3) >> 2, nby = (unsigned)(g.py + 3) >> 2;
+    const size_t total = (size_t)g.px * g.py * g.pz, sy = (size_t)g.px, sz = (size_t)g.px * g.py;
+    for (size_t n = (size_t)blockIdx.x * kBlock + threadIdx.x; n < total; n += (size_t)gridDim.x * kBlock) {
+        const unsigned x = (unsigned)(n % g.px), y = (unsigned)((n / g.px) % g.py), z = (unsigned)(n / sz);
+        const size_t nz = n + sz < total ? n + sz : n, ny = n + sy < total ? n + sy : n, nyz = n + sy + sz < total ? n + sy + sz : n;
+        qd[brick_index(x, y, z, nbx, nby)] = make_float4(lut[n], lut[nz], lut[ny], lut[nyz]);
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void lut_quad_kernel(const float* __restrict__ lut, LutGeom g, float4* __restrict__ qd) {
     const size_t total = (size_t)g.px * g.py * g.pz, sy = (size_t)g.px, sz = (size_t)g.px * g.py;
     for (size_t n = (size_t)blockIdx.x * kBlock + threadIdx.x; n < total; n += (size_t)gridDim.x * kBlock) {
@@ -514,17 +542,20 @@ __global__ __launch_bounds__(THREADS * WPG) void bounds_sorted_kernel(const floa
             ta[k].o &= (size_t)4095;
 #endif
         }
-        QuadPairLoads qp[ZPAIR == 3 ? P : 1];
+        QuadPairLoads qp[(ZPAIR == 3 || ZPAIR == 4) ? P : 1];
         const int odd = (int)tix & 1;
-        if (ZPAIR == 3) {
+        if (ZPAIR == 3 || ZPAIR == 4) {
+            const unsigned nbx = (unsigned)(g.px + 3) >> 2, nby = (unsigned)(g.py + 3) >> 2;
 #pragma unroll
-            for (int k = 0; k < P; ++k) qp[k] = quad_pair_issue(reinterpret_cast<const float4*>(zp), ta[k], odd);
+            for (int k = 0; k < P; ++k)
+                qp[k] = ZPAIR == 4 ? quad_pair_issue_bricked(reinterpret_cast<const float4*>(zp), ta[k], odd, nbx, nby)
+                                   : quad_pair_issue(reinterpret_cast<const float4*>(zp), ta[k], odd);
 #pragma unroll
             for (int k = 0; k < P; ++k) quad_pair_finish(qp[k], odd, v00[k], v10[k], v01[k], v11[k]);
         }
 #pragma unroll
         for (int k = 0; k < P; ++k) {
-            if (ZPAIR == 3) {
+            if (ZPAIR == 3 || ZPAIR == 4) {
             } else if (ZPAIR == 2) {
                 quad_gather(reinterpret_cast<const float4*>(zp), ta[k], v00[k], v10[k], v01[k], v11[k]);
             } else if (ZPAIR == 1) {
@@ -1768,6 +1799,8 @@ void launch_bounds_sorted(const float4* src, int ns, const float* lut, const flo
         if (trim_variant == 2) {
             if (zp && layout == 2) FGOICP_LAUNCH_SORTED(64, 4, 3, 1); else if (zp) FGOICP_LAUNCH_SORTED(64, 4, 1, 1); else FGOICP_LAUNCH_SORTED(64, 4, 0, 1);
         } else if (zp && layout == 2) FGOICP_LAUNCH_SORTED(128, 2, 2, 1); else if (zp) FGOICP_LAUNCH_SORTED(128, 2, 1, 1); else FGOICP_LAUNCH_SORTED(128, 2, 0, 1);
+    } else if (zp && layout == 3) {
+        FGOICP_LAUNCH_SORTED(64, 4, 4, 0);
     } else if (zp && layout == 2) {
         static const int paired = [] { const char* e = std::getenv("FGOICP_QUAD_PAIRED"); return e ? std::atoi(e) : 1; }();  // tuning knob (1 = default)
         if (variant == 2 && paired) FGOICP_LAUNCH_SORTED(64, 4, 3, 0); else
@@ -1793,6 +1826,10 @@ void launch_lut_build(const float4* tgt_shifted, int nt, const LutGeom& g, float
     const size_t per_block = (size_t)kBlock * kLutNodes;
     const unsigned blocks = (unsigned)((total + per_block - 1) / per_block);
     hipLaunchKernelGGL(lut_build_kernel, dim3(blocks), dim3(kBlock), 0, s, tgt_shifted, nt, g, lut_padded);
+}
+
+void launch_lut_quad_bricked(const float* lut_padded, const LutGeom& g, float4* qd, hipStream_t s) {
+    hipLaunchKernelGGL(lut_quad_bricked_kernel, dim3(8192), dim3(kBlock), 0, s, lut_padded, g, qd);
 }
 
 void launch_lut_quad(const float* lut_padded, const LutGeom& g, float4* qd, hipStream_t s) {

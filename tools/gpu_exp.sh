@@ -1,12 +1,15 @@
 # scratch script for ad-hoc GPU experiments (edited per experiment; see tools/gpu_profile.sh for the round profile)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests -m gpu -x -q --durations=6 2>&1 | tail -14
-timeout -k 10 300 python bench.py --only default_threshold 2>/dev/null | python3 -c "
+for rep in 1 2; do
+for Z in 2 3; do
+echo "layout $Z: $(FGOICP_LUT_ZPAIR=$Z timeout -k 10 300 python tools/op_bench.py bunny 1024 5 2>/dev/null)"
+done; done
+for Z in 2 3; do
+FGOICP_LUT_ZPAIR=$Z timeout -k 10 200 python bench.py --only headline --steps 3 --warmup 1 2>/dev/null | python3 -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{\"metric\"'):
-        d=json.loads(l); r=d['reference_default_threshold']; print({k:r[k] for k in ('wall_clock_to_optimum_s','seconds_icp_rank0','icp_runs_rank0','subcubes_per_step','best_sse')})
+        d=json.loads(l); r=d['roofline']; print('layout $Z headline value %.4g kernel GB/s %.0f avg_launch_us %.1f best_sse %r' % (d['value'], r['achieved'], r['avg_launch_us'], d['result']['best_sse']))
 "
-for W in 8; do timeout -k 10 300 python tools/scale_replay.py $W bunny 5e-5 0.005 2 2>/dev/null | cut -c1-700; done
-timeout -k 10 400 python tools/scale_replay.py 8 dragon 5e-6 0.005 1 2>/dev/null | cut -c1-700
+done
