@@ -35,7 +35,7 @@ work is fixed, so "scaling" is "strong".
 
 "roofline" (one object per workload): HIP events around every launch of the bounds kernel on the stream
 it runs on (fgoicp_ctx_profile).  `achieved` = algorithmic bytes of the EVALUATIONS the launches did
-(ns * (32 + 12/32) B each; a twin pair is two subcubes and one evaluation) / the launches'
+(ns * (32 + 12/32) B each; a node both tasks of a rotation cube need is two subcubes and one evaluation) / the launches'
 duration; `traffic` = HBM bytes per launch from separate rocprofv3 --pmc passes of `--only LEG`
 (profiles/bench_pmc.json, see tools/gpu_profile.sh); `hbm_actual_GBps` = traffic / duration."""
 import argparse
@@ -181,16 +181,16 @@ def roofline(leg, pmc, extra=None):
         return None
     ub = unit_bytes(ns)
     ach = p["evaluations"] * ub / (kms * 1e-3) / 1e9
-    served = p["subcubes"] * ub / (kms * 1e-3) / 1e9
+    served = leg["subcubes_rank"] * ub / (kms * 1e-3) / 1e9  # subcubes the tasks consumed (`count`, fgoicp.cpp:132) — twins and memo hits included
     r = {"bound": "hbm", "kernel": "bounds_sorted_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
          "traffic": None, "frac_of_measured_copy_rate": ach / HBM_COPY_GBS,
          "avg_launch_us": kms * 1e3 / launches, "launches": int(launches), "evaluations_per_launch": p["evaluations"] / launches,
-         "subcubes_per_launch": p["subcubes"] / launches, "algorithmic_bytes_per_evaluation": ub,
+         "subcubes_per_launch": leg["subcubes_rank"] / launches, "output_rows_per_launch": p["subcubes"] / launches, "algorithmic_bytes_per_evaluation": ub,
          "algorithmic_bytes_per_launch": p["evaluations"] * ub / launches,
          "achieved_per_subcube_served": served, "frac_per_subcube_served": served / HBM_PEAK_GBS,
-         "every_counted_subcube_profiled": bool(p["subcubes"] == leg["subcubes_rank"]),
          "note": "achieved = algorithmic bytes of the EVALUATIONS (SURVEY 8d unit x evaluations per launch) / launch duration, HIP events on the kernel's own stream; a "
-                 "translation node held by both the UB and the LB task of a rotation cube in one tick is two subcubes served by one evaluation (achieved_per_subcube_served)"}
+                 "translation node that both the UB and the LB task of a rotation cube need is evaluated once for both (same tick: twin; later: the LB task takes it from "
+                 "its memo) — two subcubes served by one evaluation (achieved_per_subcube_served); output rows include the memo's look-ahead rows"}
     if pmc:
         r["traffic"] = pmc.get("hbm_bytes_per_launch")
         r["traffic_source"] = pmc.get("source")

@@ -5,6 +5,7 @@
 //     int    Ops::bounds_multi(G, R9, rot_span, fix_rot, offsets, tnodes4, lb, ub)   (fgoicp_bounds_multi)
 //     int    Ops::bounds_submit(slot, G, ...tnodes4, twin) / bounds_collect(slot, lb, ub)  (fgoicp_bounds_submit_twins / _collect)
 //     bool   Ops::async()                                                            two slots available?
+//     bool   Ops::twins()                                                            does bounds_submit evaluate a twin pair once? (then the memo is free)
 //     int    Ops::icp(R0, t0, max_iter, thr, &sse, R9, t3, &iters)                   (fgoicp_icp)
 //
 // The product instantiates it with the HIP context only (solver.cpp).  tests/ instantiate it with
@@ -187,8 +188,60 @@ struct InnerTask {
     }
 };
 
+using NodeKey = std::array<uint32_t, 4>;  // bit pattern of a translation node {t.x, t.y, t.z, span}
+inline NodeKey node_key(const TransCube& c) {
+    NodeKey k;
+    std::memcpy(k.data(), &c.t.x, 12);
+    std::memcpy(&k[3], &c.span, 4);
+    return k;
+}
+struct NodeKeyHash {
+    size_t operator()(const NodeKey& b) const {
+        uint32_t x = b[0] * 0x9E3779B1u ^ b[1] * 0x85EBCA77u ^ b[2] * 0xC2B2AE3Du ^ b[3] * 0x27D4EB2Fu;
+        return x ^ (x >> 15);
+    }
+};
+
+// Flat open-addressing table NodeKey -> {lb, ub} (a task's memo holds ~100 entries; no allocation per insert).
+class NodeMemo {
+public:
+    bool empty() const { return n_ == 0; }
+    const std::pair<float, float>* find(const NodeKey& k) const {
+        if (n_ == 0) return nullptr;
+        for (size_t i = NodeKeyHash()(k) & mask_;; i = (i + 1) & mask_) {
+            if (!used_[i]) return nullptr;
+            if (keys_[i] == k) return &vals_[i];
+        }
+    }
+    void insert(const NodeKey& k, float lb, float ub) {
+        if ((n_ + 1) * 2 > keys_.size()) grow();
+        size_t i = NodeKeyHash()(k) & mask_;
+        while (used_[i]) { if (keys_[i] == k) return; i = (i + 1) & mask_; }
+        used_[i] = 1; keys_[i] = k; vals_[i] = {lb, ub}; ++n_;
+    }
+    void clear() { keys_.clear(); vals_.clear(); used_.clear(); n_ = 0; mask_ = 0; }
+private:
+    void grow() {
+        std::vector<NodeKey> ok; std::vector<std::pair<float, float>> ov; std::vector<char> ou;
+        ok.swap(keys_); ov.swap(vals_); ou.swap(used_);
+        const size_t cap = ok.empty() ? 64 : ok.size() * 2;
+        keys_.resize(cap); vals_.resize(cap); used_.assign(cap, 0); mask_ = cap - 1; n_ = 0;
+        for (size_t i = 0; i < ok.size(); ++i) if (ou[i]) insert(ok[i], ov[i].first, ov[i].second);
+    }
+    std::vector<NodeKey> keys_;
+    std::vector<std::pair<float, float>> vals_;
+    std::vector<char> used_;
+    size_t n_ = 0, mask_ = 0;
+};
+
 struct Task : InnerTask {
-    std::vector<std::array<uint32_t, 4>> seen;  // FGOICP_OVERLAP_STATS only: every node this task had evaluated
+    std::vector<NodeKey> seen;  // FGOICP_OVERLAP_STATS only: every node this task had evaluated
+    // --- memo of the twin task's evaluations (LB tasks, see prepare_half) ---
+    NodeMemo memo;                   // node -> {lb, ub} of THIS task's variant, computed when the UB twin evaluated the node
+    std::vector<float> blb, bub;     // bounds of the current batch, batch order (memo hits filled in at pop time)
+    std::vector<int> brow;           // per batch node: its row inside the task's group of the submission, or -1 = served from the memo
+    int nrows = 0;                   // rows of the group that belong to the batch
+    std::vector<TransCube> phantom;  // rows after them: nodes of the twin's batch evaluated for the memo
     bool done = false;
     bool has_batch = false;
     uint64_t batches = 0;  // operator calls this task took part in (= compute_sse_error calls of the reference for it)
@@ -643,31 +696,89 @@ private:
         std::vector<float> R9, spans, tn4, lb, ub;
         std::vector<int> fix, offsets;
         std::vector<int> twin;         // per subcube: the same translation node in the paired task's batch (or -1)
+        std::vector<std::vector<std::pair<int, int>>> pair_twins;  // per (UB, LB) pair: {row in the UB group, row in the LB group}
         bool inflight = false;
     };
 
-    // pops the next batch of every task of the half and packs them; false if none is left
-    bool prepare_half(Half& h, std::vector<Task*>& tasks, const std::vector<const RotCube*>& cubes, bool par) {
+    // Pops the next batch of every task of the half and packs them; false if none is left.
+    //
+    // The UB task and the LB task of one child (tasks 2c, 2c+1, neighbours in `live`) walk the same translation tree under the same
+    // rotation; 85 % of the UB task's nodes are also evaluated by the (five times larger) LB task.  Two savings, both leaving every
+    // task's own sequence of batches, bounds and counters untouched:
+    //   twins   a node both hold in THIS submission is evaluated once — one lookup per point, both variants of the bound formulae
+    //           (fgoicp_bounds_submit_twins);
+    //   memo    every other node of the UB batch is evaluated that way too: a "phantom" row in the LB task's group receives the LB
+    //           variant's sums and goes into the LB task's memo; when the LB task pops that node later it is served from the memo
+    //           (a batch served entirely is consumed on the spot, without a device round trip).  The sums depend on the node and the
+    //           rotation only, and the dual evaluation is bit-identical to a separate one, so the LB task cannot tell.
+    bool prepare_half(Half& h, std::vector<Task*>& tasks, const std::vector<const RotCube*>& cubes, bool par, bool twins_honoured) {
+        const bool memo_on = use_memo_ && use_twins_ && twins_honoured;  // phantom rows cost nothing only where the twin hint is used
         const std::function<void(size_t)> pop_fn = [&](size_t k) {
             Task& tk = *tasks[h.members[k]];
             tk.has_batch = false;
+            tk.phantom.clear();
             if (tk.done) return;
-            if (!tk.next_batch(sse_threshold_)) { tk.done = true; return; }
+            for (;;) {
+                if (!tk.next_batch(sse_threshold_)) { tk.done = true; return; }
+                tk.batches++;
+                if (overlap_stats_)
+                    for (const TransCube& c : tk.batch) tk.seen.push_back(node_key(c));
+                const size_t n = tk.batch.size();
+                tk.brow.resize(n); tk.blb.resize(n); tk.bub.resize(n);
+                tk.nrows = 0;
+                for (size_t q = 0; q < n; ++q) {
+                    if (!tk.memo.empty()) {
+                        if (const auto* hit = tk.memo.find(node_key(tk.batch[q]))) { tk.blb[q] = hit->first; tk.bub[q] = hit->second; tk.brow[q] = -1; continue; }
+                    }
+                    tk.brow[q] = tk.nrows++;
+                }
+                if (tk.nrows > 0) break;
+                tk.consume(tk.blb.data(), tk.bub.data());  // the whole batch came from the memo
+            }
             tk.has_batch = true;
-            tk.batches++;
-            if (overlap_stats_)
-                for (const TransCube& c : tk.batch) { std::array<uint32_t, 4> k; std::memcpy(k.data(), &c.t.x, 12); std::memcpy(&k[3], &c.span, 4); tk.seen.push_back(k); }
         };
         if (par) pool_->parallel_for(h.members.size(), pop_fn);
         else for (size_t k = 0; k < h.members.size(); ++k) pop_fn(k);
         h.live.clear();
-        h.offsets.assign(1, 0);
         h.members.erase(std::remove_if(h.members.begin(), h.members.end(), [&](size_t i) { return tasks[i]->done; }), h.members.end());
-        for (size_t i : h.members) {  // a member that is not done has a batch
-            h.live.push_back((int)i);
-            h.offsets.push_back(h.offsets.back() + (int)tasks[i]->batch.size());
-        }
-        const size_t G = h.live.size(), total = (size_t)h.offsets.back();
+        for (size_t i : h.members) h.live.push_back((int)i);  // a member that is not done has a batch
+        const size_t G = h.live.size();
+        // pairs: (UB task, LB task) of one child, neighbours in `live`.  Per pair: the twins (local rows) and the LB group's phantoms.
+        std::vector<size_t> pairs;
+        if (use_twins_)
+            for (size_t a = 0; a + 1 < G; ++a)
+                if ((h.live[a] ^ 1) == h.live[a + 1] && cubes[h.live[a]] == cubes[h.live[a + 1]] && tasks[h.live[a]]->fix_rot && !tasks[h.live[a + 1]]->fix_rot) pairs.push_back(a);
+        h.pair_twins.assign(pairs.size(), {});
+        const std::function<void(size_t)> match_fn = [&](size_t q) {
+            Task &ub = *tasks[h.live[pairs[q]]], &lb = *tasks[h.live[pairs[q] + 1]];
+            auto& tw = h.pair_twins[q];
+            const size_t n0 = ub.batch.size(), n1 = lb.batch.size();
+            if (n0 > 64 || n1 > 64) return;  // batches hold <= 32 nodes (fgoicp.cpp:122); the table below assumes it
+            int table[128];
+            for (int& x : table) x = -1;
+            for (size_t j = 0; j < n1; ++j) {
+                if (lb.brow[j] < 0) continue;
+                uint32_t sl = (uint32_t)NodeKeyHash()(node_key(lb.batch[j])) & 127u;
+                while (table[sl] >= 0) sl = (sl + 1) & 127u;
+                table[sl] = (int)j;
+            }
+            for (size_t i = 0; i < n0; ++i) {
+                const NodeKey ki = node_key(ub.batch[i]);
+                int hit = -1;
+                for (uint32_t sl = (uint32_t)NodeKeyHash()(ki) & 127u; table[sl] >= 0; sl = (sl + 1) & 127u)
+                    if (node_key(lb.batch[(size_t)table[sl]]) == ki) { hit = table[sl]; break; }
+                if (hit >= 0) tw.push_back({ub.brow[i], lb.brow[(size_t)hit]});
+                else if (memo_on && !lb.memo.find(ki)) {
+                    tw.push_back({ub.brow[i], lb.nrows + (int)lb.phantom.size()});
+                    lb.phantom.push_back(ub.batch[i]);
+                }
+            }
+        };
+        if (par && pairs.size() >= 64) pool_->parallel_for(pairs.size(), match_fn);
+        else for (size_t q = 0; q < pairs.size(); ++q) match_fn(q);
+        h.offsets.assign(1, 0);
+        for (size_t a = 0; a < G; ++a) h.offsets.push_back(h.offsets.back() + tasks[h.live[a]]->nrows + (int)tasks[h.live[a]]->phantom.size());
+        const size_t total = (size_t)h.offsets.back();
         h.R9.resize(9 * G); h.spans.resize(G); h.fix.resize(G); h.tn4.resize(4 * total);
         const std::function<void(size_t)> pack_fn = [&](size_t a) {  // groups are independent: packed in parallel
             const int i = h.live[a];
@@ -675,52 +786,24 @@ private:
             std::memcpy(&h.R9[9 * a], cubes[i]->q.R.m, 9 * sizeof(float));
             h.spans[a] = cubes[i]->span;
             h.fix[a] = tk.fix_rot ? 1 : 0;
-            float* out = &h.tn4[4 * (size_t)h.offsets[a]];
-            for (const TransCube& c : tk.batch) { out[0] = c.t.x; out[1] = c.t.y; out[2] = c.t.z; out[3] = c.span; out += 4; }
+            float* base = &h.tn4[4 * (size_t)h.offsets[a]];
+            for (size_t q = 0; q < tk.batch.size(); ++q) {
+                if (tk.brow[q] < 0) continue;
+                const TransCube& c = tk.batch[q];
+                float* out = base + 4 * (size_t)tk.brow[q];
+                out[0] = c.t.x; out[1] = c.t.y; out[2] = c.t.z; out[3] = c.span;
+            }
+            float* out = base + 4 * (size_t)tk.nrows;
+            for (const TransCube& c : tk.phantom) { out[0] = c.t.x; out[1] = c.t.y; out[2] = c.t.z; out[3] = c.span; out += 4; }
         };
         if (par && G >= 256) pool_->parallel_for(G, pack_fn);
         else for (size_t a = 0; a < G; ++a) pack_fn(a);
-        h.lb.resize(h.tn4.size() / 4);
-        h.ub.resize(h.tn4.size() / 4);
-        // twins: the UB and the LB task of one child (tasks 2c, 2c+1, neighbours in `live`) walk the top of the same translation
-        // tree; a node both hold in this submission is evaluated once (fgoicp_bounds_submit_twins).  Matched through a small
-        // open-addressing table per pair (<= 32 nodes a side).
-        h.twin.assign(h.tn4.size() / 4, -1);
-        if (use_twins_) {
-            std::vector<size_t> pairs;
-            for (size_t a = 0; a + 1 < h.live.size(); ++a)
-                if ((h.live[a] ^ 1) == h.live[a + 1] && cubes[h.live[a]] == cubes[h.live[a + 1]]) pairs.push_back(a);
-            const std::function<void(size_t)> match_fn = [&](size_t q) {
-                const size_t a = pairs[q];
-                const int o0 = h.offsets[a], n0 = h.offsets[a + 1] - o0, o1 = h.offsets[a + 1], n1 = h.offsets[a + 2] - o1;
-                if (n0 > 64 || n1 > 64) return;  // batches hold <= 32 nodes (fgoicp.cpp:122); the table below assumes it
-                int table[128];
-                for (int& x : table) x = -1;
-                auto hash = [&](const float* t) {
-                    uint32_t b[4];
-                    std::memcpy(b, t, 16);
-                    uint32_t x = b[0] * 0x9E3779B1u ^ b[1] * 0x85EBCA77u ^ b[2] * 0xC2B2AE3Du ^ b[3] * 0x27D4EB2Fu;
-                    return (x ^ (x >> 15)) & 127u;
-                };
-                for (int i = 0; i < n0; ++i) {
-                    uint32_t s = hash(&h.tn4[4 * (size_t)(o0 + i)]);
-                    while (table[s] >= 0) s = (s + 1) & 127u;
-                    table[s] = o0 + i;
-                }
-                for (int j = 0; j < n1; ++j) {
-                    const float* t = &h.tn4[4 * (size_t)(o1 + j)];
-                    for (uint32_t s = hash(t); table[s] >= 0; s = (s + 1) & 127u) {
-                        const int i = table[s];
-                        if (h.twin[(size_t)i] < 0 && std::memcmp(&h.tn4[4 * (size_t)i], t, 16) == 0) {
-                            h.twin[(size_t)i] = o1 + j;
-                            h.twin[(size_t)(o1 + j)] = i;
-                            break;
-                        }
-                    }
-                }
-            };
-            if (par && pairs.size() >= 64) pool_->parallel_for(pairs.size(), match_fn);
-            else for (size_t q = 0; q < pairs.size(); ++q) match_fn(q);
+        h.lb.resize(total);
+        h.ub.resize(total);
+        h.twin.assign(total, -1);
+        for (size_t q = 0; q < pairs.size(); ++q) {
+            const int o0 = h.offsets[pairs[q]], o1 = h.offsets[pairs[q] + 1];
+            for (const auto& pr : h.pair_twins[q]) { h.twin[(size_t)(o0 + pr.first)] = o1 + pr.second; h.twin[(size_t)(o1 + pr.second)] = o0 + pr.first; }
         }
         return !h.live.empty();
     }
@@ -750,13 +833,18 @@ private:
         from.members.swap(keep);
     }
     void consume_half(Half& h, std::vector<Task*>& tasks, bool par) {
-        const std::function<void(size_t)> push_fn = [&](size_t k) { tasks[h.live[k]]->consume(h.lb.data() + h.offsets[k], h.ub.data() + h.offsets[k]); };
+        const std::function<void(size_t)> push_fn = [&](size_t k) {
+            Task& tk = *tasks[h.live[k]];
+            const float *lb = h.lb.data() + h.offsets[k], *ub = h.ub.data() + h.offsets[k];
+            for (size_t q = 0; q < tk.batch.size(); ++q)
+                if (tk.brow[q] >= 0) { tk.blb[q] = lb[tk.brow[q]]; tk.bub[q] = ub[tk.brow[q]]; }
+            for (size_t j = 0; j < tk.phantom.size(); ++j)  // the twin's nodes, evaluated for later
+                tk.memo.insert(node_key(tk.phantom[j]), lb[tk.nrows + (int)j], ub[tk.nrows + (int)j]);
+            tk.consume(tk.blb.data(), tk.bub.data());
+        };
         if (par) pool_->parallel_for(h.live.size(), push_fn);
         else for (size_t k = 0; k < h.live.size(); ++k) push_fn(k);
-        if (account_submissions_) {  // ROUND: one operator submission serves many tasks
-            stats_.bounds_calls++;
-            stats_.trans_cubes += h.tn4.size() / 4;
-        }
+        if (account_submissions_) stats_.bounds_calls++;  // ROUND: one operator submission serves many tasks
     }
 
     // Advance a set of inner tasks to completion.  Every submission carries the current batch of every
@@ -777,6 +865,8 @@ private:
     int run_task_list(std::vector<Task*>& tasks, const std::vector<const RotCube*>& cubes) {
         const int rc_ = run_task_list_impl(tasks, cubes);
         if (overlap_stats_) overlap_report(tasks, cubes);
+        if (account_submissions_)  // ROUND: subcubes = what the tasks consumed (`count`, fgoicp.cpp:132), however they were served
+            for (const Task* t : tasks) stats_.trans_cubes += t->count;
         return rc_;
     }
     int run_task_list_impl(std::vector<Task*>& tasks, const std::vector<const RotCube*>& cubes) {
@@ -800,7 +890,7 @@ private:
                     h[k].live.clear();
                     const auto tc = clock::now();
                     rebalance(h[k], h[1 - k]);
-                    if (!h[k].members.empty() && prepare_half(h[k], tasks, cubes, par)) {
+                    if (!h[k].members.empty() && prepare_half(h[k], tasks, cubes, par, ops_.twins())) {
                         int rc = ops_.bounds_submit(k, (int)h[k].live.size(), h[k].R9.data(), h[k].spans.data(), h[k].fix.data(), h[k].offsets.data(), h[k].tn4.data(), h[k].twin.data());
                         if (rc) return rc;
                         h[k].inflight = true;
@@ -819,7 +909,7 @@ private:
         for (size_t i = 0; i < tasks.size(); ++i) h.members.push_back(i);
         for (;;) {
             const auto ta = clock::now();
-            if (!prepare_half(h, tasks, cubes, par)) return kDriverOk;
+            if (!prepare_half(h, tasks, cubes, par, false)) return kDriverOk;
             const auto tb = clock::now();
             int rc = ops_.bounds_multi((int)h.live.size(), h.R9.data(), h.spans.data(), h.fix.data(), h.offsets.data(), h.tn4.data(), h.lb.data(), h.ub.data());
             if (rc) return rc;
@@ -837,6 +927,7 @@ private:
     double t_pop_ = 0, t_ops_ = 0, t_push_ = 0;
     const bool timing_ = std::getenv("FGOICP_TIMING") != nullptr;  // host-side timing lines on stderr
     bool use_twins_ = [] { const char* e = std::getenv("FGOICP_TWINS"); return !e || std::atoi(e) != 0; }();  // tuning knob
+    bool use_memo_ = [] { const char* e = std::getenv("FGOICP_MEMO"); return !e || std::atoi(e) != 0; }();    // tuning knob: memo of the twin task's evaluations
     const bool overlap_stats_ = std::getenv("FGOICP_OVERLAP_STATS") != nullptr;  // diagnostic: how many nodes both tasks of a rotation cube evaluate
     uint64_t ov_ub_ = 0, ov_lb_ = 0, ov_both_ = 0;
     bool account_submissions_ = true;   // false while SERIAL speculates: work is accounted per committed task instead

@@ -25,6 +25,7 @@ struct HipOps {
     }
     int bounds_collect(int slot, float* lb, float* ub) { return ctx_bounds_collect(ctx, slot, lb, ub); }
     bool async() const { return ctx->sorted_bounds && pipeline; }
+    bool twins() const { return true; }
     int icp(const float* R0, const float* t0, size_t max_iter, float thr, float* sse, float* R9, float* t3, int* iters) {
         return ctx_icp(ctx, R0, t0, max_iter, thr, sse, R9, t3, iters);
     }

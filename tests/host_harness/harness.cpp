@@ -31,8 +31,9 @@ struct OracleOps {
     }
     // "asynchronous" slots for the pipelined driver path: evaluated at submit, handed out at collect
     std::vector<float> slot_lb[2], slot_ub[2];
-    bool use_async = false;
+    bool use_async = false, claim_twins = false;
     bool async() const { return use_async; }
+    bool twins() const { return claim_twins; }  // the oracle evaluates every row; claiming twins only switches the driver's memo logic on (schedule 4, 5)
     int bounds_submit(int slot, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets, const float* tn4,
                       const int* /*twin: a device-side saving, the oracle evaluates every subcube*/) {
         slot_lb[slot].assign(offsets[G], 0.f);
@@ -93,8 +94,9 @@ void* harness_create_ex(const float* tgt, size_t nt, const float* src, size_t ns
     h->reg.reset(new orc::Registration(h->opct, h->opcs, b, lut_res, build_lut != 0));
     if (use_grid) h->reg->use_grid(true);
     h->ops.reg = h->reg.get(); h->ops.pct = &h->opct; h->ops.pcs = &h->opcs;
-    h->ops.use_async = schedule >= 2;  // schedule 2 = ROUND, 3 = SERIAL, both with the two-slot pipelined task loop
-    schedule = schedule == 2 ? 1 : schedule == 3 ? 0 : schedule;
+    h->ops.use_async = schedule >= 2;  // schedule 2 = ROUND, 3 = SERIAL, both with the two-slot pipelined task loop; 4, 5 = the same with the twin-task memo
+    h->ops.claim_twins = schedule >= 4;
+    schedule = (schedule == 2 || schedule == 4) ? 1 : (schedule == 3 || schedule == 5) ? 0 : schedule;
     size_t n_thr = ns;  // as solver.cpp: the threshold runs over the inliers when trimming
     if (trim_fraction > 0.0f) {
         size_t k = (size_t)((double)ns * (1.0 - (double)trim_fraction));

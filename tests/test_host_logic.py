@@ -104,6 +104,22 @@ def test_pipelined_and_synchronous_task_loops_are_equivalent():
     assert a["stats"]["bounds_calls"] <= b["stats"]["bounds_calls"] <= 2 * a["stats"]["bounds_calls"]
 
 
+def test_twin_task_memo_changes_nothing_a_task_can_see():
+    """The memo of the twin task's evaluations (driver.hpp prepare_half: phantom rows for the UB task's nodes, LB batches served
+    from the memo, whole batches consumed without a submission): every counter and the result are those of the run without it —
+    under expansion rounds (schedule 4 vs 2) and under the reference's order with speculation (5 vs 3, which also equals the
+    oracle's literal driver)."""
+    pre = "runsyn_"
+    args = (G[pre + "tgt"], G[pre + "src"], float(G[pre + "res"]), float(G[pre + "mse"]))
+    for plain, memo, K in ((2, 4, 4), (3, 5, 1)):
+        a = hh.HostDriver(*args, schedule=plain, round_width=K).run()
+        b = hh.HostDriver(*args, schedule=memo, round_width=K).run()
+        assert np.array_equal(a["R"], b["R"]) and np.array_equal(a["t"], b["t"]) and a["best_sse"] == b["best_sse"]
+        for k in ("trans_cubes", "rot_cubes", "icp_runs", "icp_iters", "inner_bnb", "rounds"):
+            assert a["stats"][k] == b["stats"][k], (plain, k)
+    assert [b["stats"][k] for k in KEYS] == list(G[pre + "stats"])  # schedule 5: the oracle's counters
+
+
 def test_serial_speculation_modes_walk_the_same_trajectory(tmp_path):
     """FGOICP_SERIAL_SPECULATE = 0 (literal, one task at a time), 1 (inside the popped node), 2 (across the tops of the queue,
     default): the same pops, counters and result — speculation only changes how many tasks share an operator submission."""

@@ -2,14 +2,16 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 for rep in 1 2; do
-for Z in 2 3; do
-echo "layout $Z: $(FGOICP_LUT_ZPAIR=$Z timeout -k 10 300 python tools/op_bench.py bunny 1024 5 2>/dev/null)"
-done; done
-for Z in 2 3; do
-FGOICP_LUT_ZPAIR=$Z timeout -k 10 200 python bench.py --only headline --steps 3 --warmup 1 2>/dev/null | python3 -c "
+for M in 0 1; do
+for LEG in headline; do
+FGOICP_MEMO=$M timeout -k 10 300 python bench.py --only $LEG --steps 3 --warmup 1 2>/dev/null | python3 -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{\"metric\"'):
-        d=json.loads(l); r=d['roofline']; print('layout $Z headline value %.4g kernel GB/s %.0f avg_launch_us %.1f best_sse %r' % (d['value'], r['achieved'], r['avg_launch_us'], d['result']['best_sse']))
+        d=json.loads(l)
+        r=d.get('roofline')
+        print('memo=$M $LEG value %.4g evaluations/launch %.0f avg_launch_us %.1f seconds_bnb %.4f' % (d['value'], r['evaluations_per_launch'], r['avg_launch_us'], d['seconds_bnb_rank0']))
 "
-done
+done; done; done
+FGOICP_TIMING=1 FGOICP_MEMO=1 timeout -k 10 100 python tools/run_probe.py 0 5e-5 bunny 2>&1 | grep "timing\] run"
+FGOICP_TIMING=1 FGOICP_MEMO=0 timeout -k 10 100 python tools/run_probe.py 0 5e-5 bunny 2>&1 | grep "timing\] run"
