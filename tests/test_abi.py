@@ -89,3 +89,31 @@ def test_cpp_facades_compile_against_the_c_abi_alone(fg, tmp_path):
         pytest.skip("GPU present: the run itself is covered by the gpu test")
     p = subprocess.run([exe, str(tmp_path / "pc.txt"), str(tmp_path / "pc.txt"), "0.05", str(tmp_path / "b.txt")], capture_output=True, text=True)
     assert p.returncode != 0 and "no HIP device" in (p.stderr + p.stdout)
+
+
+def test_invalid_arguments_are_refused_before_any_device_work(fg):
+    """NULL pointers, empty device lists and out-of-range ranks come back as FGOICP_ERR_INVALID_ARG (1) from the entry points added in
+    round 2 — checked on the CPU: none of these calls reaches the GPU."""
+    import ctypes as C
+    lib = fg._lib.load()
+    assert lib.fgoicp_lut_nodes(None, None, 1, None) == 1
+    assert lib.fgoicp_bounds_point_distances(None, None, 0.0, None, 0, None) == 1
+    assert lib.fgoicp_ctx_sort_fallbacks(None, None, None) == 1
+    assert lib.fgoicp_ctx_profile_select_ms(None, None) == 1
+    assert lib.fgoicp_icp_batch(None, 1, None, None, 10, 0.1, None, None, None, None) == 1
+    assert lib.fgoicp_bounds_collect(None, 0, None, None) == 1
+    assert lib.fgoicp_rccl_unique_id(None) == 1
+    h = C.c_void_p()
+    ident = (C.c_ubyte * 128)()
+    assert lib.fgoicp_rccl_create(0, 1, None, 0, C.byref(h)) == 1 and not h.value
+    assert lib.fgoicp_rccl_create(2, 2, ident, 0, C.byref(h)) == 1 and lib.fgoicp_rccl_create(0, 0, ident, 0, C.byref(h)) == 1
+    assert lib.fgoicp_rccl_exchange(None, None) == 1 and lib.fgoicp_rccl_calls(None, None) == 1
+    pts = np.zeros((4, 3), np.float32)
+    fp = pts.ctypes.data_as(fg._lib.c_float_p)
+    assert lib.fgoicp_multi_create(fp, 4, fp, 4, 0.1, 1e-3, None, None, 0, fg.TRANSPORT_RCCL, C.byref(h)) == 1
+    dev = (C.c_int * 1)(0)
+    assert lib.fgoicp_multi_create(fp, 4, fp, 4, 0.1, 1e-3, None, dev, 1, 7, C.byref(h)) == 1  # unknown transport
+    assert lib.fgoicp_multi_run(None, None, None) == 1 and lib.fgoicp_multi_world(None) == 0 and not lib.fgoicp_multi_solver(None, 0)
+    assert lib.fgoicp_multi_set_record(None, 1) == 1 and lib.fgoicp_multi_replay_rank(None, 0, None) == 1 and lib.fgoicp_multi_seconds(None, 0, None) == 1
+    lib.fgoicp_multi_destroy(None); lib.fgoicp_rccl_destroy(None)  # no-ops
+    assert b"invalid" in lib.fgoicp_last_error() or b"" == lib.fgoicp_last_error()[:0]

@@ -52,6 +52,21 @@ def test_duplicate_points_and_exact_ties(fg, oracle, gpu_required):
     _cmp_ops(fg, oracle, tgt, src, B3, 0.2)
 
 
+def test_correspondence_tie_rule_compares_square_roots(fg, gpu_required):
+    """The hand-derived case of tests/test_oracle_kat.py on the device, scan and brute-force kernels: squared distances one ulp
+    apart with equal fp32 square roots tie, the first index wins (icp3d.cu:20-25); the SSE takes the smaller square."""
+    from oracle import np_restatement as npr
+    from tests.test_oracle_kat import sqrt_tie_pair
+    near, far = sqrt_tie_pair()
+    q = np.zeros((1, 3), f32)
+    for flags in (0, fg.FLAG_BRUTE_FORCE_NN):
+        for tgt, want in ((np.stack([far, near]), 0), (np.stack([near, far]), 0), (np.stack([far * 2, far, near]), 1)):
+            reg = fg.Registration(tgt.astype(f32), q, B3, 0.5, flags=flags)
+            assert reg.procrustes(q)[-1][0] == want
+            assert reg.compute_sse_error(np.eye(3, dtype=f32), np.zeros(3, f32)) == npr.dist_sq(near[None, :], q)[0]
+            reg.close()
+
+
 def test_coplanar_and_collinear_clouds(fg, oracle, gpu_required):
     """Rank-deficient cross-covariance: the SVD-based rotation must still be a proper rotation."""
     rng = np.random.default_rng(4)

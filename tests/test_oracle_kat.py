@@ -286,3 +286,32 @@ def test_grid_nn_of_the_cpu_baseline_equals_the_brute_force_loops(oracle, fg, ca
     assert np.array_equal(brute.procrustes(w)[-1], grid.procrustes(w)[-1])
     grid.set_inliers(len(pcs) // 2); brute.set_inliers(len(pcs) // 2)
     assert brute.compute_sse_error(R, t).view(np.uint32) == grid.compute_sse_error(R, t).view(np.uint32)
+
+
+def sqrt_tie_pair():
+    """Two points whose squared distances to the origin differ by one ulp while their fp32 square roots are equal (found by stepping
+    one coordinate one ulp at a time; deterministic)."""
+    rng = np.random.default_rng(0)
+    d2 = lambda p: npr.dist_sq(p[None, :], np.zeros((1, 3), np.float32))[0]
+    while True:
+        a = rng.uniform(0.3, 0.6, 3).astype(np.float32)
+        b = a.copy()
+        b[0] = np.nextafter(b[0], np.float32(1))
+        da, db = d2(a), d2(b)
+        if db > da and np.sqrt(da, dtype=np.float32) == np.sqrt(db, dtype=np.float32):
+            return a, b
+
+
+def test_correspondence_tie_rule_compares_square_roots(oracle):
+    """kernFindNearestNeighbor compares glm::distance (a square root) with a strict '>' (icp3d.cu:20-25): two targets whose
+    SQUARED distances differ by one ulp but whose square roots round to the same float tie, and the first index wins — even when
+    it is the (by one ulp) farther one.  kernComputeClosestError compares squared distances (registration.cu:162-174) and takes
+    the smaller."""
+    near, far = sqrt_tie_pair()
+    q = np.zeros((1, 3), np.float32)
+    bounds = np.array([[-1, 1]] * 3, np.float32)
+    for tgt, want in ((np.stack([far, near]), 0), (np.stack([near, far]), 0), (np.stack([far * 2, far, near]), 1)):
+        reg = oracle.Registration(tgt.astype(np.float32), q, bounds, 0.5, build_lut=False)
+        assert reg.procrustes(q)[-1][0] == want
+        sse = reg.compute_sse_error(np.eye(3, dtype=np.float32), np.zeros(3, np.float32))
+        assert sse == npr.dist_sq(near[None, :], q)[0]

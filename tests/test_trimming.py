@@ -194,3 +194,26 @@ def test_hip_device_wide_selection_equals_the_one_block_selection(fg, gpu_requir
     (s1, e1, R1, t1, it1), (s0, e0, R0, t0, it0) = out["1"], out["0"]
     assert s1 == pytest.approx(s0, rel=1e-6) and it1 == it0
     assert float(e1) == pytest.approx(float(e0), rel=1e-5) and np.allclose(R1, R0, atol=1e-5) and np.allclose(t1, t0, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ns", [301, 1202, 2051])
+def test_hip_trimmed_rows_with_sizes_that_are_not_multiples_of_four(fg, oracle, gpu_required, ns):
+    """Rows of the per-point distances start 16-byte aligned (row stride = ns rounded up to 4) and are read as float4 plus a tail:
+    sizes with ns % 4 = 1, 2, 3, including one above a whole 1024-thread sweep, against the oracle."""
+    tgt, src, _, _ = fg.synth.make_pair(1500, ns, (0.156, 0.152, 0.118), seed=ns)
+    pct, pcs, *_, bounds = fg.synth.preprocess(tgt, src)
+    hip = fg.Registration(pct, pcs, bounds, 0.05)
+    orc = oracle.Registration(pct, pcs, bounds, 0.05)
+    rng = np.random.default_rng(ns)
+    rn = fg.RotNode(0.2, -0.15, 0.3, 0.125)
+    tn = np.concatenate([rng.uniform(-0.5, 0.5, (40, 3)), rng.choice([0.5, 0.125, 0.0625], (40, 1))], 1).astype(f32)
+    for k in (ns - 1, int(0.7 * ns), 5):
+        hip.set_inliers(k); orc.set_inliers(k)
+        for fix in (True, False):
+            lb, ub = hip.compute_sse_error(rn, tn, fix)
+            lbo, ubo = orc.compute_bounds(rn.q.R, rn.span, tn, fix)
+            assert np.allclose(ub, ubo, rtol=1e-6, atol=1e-12) and np.allclose(lb, lbo, rtol=1e-6, atol=1e-6 * max(float(ubo.max()), 1e-12))
+        e = hip.point_distances(rn.q.R, rn.span, tn[3], False)
+        assert e.shape == (ns,) and np.array_equal(e.view(np.uint32), npr.point_distances(hip.lut_read(), bounds, 0.05, pcs, rn.q.R, rn.span, tn[3], False).view(np.uint32))
+    hip.close()
