@@ -102,6 +102,7 @@ class Env:
         self.dist = None
         self.red_dev = "cuda"
         self.ex = None
+        self.transport = None
         if self.world > 1:
             import torch.distributed as dist
             self.dist = dist
@@ -113,13 +114,25 @@ class Env:
             if a.rehearse_on_one_gpu:
                 from fgoicp_amd.dist import TorchExchange
                 self.ex = TorchExchange()
+                self.transport = "torch.distributed gloo (rehearsal)"
             else:  # the library's own RCCL transport (no Python in the per-round collectives); the id travels over torch.distributed
                 import fgoicp_amd as fg
-                ident = torch.zeros(128, dtype=torch.uint8, device="cuda")
-                if self.rank == 0:
-                    ident.copy_(torch.frombuffer(bytearray(fg.rccl_unique_id()), dtype=torch.uint8))
-                dist.broadcast(ident, 0)
-                self.ex = fg.RcclExchange(self.rank, self.world, bytes(ident.cpu().numpy().tobytes()), self.local_rank)
+                self.transport = "rccl inside libfgoicp_amd.so (fgoicp_rccl_*)"
+                try:
+                    ident = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                    if self.rank == 0:
+                        ident.copy_(torch.frombuffer(bytearray(fg.rccl_unique_id()), dtype=torch.uint8))
+                    dist.broadcast(ident, 0)
+                    self.ex = fg.RcclExchange(self.rank, self.world, bytes(ident.cpu().numpy().tobytes()), self.local_rank)
+                    ok = torch.tensor([1.0], device="cuda")
+                except Exception as e:  # keep the run alive on the torch.distributed transport (ctypes callbacks) and say so
+                    print(f"[bench] rank {self.rank}: in-library RCCL exchange unavailable ({e!r})", file=sys.stderr, flush=True)
+                    ok = torch.tensor([0.0], device="cuda")
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if float(ok) < 1.0:  # every rank must use the same transport
+                    from fgoicp_amd.dist import TorchExchange
+                    self.ex = TorchExchange()
+                    self.transport = "torch.distributed nccl through ctypes callbacks (fallback)"
             self.ex.warmup()  # communicator setup is not part of a registration run
 
     def barrier(self):
@@ -246,6 +259,8 @@ def cpu_baseline(fg, reg, tgt, src, res, mse, sched_id, K, seconds, gpu_leg):
     bounded sample."""
     from oracle import pyoracle
     from tests import host_harness as hh
+    os.environ["FGOICP_HOST_SPIN"] = "0"     # the CPU run's driver shares the cores with the oracle's OpenMP team, which does the parallel work:
+    os.environ["FGOICP_HOST_THREADS"] = "1"  # no polling worker threads next to it
     pyoracle.build()
     cores = int(pyoracle.lib().orc_num_threads())
     h = hh.HostDriver(tgt, src, res, mse, schedule=sched_id, round_width=K, build_lut=False, use_grid=True)
@@ -318,7 +333,7 @@ def main():
                      "config": {"workload": f"{a.workload}-shape synthetic pair (nt={len(tgt)}, ns={len(src)}), lut_resolution={a.lut_resolution}, "
                                             f"mse_threshold={a.mse_threshold}, full FastGoICP::run() per step",
                                 "schedule": a.schedule, "round_width": K if K > 0 else "adaptive (32 per rank, doubled after each round that leaves the incumbent standing)",
-                                "lut_dims": head["lut_dims"], "parallelism": f"rotation cubes sharded over {world} rank(s), one RCCL allreduce(min) + one allgather per round inside libfgoicp_amd.so"},
+                                "lut_dims": head["lut_dims"], "parallelism": f"rotation cubes sharded over {world} rank(s), one allreduce(min) + one allgather per round" + (f"; transport: {env.transport}" if env.transport else "")},
                      "wall_clock_to_optimum_s": head["elapsed"] / a.steps, "subcubes_per_step": head["subcubes"] / a.steps})
         s = leg_summary(head, R_gt, t_gt, "headline")
         line.update({k: s[k] for k in ("rot_cubes_rank0", "icp_runs_rank0", "rounds", "seconds_bnb_rank0", "seconds_icp_rank0", "setup_s_upload_plus_lut_build")})

@@ -250,16 +250,19 @@ struct Task : InnerTask {
 // A few host threads for the per-task queue work of a tick (the inner BnBs of a round are independent:
 // popping the next batch and pushing the children of the evaluated one touch only the task's own
 // priority queue).  The calling thread takes part; results do not depend on the thread count.
+// A tick needs three or four of these fork-joins and lasts 0.1-1 ms, so the hand-off has to cost microseconds: the workers
+// spin on a generation counter for a short while after each job (the next one usually follows within that time) before they
+// sleep on a condition variable, and every participant takes a fixed slice of the index range (no shared counter).
 class WorkerPool {
 public:
     explicit WorkerPool(int nthreads) {
-        for (int i = 1; i < nthreads; ++i) threads_.emplace_back([this] { worker(); });
+        for (int i = 1; i < nthreads; ++i) threads_.emplace_back([this, i] { worker((size_t)i); });
     }
     ~WorkerPool() {
         {
             std::lock_guard<std::mutex> g(m_);
             stop_ = true;
-            ++generation_;
+            generation_.fetch_add(1, std::memory_order_release);
         }
         cv_start_.notify_all();
         for (auto& t : threads_) t.join();
@@ -270,52 +273,60 @@ public:
             for (size_t i = 0; i < n; ++i) f(i);
             return;
         }
-        {
-            std::lock_guard<std::mutex> g(m_);
-            fn_ = &f;
-            n_ = n;
-            next_.store(0, std::memory_order_relaxed);
-            active_ = threads_.size();
-            ++generation_;
+        fn_ = &f;
+        n_ = n;
+        active_.store(threads_.size(), std::memory_order_relaxed);
+        generation_.fetch_add(1, std::memory_order_release);  // publishes the job to spinning workers
+        if (sleepers_.load(std::memory_order_acquire) > 0) {
+            std::lock_guard<std::mutex> g(m_);  // pairs with the sleeper's predicate check: no lost wake-up
+            cv_start_.notify_all();
         }
-        cv_start_.notify_all();
-        drain();
-        std::unique_lock<std::mutex> lk(m_);
-        cv_done_.wait(lk, [this] { return active_ == 0; });
+        drain(0);
+        for (int spin = 0; active_.load(std::memory_order_acquire) != 0; ++spin)
+            if (spin > 2000) std::this_thread::yield();
         fn_ = nullptr;
     }
 
 private:
-    void drain() {
-        for (;;) {
-            const size_t i = next_.fetch_add(1, std::memory_order_relaxed);
-            if (i >= n_) break;
-            (*fn_)(i);
-        }
+    // Static blocks: participant p always takes the p-th slice of the index range.  The per-task state (priority queue, batch,
+    // memo: a few KB) then stays in the cache of the core that touched it in the previous tick; handing indices out dynamically
+    // moved it between cores every tick and scaled worse than it looked (4 threads: 1.3x; static: see DESIGN.md §5).
+    void drain(size_t p) {
+        const size_t parts = threads_.size() + 1;
+        const size_t a = n_ * p / parts, b = n_ * (p + 1) / parts;
+        for (size_t i = a; i < b; ++i) (*fn_)(i);
     }
-    void worker() {
-        int seen = 0;
+    void worker(size_t id) {
+        uint64_t seen = 0;
         for (;;) {
-            {
+            bool got = false;
+            for (int spin = 0; spin < spin_budget_; ++spin) {  // ~50-100 us of polling before going to sleep
+                if (generation_.load(std::memory_order_acquire) != seen) { got = true; break; }
+#if defined(__x86_64__) || defined(__i386__)
+                __builtin_ia32_pause();
+#endif
+            }
+            if (!got) {
                 std::unique_lock<std::mutex> lk(m_);
-                cv_start_.wait(lk, [&] { return generation_ != seen; });
-                seen = generation_;
-                if (stop_) return;
+                sleepers_.fetch_add(1, std::memory_order_release);
+                cv_start_.wait(lk, [&] { return generation_.load(std::memory_order_acquire) != seen; });
+                sleepers_.fetch_sub(1, std::memory_order_release);
             }
-            drain();
-            {
-                std::lock_guard<std::mutex> g(m_);
-                if (--active_ == 0) cv_done_.notify_one();
-            }
+            seen = generation_.load(std::memory_order_acquire);
+            if (stop_) return;
+            drain(id);
+            active_.fetch_sub(1, std::memory_order_release);
         }
     }
     std::vector<std::thread> threads_;
     std::mutex m_;
-    std::condition_variable cv_start_, cv_done_;
+    std::condition_variable cv_start_;
     const std::function<void(size_t)>* fn_ = nullptr;
-    size_t n_ = 0, active_ = 0;
-    std::atomic<size_t> next_{0};
-    int generation_ = 0;
+    size_t n_ = 0;
+    std::atomic<size_t> active_{0};
+    std::atomic<uint64_t> generation_{0};
+    std::atomic<int> sleepers_{0};
+    const int spin_budget_ = [] { const char* e = std::getenv("FGOICP_HOST_SPIN"); return e ? std::atoi(e) : 20000; }();  // tuning knob: 0 = workers sleep at once
     bool stop_ = false;
 };
 
@@ -375,7 +386,9 @@ public:
         if (timing_)
             std::fprintf(stderr, "[fgoicp timing] run %.3f s: pop+pack %.3f s, operator %.3f s, push %.3f s, icp %.3f s, calls %llu\n", stats_.seconds_total, t_pop_, t_ops_,
                          t_push_, stats_.seconds_icp, (unsigned long long)stats_.bounds_calls);
+        if (timing_) std::fprintf(stderr, "[fgoicp timing] prepare: pops %.3f s, pairs %.3f s, pack %.3f s\n", t_prep_[0], t_prep_[1], t_prep_[2]);
         t_pop_ = t_ops_ = t_push_ = 0;
+        t_prep_[0] = t_prep_[1] = t_prep_[2] = 0;
         if (overlap_stats_) {
             std::fprintf(stderr, "[fgoicp overlap] UB-task nodes %llu, LB-task nodes %llu, in both %llu (%.1f %% of all subcubes could be served from the twin's evaluation)\n",
                          (unsigned long long)ov_ub_, (unsigned long long)ov_lb_, (unsigned long long)ov_both_, 100.0 * ov_both_ / std::max<double>(1.0, (double)(ov_ub_ + ov_lb_)));
@@ -713,6 +726,7 @@ private:
     //           rotation only, and the dual evaluation is bit-identical to a separate one, so the LB task cannot tell.
     bool prepare_half(Half& h, std::vector<Task*>& tasks, const std::vector<const RotCube*>& cubes, bool par, bool twins_honoured) {
         const bool memo_on = use_memo_ && use_twins_ && twins_honoured;  // phantom rows cost nothing only where the twin hint is used
+        const auto tp0 = clock::now();
         const std::function<void(size_t)> pop_fn = [&](size_t k) {
             Task& tk = *tasks[h.members[k]];
             tk.has_batch = false;
@@ -739,6 +753,7 @@ private:
         };
         if (par) pool_->parallel_for(h.members.size(), pop_fn);
         else for (size_t k = 0; k < h.members.size(); ++k) pop_fn(k);
+        const auto tp1 = clock::now();
         h.live.clear();
         h.members.erase(std::remove_if(h.members.begin(), h.members.end(), [&](size_t i) { return tasks[i]->done; }), h.members.end());
         for (size_t i : h.members) h.live.push_back((int)i);  // a member that is not done has a batch
@@ -776,6 +791,7 @@ private:
         };
         if (par && pairs.size() >= 64) pool_->parallel_for(pairs.size(), match_fn);
         else for (size_t q = 0; q < pairs.size(); ++q) match_fn(q);
+        const auto tp2 = clock::now();
         h.offsets.assign(1, 0);
         for (size_t a = 0; a < G; ++a) h.offsets.push_back(h.offsets.back() + tasks[h.live[a]]->nrows + (int)tasks[h.live[a]]->phantom.size());
         const size_t total = (size_t)h.offsets.back();
@@ -804,6 +820,12 @@ private:
         for (size_t q = 0; q < pairs.size(); ++q) {
             const int o0 = h.offsets[pairs[q]], o1 = h.offsets[pairs[q] + 1];
             for (const auto& pr : h.pair_twins[q]) { h.twin[(size_t)(o0 + pr.first)] = o1 + pr.second; h.twin[(size_t)(o1 + pr.second)] = o0 + pr.first; }
+        }
+        if (timing_) {
+            const auto tp3 = clock::now();
+            t_prep_[0] += std::chrono::duration<double>(tp1 - tp0).count();
+            t_prep_[1] += std::chrono::duration<double>(tp2 - tp1).count();
+            t_prep_[2] += std::chrono::duration<double>(tp3 - tp2).count();
         }
         return !h.live.empty();
     }
@@ -925,6 +947,7 @@ private:
 
     Ops& ops_;
     double t_pop_ = 0, t_ops_ = 0, t_push_ = 0;
+    double t_prep_[3] = {0, 0, 0};  // FGOICP_TIMING: pops / pair matching / packing inside prepare_half
     const bool timing_ = std::getenv("FGOICP_TIMING") != nullptr;  // host-side timing lines on stderr
     bool use_twins_ = [] { const char* e = std::getenv("FGOICP_TWINS"); return !e || std::atoi(e) != 0; }();  // tuning knob
     bool use_memo_ = [] { const char* e = std::getenv("FGOICP_MEMO"); return !e || std::atoi(e) != 0; }();    // tuning knob: memo of the twin task's evaluations

@@ -12,6 +12,16 @@ if REPO not in sys.path:
 from oracle.pyoracle import usable_cpus  # noqa: E402
 
 os.environ.setdefault("OMP_NUM_THREADS", str(usable_cpus()))
+# the driver's worker threads poll for ~100 us between jobs; next to the oracle's OpenMP team (the CPU tests drive the oracle through the
+# product's driver) they only steal cores, so CPU test processes run the driver on one thread unless a test asks otherwise (the GPU tests
+# of the full-size runs and tests/test_dist_gloo.py use the pool)
+os.environ.setdefault("FGOICP_HOST_SPIN", "0")
+try:
+    import torch as _torch
+    if not _torch.cuda.is_available():
+        os.environ.setdefault("FGOICP_HOST_THREADS", "1")
+except Exception:
+    os.environ.setdefault("FGOICP_HOST_THREADS", "1")
 
 
 def pytest_configure(config):

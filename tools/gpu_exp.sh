@@ -1,17 +1,9 @@
 # scratch script for ad-hoc GPU experiments (edited per experiment; see tools/gpu_profile.sh for the round profile)
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-for rep in 1 2; do
-for M in 0 1; do
-for LEG in headline; do
-FGOICP_MEMO=$M timeout -k 10 300 python bench.py --only $LEG --steps 3 --warmup 1 2>/dev/null | python3 -c "
-import json,sys
-for l in sys.stdin:
-    if l.startswith('{\"metric\"'):
-        d=json.loads(l)
-        r=d.get('roofline')
-        print('memo=$M $LEG value %.4g evaluations/launch %.0f avg_launch_us %.1f seconds_bnb %.4f' % (d['value'], r['evaluations_per_launch'], r['avg_launch_us'], d['seconds_bnb_rank0']))
-"
-done; done; done
-FGOICP_TIMING=1 FGOICP_MEMO=1 timeout -k 10 100 python tools/run_probe.py 0 5e-5 bunny 2>&1 | grep "timing\] run"
-FGOICP_TIMING=1 FGOICP_MEMO=0 timeout -k 10 100 python tools/run_probe.py 0 5e-5 bunny 2>&1 | grep "timing\] run"
+for T in 1 2 4 8 16; do
+echo "threads $T toml: $(PROBE_RES=0.002 FGOICP_HOST_THREADS=$T FGOICP_TIMING=1 timeout -k 10 200 python tools/run_probe.py 0 1e-4 bunny_toml 2>&1 | grep -E "timing\] (run|prepare)" | cut -c1-150 | tr '\n' ' ')"
+done
+for T in 4 8; do
+echo "threads $T bunny: $(FGOICP_HOST_THREADS=$T FGOICP_TIMING=1 timeout -k 10 200 python tools/run_probe.py 0 5e-5 bunny 2>&1 | grep -E "timing\] run" | cut -c1-200)"
+done
+for W in 8; do FGOICP_HOST_THREADS=4 timeout -k 10 300 python tools/scale_replay.py $W bunny 5e-5 0.005 2 2>/dev/null | cut -c1-400; done
