@@ -79,8 +79,13 @@ static int tick_launch_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
     *sl.h_sort_err = 0u;
     if (!small) {
         // descriptors + locality sort on the slot's side stream (overlaps the other slot's bounds kernel); the main stream joins behind it
-        HIPCHK(hipMemcpyAsync(sl.d_groups, sl.h_groups, sizeof(TickGroup) * ng, hipMemcpyHostToDevice, sl.sort_stream));
-        HIPCHK(hipMemcpyAsync(sl.d_subs, sl.h_subs, sizeof(TickSub) * neval, hipMemcpyHostToDevice, sl.sort_stream));
+        static const int upload_kernel = [] { const char* e = std::getenv("FGOICP_UPLOAD_KERNEL"); return e ? std::atoi(e) : 1; }();  // tuning knob: 0 = two hipMemcpyAsync
+        if (upload_kernel) {
+            launch_tick_upload(sl.hd_groups, sl.d_groups, ng, sl.hd_subs, sl.d_subs, neval, sl.sort_stream);
+        } else {
+            HIPCHK(hipMemcpyAsync(sl.d_groups, sl.h_groups, sizeof(TickGroup) * ng, hipMemcpyHostToDevice, sl.sort_stream));
+            HIPCHK(hipMemcpyAsync(sl.d_subs, sl.h_subs, sizeof(TickSub) * neval, hipMemcpyHostToDevice, sl.sort_stream));
+        }
         ++c->sorted_ticks;
         const int fault = c->sort_fault_tick && c->sorted_ticks == (uint64_t)c->sort_fault_tick;
         launch_tick_sort(c->geom, c->d_chunk_cen, c->nchunk1, sl.d_groups, sl.d_subs, neval, c->cell_shift, sl.d_keys, sl.d_ranks, sl.d_hist, sl.d_hist_xcd, sl.d_xoff, sl.d_block_sums, sl.d_cursor, sl.d_sorted,

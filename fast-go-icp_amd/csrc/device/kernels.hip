@@ -463,6 +463,15 @@ __global__ __launch_bounds__(64) void tick_check_kernel(const unsigned* __restri
     for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < nitems; i += (size_t)gridDim.x * 64) bad = bad || sorted[i] >= nitems;
     if (__any(bad) && threadIdx.x == 0) *err = 1u;
 }
+// The tick's descriptors from the pinned staging buffers into device memory: one launch instead of two hipMemcpyAsync calls (each
+// costs the submitting thread ~10 us; the bytes — <= 150 KB — cross PCIe either way).
+__global__ __launch_bounds__(64) void tick_upload_kernel(const uint4* __restrict__ hg, uint4* __restrict__ dg, unsigned ng16, const uint4* __restrict__ hs,
+                                                         uint4* __restrict__ ds, unsigned ns16) {
+    for (unsigned i = blockIdx.x * 64 + threadIdx.x; i < ng16 + ns16; i += gridDim.x * 64) {
+        if (i < ng16) dg[i] = hg[i];
+        else ds[i - ng16] = hs[i - ng16];
+    }
+}
 // one-wave workgroups like the rest of the sort (a runtime memset uses wide workgroups, which wait for several free wave slots
 // on ONE CU while the other slot's bounds kernel keeps them all taken: measured 390 us per call instead of a few)
 __global__ __launch_bounds__(64) void tick_prefill_kernel(unsigned* __restrict__ sorted, size_t nitems) {
@@ -1815,6 +1824,13 @@ void launch_bounds_sorted(const float4* src, int ns, const float* lut, const flo
 #undef FGOICP_LAUNCH_SORTED
 #undef FGOICP_LAUNCH_WPG
     if (ev_stop) (void)hipEventRecord(ev_stop, s);
+}
+
+void launch_tick_upload(const TickGroup* h_groups, TickGroup* d_groups, int ngroups, const TickSub* h_subs, TickSub* d_subs, int nsubs, hipStream_t s) {
+    static_assert(sizeof(TickGroup) % 16 == 0 && sizeof(TickSub) % 16 == 0, "descriptors are copied in 16-byte units");
+    const unsigned ng16 = (unsigned)ngroups * (sizeof(TickGroup) / 16), ns16 = (unsigned)nsubs * (sizeof(TickSub) / 16);
+    hipLaunchKernelGGL(tick_upload_kernel, dim3(std::min(1024u, (ng16 + ns16 + 63) / 64)), dim3(64), 0, s, reinterpret_cast<const uint4*>(h_groups),
+                       reinterpret_cast<uint4*>(d_groups), ng16, reinterpret_cast<const uint4*>(h_subs), reinterpret_cast<uint4*>(d_subs), ns16);
 }
 
 void launch_bounds_finalize(const double2* partials, int nchunk, int total, float* out_lb, float* out_ub, hipStream_t s) {
