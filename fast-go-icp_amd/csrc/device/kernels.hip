@@ -1258,10 +1258,10 @@ __global__ __launch_bounds__(kBlock) void nn_first_index_kernel(const float4* __
 }
 
 // ---------------------------------------------------------------------------------------------
-// Exact nearest neighbour by a two-level box scan over the Morton-sorted targets (bvh.hpp):
-// "leaves" of kBvhLeaf = 32 consecutive points and "super-leaves" of 32 leaves (1024 points), each
-// with its bounding box (two levels of the implicit tree).  Every query walks the SAME sequence
-//     for each super-leaf:  box test  ->  for each of its leaves:  box test  ->  its 32 points
+// Exact nearest neighbour by a three-level box scan over the Morton-sorted targets (bvh.hpp):
+// "leaves" of kBvhLeaf = 32 consecutive points, "super-leaves" of 32 leaves (1024 points) and "top boxes" of 32 super-leaves, each
+// with its bounding box (three levels of the implicit tree).  Every query walks the SAME sequence
+//     for each top box:  box test  ->  for each of its super-leaves:  box test  ->  for each of its leaves:  box test  ->  its 32 points
 // so control flow is wave-uniform (a branch is taken when ANY lane needs it) and every box and point
 // load has a wave-uniform address (one broadcast transaction, scalar-cacheable) — no dependent-load
 // chains, no stack, no divergence beyond the exec mask.  The queries of a wave are Morton neighbours
@@ -1327,44 +1327,60 @@ __device__ __forceinline__ void box_scan(const BvhView t, float qx, float qy, fl
     const int nsuper = 1 << sdepth;
     const int lps = 1 << (t.depth - sdepth);  // leaves per super-leaf (<= 32)
     const int first_super = nsuper - 1;
-    for (int sb = 0; sb < nsuper; sb += 64) {
-        bool sc = false;
-        if (sb + lane < nsuper) {
-            const int sn = first_super + sb + lane;
-            sc = !(boxbox_d2(t.box[2 * sn], t.box[2 * sn + 1], wl, wh) * kBoxShrink > r2);
+    // a third level above the super-leaves ("top boxes", 32 super-leaves = 1024 leaves = 32768 points each): without it every wave
+    // tests every super-leaf box — 977 of them for a million targets, 16 dependent rounds before the first leaf
+    const int tdepth = sdepth > kSuperShift ? sdepth - kSuperShift : 0;
+    const int ntop = 1 << tdepth;
+    const int spt = 1 << (sdepth - tdepth);   // super-leaves per top box (<= 32)
+    const int first_top = ntop - 1;
+    for (int tb = 0; tb < ntop; tb += 64) {
+        bool tc = false;
+        if (tb + lane < ntop) {
+            const int tn = first_top + tb + lane;
+            tc = !(boxbox_d2(t.box[2 * tn], t.box[2 * tn + 1], wl, wh) * kBoxShrink > r2);
         }
-        unsigned long long smask = __ballot(sc);
-        while (smask) {
-            const int s = sb + __ffsll((long long)smask) - 1;
-            smask &= smask - 1;
-            float4 llo = make_float4(big, big, big, 0.f), lhi = make_float4(-big, -big, -big, 0.f);
-            bool lc = false;
-            if (lane < lps) {
-                const int ln = t.first_leaf + s * lps + lane;
-                llo = t.box[2 * ln];
-                lhi = t.box[2 * ln + 1];
-                lc = !(boxbox_d2(llo, lhi, wl, wh) * kBoxShrink > r2);
+        unsigned long long tmask = __ballot(tc);
+        while (tmask) {
+            const int top = tb + __ffsll((long long)tmask) - 1;
+            tmask &= tmask - 1;
+            bool sc = false;
+            if (lane < spt) {
+                const int sn = first_super + top * spt + lane;
+                sc = !(boxbox_d2(t.box[2 * sn], t.box[2 * sn + 1], wl, wh) * kBoxShrink > r2);
             }
-            unsigned long long lmask = __ballot(lc);
-            while (lmask) {
-                const int l = __ffsll((long long)lmask) - 1;
-                lmask &= lmask - 1;
-                if (nparts > 1) {
-                    const bool mine = turn == part;
-                    turn = turn + 1 == nparts ? 0 : turn + 1;
-                    if (!mine) continue;
+            unsigned long long smask = __ballot(sc);
+            while (smask) {
+                const int s = top * spt + __ffsll((long long)smask) - 1;
+                smask &= smask - 1;
+                float4 llo = make_float4(big, big, big, 0.f), lhi = make_float4(-big, -big, -big, 0.f);
+                bool lc = false;
+                if (lane < lps) {
+                    const int ln = t.first_leaf + s * lps + lane;
+                    llo = t.box[2 * ln];
+                    lhi = t.box[2 * ln + 1];
+                    lc = !(boxbox_d2(llo, lhi, wl, wh) * kBoxShrink > r2);
                 }
-                const float4 lo = make_float4(bcast(llo.x, l), bcast(llo.y, l), bcast(llo.z, l), 0.f);
-                const float4 hi = make_float4(bcast(lhi.x, l), bcast(lhi.y, l), bcast(lhi.z, l), 0.f);
-                const bool pl = active && !(box_d2(lo, hi, qx, qy, qz) * kBoxShrink > bound());
-                if (!__any(pl)) continue;
-                const float4 pp = t.pts[(size_t)(s * lps + l) * kBvhLeaf + (lane & (kBvhLeaf - 1))];
+                unsigned long long lmask = __ballot(lc);
+                while (lmask) {
+                    const int l = __ffsll((long long)lmask) - 1;
+                    lmask &= lmask - 1;
+                    if (nparts > 1) {
+                        const bool mine = turn == part;
+                        turn = turn + 1 == nparts ? 0 : turn + 1;
+                        if (!mine) continue;
+                    }
+                    const float4 lo = make_float4(bcast(llo.x, l), bcast(llo.y, l), bcast(llo.z, l), 0.f);
+                    const float4 hi = make_float4(bcast(lhi.x, l), bcast(lhi.y, l), bcast(lhi.z, l), 0.f);
+                    const bool pl = active && !(box_d2(lo, hi, qx, qy, qz) * kBoxShrink > bound());
+                    if (!__any(pl)) continue;
+                    const float4 pp = t.pts[(size_t)(s * lps + l) * kBvhLeaf + (lane & (kBvhLeaf - 1))];
 #pragma unroll
-                for (int k = 0; k < kBvhLeaf; ++k) {
-                    const float4 c = make_float4(bcast(pp.x, k), bcast(pp.y, k), bcast(pp.z, k), bcast(pp.w, k));
-                    if (pl) leaf(c);
+                    for (int k = 0; k < kBvhLeaf; ++k) {
+                        const float4 c = make_float4(bcast(pp.x, k), bcast(pp.y, k), bcast(pp.z, k), bcast(pp.w, k));
+                        if (pl) leaf(c);
+                    }
+                    if (nparts == 1) r2 = wave_max_f(active ? bound() : 0.0f);  // the wave radius only shrinks
                 }
-                if (nparts == 1) r2 = wave_max_f(active ? bound() : 0.0f);  // the wave radius only shrinks
             }
         }
     }

@@ -217,3 +217,24 @@ def test_hip_trimmed_rows_with_sizes_that_are_not_multiples_of_four(fg, oracle, 
         e = hip.point_distances(rn.q.R, rn.span, tn[3], False)
         assert e.shape == (ns,) and np.array_equal(e.view(np.uint32), npr.point_distances(hip.lut_read(), bounds, 0.05, pcs, rn.q.R, rn.span, tn[3], False).view(np.uint32))
     hip.close()
+
+
+@pytest.mark.gpu
+def test_hip_trimmed_bounds_across_several_windows(fg, oracle, tiny_case, gpu_required, monkeypatch):
+    """A trimmed submission larger than one window of per-point rows (forced: 64 subcubes per window) is split, every window runs its
+    own selection, the results are those of the oracle — including groups cut in the middle and twin hints that straddle a cut."""
+    monkeypatch.setenv("FGOICP_MAX_SUBCUBES", "64")
+    c = tiny_case
+    hip = fg.Registration(c["pct"], c["pcs"], c["bounds"], c["res"])
+    orc = oracle.Registration(c["pct"], c["pcs"], c["bounds"], c["res"])
+    k = int(len(c["pcs"]) * 0.75)
+    hip.set_inliers(k); orc.set_inliers(k)
+    rng = np.random.default_rng(23)
+    nodes = [fg.RotNode(*rng.uniform(-0.4, 0.4, 3), 0.125) for _ in range(4)]
+    groups = [np.concatenate([rng.uniform(-0.6, 0.6, (n, 3)), rng.choice([0.5, 0.25, 0.0625], (n, 1))], 1).astype(f32) for n in (90, 7, 130, 40)]
+    fixes = [True, False, False, True]
+    got = hip.compute_bounds_multi([n.q.R for n in nodes], [n.span for n in nodes], fixes, groups)
+    for n, g, f, (lb, ub) in zip(nodes, groups, fixes, got):
+        lbo, ubo = orc.compute_bounds(n.q.R, n.span, g, f)
+        assert np.allclose(ub, ubo, rtol=1e-6, atol=1e-12) and np.allclose(lb, lbo, rtol=1e-6, atol=1e-6 * max(float(ubo.max()), 1e-12))
+    hip.close()
