@@ -427,12 +427,14 @@ def main():
         if a.only and a.only != "headline":
             line["only"] = a.only
         print(json.dumps(line), flush=True)
-    if env.dist is not None:
-        env.dist.barrier()
-        env.dist.destroy_process_group()
     for leg in (head, dflt):
         if leg is not None:
             leg["solver"].close()
+    if env.ex is not None and hasattr(env.ex, "close"):
+        env.ex.close()  # the RCCL communicator goes before the process group and well before interpreter teardown
+    if env.dist is not None:
+        env.dist.barrier()
+        env.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -122,7 +122,9 @@ __device__ __forceinline__ TexAddr lut_address(const LutGeom& g, float qx, float
     tex_axis(x, g.dx, g.quantize, ix, t.a);
     tex_axis(y, g.dy, g.quantize, iy, t.b);
     tex_axis(z, g.dz, g.quantize, iz, t.c);
-    t.o = ((size_t)iz * g.py + iy) * (size_t)g.px + ix;
+    // indices are >= 0 and < 4096: the row number fits 24 + bits, one 32 x 32 -> 64 multiply-add finishes the offset (signed size_t
+    // arithmetic cost seven instructions here, a point is ~120)
+    t.o = (size_t)((unsigned long long)((unsigned)iz * (unsigned)g.py + (unsigned)iy) * (unsigned)g.px + (unsigned)ix);
     t.pk = (unsigned)ix | ((unsigned)iy << 10) | ((unsigned)iz << 20);
     return t;
 }

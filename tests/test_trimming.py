@@ -238,3 +238,33 @@ def test_hip_trimmed_bounds_across_several_windows(fg, oracle, tiny_case, gpu_re
         lbo, ubo = orc.compute_bounds(n.q.R, n.span, g, f)
         assert np.allclose(ub, ubo, rtol=1e-6, atol=1e-12) and np.allclose(lb, lbo, rtol=1e-6, atol=1e-6 * max(float(ubo.max()), 1e-12))
     hip.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["cluster", "identical", "mostly_zero"])
+def test_hip_trimmed_selection_paths(fg, oracle, gpu_required, shape):
+    """The rare paths of trim_rows_kernel against the oracle: a histogram bin with more members than the gather buffer holds
+    (20 000 source points in a 1e-5 cluster: distinct values within one 1/512-octave bin -> refinement passes), all values equal
+    (identical points: the cut's range shrinks to one bit pattern, no gather), and rows whose k smallest are all zero."""
+    rng = np.random.default_rng(31)
+    tgt = rng.uniform(-0.8, 0.8, (400, 3)).astype(f32)
+    bounds = np.array([[tgt[:, a].min(), tgt[:, a].max()] for a in range(3)], f32)
+    n = 20000
+    if shape == "identical":
+        src = np.tile(np.array([[0.31, -0.22, 0.17]], f32), (n, 1))
+    else:
+        src = (np.array([[0.31, -0.22, 0.17]]) + rng.normal(scale=1e-5 if shape == "cluster" else 0.2, size=(n, 3))).astype(f32)
+    hip = fg.Registration(tgt, src, bounds, 0.05)
+    orc = oracle.Registration(tgt, src, bounds, 0.05)
+    span_r = 0.5 if shape == "mostly_zero" else 0.0625
+    rn = fg.RotNode(0.1, -0.2, 0.15, span_r)
+    tn = np.concatenate([rng.uniform(-0.3, 0.3, (12, 3)), rng.choice([0.25, 0.0625], (12, 1))], 1).astype(f32)
+    for k in (n // 2, n - 3, 17):
+        hip.set_inliers(k); orc.set_inliers(k)
+        for fix in (True, False):
+            lb, ub = hip.compute_sse_error(rn, tn, fix)
+            lbo, ubo = orc.compute_bounds(rn.q.R, rn.span, tn, fix)
+            assert np.allclose(ub, ubo, rtol=1e-6, atol=1e-12) and np.allclose(lb, lbo, rtol=1e-6, atol=1e-6 * max(float(ubo.max()), 1e-12)), (shape, k, fix)
+    if shape == "mostly_zero":
+        assert (hip.point_distances(rn.q.R, rn.span, tn[0], False) == 0).mean() > 0.3
+    hip.close()
