@@ -303,3 +303,42 @@ def test_tick_sort_is_checked_on_the_device_and_falls_back(fg, tiny_case, gpu_re
     ticks, fb = reg.sort_fallbacks()
     assert ticks >= 3 and fb == 1
     reg.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# configs[0] on the REAL clouds: the inputs of test/bunny.toml as the CLI's loader produces them (tests/golden/bunny_toml_clouds.npz)
+# ------------------------------------------------------------------------------------------------
+def test_bunny_toml_on_the_stanford_bunny_clouds(fg, oracle, gpu_required):
+    """The reference's example run (test/bunny.toml: model_bunny.txt at 0.5, data_bunny.txt at 0.1, lut_resolution 0.002,
+    mse_threshold 1e-3) through FastGoICP::run() in the CLI's schedule.  The oracle cannot build a 6e8-node LUT, but its EXACT
+    operators need none: the residual of the returned (R, t) is re-evaluated by the oracle's brute-force SSE on the oracle's own
+    pre-processing (registration.cu:62-86, fgoicp.cpp:176-287), and the oracle's ICP continued from there stays in the same basin (the
+    refinement stops when an iteration gains less than 0.05 %, fgoicp.cpp:22-23, so a continued ICP may still creep by a fraction of a
+    percent).  Expansion rounds end in the same optimum, to the band two eps-optimal runs agree to (see test_bunny_toml_shape_runs)."""
+    import os
+    F = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bunny_toml_clouds.npz"))
+    tgt, src = F["tgt"], F["src"]
+    res = {}
+    for name, sched, K in (("serial", fg.SCHEDULE_SERIAL, 1), ("round", fg.SCHEDULE_ROUND, 0)):
+        s = fg.FastGoICP(tgt, src, float(F["lut_resolution"]), float(F["mse_threshold"]), schedule=sched, round_width=K)
+        if name == "serial":
+            dims = s.registration.lut_dims()
+            assert all(600 < d < 1000 for d in dims) and dims[0] * dims[1] * dims[2] > 4e8  # SURVEY: 923 x 906 x 711 on the full clouds
+        R, t = s.run()
+        R_s, t_s = s.get_best_transform()  # scaled frame
+        res[name] = (R, t, float(s.get_best_error()), s.stats(), R_s, t_s)
+        s.close()
+    (Rs, ts, es, st, R_scaled, t_scaled), (Rr, tr, er, *_) = res["serial"], res["round"]
+    print(f"bunny.toml: sse {es:.6f} ({st['trans_cubes']} subcubes, {st['rot_cubes']} rotation cubes, {st['icp_runs']} ICP runs); round sse {er:.6f}")
+    assert st["trans_cubes"] > 1000 and st["icp_runs"] >= 2
+    assert abs(es - er) <= 2e-3 * es and np.allclose(Rs, Rr, atol=2e-3)
+    # the oracle on the same inputs: its pre-processing, its exact SSE of the returned transform
+    o = oracle.FastGoICP(tgt, src, 0.5, 1e-3)  # the LUT resolution only sizes a LUT this check never reads
+    pp = o.preproc()
+    reg = oracle.Registration(pp["pct"], pp["pcs"], pp["bounds"], 0.5, build_lut=False)
+    assert float(reg.compute_sse_error(R_scaled, t_scaled)) == pytest.approx(es, rel=1e-5)
+    sse_o, R_o, t_o, it = reg.icp(R_scaled, t_scaled, 100, 0.0005)
+    assert es * (1 - 0.02) <= float(sse_o) <= es * (1 + 1e-5) and np.allclose(R_o, R_scaled, atol=1e-2)
+    # restore_translation (fgoicp.hpp:87-90) with the oracle's offsets and scale
+    t_rest = t_scaled.astype(np.float64) / float(pp["scale"]) + R_scaled.astype(np.float64) @ pp["offset_pcs"] - pp["offset_pct"]
+    assert np.allclose(t_rest, ts, atol=1e-5)
