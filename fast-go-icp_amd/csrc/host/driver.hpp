@@ -139,6 +139,8 @@ struct InnerTask {
     uint64_t count = 0;
     std::priority_queue<TransCube> cand;
     std::vector<TransCube> batch;
+    size_t batch_cap = 32;  // nodes per operator call (fgoicp.cpp:122).  ROUND uses 48 (FGOICP_ROUND_BATCH): a task's batches are a chain of device
+                            // round trips, a third fewer of them costs ~1 % more subcubes and shortens every latency-bound phase
 
     void start(bool fix, float best_sse, float rnode_ub) {
         fix_rot = fix;
@@ -156,7 +158,7 @@ struct InnerTask {
         while (batch.empty()) {
             if (cand.empty()) return false;
             if (best_error - cand.top().lb < sse_threshold) return false;  // :120
-            while (!cand.empty() && batch.size() < 32) {
+            while (!cand.empty() && batch.size() < batch_cap) {
                 TransCube tn = cand.top();
                 cand.pop();
                 if (tn.lb < best_error) batch.push_back(tn);
@@ -612,6 +614,7 @@ private:
             std::vector<Task*> tasks;
             std::vector<const RotCube*> cubes;
             for (size_t k = 0; k < mine.size(); ++k) {
+                boxes[2 * k].batch_cap = boxes[2 * k + 1].batch_cap = round_batch_;
                 boxes[2 * k].start(true, snapshot, children[mine[k]].ub);
                 boxes[2 * k + 1].start(false, snapshot, children[mine[k]].ub);
                 tasks.push_back(&boxes[2 * k]); cubes.push_back(&children[mine[k]]);
@@ -950,6 +953,7 @@ private:
     double t_prep_[3] = {0, 0, 0};  // FGOICP_TIMING: pops / pair matching / packing inside prepare_half
     const bool timing_ = std::getenv("FGOICP_TIMING") != nullptr;  // host-side timing lines on stderr
     bool use_twins_ = [] { const char* e = std::getenv("FGOICP_TWINS"); return !e || std::atoi(e) != 0; }();  // tuning knob
+    const size_t round_batch_ = [] { const char* e = std::getenv("FGOICP_ROUND_BATCH"); const int v = e ? std::atoi(e) : 48; return (size_t)(v >= 8 && v <= 64 ? v : 48); }();  // tuning knob (ROUND only; SERIAL keeps the reference's 32)
     bool use_memo_ = [] { const char* e = std::getenv("FGOICP_MEMO"); return !e || std::atoi(e) != 0; }();    // tuning knob: memo of the twin task's evaluations
     const bool overlap_stats_ = std::getenv("FGOICP_OVERLAP_STATS") != nullptr;  // diagnostic: how many nodes both tasks of a rotation cube evaluate
     uint64_t ov_ub_ = 0, ov_lb_ = 0, ov_both_ = 0;
