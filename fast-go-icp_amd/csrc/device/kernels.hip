@@ -356,9 +356,11 @@ constexpr int kTickXcds = 16;  // the XCC_ID field is 4 bits wide
 template <int HILBERT, int XCD>
 __global__ __launch_bounds__(64) void tick_keys_kernel(const float4* __restrict__ chunk_cen, int nchunk, const TickGroup* __restrict__ groups,
                                                            const TickSub* __restrict__ subs, int nsub, LutGeom g, int cell_shift,
-                                                           unsigned short* __restrict__ keys, unsigned* __restrict__ ranks, unsigned* __restrict__ hist) {
+                                                           unsigned short* __restrict__ keys, unsigned* __restrict__ ranks, unsigned* __restrict__ hist,
+                                                           unsigned* __restrict__ prefill /* optional: `sorted`, filled with 0xFFFFFFFF for tick_check_kernel */) {
     const size_t nitems = (size_t)nsub * nchunk;
     for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < nitems; i += (size_t)gridDim.x * 64) {
+        if (prefill) prefill[i] = 0xFFFFFFFFu;
         const int s = (int)(i / nchunk), c = (int)(i - (size_t)s * nchunk);
         const TickSub sb = subs[s];
         const TickGroup& gr = groups[sb.group];
@@ -435,19 +437,31 @@ __global__ __launch_bounds__(64) void tick_scan_apply_kernel(unsigned* __restric
     c4[1] = o1;
 }
 
-// The per-XCD histograms folded: hist[k] = sum over XCDs (input of the scan), xoff[x][k] = items of key k on XCDs before x;
-// leaves the per-XCD histograms zeroed for the next tick.
-__global__ __launch_bounds__(64) void tick_fold_xcds_kernel(unsigned* __restrict__ hist_xcd, unsigned* __restrict__ xoff, unsigned* __restrict__ hist) {
-    const int k = blockIdx.x * 64 + threadIdx.x;
-    unsigned run = 0;
-#pragma unroll
+// The per-XCD histograms folded AND the first scan level, one kernel of kScanBlocks one-wave blocks (512 keys per block, 8 per lane):
+// hist[k] = sum over XCDs (input of tick_scan_apply_kernel), xoff[x][k] = items of key k on XCDs before x, block_sums[b] = items of the
+// block's keys; leaves the per-XCD histograms zeroed for the next tick.
+__global__ __launch_bounds__(64) void tick_fold_sums_kernel(unsigned* __restrict__ hist_xcd, unsigned* __restrict__ xoff, unsigned* __restrict__ hist,
+                                                            unsigned* __restrict__ block_sums) {
+    const int lane = threadIdx.x;
+    const size_t k0 = (size_t)blockIdx.x * 512 + 8 * lane;  // this lane's 8 consecutive keys (two 16-byte accesses per XCD histogram)
+    uint4 ra = make_uint4(0u, 0u, 0u, 0u), rb = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll 4
     for (int x = 0; x < kTickXcds; ++x) {
-        const unsigned v = hist_xcd[(size_t)x * kNumKeys + k];
-        xoff[(size_t)x * kNumKeys + k] = run;
-        run += v;
-        hist_xcd[(size_t)x * kNumKeys + k] = 0u;
+        uint4* h4 = reinterpret_cast<uint4*>(hist_xcd + (size_t)x * kNumKeys + k0);
+        uint4* o4 = reinterpret_cast<uint4*>(xoff + (size_t)x * kNumKeys + k0);
+        const uint4 a = h4[0], b = h4[1];
+        o4[0] = ra; o4[1] = rb;
+        ra.x += a.x; ra.y += a.y; ra.z += a.z; ra.w += a.w;
+        rb.x += b.x; rb.y += b.y; rb.z += b.z; rb.w += b.w;
+        h4[0] = make_uint4(0u, 0u, 0u, 0u);
+        h4[1] = make_uint4(0u, 0u, 0u, 0u);
     }
-    hist[k] = run;
+    uint4* d4 = reinterpret_cast<uint4*>(hist + k0);
+    d4[0] = ra; d4[1] = rb;
+    unsigned sum = ra.x + ra.y + ra.z + ra.w + rb.x + rb.y + rb.z + rb.w;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane == 0) block_sums[blockIdx.x] = sum;
 }
 __global__ __launch_bounds__(64) void tick_scatter_xcd_kernel(const unsigned short* __restrict__ keys, const unsigned* __restrict__ ranks, size_t nitems,
                                                               const unsigned* __restrict__ cursor, const unsigned* __restrict__ xoff, unsigned* __restrict__ sorted) {
@@ -473,14 +487,6 @@ __global__ __launch_bounds__(64) void tick_upload_kernel(const uint4* __restrict
         if (i < ng16) dg[i] = hg[i];
         else ds[i - ng16] = hs[i - ng16];
     }
-}
-// one-wave workgroups like the rest of the sort (a runtime memset uses wide workgroups, which wait for several free wave slots
-// on ONE CU while the other slot's bounds kernel keeps them all taken: measured 390 us per call instead of a few)
-__global__ __launch_bounds__(64) void tick_prefill_kernel(unsigned* __restrict__ sorted, size_t nitems) {
-    uint4* s4 = reinterpret_cast<uint4*>(sorted);
-    const size_t n4 = nitems >> 2;
-    for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 64) s4[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
-    if (blockIdx.x == 0 && threadIdx.x < (nitems & 3)) sorted[(n4 << 2) + threadIdx.x] = ~0u;
 }
 __global__ void tick_fault_kernel(unsigned* sorted) { sorted[0] = 0xFFFFFFFFu; }  // test hook (FGOICP_SORT_FAULT_TICK): a slot no item was scattered to
 // A/B only (FGOICP_SORT_RANKS=0): the classic scatter with its own atomic per item
@@ -1780,16 +1786,15 @@ void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, con
     static const int hilbert = [] { const char* e = std::getenv("FGOICP_SORT_CURVE"); return e ? std::atoi(e) : 1; }();  // tuning knob: 1 = Hilbert (default), 0 = Z-order
     static const int use_ranks = [] { const char* e = std::getenv("FGOICP_SORT_RANKS"); return e ? std::atoi(e) : 1; }();  // tuning knob
     const bool xcd = allow_xcd && use_ranks && hist_xcd && xoff;  // allow_xcd: FGOICP_SORT_XCD per context, cleared by a failed permutation check
-    if (check_err) hipLaunchKernelGGL(tick_prefill_kernel, dim3((unsigned)std::min<size_t>((nitems / 4 + 63) / 64 + 1, 4096)), dim3(64), 0, s, sorted, nitems);
     if (xcd) {
-        if (hilbert) hipLaunchKernelGGL((tick_keys_kernel<1, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd);
-        else hipLaunchKernelGGL((tick_keys_kernel<0, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd);
-        hipLaunchKernelGGL(tick_fold_xcds_kernel, dim3(kNumKeys / 64), dim3(64), 0, s, hist_xcd, xoff, hist);
+        if (hilbert) hipLaunchKernelGGL((tick_keys_kernel<1, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd, check_err ? sorted : nullptr);
+        else hipLaunchKernelGGL((tick_keys_kernel<0, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd, check_err ? sorted : nullptr);
+        hipLaunchKernelGGL(tick_fold_sums_kernel, dim3(kScanBlocks), dim3(64), 0, s, hist_xcd, xoff, hist, block_sums);
     } else {
-        if (hilbert) hipLaunchKernelGGL((tick_keys_kernel<1, 0>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist);
-        else hipLaunchKernelGGL((tick_keys_kernel<0, 0>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist);
+        if (hilbert) hipLaunchKernelGGL((tick_keys_kernel<1, 0>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist, check_err ? sorted : nullptr);
+        else hipLaunchKernelGGL((tick_keys_kernel<0, 0>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist, check_err ? sorted : nullptr);
     }
-    hipLaunchKernelGGL(tick_scan_sums_kernel, dim3(kScanBlocks), dim3(64), 0, s, hist, block_sums);
+    if (!xcd) hipLaunchKernelGGL(tick_scan_sums_kernel, dim3(kScanBlocks), dim3(64), 0, s, hist, block_sums);
     hipLaunchKernelGGL(tick_scan_apply_kernel, dim3(kScanBlocks), dim3(64), 0, s, hist, block_sums, cursor);
     if (xcd) hipLaunchKernelGGL(tick_scatter_xcd_kernel, dim3(kb), dim3(64), 0, s, keys, ranks, nitems, cursor, xoff, sorted);
     else if (use_ranks) hipLaunchKernelGGL(tick_scatter_kernel, dim3(kb), dim3(64), 0, s, keys, ranks, nitems, cursor, sorted);
