@@ -81,6 +81,7 @@ _SIGS = {
     "fgoicp_rccl_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.POINTER(C.c_void_p)]),
     "fgoicp_rccl_exchange": (C.c_int, [C.c_void_p, C.POINTER(Exchange)]),
     "fgoicp_rccl_calls": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "fgoicp_rccl_abort": (C.c_int, [C.c_void_p]),
     "fgoicp_rccl_destroy": (None, [C.c_void_p]),
     "fgoicp_multi_create": (C.c_int, [c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_float, C.c_float, C.POINTER(SolverOpts), c_int_p, C.c_int, C.c_int,
                                       C.POINTER(C.c_void_p)]),

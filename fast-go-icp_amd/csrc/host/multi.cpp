@@ -12,8 +12,11 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -40,6 +43,7 @@ struct fgoicp_rccl {
     size_t cap = 0;                               // floats per rank the buffers hold
     int rank = 0, world = 1, device = 0;
     uint64_t calls = 0;
+    std::atomic<bool> dead{false};                // communicator aborted (fgoicp_rccl_abort): every later collective fails at once
 };
 
 namespace {
@@ -72,6 +76,7 @@ int rccl_reserve(fgoicp_rccl* x, size_t n) {
 
 int rccl_allreduce_min(float* buf, size_t n, void* user) {
     fgoicp_rccl* x = static_cast<fgoicp_rccl*>(user);
+    if (x->dead.load()) { set_error("exchange aborted: another rank failed"); return 1; }
     RCCL_HIP(hipSetDevice(x->device));
     if (rccl_reserve(x, n)) return 1;
     std::memcpy(x->h_pin, buf, sizeof(float) * n);
@@ -79,6 +84,7 @@ int rccl_allreduce_min(float* buf, size_t n, void* user) {
     RCCL_NCCL(ncclAllReduce(x->d_send, x->d_recv, n, ncclFloat, ncclMin, x->comm, x->stream));
     RCCL_HIP(hipMemcpyAsync(x->h_pin, x->d_recv, sizeof(float) * n, hipMemcpyDeviceToHost, x->stream));
     RCCL_HIP(hipStreamSynchronize(x->stream));
+    if (x->dead.load()) { set_error("exchange aborted: another rank failed"); return 1; }
     std::memcpy(buf, x->h_pin, sizeof(float) * n);
     x->calls++;
     return 0;
@@ -86,6 +92,7 @@ int rccl_allreduce_min(float* buf, size_t n, void* user) {
 
 int rccl_allgather(const float* send, float* recv, size_t n, void* user) {
     fgoicp_rccl* x = static_cast<fgoicp_rccl*>(user);
+    if (x->dead.load()) { set_error("exchange aborted: another rank failed"); return 1; }
     RCCL_HIP(hipSetDevice(x->device));
     if (rccl_reserve(x, n)) return 1;
     std::memcpy(x->h_pin, send, sizeof(float) * n);
@@ -93,6 +100,7 @@ int rccl_allgather(const float* send, float* recv, size_t n, void* user) {
     RCCL_NCCL(ncclAllGather(x->d_send, x->d_recv, n, ncclFloat, x->comm, x->stream));
     RCCL_HIP(hipMemcpyAsync(x->h_pin + x->cap, x->d_recv, sizeof(float) * n * x->world, hipMemcpyDeviceToHost, x->stream));
     RCCL_HIP(hipStreamSynchronize(x->stream));
+    if (x->dead.load()) { set_error("exchange aborted: another rank failed"); return 1; }
     std::memcpy(recv, x->h_pin + x->cap, sizeof(float) * n * x->world);
     x->calls++;
     return 0;
@@ -115,8 +123,8 @@ int fgoicp_rccl_unique_id(unsigned char* id128) {
 void fgoicp_rccl_destroy(fgoicp_rccl* x) {
     if (!x) return;
     (void)hipSetDevice(x->device);
-    if (x->stream) (void)hipStreamSynchronize(x->stream);
-    if (x->comm) (void)ncclCommDestroy(x->comm);
+    if (x->stream && !x->dead.load()) (void)hipStreamSynchronize(x->stream);
+    if (x->comm && !x->dead.load()) (void)ncclCommDestroy(x->comm);  // an aborted communicator is already released
     (void)hipFree(x->d_send); (void)hipFree(x->d_recv);
     if (x->h_pin) (void)hipHostFree(x->h_pin);
     if (x->stream) (void)hipStreamDestroy(x->stream);
@@ -146,6 +154,14 @@ int fgoicp_rccl_create(int rank, int world, const unsigned char* id128, int devi
     }
     if (rccl_reserve(x.get(), 64)) { fgoicp_rccl_destroy(x.release()); return FGOICP_ERR_HIP; }
     *out = x.release();
+    return FGOICP_OK;
+}
+
+// Ends every collective in flight on this communicator and fails all later ones: what a rank's owner calls when ANOTHER rank has
+// failed, so that this one does not wait for it for ever.  Callable from any thread, once or more.
+int fgoicp_rccl_abort(fgoicp_rccl* x) {
+    if (!x) return FGOICP_ERR_INVALID_ARG;
+    if (!x->dead.exchange(true) && x->comm) (void)ncclCommAbort(x->comm);
     return FGOICP_OK;
 }
 
@@ -179,9 +195,22 @@ struct Rendezvous {
     std::condition_variable cv;
     int world = 1, arrived = 0;
     uint64_t gen = 0;
+    bool aborted = false;  // a rank failed: nobody waits for it (reset by fgoicp_multi_run)
     std::vector<float> acc[2];
-    void run(size_t total, const std::function<void(std::vector<float>&, bool first)>& contribute, const std::function<void(const std::vector<float>&)>& collect) {
+    void abort() {
+        std::lock_guard<std::mutex> lk(m);
+        aborted = true;
+        cv.notify_all();
+    }
+    void reset() {
+        std::lock_guard<std::mutex> lk(m);
+        aborted = false;
+        arrived = 0;
+    }
+    // false: aborted
+    bool run(size_t total, const std::function<void(std::vector<float>&, bool first)>& contribute, const std::function<void(const std::vector<float>&)>& collect) {
         std::unique_lock<std::mutex> lk(m);
+        if (aborted) return false;
         const uint64_t g = gen;
         std::vector<float>& a = acc[g & 1];
         const bool first = arrived == 0;
@@ -192,9 +221,11 @@ struct Rendezvous {
             ++gen;
             cv.notify_all();
         } else {
-            cv.wait(lk, [&] { return gen != g; });
+            cv.wait(lk, [&] { return gen != g || aborted; });
+            if (gen == g) return false;
         }
         collect(a);
+        return true;
     }
 };
 
@@ -206,6 +237,7 @@ struct RankLink {        // what one rank's exchange callbacks see
     std::vector<std::vector<float>>* log = nullptr;   // results of every exchange, in order
     size_t replay_pos = 0;
     bool replay = false;
+    long fail_at = -1, calls = 0;                 // test hook (FGOICP_MULTI_FAULT = "rank:call"): that exchange of that rank fails
 };
 
 int link_allreduce_min(float* buf, size_t n, void* user) {
@@ -215,11 +247,13 @@ int link_allreduce_min(float* buf, size_t n, void* user) {
         std::memcpy(buf, (*l->log)[l->replay_pos++].data(), sizeof(float) * n);
         return 0;
     }
+    if (l->calls++ == l->fail_at) { set_error("injected exchange fault (FGOICP_MULTI_FAULT)"); return 1; }
     int rc = 0;
     if (l->rv) {
-        l->rv->run(n,
-                   [&](std::vector<float>& a, bool first) { for (size_t i = 0; i < n; ++i) a[i] = first ? buf[i] : (buf[i] < a[i] ? buf[i] : a[i]); },
-                   [&](const std::vector<float>& a) { std::memcpy(buf, a.data(), sizeof(float) * n); });
+        rc = l->rv->run(n,
+                        [&](std::vector<float>& a, bool first) { for (size_t i = 0; i < n; ++i) a[i] = first ? buf[i] : (buf[i] < a[i] ? buf[i] : a[i]); },
+                        [&](const std::vector<float>& a) { std::memcpy(buf, a.data(), sizeof(float) * n); }) ? 0 : 1;
+        if (rc) set_error("exchange aborted: another rank failed");
     } else {
         rc = l->inner.allreduce_min(buf, n, l->inner.user);
     }
@@ -234,11 +268,13 @@ int link_allgather(const float* send, float* recv, size_t n, void* user) {
         std::memcpy(recv, (*l->log)[l->replay_pos++].data(), sizeof(float) * n * l->world);
         return 0;
     }
+    if (l->calls++ == l->fail_at) { set_error("injected exchange fault (FGOICP_MULTI_FAULT)"); return 1; }
     int rc = 0;
     if (l->rv) {
-        l->rv->run(n * (size_t)l->world,
-                   [&](std::vector<float>& a, bool) { std::memcpy(a.data() + n * (size_t)l->rank, send, sizeof(float) * n); },
-                   [&](const std::vector<float>& a) { std::memcpy(recv, a.data(), sizeof(float) * n * l->world); });
+        rc = l->rv->run(n * (size_t)l->world,
+                        [&](std::vector<float>& a, bool) { std::memcpy(a.data() + n * (size_t)l->rank, send, sizeof(float) * n); },
+                        [&](const std::vector<float>& a) { std::memcpy(recv, a.data(), sizeof(float) * n * l->world); }) ? 0 : 1;
+        if (rc) set_error("exchange aborted: another rank failed");
     } else {
         rc = l->inner.allgather(send, recv, n, l->inner.user);
     }
@@ -318,6 +354,10 @@ int fgoicp_multi_create(const float* tgt_xyz, size_t nt, const float* src_xyz, s
         l->rank = r;
         l->world = ndev;
         l->log = &m->logs[r];
+        if (const char* e = std::getenv("FGOICP_MULTI_FAULT")) {
+            int fr = -1; long fc = -1;
+            if (std::sscanf(e, "%d:%ld", &fr, &fc) == 2 && fr == r) l->fail_at = fc;
+        }
         if (ndev > 1 && transport == FGOICP_TRANSPORT_RCCL) fgoicp_rccl_exchange(m->rccl[r], &l->inner);
         else l->rv = &m->rv;
         fgoicp_exchange ex{r, ndev, link_allreduce_min, link_allgather, l.get()};
@@ -346,18 +386,28 @@ int fgoicp_multi_run(fgoicp_multi* m, float* R_out9, float* t_out3) {
     std::vector<int> rcs(n, 0);
     std::vector<std::string> errs(n);
     std::vector<float> R(9 * (size_t)n), t(3 * (size_t)n);
-    for (auto& l : m->links) { l->replay = false; if (l->record) l->log->clear(); }
+    for (auto& l : m->links) { l->replay = false; l->calls = 0; if (l->record) l->log->clear(); }
+    m->rv.reset();
+    std::atomic<int> first_failed{-1};
     std::vector<std::thread> th;
     for (int r = 0; r < n; ++r)
         th.emplace_back([&, r] {
             const auto t0 = std::chrono::steady_clock::now();
             rcs[r] = fgoicp_solver_run(m->solvers[r], &R[9 * (size_t)r], &t[3 * (size_t)r]);
-            if (rcs[r]) errs[r] = fgoicp_last_error();
+            if (rcs[r]) {  // the others would wait for this rank in their next collective for ever: end the exchange for all
+                errs[r] = fgoicp_last_error();
+                int none = -1;
+                first_failed.compare_exchange_strong(none, r);
+                m->rv.abort();
+                for (fgoicp_rccl* x : m->rccl) (void)fgoicp_rccl_abort(x);
+            }
             m->seconds[r] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         });
     for (auto& x : th) x.join();
-    for (int r = 0; r < n; ++r)
-        if (rcs[r]) { set_error("rank " + std::to_string(r) + ": " + errs[r]); return rcs[r]; }
+    if (const int r = first_failed.load(); r >= 0) {  // the rank that failed on its own, not the ones it took down
+        set_error("rank " + std::to_string(r) + ": " + errs[r]);
+        return rcs[r];
+    }
     for (int r = 1; r < n; ++r)
         if (std::memcmp(&R[0], &R[9 * (size_t)r], 36) != 0 || std::memcmp(&t[0], &t[3 * (size_t)r], 12) != 0) {
             set_error("fgoicp_multi_run: ranks ended with different incumbents");

@@ -35,6 +35,10 @@ class RcclExchange:
         _lib.check(self._lib.fgoicp_rccl_calls(self._h, C.byref(n)), "fgoicp_rccl_calls")
         return n.value
 
+    def abort(self):
+        """A peer rank failed: end the collective in flight here and fail every later one (fgoicp_rccl_abort)."""
+        _lib.check(self._lib.fgoicp_rccl_abort(self._h), "fgoicp_rccl_abort")
+
     def warmup(self):
         a = (C.c_float * 2)(1.0, 2.0)
         r = (C.c_float * (2 * self.world))()

@@ -246,6 +246,10 @@ int fgoicp_rccl_unique_id(unsigned char* id128);
 int fgoicp_rccl_create(int rank, int world_size, const unsigned char* id128, int device, fgoicp_rccl** out);
 int fgoicp_rccl_exchange(fgoicp_rccl* x, fgoicp_exchange* out);   /* `out` borrows x: keep x alive while a solver uses it */
 int fgoicp_rccl_calls(const fgoicp_rccl* x, uint64_t* collectives);
+/* Ends the collective in flight on x (ncclCommAbort) and fails every later one at once.  For the owner of a rank whose PEER has
+ * failed: without it this rank would wait for the peer in its next collective for ever.  Any thread; x stays valid until
+ * fgoicp_rccl_destroy but cannot be used for another run. */
+int fgoicp_rccl_abort(fgoicp_rccl* x);
 void fgoicp_rccl_destroy(fgoicp_rccl* x);
 
 /* One process, one host thread + one solver per device — what `fast-go-icp --gpus N` runs.  devices[r] = HIP ordinal of rank r.
@@ -256,7 +260,9 @@ enum { FGOICP_TRANSPORT_RCCL = 0, FGOICP_TRANSPORT_IN_PROCESS = 1 };
 int fgoicp_multi_create(const float* tgt_xyz, size_t nt, const float* src_xyz, size_t ns, float lut_resolution, float mse_threshold,
                         const fgoicp_solver_opts* opts, const int* devices, int ndev, int transport, fgoicp_multi** out);
 void fgoicp_multi_destroy(fgoicp_multi* m);
-/* FastGoICP::run() on all ranks at once; R, t as fgoicp_solver_run (every rank ends with the same incumbent — checked). */
+/* FastGoICP::run() on all ranks at once; R, t as fgoicp_solver_run (every rank ends with the same incumbent — checked).
+ * If a rank fails, the exchange is aborted for all of them (nobody waits for the failed rank) and the call returns that rank's
+ * status and message; with the RCCL transport the object cannot run again afterwards. */
 int fgoicp_multi_run(fgoicp_multi* m, float* R_out9, float* t_out3);
 int fgoicp_multi_world(const fgoicp_multi* m);
 fgoicp_solver* fgoicp_multi_solver(fgoicp_multi* m, int rank);     /* borrowed: stats, getters */

@@ -107,7 +107,7 @@ def test_invalid_arguments_are_refused_before_any_device_work(fg):
     ident = (C.c_ubyte * 128)()
     assert lib.fgoicp_rccl_create(0, 1, None, 0, C.byref(h)) == 1 and not h.value
     assert lib.fgoicp_rccl_create(2, 2, ident, 0, C.byref(h)) == 1 and lib.fgoicp_rccl_create(0, 0, ident, 0, C.byref(h)) == 1
-    assert lib.fgoicp_rccl_exchange(None, None) == 1 and lib.fgoicp_rccl_calls(None, None) == 1
+    assert lib.fgoicp_rccl_exchange(None, None) == 1 and lib.fgoicp_rccl_calls(None, None) == 1 and lib.fgoicp_rccl_abort(None) == 1
     pts = np.zeros((4, 3), np.float32)
     fp = pts.ctypes.data_as(fg._lib.c_float_p)
     assert lib.fgoicp_multi_create(fp, 4, fp, 4, 0.1, 1e-3, None, None, 0, fg.TRANSPORT_RCCL, C.byref(h)) == 1

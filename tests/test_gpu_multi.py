@@ -43,6 +43,36 @@ def test_ranks_on_one_gpu_reach_the_single_gpu_optimum(fg, gpu_required, world):
     m.close()
 
 
+def test_a_failing_rank_ends_the_run_for_all_ranks(fg, gpu_required, monkeypatch):
+    """One rank's exchange fails mid-run (FGOICP_MULTI_FAULT = "rank:call", a test hook): the others must not wait for it in
+    their next collective; the call returns that rank's error and the same object runs cleanly afterwards."""
+    tgt, src, _, _ = fg.synth.workload("small", angle_deg=150.0, min_angle_deg=110.0)
+    monkeypatch.setenv("FGOICP_MULTI_FAULT", "1:3")
+    m = fg.MultiGoICP(tgt, src, 0.01, 2e-4, devices=[0, 0, 0], transport=fg.TRANSPORT_IN_PROCESS)
+    monkeypatch.delenv("FGOICP_MULTI_FAULT")
+    with pytest.raises(fg.FgoicpError, match=r"rank 1: .*exchange callback failed"):
+        m.run()
+    m.close()
+    ok = fg.MultiGoICP(tgt, src, 0.01, 2e-4, devices=[0, 0, 0], transport=fg.TRANSPORT_IN_PROCESS)
+    ok.run()
+    e = ok.get_best_error()
+    ok.close()
+    one = fg.FastGoICP(tgt, src, 0.01, 2e-4, schedule=fg.SCHEDULE_ROUND, round_width=0)
+    one.run()
+    assert abs(one.get_best_error() - e) <= 1e-5 * e
+    one.close()
+
+
+def test_rccl_abort_fails_later_collectives(fg, gpu_required):
+    ex = fg.RcclExchange(0, 1, fg.rccl_unique_id(), 0)
+    assert ex.warmup()
+    ex.abort(); ex.abort()  # idempotent
+    buf = (C.c_float * 1)(1.0)
+    assert ex.struct.allreduce_min(buf, 1, ex.struct.user) != 0
+    assert b"aborted" in fg._lib.load().fgoicp_last_error()
+    ex.close()
+
+
 def test_rccl_transport_with_one_rank(fg, gpu_required):
     """ncclCommInitRank + all-reduce(min) + all-gather on device buffers (world size 1 is all a one-GPU box can form)."""
     ident = fg.rccl_unique_id()
