@@ -39,6 +39,8 @@ int ctx_flush_profile(fgoicp_ctx* c) {
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, c->ev_start[i], c->ev_stop[i]));
         c->prof_ms += ms;
+        static const bool tick_log = std::getenv("FGOICP_TICK_LOG") != nullptr;  // debugging aid: one line per bounds launch on stderr
+        if (tick_log && i < (int)c->ev_evals.size()) std::fprintf(stderr, "[tick] evals %d us %.1f\n", c->ev_evals[i], ms * 1e3);
         if (c->ev_has_sel[i]) {  // trimmed mode: the selection kernel of the same window (side stream)
             HIPCHK(hipEventSynchronize(c->ev_sel_stop[i]));
             HIPCHK(hipEventElapsedTime(&ms, c->ev_sel_start[i], c->ev_sel_stop[i]));
@@ -102,6 +104,8 @@ static int tick_launch_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
         }
         e0 = c->ev_start[c->ev_used];
         e1 = c->ev_stop[c->ev_used];
+        if ((int)c->ev_evals.size() <= c->ev_used) c->ev_evals.resize(c->ev_start.size(), 0);
+        c->ev_evals[c->ev_used] = neval;
         c->ev_used++;
         c->prof_launches++;
         c->prof_subcubes += rows;

@@ -108,6 +108,7 @@ struct fgoicp_ctx {
     // HIP-event profile of the bounds kernel
     std::vector<hipEvent_t> ev_start, ev_stop, ev_sel_start, ev_sel_stop;   // bounds kernel / trimmed selection kernel of the same window
     std::vector<char> ev_has_sel;
+    std::vector<int> ev_evals;          // evaluations of the launch an event pair brackets (FGOICP_TICK_LOG)
     double prof_sel_ms = 0.0, prof_sel_ms_last = 0.0;
     int ev_used = 0;
     double prof_ms = 0.0;

@@ -1814,8 +1814,9 @@ void launch_bounds_sorted(const float4* src, int ns, const float* lut, const flo
     const dim3 grid((unsigned)nitems);
     static const int wpg = [] { const char* e = std::getenv("FGOICP_ITEMS_PER_WG"); return e ? std::atoi(e) : 1; }();   // tuning knob: 1, 2 or 4 one-wave items per workgroup
     static const int nt_src = [] { const char* e = std::getenv("FGOICP_NT_SOURCE"); return e ? std::atoi(e) : 0; }();   // tuning knob: non-temporal source loads
+    static const unsigned lds_pad = [] { const char* e = std::getenv("FGOICP_LDS_PAD"); return e ? (unsigned)std::atoi(e) : 0u; }();  // tuning knob: unused dynamic LDS per workgroup = fewer resident waves per CU
 #define FGOICP_LAUNCH_SORTED(T, PP, Z, TR) \
-    hipLaunchKernelGGL((bounds_sorted_kernel<T, PP, Z, TR>), grid, dim3(T), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, chunk_pts, partials, evals, erow, (unsigned)nitems)
+    hipLaunchKernelGGL((bounds_sorted_kernel<T, PP, Z, TR>), grid, dim3(T), lds_pad, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, chunk_pts, partials, evals, erow, (unsigned)nitems)
 #define FGOICP_LAUNCH_WPG(Z, W, N) \
     hipLaunchKernelGGL((bounds_sorted_kernel<64, 4, Z, 0, W, N>), dim3((unsigned)((nitems + W - 1) / W)), dim3(64 * W), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, chunk_pts, partials, evals, erow, (unsigned)nitems)
     if (!evals && variant == 2 && (wpg > 1 || nt_src)) {  // experimental variants of the default 64 x 4 kernel
