@@ -730,8 +730,13 @@ private:
     bool prepare_half(Half& h, std::vector<Task*>& tasks, const std::vector<const RotCube*>& cubes, bool par, bool twins_honoured) {
         const bool memo_on = use_memo_ && use_twins_ && twins_honoured;  // phantom rows cost nothing only where the twin hint is used
         const auto tp0 = clock::now();
+        // ROUND, tail of a round: a few long-running tasks are left and every tick is a latency-bound device round trip that fills a
+        // fraction of the GPU.  Such a half takes bigger batches (the extra nodes are the next-best of the task's own queue: some
+        // would have been pruned by the results of the batch before — paid with idle capacity — and the round ends in fewer ticks).
+        const size_t tail_cap = (tail_batch_ && h.members.size() <= tail_tasks_) ? tail_batch_ : 0;
         const std::function<void(size_t)> pop_fn = [&](size_t k) {
             Task& tk = *tasks[h.members[k]];
+            if (tk.batch_cap != 32) tk.batch_cap = tail_cap ? tail_cap : round_batch_;  // SERIAL tasks keep the reference's 32 (fgoicp.cpp:122)
             tk.has_batch = false;
             tk.phantom.clear();
             if (tk.done) return;
@@ -771,19 +776,19 @@ private:
             Task &ub = *tasks[h.live[pairs[q]]], &lb = *tasks[h.live[pairs[q] + 1]];
             auto& tw = h.pair_twins[q];
             const size_t n0 = ub.batch.size(), n1 = lb.batch.size();
-            if (n0 > 64 || n1 > 64) return;  // batches hold <= 32 nodes (fgoicp.cpp:122); the table below assumes it
-            int table[128];
+            if (n0 > 128 || n1 > 128) return;  // batches hold <= 128 nodes (32 in the reference, fgoicp.cpp:122); the table below assumes it
+            int table[256];
             for (int& x : table) x = -1;
             for (size_t j = 0; j < n1; ++j) {
                 if (lb.brow[j] < 0) continue;
-                uint32_t sl = (uint32_t)NodeKeyHash()(node_key(lb.batch[j])) & 127u;
-                while (table[sl] >= 0) sl = (sl + 1) & 127u;
+                uint32_t sl = (uint32_t)NodeKeyHash()(node_key(lb.batch[j])) & 255u;
+                while (table[sl] >= 0) sl = (sl + 1) & 255u;
                 table[sl] = (int)j;
             }
             for (size_t i = 0; i < n0; ++i) {
                 const NodeKey ki = node_key(ub.batch[i]);
                 int hit = -1;
-                for (uint32_t sl = (uint32_t)NodeKeyHash()(ki) & 127u; table[sl] >= 0; sl = (sl + 1) & 127u)
+                for (uint32_t sl = (uint32_t)NodeKeyHash()(ki) & 255u; table[sl] >= 0; sl = (sl + 1) & 255u)
                     if (node_key(lb.batch[(size_t)table[sl]]) == ki) { hit = table[sl]; break; }
                 if (hit >= 0) tw.push_back({ub.brow[i], lb.brow[(size_t)hit]});
                 else if (memo_on && !lb.memo.find(ki)) {
@@ -954,6 +959,8 @@ private:
     const bool timing_ = std::getenv("FGOICP_TIMING") != nullptr;  // host-side timing lines on stderr
     bool use_twins_ = [] { const char* e = std::getenv("FGOICP_TWINS"); return !e || std::atoi(e) != 0; }();  // tuning knob
     const size_t round_batch_ = [] { const char* e = std::getenv("FGOICP_ROUND_BATCH"); const int v = e ? std::atoi(e) : 48; return (size_t)(v >= 8 && v <= 64 ? v : 48); }();  // tuning knob (ROUND only; SERIAL keeps the reference's 32)
+    const size_t tail_batch_ = [] { const char* e = std::getenv("FGOICP_TAIL_BATCH"); const int v = e ? std::atoi(e) : 128; return (size_t)(v >= 8 && v <= 128 ? v : 0); }();  // tuning knob (ROUND): batch of a half with few tasks left (0 = off)
+    const size_t tail_tasks_ = [] { const char* e = std::getenv("FGOICP_TAIL_TASKS"); const int v = e ? std::atoi(e) : 32; return (size_t)(v >= 0 ? v : 32); }();  // ... "few" = at most this many
     bool use_memo_ = [] { const char* e = std::getenv("FGOICP_MEMO"); return !e || std::atoi(e) != 0; }();    // tuning knob: memo of the twin task's evaluations
     const bool overlap_stats_ = std::getenv("FGOICP_OVERLAP_STATS") != nullptr;  // diagnostic: how many nodes both tasks of a rotation cube evaluate
     uint64_t ov_ub_ = 0, ov_lb_ = 0, ov_both_ = 0;
