@@ -381,8 +381,14 @@ int ctx_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out, con
 
 // IterativeClosestPoint3D::procrustes() on L.d_work — icp3d.cu:140-172.  The device half (enqueue only): correspondences
 // into `idx`, centroids and covariance into pinned memory; `wide` is the selection scratch of the trimmed variant.
-static int procrustes_enqueue(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const uint32_t* seed_idx, uint32_t* idx, uint32_t* wide, hipStream_t st) {
+// move9 / move3 (optional): the working cloud is first moved by this (R_, t_) — icp3d.cu:100 of the iteration before — inside the
+// correspondence scan where that is possible (one launch less on the iteration's critical chain), by its own kernel otherwise.
+static int procrustes_enqueue(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const uint32_t* seed_idx, uint32_t* idx, uint32_t* wide, hipStream_t st,
+                              const float* move9 = nullptr, const float* move3 = nullptr) {
     const int ns = (int)c->ns, nt = (int)c->nt;
+    static const bool fold_move = [] { const char* e = std::getenv("FGOICP_ICP_FOLD_MOVE"); return !e || std::atoi(e) != 0; }();  // tuning knob / A-B
+    const bool fold = move9 && fold_move && !c->brute_force_nn && !(c->inliers && c->trim_skip);
+    if (move9 && !fold) launch_transform_inplace(L.d_work, ns, move9, move3, st);
     // kernFindNearestNeighbor (icp3d.cu:11-28): min distance, tie set, lowest index
     if (c->brute_force_nn) {
         launch_fill_u32(L.d_min_bits, 0x501502F9u, c->ns, st);
@@ -399,7 +405,8 @@ static int procrustes_enqueue(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const uint3
             skip_lb = L.d_nn_lb2;
             skip_u = L.d_sel + 4;
         }
-        launch_nn_scan(L.d_work, ns, c->bvh_tgt.view(), c->d_lut, c->geom, nullptr, nullptr, 0, 1, c->d_tgt, nt, seed_idx, skip_lb, skip_u, idx, st);
+        launch_nn_scan(L.d_work, ns, c->bvh_tgt.view(), c->d_lut, c->geom, fold ? move9 : nullptr, fold ? move3 : nullptr, fold ? 1 : 0, 1, c->d_tgt, nt, seed_idx, skip_lb,
+                       skip_u, idx, st, fold ? L.d_work : nullptr);
     }
     const int nb = reduce_blocks_for(ns);
     const unsigned char* use = nullptr;
@@ -409,6 +416,8 @@ static int procrustes_enqueue(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const uint3
         use = L.d_use;
         ncount = (int)c->inliers;
     }
+    // (Folding the block partials in the grid's last block instead of a follow-up one-block kernel — the threadfence reduction —
+    // was measured and lost, 62 -> 91 us per iteration: an agent-scope fence per block writes back the XCD's L2 on this 8-XCD part.)
     launch_icp_sums(L.d_work, c->d_tgt, idx, ns, nt, use, L.d_bp, nb, st);
     launch_icp_centroids(L.d_bp, nb, ncount, L.d_cen, L.hd_cen, st);  // icp3d.cu:152-156, no host round trip
     launch_icp_cov(L.d_work, c->d_tgt, idx, ns, nt, L.d_cen, use, L.d_bp2, nb, st);
@@ -487,25 +496,29 @@ static int lane_icp(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0, cons
             if (rc) return rc;
         }
         const float tn3[3] = {tn.x, tn.y, tn.z};
-        launch_transform_inplace(L.d_work, ns, Rn.m, tn3, A);  // :100
         R = Rn * R;                                              // :101
         t = Rn * t + tn;                                         // :102
         const float t3[3] = {t.x, t.y, t.z};
         if (overlap) {
-            HIPCHK(hipEventRecord(L.icp_ev_w, A));
-            int rc = sse_enqueue(c, L, R.m, t3, seeding ? idx[cur] : nullptr, A);  // :103
-            if (rc) return rc;
-            if (iter < max_iter) {  // the next iteration's pass, next to this iteration's SSE
-                HIPCHK(hipStreamWaitEvent(B, L.icp_ev_w, 0));
-                rc = procrustes_enqueue(c, L, seeding ? idx[cur] : nullptr, idx[cur ^ 1], L.d_sel_wide2, B);
+            // The working cloud and the next iteration's pass are the critical path (transform -> correspondences -> sums -> host):
+            // they go to the side stream FIRST; this iteration's SSE, which needs nothing but (R, t), is enqueued behind them on the
+            // main stream.  (Enqueued after the SSE chain, the correspondence scan started 25 us late: five launches of host time.)
+            const uint32_t* seed = seeding ? idx[cur] : nullptr;  // the pass the host has just consumed
+            if (iter < max_iter) {  // the next iteration's pass (it moves the cloud first, :100), next to this iteration's SSE
+                int rc = procrustes_enqueue(c, L, seed, idx[cur ^ 1], L.d_sel_wide2, B, Rn.m, tn3);
                 if (rc) return rc;
-                HIPCHK(hipEventRecord(L.icp_ev_b, B));
-                chain_pending = true;
                 cur ^= 1;
+            } else {
+                launch_transform_inplace(L.d_work, ns, Rn.m, tn3, B);  // :100 (B is in order behind the pass that read d_work)
             }
+            HIPCHK(hipEventRecord(L.icp_ev_b, B));
+            chain_pending = true;
+            int rc = sse_enqueue(c, L, R.m, t3, seed, A);  // :103
+            if (rc) return rc;
             HIPCHK(hipStreamSynchronize(A));
             sse = sse_result(c, L);
         } else {
+            launch_transform_inplace(L.d_work, ns, Rn.m, tn3, A);  // :100
             int rc = lane_sse(c, L, R.m, t3, &sse, seeding ? L.d_first_idx : nullptr);  // :103
             if (rc) return rc;
         }

@@ -1497,9 +1497,10 @@ __global__ __launch_bounds__(kBlock) void nn_prep_kernel(const float4* __restric
 constexpr int kMaxParts = 16;
 
 template <int WANT_INDEX>
-__global__ __launch_bounds__(64 * kMaxParts) void nn_scan_kernel(const float4* __restrict__ pts, int n, BvhView t, const float* __restrict__ lut,
+__global__ __launch_bounds__(64 * kMaxParts) void nn_scan_kernel(const float4* pts, int n, BvhView t, const float* __restrict__ lut,
                                                                  LutGeom g, Rt rt, int apply, const float4* __restrict__ tgt, int nt,
-                                                                 const uint32_t* seed_idx, const float* __restrict__ skip_lb, const uint32_t* __restrict__ skip_u, uint32_t* out) {
+                                                                 const uint32_t* seed_idx, const float* __restrict__ skip_lb, const uint32_t* __restrict__ skip_u, uint32_t* out,
+                                                                 float4* writeback) {
     __shared__ uint32_t comb[kMaxParts][64];
     __shared__ uint32_t comb_i[WANT_INDEX ? kMaxParts : 1][64];
     __shared__ uint32_t comb_2[WANT_INDEX ? kMaxParts : 1][64];
@@ -1607,6 +1608,10 @@ __global__ __launch_bounds__(64 * kMaxParts) void nn_scan_kernel(const float4* _
         result = idx;
     }
     if (active && part == 0) out[i] = result;
+    // ICP: the queries are the working cloud moved by this iteration's (R_, t_) — kernRotateTranslateInplace (icp3d.cu:30-36, :100)
+    // folded into the pass that needs its result first; the moved points go back to the cloud (`writeback` may be `pts`: every
+    // wave of the block read its point before the barriers above, only wave 0 writes).
+    if (writeback && part == 0 && i < n) writeback[i] = make_float4(qx, qy, qz, p.w);
 }
 
 // buildLUTKernel (registration.cu:258-278) through the box scan of the shifted targets, coarse to fine:
@@ -1922,7 +1927,8 @@ void launch_nn_first_index(const float4* pts, int n, const float4* tgt, int nt, 
 }
 
 void launch_nn_scan(const float4* pts, int n, const BvhView& t, const float* lut, const LutGeom& g, const float* R9, const float* t3, int apply,
-                    int want_index, const float4* tgt, int nt, const uint32_t* seed_idx, const float* skip_lb, const uint32_t* skip_u, uint32_t* out, hipStream_t s) {
+                    int want_index, const float4* tgt, int nt, const uint32_t* seed_idx, const float* skip_lb, const uint32_t* skip_u, uint32_t* out, hipStream_t s,
+                    float4* writeback) {
     const int groups = (n + 63) / 64;
     // waves per 64 queries.  The scan is a chain of dependent steps per wave (boxes -> leaf boxes -> points), so its run time is
     // that chain's latency: splitting the candidate leaves of a query group over 4-8 waves shortens the chain even when the
@@ -1931,8 +1937,8 @@ void launch_nn_scan(const float4* pts, int n, const BvhView& t, const float* lut
     while (nparts < 8 && groups * nparts < 4096) nparts <<= 1;
     static const int forced = [] { const char* e = std::getenv("FGOICP_NN_PARTS"); const int v = e ? std::atoi(e) : 0; return v; }();  // tuning knob
     if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16) nparts = forced;
-    if (want_index) hipLaunchKernelGGL(nn_scan_kernel<1>, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, skip_lb, skip_u, out);
-    else hipLaunchKernelGGL(nn_scan_kernel<0>, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, skip_lb, skip_u, out);
+    if (want_index) hipLaunchKernelGGL(nn_scan_kernel<1>, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, skip_lb, skip_u, out, writeback);
+    else hipLaunchKernelGGL(nn_scan_kernel<0>, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, skip_lb, skip_u, out, writeback);
 }
 
 void launch_nn_prep(const float4* pts, int n, const float* lut, const LutGeom& g, const float* R9, const float* t3, int apply, const float4* tgt, int nt,

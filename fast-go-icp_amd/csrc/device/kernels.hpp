@@ -111,7 +111,8 @@ void launch_nn_first_index(const float4* pts, int n, const float4* tgt, int nt, 
 // previous ICP pass; its distance tightens the pruning bound, the result is the same exact minimum.
 void launch_nn_scan(const float4* pts, int n, const BvhView& t, const float* lut, const LutGeom& g, const float* R9, const float* t3, int apply,
                     int want_index, const float4* tgt, int nt, const uint32_t* seed_idx,
-                    const float* skip_lb /* optional (trimmed): queries with skip_lb[i] > float(skip_u[0]) are left out */, const uint32_t* skip_u, uint32_t* out, hipStream_t s);
+                    const float* skip_lb /* optional (trimmed): queries with skip_lb[i] > float(skip_u[0]) are left out */, const uint32_t* skip_u, uint32_t* out, hipStream_t s,
+                    float4* writeback = nullptr /* optional, with apply: the moved queries are stored here (may be `pts`: kernRotateTranslateInplace folded in) */);
 // EXTENSION (trimmed Go-ICP): per query a rigorous bracket [lb, ub] of its nearest squared distance from the LUT (kernels.hip, nn_prep_kernel);
 // box6 = the target's bounding box {minx,maxx,miny,maxy,minz,maxz}
 void launch_nn_prep(const float4* pts, int n, const float* lut, const LutGeom& g, const float* R9, const float* t3, int apply, const float4* tgt, int nt,
