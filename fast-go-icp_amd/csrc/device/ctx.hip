@@ -339,9 +339,12 @@ int ctx_bounds_multi(fgoicp_ctx* c, int G, const float* R9, const float* rot_spa
 
 // float Registration::compute_sse_error(glm::mat3, glm::vec3) — registration.cu:62-86.  Enqueue only: the result lands in
 // pinned memory (sse_result) once `st` has drained.
-static int sse_enqueue(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R9, const float* t3, const uint32_t* seed_idx, hipStream_t st) {
+// `part`: 0 = everything, 1 = the search only, 2 = the sum only (the ICP loop interleaves the launches of its two streams: both long
+// scans first — a launch costs the submitting thread ~5 us, and whatever is enqueued last starts that much later).
+static int sse_enqueue(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R9, const float* t3, const uint32_t* seed_idx, hipStream_t st, int part = 0) {
     const int ns = (int)c->ns;
-    if (c->brute_force_nn) {
+    if (part == 2) {
+    } else if (c->brute_force_nn) {
         launch_fill_u32(L.d_min_bits, 0x501502F9u /* bits(1e10f) */, c->ns, st);
         launch_nn_min(c->d_src, ns, c->d_tgt, (int)c->nt, R9, t3, 1, L.d_min_bits, st);
     } else {
@@ -355,7 +358,8 @@ static int sse_enqueue(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R9, c
         }
         launch_nn_scan(c->d_src, ns, c->bvh_tgt.view(), c->d_lut, c->geom, R9, t3, 1, 0, c->d_tgt, (int)c->nt, seed_idx, skip_lb, skip_u, L.d_min_bits, st);
     }
-    if (c->inliers) {  // trimmed SSE: the k smallest nearest-neighbour terms
+    if (part == 1) {
+    } else if (c->inliers) {  // trimmed SSE: the k smallest nearest-neighbour terms
         launch_trim_select(reinterpret_cast<const float*>(L.d_min_bits), ns, (int)c->inliers, L.hd_trim, nullptr, L.d_sel_wide, st);
     } else {
         const int nb = reduce_blocks_for(ns);
@@ -383,31 +387,35 @@ int ctx_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out, con
 // into `idx`, centroids and covariance into pinned memory; `wide` is the selection scratch of the trimmed variant.
 // move9 / move3 (optional): the working cloud is first moved by this (R_, t_) — icp3d.cu:100 of the iteration before — inside the
 // correspondence scan where that is possible (one launch less on the iteration's critical chain), by its own kernel otherwise.
+// `part` as for sse_enqueue: 1 = up to and including the correspondence search, 2 = the inlier cut and the sums.
 static int procrustes_enqueue(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const uint32_t* seed_idx, uint32_t* idx, uint32_t* wide, hipStream_t st,
-                              const float* move9 = nullptr, const float* move3 = nullptr) {
+                              const float* move9 = nullptr, const float* move3 = nullptr, int part = 0) {
     const int ns = (int)c->ns, nt = (int)c->nt;
-    static const bool fold_move = [] { const char* e = std::getenv("FGOICP_ICP_FOLD_MOVE"); return !e || std::atoi(e) != 0; }();  // tuning knob / A-B
-    const bool fold = move9 && fold_move && !c->brute_force_nn && !(c->inliers && c->trim_skip);
-    if (move9 && !fold) launch_transform_inplace(L.d_work, ns, move9, move3, st);
-    // kernFindNearestNeighbor (icp3d.cu:11-28): min distance, tie set, lowest index
-    if (c->brute_force_nn) {
-        launch_fill_u32(L.d_min_bits, 0x501502F9u, c->ns, st);
-        launch_fill_u32(idx, 0x7fffffffu, c->ns, st);
-        launch_nn_min(L.d_work, ns, c->d_tgt, nt, nullptr, nullptr, 0, L.d_min_bits, st);
-        launch_nn_tie_threshold(L.d_min_bits, ns, L.d_thr_bits, st);
-        launch_nn_first_index(L.d_work, ns, c->d_tgt, nt, L.d_thr_bits, idx, st);
-    } else {
-        const float* skip_lb = nullptr;
-        const uint32_t* skip_u = nullptr;
-        if (c->inliers && c->trim_skip) {  // trimmed: points provably outside the inlier set get no correspondence
-            launch_nn_prep(L.d_work, ns, c->d_lut, c->geom, nullptr, nullptr, 0, c->d_tgt, nt, seed_idx, c->bounds6, L.d_nn_ub2, L.d_nn_lb2, st);
-            launch_trim_select(L.d_nn_ub2, ns, (int)c->inliers, nullptr, L.d_sel + 4, wide, st);
-            skip_lb = L.d_nn_lb2;
-            skip_u = L.d_sel + 4;
+    if (part != 2) {
+        static const bool fold_move = [] { const char* e = std::getenv("FGOICP_ICP_FOLD_MOVE"); return !e || std::atoi(e) != 0; }();  // tuning knob / A-B
+        const bool fold = move9 && fold_move && !c->brute_force_nn && !(c->inliers && c->trim_skip);
+        if (move9 && !fold) launch_transform_inplace(L.d_work, ns, move9, move3, st);
+        // kernFindNearestNeighbor (icp3d.cu:11-28): min distance, tie set, lowest index
+        if (c->brute_force_nn) {
+            launch_fill_u32(L.d_min_bits, 0x501502F9u, c->ns, st);
+            launch_fill_u32(idx, 0x7fffffffu, c->ns, st);
+            launch_nn_min(L.d_work, ns, c->d_tgt, nt, nullptr, nullptr, 0, L.d_min_bits, st);
+            launch_nn_tie_threshold(L.d_min_bits, ns, L.d_thr_bits, st);
+            launch_nn_first_index(L.d_work, ns, c->d_tgt, nt, L.d_thr_bits, idx, st);
+        } else {
+            const float* skip_lb = nullptr;
+            const uint32_t* skip_u = nullptr;
+            if (c->inliers && c->trim_skip) {  // trimmed: points provably outside the inlier set get no correspondence
+                launch_nn_prep(L.d_work, ns, c->d_lut, c->geom, nullptr, nullptr, 0, c->d_tgt, nt, seed_idx, c->bounds6, L.d_nn_ub2, L.d_nn_lb2, st);
+                launch_trim_select(L.d_nn_ub2, ns, (int)c->inliers, nullptr, L.d_sel + 4, wide, st);
+                skip_lb = L.d_nn_lb2;
+                skip_u = L.d_sel + 4;
+            }
+            launch_nn_scan(L.d_work, ns, c->bvh_tgt.view(), c->d_lut, c->geom, fold ? move9 : nullptr, fold ? move3 : nullptr, fold ? 1 : 0, 1, c->d_tgt, nt, seed_idx, skip_lb,
+                           skip_u, idx, st, fold ? L.d_work : nullptr);
         }
-        launch_nn_scan(L.d_work, ns, c->bvh_tgt.view(), c->d_lut, c->geom, fold ? move9 : nullptr, fold ? move3 : nullptr, fold ? 1 : 0, 1, c->d_tgt, nt, seed_idx, skip_lb,
-                       skip_u, idx, st, fold ? L.d_work : nullptr);
     }
+    if (part == 1) { HIPCHK(hipGetLastError()); return FGOICP_OK; }
     const int nb = reduce_blocks_for(ns);
     const unsigned char* use = nullptr;
     int ncount = ns;
@@ -504,16 +512,21 @@ static int lane_icp(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0, cons
             // they go to the side stream FIRST; this iteration's SSE, which needs nothing but (R, t), is enqueued behind them on the
             // main stream.  (Enqueued after the SSE chain, the correspondence scan started 25 us late: five launches of host time.)
             const uint32_t* seed = seeding ? idx[cur] : nullptr;  // the pass the host has just consumed
-            if (iter < max_iter) {  // the next iteration's pass (it moves the cloud first, :100), next to this iteration's SSE
-                int rc = procrustes_enqueue(c, L, seed, idx[cur ^ 1], L.d_sel_wide2, B, Rn.m, tn3);
+            const bool next = iter < max_iter;  // the next iteration's pass (it moves the cloud first, :100), next to this iteration's SSE
+            int rc = FGOICP_OK;
+            if (next) rc = procrustes_enqueue(c, L, seed, idx[cur ^ 1], L.d_sel_wide2, B, Rn.m, tn3, 1);
+            else launch_transform_inplace(L.d_work, ns, Rn.m, tn3, B);  // :100 (B is in order behind the pass that read d_work)
+            if (rc) return rc;
+            rc = sse_enqueue(c, L, R.m, t3, seed, A, 1);  // :103
+            if (rc) return rc;
+            if (next) {
+                rc = procrustes_enqueue(c, L, seed, idx[cur ^ 1], L.d_sel_wide2, B, nullptr, nullptr, 2);
                 if (rc) return rc;
                 cur ^= 1;
-            } else {
-                launch_transform_inplace(L.d_work, ns, Rn.m, tn3, B);  // :100 (B is in order behind the pass that read d_work)
             }
             HIPCHK(hipEventRecord(L.icp_ev_b, B));
             chain_pending = true;
-            int rc = sse_enqueue(c, L, R.m, t3, seed, A);  // :103
+            rc = sse_enqueue(c, L, R.m, t3, seed, A, 2);
             if (rc) return rc;
             HIPCHK(hipStreamSynchronize(A));
             sse = sse_result(c, L);
