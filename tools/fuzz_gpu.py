@@ -31,9 +31,14 @@ def make_cloud(rng, n, box, kind):
     return (p * box[None, :]).astype(f32)
 
 
+SCALE = int(os.environ.get("FUZZ_SCALE", "1"))  # > 1: clouds SCALE times larger (several windows per tick, long rows)
+
+
 def one_case(rng, idx):
     nt = int(rng.choice([1, 2, 31, 32, 33, 64, 100, 255, 257, 1000, 2049, 6000])) if rng.random() < 0.5 else int(rng.integers(1, 4000))
     ns = int(rng.choice([1, 2, 3, 63, 64, 65, 255, 256, 257, 511, 1025, 4097])) if rng.random() < 0.5 else int(rng.integers(1, 5000))
+    if SCALE > 1:
+        nt, ns = nt * SCALE + int(rng.integers(0, SCALE)), ns * SCALE + int(rng.integers(0, SCALE))
     box = rng.uniform(0.15, 0.9, 3)
     tgt = make_cloud(rng, nt, box, int(rng.integers(0, 3)))
     src = (make_cloud(rng, ns, box, int(rng.integers(0, 3))) * f32(rng.uniform(0.5, 1.0))).astype(f32)
