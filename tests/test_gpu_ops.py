@@ -324,10 +324,10 @@ def test_icp_two_stream_loop_is_bit_identical_to_the_one_stream_loop(fg, gpu_req
         monkeypatch.setenv("FGOICP_ICP_OVERLAP", mode)
         reg = fg.Registration(pct, pcs, bounds, res)
         runs = []
-        for thr, ang in ((0.05, 40.0), (0.005, 15.0), (0.0005, 3.0)):
+        for thr, ang, max_iter in ((0.05, 40.0, 100), (0.005, 15.0, 100), (0.0005, 3.0, 100), (0.0, 25.0, 3)):  # the last one ends on max_iter
             R0 = fg.synth.random_rotation(np.random.default_rng(int(ang)), ang).astype(np.float32)
             t0 = np.array([0.01, -0.02, 0.005], np.float32)
-            icp = fg.IterativeClosestPoint3D(reg, None, None, 100, thr, R0, t0)
+            icp = fg.IterativeClosestPoint3D(reg, None, None, max_iter, thr, R0, t0)
             sse, R, t = icp.run()
             runs.append((np.float32(sse).view(np.uint32), R.copy(), t.copy(), icp.iterations))
         # a Procrustes step and an SSE after ICP runs: the scratch buffers are back in a consistent state
@@ -336,9 +336,10 @@ def test_icp_two_stream_loop_is_bit_identical_to_the_one_stream_loop(fg, gpu_req
         runs.append(np.float32(reg.compute_sse_error(R, t)).view(np.uint32))
         out[mode] = runs
         reg.close()
-    for a, b in zip(out["1"][:3], out["0"][:3]):
+    for a, b in zip(out["1"][:4], out["0"][:4]):
         assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
-    assert np.array_equal(out["1"][3], out["0"][3]) and out["1"][4] == out["0"][4]
+    assert out["1"][3][3] == 3  # ran into max_iter: the loop's last move of the working cloud has no pass to ride on
+    assert np.array_equal(out["1"][4], out["0"][4]) and out["1"][5] == out["0"][5]
 
 
 @pytest.mark.parametrize("window", [0, 32])
