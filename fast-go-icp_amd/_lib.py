@@ -9,6 +9,17 @@ c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int)
 
 
+class CtxInfo(C.Structure):
+    _fields_ = [("lut_dims", C.c_int * 3), ("lut_layout", C.c_int), ("lut_nodes", C.c_uint64), ("lut_bytes", C.c_uint64),
+                ("source_points_per_face_voxel", C.c_double), ("points_per_item", C.c_int), ("items_per_evaluation", C.c_int),
+                ("max_subcubes_per_window", C.c_int)]
+
+
+class CloudStats(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("centroid", C.c_float * 3), ("min", C.c_float * 3), ("max", C.c_float * 3), ("max_abs_centred", C.c_float),
+                ("rms_radius", C.c_float)]
+
+
 class Exchange(C.Structure):
     ALLREDUCE_MIN = C.CFUNCTYPE(C.c_int, c_float_p, C.c_size_t, C.c_void_p)
     ALLGATHER = C.CFUNCTYPE(C.c_int, c_float_p, c_float_p, C.c_size_t, C.c_void_p)
@@ -44,6 +55,8 @@ _SIGS = {
                                     C.POINTER(C.c_void_p)]),
     "fgoicp_ctx_destroy": (None, [C.c_void_p]),
     "fgoicp_lut_dims": (C.c_int, [C.c_void_p, c_int_p]),
+    "fgoicp_ctx_get_info": (C.c_int, [C.c_void_p, C.POINTER(CtxInfo)]),
+    "fgoicp_cloud_stats": (C.c_int, [c_float_p, C.c_size_t, C.POINTER(CloudStats)]),
     "fgoicp_lut_read": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t]),
     "fgoicp_lut_search": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t, c_float_p]),
     "fgoicp_lut_nodes": (C.c_int, [C.c_void_p, c_int_p, C.c_size_t, c_float_p]),

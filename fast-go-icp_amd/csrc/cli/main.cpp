@@ -48,6 +48,13 @@ int main(int argc, char* argv[]) {
     cli::load_cloud(config.io.source, config.params.source_subsample, pcs, config.params.seed < 0 ? -1 : config.params.seed + 1);
     icp::Logger(icp::LogLevel::Info) << "Source point cloud (" << pcs.size() << ") loaded from " << config.io.source;
     const std::vector<icp::vec3> pct_in = pct, pcs_in = pcs;
+    for (const auto* pc : {&pct, &pcs}) {  // verbose: the statistics the pre-processing normalises by (TODO.md:7 of the reference)
+        fgoicp_cloud_stats_t cs{};
+        if (fgoicp_cloud_stats(&pc->data()->x, pc->size(), &cs) == FGOICP_OK)
+            icp::Logger(icp::LogLevel::Debug) << (pc == &pct ? "Target" : "Source") << " statistics: centroid " << icp::vec3{cs.centroid[0], cs.centroid[1], cs.centroid[2]}
+                                              << ", box [" << cs.min[0] << ", " << cs.max[0] << "] x [" << cs.min[1] << ", " << cs.max[1] << "] x [" << cs.min[2] << ", " << cs.max[2]
+                                              << "], largest centred coordinate " << cs.max_abs_centred << ", RMS radius " << cs.rms_radius;
+    }
 
     const int schedule = config.params.schedule == "round" ? FGOICP_SCHEDULE_ROUND : FGOICP_SCHEDULE_SERIAL;
     const int gpus = gpus_flag > 0 ? gpus_flag : config.params.gpus;

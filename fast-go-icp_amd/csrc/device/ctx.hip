@@ -972,6 +972,22 @@ int fgoicp_lut_dims(const fgoicp_ctx* c, int* dims3) {
     return FGOICP_OK;
 }
 
+int fgoicp_ctx_get_info(const fgoicp_ctx* c, fgoicp_ctx_info* out) {
+    if (!c || !out) return FGOICP_ERR_INVALID_ARG;
+    const LutGeom& g = c->geom;
+    *out = fgoicp_ctx_info{};
+    out->lut_dims[0] = g.dx; out->lut_dims[1] = g.dy; out->lut_dims[2] = g.dz;
+    out->lut_layout = c->d_lut_zp ? c->lut_layout : 0;
+    out->lut_nodes = (uint64_t)g.dx * g.dy * g.dz;
+    const uint64_t padded = (uint64_t)g.px * g.py * g.pz;
+    out->lut_bytes = padded * sizeof(float) + (c->d_lut_zp ? padded * (c->lut_layout == 2 ? sizeof(float4) : sizeof(float2)) : 0);
+    out->source_points_per_face_voxel = (double)c->ns / ((double)g.dx * g.dy + (double)g.dy * g.dz + (double)g.dx * g.dz);
+    out->points_per_item = c->chunk_pts;
+    out->items_per_evaluation = c->nchunk1;
+    out->max_subcubes_per_window = c->max_subcubes;
+    return FGOICP_OK;
+}
+
 int fgoicp_lut_read(fgoicp_ctx* c, float* out, size_t capacity) {
     if (!c || !out) return FGOICP_ERR_INVALID_ARG;
     const size_t total = (size_t)c->geom.dx * c->geom.dy * c->geom.dz;

@@ -2,6 +2,7 @@
 // context.  The driver template is instantiated with the HIP backend ONLY — there is no CPU
 // backend in this library.
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -178,6 +179,34 @@ int fgoicp_solver_preproc(const fgoicp_solver* s, float* offs6, float* scale, fl
     }
     if (scale) *scale = s->scaling_factor;
     if (bounds6) std::memcpy(bounds6, s->bounds6, sizeof(s->bounds6));
+    return FGOICP_OK;
+}
+
+int fgoicp_cloud_stats(const float* xyz, size_t n, fgoicp_cloud_stats_t* out) {
+    if (!out || (!xyz && n)) return FGOICP_ERR_INVALID_ARG;
+    *out = fgoicp_cloud_stats_t{};
+    out->n = n;
+    if (n == 0) return FGOICP_OK;
+    double sum[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k) { out->min[k] = xyz[k]; out->max[k] = xyz[k]; }
+    for (size_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            const float v = xyz[3 * i + k];
+            sum[k] += (double)v;
+            out->min[k] = v < out->min[k] ? v : out->min[k];
+            out->max[k] = v > out->max[k] ? v : out->max[k];
+        }
+    double c[3];
+    for (int k = 0; k < 3; ++k) { c[k] = sum[k] / (double)n; out->centroid[k] = (float)c[k]; }
+    double r2 = 0.0, mx = 0.0;
+    for (size_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            const double d = (double)xyz[3 * i + k] - c[k];
+            r2 += d * d;
+            mx = std::fabs(d) > mx ? std::fabs(d) : mx;
+        }
+    out->max_abs_centred = (float)mx;
+    out->rms_radius = (float)std::sqrt(r2 / (double)n);
     return FGOICP_OK;
 }
 

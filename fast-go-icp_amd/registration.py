@@ -28,6 +28,15 @@ class StreamPool:
         self.size = size
 
 
+def cloud_stats(points):
+    """fgoicp_cloud_stats: count, centroid, bounding box, largest centred coordinate, RMS radius of a raw cloud (host side)."""
+    p = _cloud(points)
+    st = _lib.CloudStats()
+    _lib.check(_lib.load().fgoicp_cloud_stats(_fp(p), len(p), C.byref(st)), "fgoicp_cloud_stats")
+    return dict(n=int(st.n), centroid=np.array(st.centroid, np.float32), min=np.array(st.min, np.float32), max=np.array(st.max, np.float32),
+                max_abs_centred=float(st.max_abs_centred), rms_radius=float(st.rms_radius))
+
+
 class Registration:
     """icp::Registration (fgoicp/registration.hpp:49-98) + its NearestNeighborLUT member."""
 
@@ -67,6 +76,15 @@ class Registration:
         d = (C.c_int * 3)()
         _lib.check(self._lib.fgoicp_lut_dims(self._h, d), "fgoicp_lut_dims")
         return tuple(d)
+
+    def info(self):
+        """fgoicp_ctx_get_info: LUT size and layout, source density per LUT face voxel, points per work item (what the context
+        derived from the clouds' statistics)."""
+        i = _lib.CtxInfo()
+        _lib.check(self._lib.fgoicp_ctx_get_info(self._h, C.byref(i)), "fgoicp_ctx_get_info")
+        return dict(lut_dims=tuple(i.lut_dims), lut_layout=i.lut_layout, lut_nodes=i.lut_nodes, lut_bytes=i.lut_bytes,
+                    source_points_per_face_voxel=i.source_points_per_face_voxel, points_per_item=i.points_per_item,
+                    items_per_evaluation=i.items_per_evaluation, max_subcubes_per_window=i.max_subcubes_per_window)
 
     def lut_read(self):
         dx, dy, dz = self.lut_dims()

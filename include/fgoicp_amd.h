@@ -67,6 +67,20 @@ void fgoicp_ctx_destroy(fgoicp_ctx* ctx);
  * (registration.cu:186-188, :276).  Used by tests and by INTEGRATION.md's façade. */
 int fgoicp_lut_dims(const fgoicp_ctx* ctx, int* dims3);
 int fgoicp_lut_read(fgoicp_ctx* ctx, float* out, size_t capacity_floats);
+/* What the context derived from the clouds' statistics for its own scaling decisions (the reference's open item "compute point
+ * clouds' stats, normalize (For scalability)", TODO.md:7): LUT size in every layout it keeps, source points per voxel of the LUT's
+ * faces (the density that picks the packed layout and the points per work item), work items per evaluation. */
+typedef struct fgoicp_ctx_info {
+    int lut_dims[3];
+    int lut_layout;              /* 1 = z-pair copy (8 B per node), 2 = yz-quad copy (16 B per node) next to the plain fp32 LUT */
+    uint64_t lut_nodes;
+    uint64_t lut_bytes;          /* plain LUT (padded) + packed copy, device memory */
+    double source_points_per_face_voxel;
+    int points_per_item;         /* 256 .. 2048 */
+    int items_per_evaluation;    /* ceil(ns / points_per_item) */
+    int max_subcubes_per_window;
+} fgoicp_ctx_info;
+int fgoicp_ctx_get_info(const fgoicp_ctx* ctx, fgoicp_ctx_info* out);
 /* n single nodes of the LUT: out[i] = node (x, y, z) = xyz[3i..3i+2] (the value buildLUTKernel, registration.cu:258-278, stores at
  * index (z*dy + y)*dx + x).  For LUTs too large to read back whole (test/bunny.toml: 923 x 906 x 711 nodes). */
 int fgoicp_lut_nodes(fgoicp_ctx* ctx, const int* xyz, size_t n, float* out);
@@ -229,6 +243,16 @@ int fgoicp_solver_last_transform(const fgoicp_solver* s, float* R9, float* t3);
 int fgoicp_solver_stats(const fgoicp_solver* s, fgoicp_run_stats* out);
 /* Pre-processing results (tests): offs6 = {offset_pcs, offset_pct}, bounds6 as in ctx_create. */
 int fgoicp_solver_preproc(const fgoicp_solver* s, float* offs6, float* scale, float* bounds6);
+/* Statistics of a raw cloud, host side, no device needed (TODO.md:7 of the reference: "compute point clouds' stats"): what the
+ * pre-processing (fgoicp.cpp:176-287) derives its centring and scaling from, plus the spread.  Sums in double. */
+typedef struct fgoicp_cloud_stats_t {
+    uint64_t n;
+    float centroid[3];
+    float min[3], max[3];        /* axis-aligned bounding box */
+    float max_abs_centred;       /* max_i max(|x_i - c_x|, |y_i - c_y|, |z_i - c_z|): 1 / this is the scale of fgoicp.cpp:205-220 when taken over the source */
+    float rms_radius;            /* sqrt(mean |p_i - c|^2) */
+} fgoicp_cloud_stats_t;
+int fgoicp_cloud_stats(const float* xyz, size_t n, fgoicp_cloud_stats_t* out);
 /* The operator context the solver drives (borrowed; valid until solver_destroy). */
 fgoicp_ctx* fgoicp_solver_ctx(fgoicp_solver* s);
 

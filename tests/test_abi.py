@@ -117,3 +117,24 @@ def test_invalid_arguments_are_refused_before_any_device_work(fg):
     assert lib.fgoicp_multi_set_record(None, 1) == 1 and lib.fgoicp_multi_replay_rank(None, 0, None) == 1 and lib.fgoicp_multi_seconds(None, 0, None) == 1
     lib.fgoicp_multi_destroy(None); lib.fgoicp_rccl_destroy(None)  # no-ops
     assert b"invalid" in lib.fgoicp_last_error() or b"" == lib.fgoicp_last_error()[:0]
+
+
+def test_cloud_statistics_run_on_the_host(fg):
+    """fgoicp_cloud_stats (the reference's open item "compute point clouds' stats", TODO.md:7) needs no device: centroid, box,
+    the largest centred coordinate (whose reciprocal over the source is the scale of fgoicp.cpp:205-220) and the RMS radius."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    p = (rng.normal(size=(5000, 3)) * [1.0, 2.0, 0.5] + [3.0, -1.0, 0.25]).astype(np.float32)
+    st = fg.cloud_stats(p)
+    c = p.astype(np.float64).mean(0)
+    assert st["n"] == 5000 and np.allclose(st["centroid"], c, atol=1e-6)
+    assert np.array_equal(st["min"], p.min(0)) and np.array_equal(st["max"], p.max(0))
+    assert st["max_abs_centred"] == pytest.approx(float(np.abs(p - c).max()), rel=1e-6)
+    assert st["rms_radius"] == pytest.approx(float(np.sqrt(((p - c) ** 2).sum(1).mean())), rel=1e-6)
+    assert fg.cloud_stats(np.zeros((0, 3), np.float32))["n"] == 0
+    lib = fg._lib.load()
+    assert lib.fgoicp_cloud_stats(None, 3, None) == 1 and lib.fgoicp_ctx_get_info(None, None) == 1
+    # the driver's pre-processing scales by exactly this statistic of the source
+    pct, pcs, off_t, off_s, scale, bounds = fg.synth.preprocess(p[:3000], p[3000:])
+    assert float(scale) == pytest.approx(1.0 / fg.cloud_stats(p[3000:])["max_abs_centred"], rel=2e-6)
+

@@ -539,3 +539,22 @@ def test_icp_batch_equals_single_runs(fg, gpu_required, trim):
     e0, *_ = fg.icp_batch(reg, [], np.zeros((0, 3), np.float32))
     assert e0.size == 0
     reg.close()
+
+
+def test_context_reports_what_it_derived_from_the_cloud_statistics(fg, gpu_required):
+    """fgoicp_ctx_get_info: a sparse cloud (few source points per voxel of the LUT's faces) gets the yz-quad LUT copy and 256-point
+    items, a dense one the z-pair copy and bigger items (measured crossovers)."""
+    rng = np.random.default_rng(2)
+    bounds = np.array([[-1, 1]] * 3, np.float32)
+    tgt = rng.uniform(-0.9, 0.9, (4000, 3)).astype(np.float32)
+    sparse = fg.Registration(tgt, rng.uniform(-0.9, 0.9, (3000, 3)).astype(np.float32), bounds, 0.02)   # 100^3 nodes, 3000 points
+    dense = fg.Registration(tgt, rng.uniform(-0.9, 0.9, (60000, 3)).astype(np.float32), bounds, 0.02)   # 2 points per face voxel
+    a, b = sparse.info(), dense.info()
+    for i, reg in ((a, sparse), (b, dense)):
+        assert i["lut_dims"] == reg.lut_dims() and i["lut_nodes"] == int(np.prod(i["lut_dims"]))
+        assert i["items_per_evaluation"] == -(-reg.ns // i["points_per_item"]) and i["max_subcubes_per_window"] >= 32
+        assert i["lut_bytes"] >= i["lut_nodes"] * 4 * (1 + (4 if i["lut_layout"] == 2 else 2))
+    assert a["source_points_per_face_voxel"] == pytest.approx(3000 / 3e4, rel=0.05) and a["lut_layout"] == 2 and a["points_per_item"] == 256
+    assert b["source_points_per_face_voxel"] == pytest.approx(2.0, rel=0.05) and b["lut_layout"] == 1 and b["points_per_item"] == 2048
+    sparse.close(); dense.close()
+
