@@ -1,10 +1,10 @@
 # Timing-only ablation builds of the bounds kernel (cdna_hip_programming.md §7 "Ablate"): what a kernel that hoisted the rotation
 # out of the per-evaluation work (TODO.md:11 of the reference, "rotate once") or served every gather from on-chip storage
 # (LDS-staged tiles) could gain AT MOST.  Results are wrong by construction; only the kernel times matter.
-#   bash tools/ablate.sh   (on the GPU box; writes gpurun_out/profiles/r02_ablation.txt)
+#   bash tools/ablate.sh   (on the GPU box; writes gpurun_out/profiles/r02_ablation_fixed_tick.txt)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/profiles
-OUT=gpurun_out/profiles/r02_ablation.txt
+OUT=gpurun_out/profiles/r02_ablation_fixed_tick.txt
 : > $OUT
 for AB in 0 1 4 5; do
   LIB=/tmp/libfgoicp_ab$AB.so
