@@ -49,100 +49,137 @@ inline Mat3f operator*(const Mat3f& a, const Mat3f& b) {
     return r;
 }
 
-// ---- 3x3 SVD, one-sided (Hestenes) Jacobi in double --------------------------------------
-// A = U diag(S) V^T with S sorted descending; row-major double[3][3] in and out.
-inline void svd3_hestenes(const double Ain[3][3], double U[3][3], double S[3], double V[3][3]) {
-    double A[3][3];
+// ---- 3x3 SVD in double: Eigen::JacobiSVD<Matrix3d>'s algorithm ----------------------------------------
+// The reference takes its Procrustes rotation from Eigen::JacobiSVD<Eigen::Matrix3d>(H, ComputeFullU | ComputeFullV)
+// (fgoicp/icp3d.cu:118-121; Eigen3 >= 3.3, fgoicp/CMakeLists.txt:19).  On a full-rank H any SVD yields the same
+// R = V diag(1, 1, det(V U^T)) U^T; on a rank-deficient H (all correspondences on one or two target points, collinear
+// or coplanar clouds) the null-space columns of U and V are the algorithm's choice, so R is too.  Round 2 used a
+// one-sided Hestenes Jacobi here and differed from the checker on such inputs (fuzz seed 7, cases 103 / 505); this is
+// Eigen 3.3 / 3.4's two-sided Jacobi as published (JacobiSVD::compute, real_2x2_jacobi_svd, JacobiRotation::makeJacobi),
+// written out for n = 3:
+//   W = H / max|H_ij|; pairs in the order (1,0), (2,0), (2,1); a pair is worked on while |W(p,q)| or |W(q,p)| exceeds
+//   max(DBL_MIN, 2 eps maxdiag) with maxdiag the running maximum of the |diagonal|; per pair a left rotation that makes the
+//   2x2 block symmetric, then the symmetric Jacobi rotation; sigma_i = |W(i,i)| * scale with U's column negated for a
+//   negative diagonal; descending order by swapping with the first maximum of the tail, stopping at a zero.
+// A plane rotation (c, s) is the matrix [[c, s], [-s, c]]; `turn(x, y, c, s)` is (x, y) <- (c x + s y, -s x + c y) and
+// leaves the operands alone for the identity (as Eigen's apply_rotation_in_the_plane does).
+// A = U diag(S) V^T, row-major double[3][3] in and out.
+namespace detail {
+inline void turn(double& x, double& y, double c, double s) {
+    if (c == 1.0 && s == 0.0) return;
+    const double x0 = x, y0 = y;
+    x = c * x0 + s * y0;
+    y = -s * x0 + c * y0;
+}
+}  // namespace detail
+
+inline void svd3_jacobi(const double Ain[3][3], double U[3][3], double S[3], double V[3][3]) {
+    const double tiny = std::numeric_limits<double>::min();
+    const double two_eps = 2.0 * std::numeric_limits<double>::epsilon();
+    double scale = 0.0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) scale = std::fabs(Ain[i][j]) > scale ? std::fabs(Ain[i][j]) : scale;
+    if (scale == 0.0) scale = 1.0;
+    double W[3][3];
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) {
-            A[i][j] = Ain[i][j];
-            V[i][j] = (i == j) ? 1.0 : 0.0;
+            W[i][j] = Ain[i][j] / scale;
+            U[i][j] = V[i][j] = (i == j) ? 1.0 : 0.0;
         }
-    const double eps = std::numeric_limits<double>::epsilon();
-    for (int sweep = 0; sweep < 80; ++sweep) {
+    double maxdiag = std::fabs(W[0][0]);
+    if (std::fabs(W[1][1]) > maxdiag) maxdiag = std::fabs(W[1][1]);
+    if (std::fabs(W[2][2]) > maxdiag) maxdiag = std::fabs(W[2][2]);
+    static const int pairs[3][2] = {{1, 0}, {2, 0}, {2, 1}};
+    for (int sweep = 0; sweep < 1000; ++sweep) {  // Eigen sweeps until nothing rotates (3-6 sweeps); the cap only bounds a defect
         bool rotated = false;
-        for (int p = 0; p < 2; ++p)
-            for (int q = p + 1; q < 3; ++q) {
-                double alpha = 0, beta = 0, gamma = 0;
-                for (int r = 0; r < 3; ++r) {
-                    alpha += A[r][p] * A[r][p];
-                    beta += A[r][q] * A[r][q];
-                    gamma += A[r][p] * A[r][q];
-                }
-                if (gamma == 0.0 || std::fabs(gamma) <= eps * std::sqrt(alpha * beta)) continue;
-                rotated = true;
-                const double zeta = (beta - alpha) / (2.0 * gamma);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / std::sqrt(1.0 + t * t), s = c * t;
-                for (int r = 0; r < 3; ++r) {
-                    const double ap = A[r][p], aq = A[r][q];
-                    A[r][p] = c * ap - s * aq;
-                    A[r][q] = s * ap + c * aq;
-                    const double vp = V[r][p], vq = V[r][q];
-                    V[r][p] = c * vp - s * vq;
-                    V[r][q] = s * vp + c * vq;
-                }
+        for (const auto& pq : pairs) {
+            const int p = pq[0], q = pq[1];
+            const double limit = two_eps * maxdiag > tiny ? two_eps * maxdiag : tiny;
+            if (!(std::fabs(W[p][q]) > limit || std::fabs(W[q][p]) > limit)) continue;
+            rotated = true;
+            // the 2x2 block, p first
+            double m00 = W[p][p], m01 = W[p][q], m10 = W[q][p], m11 = W[q][q];
+            // left rotation (c1, s1) that makes it symmetric
+            double c1 = 1.0, s1 = 0.0;
+            const double tsum = m00 + m11, diff = m10 - m01;
+            if (!(std::fabs(diff) < tiny)) {
+                const double u = tsum / diff;
+                const double h = std::sqrt(1.0 + u * u);
+                s1 = 1.0 / h;
+                c1 = u / h;
             }
+            detail::turn(m00, m10, c1, s1);
+            detail::turn(m01, m11, c1, s1);
+            // symmetric Jacobi rotation (cr, sr) of [[m00, m01], [m01, m11]]
+            double cr = 1.0, sr = 0.0;
+            const double deno = 2.0 * std::fabs(m01);
+            if (!(deno < tiny)) {
+                const double tau = (m00 - m11) / deno;
+                const double w = std::sqrt(tau * tau + 1.0);
+                const double t = tau > 0.0 ? 1.0 / (tau + w) : 1.0 / (tau - w);
+                const double sign_t = t > 0.0 ? 1.0 : -1.0;
+                const double n = 1.0 / std::sqrt(t * t + 1.0);
+                sr = -sign_t * (m01 / std::fabs(m01)) * std::fabs(t) * n;
+                cr = n;
+            }
+            // left = rot1 * right^T
+            const double cl = c1 * cr - s1 * (-sr);
+            const double sl = c1 * (-sr) + s1 * cr;
+            for (int k = 0; k < 3; ++k) detail::turn(W[p][k], W[q][k], cl, sl);   // W <- L W      (rows p, q)
+            for (int k = 0; k < 3; ++k) detail::turn(U[k][p], U[k][q], cl, sl);   // U <- U L^T    (columns p, q)
+            for (int k = 0; k < 3; ++k) detail::turn(W[k][p], W[k][q], cr, -sr);  // W <- W R      (columns p, q)
+            for (int k = 0; k < 3; ++k) detail::turn(V[k][p], V[k][q], cr, -sr);  // V <- V R
+            const double dp = std::fabs(W[p][p]), dq = std::fabs(W[q][q]);
+            if (dp > maxdiag) maxdiag = dp;
+            if (dq > maxdiag) maxdiag = dq;
+        }
         if (!rotated) break;
     }
-    int order[3] = {0, 1, 2};
-    double norm[3];
-    for (int j = 0; j < 3; ++j) norm[j] = std::sqrt(A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j]);
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 3; ++i) {
+        const double d = W[i][i];
+        S[i] = std::fabs(d);
+        if (d < 0.0)
+            for (int r = 0; r < 3; ++r) U[r][i] = -U[r][i];
+        S[i] *= scale;
+    }
+    for (int i = 0; i < 3; ++i) {
+        int pos = i;
         for (int j = i + 1; j < 3; ++j)
-            if (norm[order[j]] > norm[order[i]]) std::swap(order[i], order[j]);
-    double Vs[3][3];
-    for (int k = 0; k < 3; ++k) {
-        const int j = order[k];
-        S[k] = norm[j];
+            if (S[j] > S[pos]) pos = j;
+        if (S[pos] == 0.0) break;
+        if (pos == i) continue;
+        std::swap(S[i], S[pos]);
         for (int r = 0; r < 3; ++r) {
-            Vs[r][k] = V[r][j];
-            U[r][k] = norm[j] > 0 ? A[r][j] / norm[j] : 0.0;
+            std::swap(U[r][i], U[r][pos]);
+            std::swap(V[r][i], V[r][pos]);
         }
-    }
-    for (int r = 0; r < 3; ++r)
-        for (int k = 0; k < 3; ++k) V[r][k] = Vs[r][k];
-    // complete U for (numerically) vanishing singular values so that it stays orthonormal
-    const double tiny = S[0] * 1e-14;
-    auto col = [&](int k, double out[3]) { for (int r = 0; r < 3; ++r) out[r] = U[r][k]; };
-    auto set = [&](int k, const double in[3]) {
-        double n = std::sqrt(in[0] * in[0] + in[1] * in[1] + in[2] * in[2]);
-        for (int r = 0; r < 3; ++r) U[r][k] = in[r] / n;
-    };
-    if (S[0] <= 0) {
-        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) U[i][j] = (i == j) ? 1.0 : 0.0;
-        return;
-    }
-    if (S[1] <= tiny) {  // rank 1: any unit vector orthogonal to u0
-        double u0[3]; col(0, u0);
-        int m = std::fabs(u0[0]) < std::fabs(u0[1]) ? (std::fabs(u0[0]) < std::fabs(u0[2]) ? 0 : 2) : (std::fabs(u0[1]) < std::fabs(u0[2]) ? 1 : 2);
-        double e[3] = {0, 0, 0}; e[m] = 1.0;
-        double u1[3] = {u0[1] * e[2] - u0[2] * e[1], u0[2] * e[0] - u0[0] * e[2], u0[0] * e[1] - u0[1] * e[0]};
-        set(1, u1);
-    }
-    if (S[2] <= tiny) {
-        double u0[3], u1[3]; col(0, u0); col(1, u1);
-        double u2[3] = {u0[1] * u1[2] - u0[2] * u1[1], u0[2] * u1[0] - u0[0] * u1[2], u0[0] * u1[1] - u0[1] * u1[0]};
-        set(2, u2);
     }
 }
 
 // closest_orthogonal_approximation, fgoicp/icp3d.cu:110-138: H(r,c) = ABt[c][r]; H = U S V^T;
-// R = V diag(1, 1, det(V U^T)) U^T in double, cast to fp32, returned in glm order.
+// R = V diag(1, 1, det(V U^T)) U^T in double, cast to fp32, returned in glm order.  Products and the determinant are
+// evaluated in Eigen's order for fixed 3x3 operands: a row-by-column product as x0 + (x1 + x2), the determinant as
+// m00 (m11 m22 - m12 m21) - m01 (m10 m22 - m12 m20) + m02 (m10 m21 - m11 m20).
 inline Mat3f closest_orthogonal_approximation(const Mat3f& ABt) {
     double H[3][3], U[3][3], V[3][3], S[3];
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) H[r][c] = (double)ABt.at(c, r);
-    svd3_hestenes(H, U, S, V);
+    svd3_jacobi(H, U, S, V);
     double VUt[3][3];
     for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) VUt[i][j] = V[i][0] * U[j][0] + V[i][1] * U[j][1] + V[i][2] * U[j][2];
+        for (int j = 0; j < 3; ++j) VUt[i][j] = V[i][0] * U[j][0] + (V[i][1] * U[j][1] + V[i][2] * U[j][2]);
     const double det = VUt[0][0] * (VUt[1][1] * VUt[2][2] - VUt[1][2] * VUt[2][1]) - VUt[0][1] * (VUt[1][0] * VUt[2][2] - VUt[1][2] * VUt[2][0]) +
                        VUt[0][2] * (VUt[1][0] * VUt[2][1] - VUt[1][1] * VUt[2][0]);
+    // D = diag(1, 1, det); R = (V D) U^T as two full 3x3 products, as icp3d.cu:129-133 forms them (the products with D's
+    // zeros and ones are kept: they decide the sign of a zero entry)
+    const double D[3][3] = {{1.0, 0.0, 0.0}, {0.0, 1.0, 0.0}, {0.0, 0.0, det}};
+    double VD[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) VD[i][k] = V[i][0] * D[0][k] + (V[i][1] * D[1][k] + V[i][2] * D[2][k]);
     Mat3f out;
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) {
-            const double rij = V[i][0] * U[j][0] + V[i][1] * U[j][1] + det * V[i][2] * U[j][2];
+            const double rij = VD[i][0] * U[j][0] + (VD[i][1] * U[j][1] + VD[i][2] * U[j][2]);
             out.at(j, i) = (float)rij;  // out[col j][row i] = R(i, j)
         }
     return out;

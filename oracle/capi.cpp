@@ -6,6 +6,7 @@
 
 #include "goicp_oracle.hpp"
 #include <queue>
+#include <string>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -53,6 +54,28 @@ void orc_set_num_threads(int n) {
     (void)n;
 #endif
 }
+
+// ---- conventions (goicp_oracle.hpp: Conventions) — process-global switches for tools/convention_flips.py ---------
+// returns 0, or -1 for an unknown name; value < -100 only reads.  *old receives the previous value when not null.
+int orc_convention(const char* name, int value, int* old) {
+    Conventions& c = conventions();
+    int* slot = nullptr;
+    const std::string n(name);
+    if (n == "fma_matvec") slot = &c.fma_matvec;
+    else if (n == "fma_dist") slot = &c.fma_dist;
+    else if (n == "fma_rot_sub") slot = &c.fma_rot_sub;
+    else if (n == "fma_trans_sub") slot = &c.fma_trans_sub;
+    else if (n == "tex_weight") slot = &c.tex_weight;
+    else if (n == "tex_blend") slot = &c.tex_blend;
+    else if (n == "sum_mode") slot = &c.sum_mode;
+    else if (n == "sin_ulps") slot = &c.sin_ulps;
+    else if (n == "svd_r2_two_sided") slot = &c.svd_r2_two_sided;
+    if (!slot) return -1;
+    if (old) *old = *slot;
+    if (value >= -100) *slot = value;
+    return 0;
+}
+void orc_conventions_reset() { conventions() = Conventions(); }
 
 // ---- types -------------------------------------------------------------------------------
 void orc_rotation(float x, float y, float z, float* R9, float* r, int* in_so3) {
@@ -152,6 +175,8 @@ void* orc_goicp_create_trim(const float* tgt, size_t nt, const float* src, size_
     return h;
 }
 void orc_goicp_destroy(void* p) { delete static_cast<GoicpHandle*>(p); }
+// exact NN through the uniform grid instead of the O(ns*nt) loops (bit-identical results; tools/convention_flips.py, to finish in minutes)
+void orc_goicp_use_grid(void* p, int on) { static_cast<GoicpHandle*>(p)->g->registration.use_grid(on != 0); }
 // offs6 = offset_pcs, offset_pct; bounds6 as (minx,maxx,miny,maxy,minz,maxz); clouds may be null
 void orc_goicp_preproc(void* p, float* offs6, float* scale, float* bounds6, float* tgt_scaled, float* src_scaled, int* lut_dims3) {
     auto& g = *static_cast<GoicpHandle*>(p)->g;

@@ -18,6 +18,18 @@ namespace goicp_oracle {
 // ---------------------------------------------------------------------------------------------
 // small math (GLM semantics: column-major mat3)
 // ---------------------------------------------------------------------------------------------
+Conventions& conventions() {
+    static Conventions c;
+    return c;
+}
+
+// a*x + b*y + c*z under the three contraction choices of Conventions
+static inline float dot3_conv(int mode, float a, float x, float b, float y, float c, float z) {
+    if (mode == 1) return std::fmaf(c, z, std::fmaf(b, y, a * x));
+    if (mode == 2) return std::fmaf(c, z, std::fmaf(a, x, b * y));
+    return a * x + b * y + c * z;
+}
+
 Mat3 mat3_identity() {
     Mat3 m;
     for (int c = 0; c < 3; ++c)
@@ -28,9 +40,10 @@ Mat3 mat3_identity() {
 // glm mat3*vec3: m[0][r]*v.x + m[1][r]*v.y + m[2][r]*v.z, device build → fma chain.
 Vec3 dev_mul(const Mat3& m, const Vec3& v) {
     Vec3 o;
-    o.x = std::fmaf(m.c[2][0], v.z, std::fmaf(m.c[1][0], v.y, m.c[0][0] * v.x));
-    o.y = std::fmaf(m.c[2][1], v.z, std::fmaf(m.c[1][1], v.y, m.c[0][1] * v.x));
-    o.z = std::fmaf(m.c[2][2], v.z, std::fmaf(m.c[1][2], v.y, m.c[0][2] * v.x));
+    const int f = conventions().fma_matvec;
+    o.x = dot3_conv(f, m.c[0][0], v.x, m.c[1][0], v.y, m.c[2][0], v.z);
+    o.y = dot3_conv(f, m.c[0][1], v.x, m.c[1][1], v.y, m.c[2][1], v.z);
+    o.z = dot3_conv(f, m.c[0][2], v.x, m.c[1][2], v.y, m.c[2][2], v.z);
     return o;
 }
 
@@ -54,7 +67,25 @@ Mat3 host_mul(const Mat3& a, const Mat3& b) {
 // device-side squared distance, registration.cu:154-160 / :250-256 (fma convention)
 static inline float dev_dist_sq(float ax, float ay, float az, float bx, float by, float bz) {
     float dx = ax - bx, dy = ay - by, dz = az - bz;
-    return std::fmaf(dz, dz, std::fmaf(dy, dy, dx * dx));
+    return dot3_conv(conventions().fma_dist, dx, dx, dy, dy, dz, dz);
+}
+// registration.cu:39-41: x*x + y*y + z*z of the source point (the "radius")
+static inline float dev_norm_sq(const Vec3& p) { return dot3_conv(conventions().fma_dist, p.x, p.x, p.y, p.y, p.z, p.z); }
+// device sin(float) of registration.cu:43, optionally moved by whole ulps (Conventions::sin_ulps)
+static inline float dev_sin(float a) {
+    float v = std::sin(a);
+    int k = conventions().sin_ulps;
+    for (; k > 0; --k) v = std::nextafterf(v, 2.0f);
+    for (; k < 0; ++k) v = std::nextafterf(v, -2.0f);
+    return v;
+}
+// Thrust reduce(float, plus) under Conventions::sum_mode 1 / 2 (mode 0 keeps the chunked fp64 sums of the callers)
+static float reduce_f32(const float* v, long n, int mode) {
+    if (n <= 0) return 0.0f;
+    if (mode == 2) { float s = 0.0f; for (long i = 0; i < n; ++i) s += v[i]; return s; }
+    if (n <= 8) { float s = v[0]; for (long i = 1; i < n; ++i) s += v[i]; return s; }
+    const long h = n / 2;
+    return reduce_f32(v, h, mode) + reduce_f32(v + h, n - h, mode);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -118,7 +149,9 @@ static inline void tex_axis(float u, int dim, bool quant, int& i0, int& i1, floa
     float ub = u - 0.5f;
     float fl = std::floor(ub);
     w = ub - fl;
-    if (quant) w = std::floor(w * 256.0f + 0.5f) * (1.0f / 256.0f);
+    const int wmode = conventions().tex_weight;
+    if (quant && wmode == 0) w = std::floor(w * 256.0f + 0.5f) * (1.0f / 256.0f);
+    else if (quant && wmode == 1) w = std::floor(w * 256.0f) * (1.0f / 256.0f);
     // clamp in float first so that huge |u| cannot overflow the int conversion
     float lo = fl < -1.0f ? -1.0f : (fl > (float)dim ? (float)dim : fl);
     int i = (int)lo;
@@ -137,6 +170,19 @@ float NearestNeighborLUT::search(const Vec3& q) const {
     tex_axis(z, dims[2], quantize_weights, z0, z1, c);
     const size_t dx = dims[0], dy = dims[1];
     auto T = [&](int xi, int yi, int zi) { return data[((size_t)zi * dy + yi) * dx + xi]; };
+    if (conventions().tex_blend == 1) {
+        // CUDA C Programming Guide, "Linear Filtering", 3-D: (1-a)(1-b)(1-c) T[i,j,k] + a(1-b)(1-c) T[i+1,j,k] + ... + abc T[i+1,j+1,k+1]
+        const float na = 1.0f - a, nb = 1.0f - b, nc = 1.0f - c;
+        float r = na * nb * nc * T(x0, y0, z0);
+        r += a * nb * nc * T(x1, y0, z0);
+        r += na * b * nc * T(x0, y1, z0);
+        r += a * b * nc * T(x1, y1, z0);
+        r += na * nb * c * T(x0, y0, z1);
+        r += a * nb * c * T(x1, y0, z1);
+        r += na * b * c * T(x0, y1, z1);
+        r += a * b * c * T(x1, y1, z1);
+        return r;
+    }
     auto lerp = [](float p, float q_, float w) { return std::fmaf(w, q_ - p, p); };
     float c00 = lerp(T(x0, y0, z0), T(x1, y0, z0), a);
     float c10 = lerp(T(x0, y1, z0), T(x1, y1, z0), a);
@@ -317,7 +363,9 @@ static constexpr long kChunk = 1024;
 
 float Registration::compute_sse_error(const Mat3& R, const Vec3& t) const {  // :62-86 + kernel :14-25
     const long ns = (long)pcs.size();
-    if (inliers > 0 && inliers < (size_t)ns) {  // EXTENSION: trimmed SSE
+    const int sum_mode = conventions().sum_mode;
+    const bool trimmed = inliers > 0 && inliers < (size_t)ns;
+    if (trimmed || sum_mode != 0) {  // per-point values kept: EXTENSION trimmed SSE, or a Thrust-order flip
         std::vector<float> e(ns);
 #pragma omp parallel for schedule(static)
         for (long i = 0; i < ns; ++i) {
@@ -325,7 +373,7 @@ float Registration::compute_sse_error(const Mat3& R, const Vec3& t) const {  // 
             const Vec3 q{rp.x + t.x, rp.y + t.y, rp.z + t.z};
             e[i] = grid ? grid->min_d2(q) : brute_force_find_nearest_neighbor(q, pct);
         }
-        return trimmed_sum(e, inliers);
+        return trimmed ? trimmed_sum(e, inliers) : reduce_f32(e.data(), ns, sum_mode);
     }
     const long nchunk = (ns + kChunk - 1) / kChunk;
     std::vector<double> part(nchunk, 0.0);
@@ -344,32 +392,43 @@ float Registration::compute_sse_error(const Mat3& R, const Vec3& t) const {  // 
     return (float)sum;
 }
 
+// kernComputeBounds :27-60 for one point: {ub_i, lb_i}.  `sin_half` and `trans_uncertain_radius` are the per-kernel constants
+// of :42-43 and :33, hoisted by the callers (they do not depend on the point).
+static inline void bounds_point(const Registration& reg, const Mat3& Rc, const Vec3& tc, const Vec3& p, bool fix_rot, float sin_half,
+                                float span_t, float& ubv, float& lbv) {
+    const Conventions& cv = conventions();
+    const float trans_uncertain_radius = kSqrt3 * span_t;             // :33
+    Vec3 rp = dev_mul(Rc, p);
+    Vec3 q{rp.x + tc.x, rp.y + tc.y, rp.z + tc.z};                    // :34
+    const float dsq = reg.nnlut.search(q);                            // :46
+    float d = std::sqrt(dsq);                                         // :48
+    if (!fix_rot) {
+        const float radius = dev_norm_sq(p);                          // :39-41 (squared norm: reference quirk)
+        if (cv.fma_rot_sub) d = std::fmaf(-(2.0f * radius), sin_half, d);
+        else d -= 2.0f * radius * sin_half;                           // :43, :51
+    }
+    ubv = d > 0.0f ? d * d : 0.0f;                                    // :54
+    const float l = cv.fma_trans_sub ? std::fmaf(-kSqrt3, span_t, d) : d - trans_uncertain_radius;  // :57
+    lbv = l > 0.0f ? l * l : 0.0f;                                    // :58
+}
+
 std::tuple<std::vector<float>, std::vector<float>>
 Registration::compute_sse_error(const RotNode& rnode, const std::vector<TransNode>& tnodes, bool fix_rot) const {
     const long B = (long)tnodes.size();
     const long ns = (long)pcs.size();
     std::vector<float> upper(B), lower(B);
-    // kernComputeBounds :27-60; the per-kernel constants are hoisted (they do not depend on the point)
     float half_angle = rnode.span * kSqrt3 * kPi / 2.0f;  // :42
-    float sin_half = std::sin(half_angle);                // float overload, as device sin(float)
-    if (inliers > 0 && inliers < (size_t)ns) {  // EXTENSION: trimmed bounds — the k smallest ub terms and the k smallest lb terms
+    float sin_half = dev_sin(half_angle);                 // float overload, as device sin(float)
+    const int sum_mode = conventions().sum_mode;
+    const bool trimmed = inliers > 0 && inliers < (size_t)ns;
+    if (trimmed || sum_mode != 0) {  // per-point values kept: EXTENSION trimmed bounds (the k smallest ub / lb terms), or a Thrust-order flip
 #pragma omp parallel for schedule(dynamic, 1)
         for (long b = 0; b < B; ++b) {
             const TransNode& tn = tnodes[b];
-            const float trans_uncertain_radius = kSqrt3 * tn.span;
             std::vector<float> vu(ns), vl(ns);
-            for (long i = 0; i < ns; ++i) {
-                const Vec3 p = pcs[i];
-                Vec3 rp = dev_mul(rnode.q.R, p);
-                Vec3 q{rp.x + tn.t.x, rp.y + tn.t.y, rp.z + tn.t.z};
-                float d = std::sqrt(nnlut.search(q));
-                if (!fix_rot) d -= 2.0f * std::fmaf(p.z, p.z, std::fmaf(p.y, p.y, p.x * p.x)) * sin_half;
-                vu[i] = d > 0.0f ? d * d : 0.0f;
-                const float l = d - trans_uncertain_radius;
-                vl[i] = l > 0.0f ? l * l : 0.0f;
-            }
-            upper[b] = trimmed_sum(vu, inliers);
-            lower[b] = trimmed_sum(vl, inliers);
+            for (long i = 0; i < ns; ++i) bounds_point(*this, rnode.q.R, tn.t, pcs[i], fix_rot, sin_half, tn.span, vu[i], vl[i]);
+            upper[b] = trimmed ? trimmed_sum(vu, inliers) : reduce_f32(vu.data(), ns, sum_mode);
+            lower[b] = trimmed ? trimmed_sum(vl, inliers) : reduce_f32(vl.data(), ns, sum_mode);
         }
         return {lower, upper};
     }
@@ -379,23 +438,10 @@ Registration::compute_sse_error(const RotNode& rnode, const std::vector<TransNod
     for (long b = 0; b < B; ++b)
         for (long c = 0; c < nchunk; ++c) {
             const TransNode& tn = tnodes[b];
-            float trans_uncertain_radius = kSqrt3 * tn.span;  // :33
             double sum_ub = 0.0, sum_lb = 0.0;
             for (long i = c * kChunk; i < std::min(ns, (c + 1) * kChunk); ++i) {
-                const Vec3 p = pcs[i];
-                Vec3 rp = dev_mul(rnode.q.R, p);
-                Vec3 q{rp.x + tn.t.x, rp.y + tn.t.y, rp.z + tn.t.z};  // :34
-                float rot_uncertain_radius = 0.f;
-                if (!fix_rot) {
-                    float radius = std::fmaf(p.z, p.z, std::fmaf(p.y, p.y, p.x * p.x));  // :39-41 (squared norm: reference quirk)
-                    rot_uncertain_radius = 2.0f * radius * sin_half;                         // :43
-                }
-                float dsq = nnlut.search(q);  // :46
-                float d = std::sqrt(dsq);     // :48
-                if (!fix_rot) d -= rot_uncertain_radius;
-                float ubv = d > 0.0f ? d * d : 0.0f;  // :54
-                float l = d - trans_uncertain_radius;  // :57
-                float lbv = l > 0.0f ? l * l : 0.0f;
+                float ubv, lbv;
+                bounds_point(*this, rnode.q.R, tn.t, pcs[i], fix_rot, sin_half, tn.span, ubv, lbv);
                 sum_ub += (double)ubv;
                 sum_lb += (double)lbv;
             }
@@ -412,27 +458,139 @@ Registration::compute_sse_error(const RotNode& rnode, const std::vector<TransNod
 }
 
 // ---------------------------------------------------------------------------------------------
-// 3x3 SVD in double (stands in for Eigen::JacobiSVD<Matrix3d>, icp3d.cu:118-121):
-// two-sided Jacobi — each (p,q) 2x2 block is first symmetrised by a left rotation, then
-// diagonalised by a symmetric Jacobi rotation.
+// 3x3 SVD in double — a restatement of the PUBLISHED ALGORITHM of Eigen::JacobiSVD<Matrix3d> (Eigen 3.3 / 3.4,
+// Eigen/src/SVD/JacobiSVD.h `compute`, Eigen/src/Jacobi/Jacobi.h `makeJacobi`, `real_2x2_jacobi_svd`), which is what
+// the reference calls at icp3d.cu:118-121 (Eigen3 >= 3.3, fgoicp/CMakeLists.txt:19; not vendored, version unpinned).
+// Eigen is absent from this image, so this is written from the algorithm as published, statement by statement:
+//   * work matrix W = A / max|A_ij| (scale 1 for the zero matrix), U = V = I;
+//   * sweeps over the index pairs (p, q) = (1,0), (2,0), (2,1) — p is the LARGER index — until a sweep rotates nothing;
+//     a pair is rotated when |W(p,q)| or |W(q,p)| exceeds max(DBL_MIN, 2 eps * maxDiag), maxDiag = the running maximum of
+//     |diagonal| (initialised from the scaled input, raised after every rotation);
+//   * the 2x2 block [[W(p,p) W(p,q)] [W(q,p) W(q,q)]] is first symmetrised by a left rotation rot1 (t = m00 + m11,
+//     d = m10 - m01, u = t/d, rot1 = (u, 1)/sqrt(1 + u^2)), then diagonalised by the symmetric Jacobi rotation j_right of
+//     makeJacobi; j_left = rot1 * j_right^T;  W <- j_left W j_right, U <- U j_left^T, V <- V j_right;
+//   * singular values |W(i,i)| * scale, U column negated where W(i,i) < 0; sorted descending by swapping with the FIRST
+//     maximum of the tail, stopping at the first zero.
+// A rotation (c, s) stands for the matrix [[c, s], [-s, c]] (Eigen's JacobiRotation).
+// On a rank-deficient matrix the null-space columns of U and V — and with them R = V diag(1,1,det) U^T — are whatever
+// this sequence of rotations leaves; round 2 restated "a two-sided Jacobi" here and a one-sided Hestenes Jacobi in the
+// product, which picked different members of the solution family (fuzz seed 7, cases 103 and 505).
 // ---------------------------------------------------------------------------------------------
 namespace {
 struct M3d { double a[3][3]; };  // row-major math matrix a[row][col]
 
 M3d m3d_identity() { M3d m{}; for (int i = 0; i < 3; ++i) m.a[i][i] = 1.0; return m; }
+M3d m3d_T(const M3d& x) { M3d o{}; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) o.a[i][j] = x.a[j][i]; return o; }
+// Eigen's coefficient-based 3x3 product: row . column through the unrolled redux, x0 + (x1 + x2)
 M3d m3d_mul(const M3d& x, const M3d& y) {
     M3d o{};
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += x.a[i][k] * y.a[k][j]; o.a[i][j] = s; }
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) o.a[i][j] = x.a[i][0] * y.a[0][j] + (x.a[i][1] * y.a[1][j] + x.a[i][2] * y.a[2][j]);
     return o;
 }
-M3d m3d_T(const M3d& x) { M3d o{}; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) o.a[i][j] = x.a[j][i]; return o; }
+// Eigen's 3x3 determinant (bruteforce_det3_helper): m(0,a) * (m(1,b) m(2,c) - m(1,c) m(2,b)), terms (0,1,2) - (1,0,2) + (2,0,1)
 double m3d_det(const M3d& m) {
-    return m.a[0][0] * (m.a[1][1] * m.a[2][2] - m.a[1][2] * m.a[2][1]) - m.a[0][1] * (m.a[1][0] * m.a[2][2] - m.a[1][2] * m.a[2][0]) +
-           m.a[0][2] * (m.a[1][0] * m.a[2][1] - m.a[1][1] * m.a[2][0]);
+    auto h = [&](int a, int b, int c) { return m.a[0][a] * (m.a[1][b] * m.a[2][c] - m.a[1][c] * m.a[2][b]); };
+    return h(0, 1, 2) - h(1, 0, 2) + h(2, 0, 1);
 }
 
+struct JacobiRot {  // [[c, s], [-s, c]]
+    double c = 1.0, s = 0.0;
+    JacobiRot transpose() const { return JacobiRot{c, -s}; }
+    JacobiRot operator*(const JacobiRot& o) const { return JacobiRot{c * o.c - s * o.s, c * o.s + s * o.c}; }
+    // makeJacobi(x, y, z): J with J^T [[x, y], [y, z]] J diagonal
+    void make_jacobi(double x, double y, double z) {
+        const double deno = 2.0 * std::fabs(y);
+        if (deno < std::numeric_limits<double>::min()) { c = 1.0; s = 0.0; return; }
+        const double tau = (x - z) / deno;
+        const double w = std::sqrt(tau * tau + 1.0);
+        const double t = tau > 0.0 ? 1.0 / (tau + w) : 1.0 / (tau - w);
+        const double sign_t = t > 0.0 ? 1.0 : -1.0;
+        const double n = 1.0 / std::sqrt(t * t + 1.0);
+        s = -sign_t * (y / std::fabs(y)) * std::fabs(t) * n;
+        c = n;
+    }
+};
+// apply_rotation_in_the_plane: (x, y) <- (c x + s y, -s x + c y); the identity rotation is skipped
+inline void rot_apply(double& x, double& y, const JacobiRot& j) {
+    if (j.c == 1.0 && j.s == 0.0) return;
+    const double xi = x, yi = y;
+    x = j.c * xi + j.s * yi;
+    y = -j.s * xi + j.c * yi;
+}
+void apply_on_the_left(M3d& m, int p, int q, const JacobiRot& j) { for (int k = 0; k < 3; ++k) rot_apply(m.a[p][k], m.a[q][k], j); }
+void apply_on_the_right(M3d& m, int p, int q, const JacobiRot& j) { const JacobiRot jt = j.transpose(); for (int k = 0; k < 3; ++k) rot_apply(m.a[k][p], m.a[k][q], jt); }
+
+void real_2x2_jacobi_svd(const M3d& W, int p, int q, JacobiRot& j_left, JacobiRot& j_right) {
+    double m[2][2] = {{W.a[p][p], W.a[p][q]}, {W.a[q][p], W.a[q][q]}};
+    JacobiRot rot1;
+    const double t = m[0][0] + m[1][1];
+    const double d = m[1][0] - m[0][1];
+    if (std::fabs(d) < std::numeric_limits<double>::min()) {
+        rot1.s = 0.0; rot1.c = 1.0;
+    } else {
+        const double u = t / d;
+        const double tmp = std::sqrt(1.0 + u * u);
+        rot1.s = 1.0 / tmp;
+        rot1.c = u / tmp;
+    }
+    for (int k = 0; k < 2; ++k) rot_apply(m[0][k], m[1][k], rot1);  // m.applyOnTheLeft(0, 1, rot1)
+    j_right.make_jacobi(m[0][0], m[0][1], m[1][1]);
+    j_left = rot1 * j_right.transpose();
+}
+
+// A = U * diag(S) * V^T, S sorted descending, S >= 0.  JacobiSVD<Matrix3d>::compute, full U and V.
+void svd3_eigen_jacobi(const M3d& Ain, M3d& U, double S[3], M3d& V) {
+    const double precision = 2.0 * std::numeric_limits<double>::epsilon();
+    const double consider_as_zero = std::numeric_limits<double>::min();
+    double scale = 0.0;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) scale = std::max(scale, std::fabs(Ain.a[i][j]));
+    if (scale == 0.0) scale = 1.0;
+    M3d W;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) W.a[i][j] = Ain.a[i][j] / scale;
+    U = m3d_identity();
+    V = m3d_identity();
+    double max_diag = std::max(std::fabs(W.a[0][0]), std::max(std::fabs(W.a[1][1]), std::fabs(W.a[2][2])));
+    bool finished = false;
+    int guard = 0;  // Eigen loops until finished; NaN input ends it there as here (comparisons false); the guard only bounds a defect
+    while (!finished && guard++ < 1000) {
+        finished = true;
+        for (int p = 1; p < 3; ++p)
+            for (int q = 0; q < p; ++q) {
+                const double threshold = std::max(consider_as_zero, precision * max_diag);
+                if (std::fabs(W.a[p][q]) > threshold || std::fabs(W.a[q][p]) > threshold) {
+                    finished = false;
+                    JacobiRot j_left, j_right;
+                    real_2x2_jacobi_svd(W, p, q, j_left, j_right);
+                    apply_on_the_left(W, p, q, j_left);
+                    apply_on_the_right(U, p, q, j_left.transpose());
+                    apply_on_the_right(W, p, q, j_right);
+                    apply_on_the_right(V, p, q, j_right);
+                    max_diag = std::max(max_diag, std::max(std::fabs(W.a[p][p]), std::fabs(W.a[q][q])));
+                }
+            }
+    }
+    for (int i = 0; i < 3; ++i) {
+        const double a = W.a[i][i];
+        S[i] = std::fabs(a);
+        if (a < 0.0) for (int r = 0; r < 3; ++r) U.a[r][i] = -U.a[r][i];
+    }
+    for (int i = 0; i < 3; ++i) S[i] *= scale;
+    for (int i = 0; i < 3; ++i) {  // sort: first maximum of the tail; stop at the first zero
+        int pos = i;
+        for (int j = i + 1; j < 3; ++j) if (S[j] > S[pos]) pos = j;
+        if (S[pos] == 0.0) break;
+        if (pos != i) {
+            std::swap(S[i], S[pos]);
+            for (int r = 0; r < 3; ++r) { std::swap(U.a[r][i], U.a[r][pos]); std::swap(V.a[r][i], V.a[r][pos]); }
+        }
+    }
+}
+
+// Round 2's stand-in ("a two-sided Jacobi", own sweep order (0,1),(0,2),(1,2), own per-pair threshold, selection sort), kept
+// ONLY as a convention flip (Conventions::svd_r2_two_sided): on full-rank H it must give the same R, on rank-deficient H it
+// shows how much of R is the SVD's choice.
 // A = U * diag(S) * V^T, S sorted descending, S >= 0.
-void svd3(const M3d& Ain, M3d& U, double S[3], M3d& V) {
+void svd3_two_sided_r2(const M3d& Ain, M3d& U, double S[3], M3d& V) {
     M3d A = Ain;
     U = m3d_identity();
     V = m3d_identity();
@@ -511,6 +669,11 @@ void svd3(const M3d& Ain, M3d& U, double S[3], M3d& V) {
             for (int r = 0; r < 3; ++r) { std::swap(U.a[r][i], U.a[r][m]); std::swap(V.a[r][i], V.a[r][m]); }
         }
     }
+}
+
+void svd3(const M3d& A, M3d& U, double S[3], M3d& V) {
+    if (conventions().svd_r2_two_sided) svd3_two_sided_r2(A, U, S, V);
+    else svd3_eigen_jacobi(A, U, S, V);
 }
 }  // namespace
 
@@ -593,30 +756,33 @@ std::tuple<Mat3, Vec3> IterativeClosestPoint3D::procrustes(ProcrustesDebug* dbg)
         nuse = (long)reg_.inliers;
         for (long k = 0; k < nuse; ++k) use[d[k].second] = 1;
     }
-    // thrust::reduce of Point3D x2 (:152-153) → double sums rounded to fp32
-    double sx = 0, sy = 0, sz = 0, cx = 0, cy = 0, cz = 0;
-    for (long i = 0; i < ns; ++i) {
-        if (!use[i]) continue;
-        sx += pcs_buf_[i].x; sy += pcs_buf_[i].y; sz += pcs_buf_[i].z;
-        cx += corrs[i].x; cy += corrs[i].y; cz += corrs[i].z;
-    }
-    Vec3 src_centroid{(float)sx, (float)sy, (float)sz};
-    Vec3 cor_centroid{(float)cx, (float)cy, (float)cz};
+    // thrust::reduce of Point3D x2 (:152-153) → double sums rounded to fp32 (Conventions::sum_mode 1 / 2: fp32 tree / serial)
+    const int sum_mode = conventions().sum_mode;
+    auto reduce_col = [&](auto&& value_of) {  // Σ over the used points of one scalar per point
+        if (sum_mode == 0) {
+            double acc = 0.0;
+            for (long i = 0; i < ns; ++i) if (use[i]) acc += (double)value_of(i);
+            return (float)acc;
+        }
+        std::vector<float> v;
+        v.reserve(ns);
+        for (long i = 0; i < ns; ++i) if (use[i]) v.push_back(value_of(i));
+        return reduce_f32(v.data(), (long)v.size(), sum_mode);
+    };
+    Vec3 src_centroid{reduce_col([&](long i) { return pcs_buf_[i].x; }), reduce_col([&](long i) { return pcs_buf_[i].y; }),
+                      reduce_col([&](long i) { return pcs_buf_[i].z; })};
+    Vec3 cor_centroid{reduce_col([&](long i) { return corrs[i].x; }), reduce_col([&](long i) { return corrs[i].y; }),
+                      reduce_col([&](long i) { return corrs[i].z; })};
     float fn = static_cast<float>(nuse);
     src_centroid = Vec3{src_centroid.x / fn, src_centroid.y / fn, src_centroid.z / fn};  // :155-156
     cor_centroid = Vec3{cor_centroid.x / fn, cor_centroid.y / fn, cor_centroid.z / fn};
     // kernCentralize x2 (:38-44), kernOuterProduct (:46-52), reduce mat3 (:165-166)
-    double acc[3][3] = {{0}};
-    for (long i = 0; i < ns; ++i) {
-        if (!use[i]) continue;
-        float a[3] = {pcs_buf_[i].x - src_centroid.x, pcs_buf_[i].y - src_centroid.y, pcs_buf_[i].z - src_centroid.z};
-        float b[3] = {corrs[i].x - cor_centroid.x, corrs[i].y - cor_centroid.y, corrs[i].z - cor_centroid.z};
-        // glm::outerProduct(c=a, r=b): m[col i][row k] = a[k]*b[i]
-        for (int col = 0; col < 3; ++col)
-            for (int row = 0; row < 3; ++row) acc[col][row] += (double)(a[row] * b[col]);
-    }
+    // glm::outerProduct(c=a, r=b): m[col][row] = a[row]*b[col]
+    auto a_of = [&](long i, int k) { return (k == 0 ? pcs_buf_[i].x : k == 1 ? pcs_buf_[i].y : pcs_buf_[i].z) - (k == 0 ? src_centroid.x : k == 1 ? src_centroid.y : src_centroid.z); };
+    auto b_of = [&](long i, int k) { return (k == 0 ? corrs[i].x : k == 1 ? corrs[i].y : corrs[i].z) - (k == 0 ? cor_centroid.x : k == 1 ? cor_centroid.y : cor_centroid.z); };
     Mat3 ABt;
-    for (int col = 0; col < 3; ++col) for (int row = 0; row < 3; ++row) ABt.c[col][row] = (float)acc[col][row];
+    for (int col = 0; col < 3; ++col)
+        for (int row = 0; row < 3; ++row) ABt.c[col][row] = reduce_col([&](long i) { return a_of(i, row) * b_of(i, col); });
     Mat3 Rn = closest_orthogonal_approximation(ABt);  // :168
     Vec3 rs = host_mul(Rn, src_centroid);
     Vec3 tn{cor_centroid.x - rs.x, cor_centroid.y - rs.y, cor_centroid.z - rs.z};  // :169

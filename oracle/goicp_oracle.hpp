@@ -22,7 +22,10 @@
 //   * Thrust reductions (unspecified fp32 tree order) are restated as a
 //     double-precision serial sum rounded once to fp32;
 //   * CUDA linear texture filtering: sample at x-0.5, i=floor, weight held in
-//     1.8 fixed point (round-to-nearest), clamp addressing, lerp x→y→z.
+//     1.8 fixed point (round-to-nearest), clamp addressing, lerp x→y→z;
+//   * Eigen::JacobiSVD<Matrix3d> restated from its published algorithm.
+// Each of these has a switch in `Conventions` below; tools/convention_flips.py
+// runs the golden cases under every flip and DESIGN.md §2 tabulates what moves.
 // ============================================================================
 #pragma once
 #include <array>
@@ -40,6 +43,26 @@ namespace goicp_oracle {
 constexpr float kPi = 3.141592653589793f;
 constexpr float kInf = 1E+10f;
 constexpr float kSqrt3 = 1.732050807568877f;
+
+// The conventions this restatement CHOOSES where the reference inherits behaviour from nvcc (-fmad=true contraction),
+// the CUDA texture unit, Thrust's reduction tree, libdevice's sinf and Eigen.  Value 0/the default is the choice the
+// fixtures are generated with; every other value is a FLIP for tools/convention_flips.py (process-global, set before use).
+struct Conventions {
+    // a*x + b*y + c*z in device code (R*p at registration.cu:20,34, icp3d.cu:35; squared distances at :159, :255 and
+    // glm::distance's dot at icp3d.cu:20; the squared norm at :39-41):
+    //   1 = fma(c,z, fma(b,y, a*x)) [default]   0 = no contraction   2 = fma(c,z, fma(a,x, b*y)) (the first product fused)
+    int fma_matvec = 1;
+    int fma_dist = 1;
+    int fma_rot_sub = 0;    // distance -= 2*radius*sin (registration.cu:43,51): 0 = product rounded, then subtracted; 1 = fma(-(2*radius), sin, distance)
+    int fma_trans_sub = 0;  // distance - M_SQRT3*span (:33, :57): 0 = product rounded; 1 = fma(-M_SQRT3, span, distance)
+    int tex_weight = 0;     // 1.8 fixed-point filter weight: 0 = round to nearest, 1 = truncate, 2 = not quantised
+    int tex_blend = 0;      // 0 = nested lerps x->y->z as fma(w, b-a, a); 1 = the CUDA programming guide's 8-term weighted sum
+    int sum_mode = 0;       // Thrust reductions (registration.cu:80,126,134; icp3d.cu:152,153,166): 0 = fp64 sum rounded once,
+                            // 1 = fp32 pairwise tree, 2 = fp32 serial in index order
+    int sin_ulps = 0;       // device sin(float) (registration.cu:43) moved by this many ulps (CUDA documents sinf within 2 ulp)
+    int svd_r2_two_sided = 0;  // 0 = Eigen's JacobiSVD algorithm; 1 = round 2's own two-sided Jacobi
+};
+Conventions& conventions();
 
 struct Vec3 { float x, y, z; };
 // glm::mat3 layout: c[col][row], 36 B, column-major.

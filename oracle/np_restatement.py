@@ -126,3 +126,81 @@ def rotation(x, y, z):
                    [2 * (x * y + w * z), ww - x * x + y * y - z * z, 2 * (y * z - w * x)],
                    [2 * (x * z - w * y), 2 * (y * z + w * x), ww - x * x - y * y + z * z]], np.float64)
     return Rq.T.astype(f32), np.sqrt(r, dtype=f32), True
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Eigen::JacobiSVD<Matrix3d> (fgoicp/icp3d.cu:118-121) — third statement of the published algorithm (Eigen 3.3 / 3.4:
+# JacobiSVD::compute, real_2x2_jacobi_svd, JacobiRotation::makeJacobi), in matrix form: every plane rotation is applied as
+# a 3x3 Givens matrix product, so rounding differs from the scalar forms in oracle/goicp_oracle.cpp and csrc/host/math3.hpp
+# in the last bits only.  Used to cross-check what those two return on rank-deficient input, where the null-space columns
+# are the algorithm's choice (pair order (1,0), (2,0), (2,1); the 2x2 block is taken with the larger index first).
+# ---------------------------------------------------------------------------------------------------------------------
+def _givens(p, q, c, s):
+    """3x3 matrix that acts as [[c, s], [-s, c]] on coordinates (p, q)"""
+    G = np.eye(3)
+    G[p, p] = c; G[p, q] = s; G[q, p] = -s; G[q, q] = c
+    return G
+
+
+def jacobi_svd3(A):
+    A = np.asarray(A, np.float64)
+    tiny = np.finfo(np.float64).tiny
+    scale = np.abs(A).max()
+    if scale == 0.0:
+        scale = 1.0
+    W = A / scale
+    U = np.eye(3); V = np.eye(3)
+    maxdiag = np.abs(np.diag(W)).max()
+    for _ in range(1000):
+        finished = True
+        for p in (1, 2):
+            for q in range(p):
+                thr = max(tiny, 2.0 * np.finfo(np.float64).eps * maxdiag)
+                if not (abs(W[p, q]) > thr or abs(W[q, p]) > thr):
+                    continue
+                finished = False
+                m = np.array([[W[p, p], W[p, q]], [W[q, p], W[q, q]]])
+                t = m[0, 0] + m[1, 1]; d = m[1, 0] - m[0, 1]
+                if abs(d) < tiny:
+                    c1, s1 = 1.0, 0.0
+                else:
+                    u = t / d; h = np.sqrt(1.0 + u * u)
+                    c1, s1 = u / h, 1.0 / h
+                m = np.array([[c1, s1], [-s1, c1]]) @ m
+                x, y, z = m[0, 0], m[0, 1], m[1, 1]
+                if 2.0 * abs(y) < tiny:
+                    cr, sr = 1.0, 0.0
+                else:
+                    tau = (x - z) / (2.0 * abs(y))
+                    w = np.sqrt(tau * tau + 1.0)
+                    tt = 1.0 / (tau + w) if tau > 0 else 1.0 / (tau - w)
+                    n = 1.0 / np.sqrt(tt * tt + 1.0)
+                    cr, sr = n, -np.sign(tt) * np.sign(y) * abs(tt) * n
+                cl = c1 * cr + s1 * sr          # rot1 * right^T
+                sl = -c1 * sr + s1 * cr
+                L = _givens(p, q, cl, sl); Rt = _givens(p, q, cr, sr)
+                W = L @ W @ Rt
+                U = U @ L.T
+                V = V @ Rt
+                maxdiag = max(maxdiag, abs(W[p, p]), abs(W[q, q]))
+        if finished:
+            break
+    S = np.abs(np.diag(W)).copy()
+    for i in range(3):
+        if W[i, i] < 0:
+            U[:, i] = -U[:, i]
+    S *= scale
+    for i in range(3):
+        pos = i + int(np.argmax(S[i:]))
+        if S[pos] == 0.0:
+            break
+        if pos != i:
+            S[[i, pos]] = S[[pos, i]]; U[:, [i, pos]] = U[:, [pos, i]]; V[:, [i, pos]] = V[:, [pos, i]]
+    return U, S, V
+
+
+def closest_orthogonal(H):
+    """icp3d.cu:110-138 for the math-convention H (row = source axis, column = correspondence axis), in fp64"""
+    U, S, V = jacobi_svd3(H)
+    d = np.linalg.det(V @ U.T)
+    return V @ np.diag([1.0, 1.0, d]) @ U.T

@@ -55,6 +55,8 @@ def lib():
         L.orc_set_num_threads.argtypes = [C.c_int]
         want = os.environ.get("FGOICP_ORACLE_THREADS") or os.environ.get("OMP_NUM_THREADS")
         L.orc_set_num_threads(int(want) if want and want.isdigit() else usable_cpus())
+        L.orc_convention.argtypes = [C.c_char_p, C.c_int, _ip]
+        L.orc_convention.restype = C.c_int
         L.orc_rotation.argtypes = [C.c_float, C.c_float, C.c_float, _fp, _fp, _ip]
         L.orc_rotnode_overlaps.argtypes = [C.c_float] * 4
         L.orc_rotnode_overlaps.restype = C.c_int
@@ -80,6 +82,7 @@ def lib():
         L.orc_goicp_create.argtypes = [_fp, C.c_size_t, _fp, C.c_size_t, C.c_float, C.c_float]
         L.orc_goicp_create.restype = C.c_void_p
         L.orc_goicp_destroy.argtypes = [C.c_void_p]
+        L.orc_goicp_use_grid.argtypes = [C.c_void_p, C.c_int]
         L.orc_goicp_preproc.argtypes = [C.c_void_p, _fp, _fp, _fp, _fp, _fp, _ip]
         L.orc_goicp_run.argtypes = [C.c_void_p, _fp, _fp, _fp, _fp, C.POINTER(C.c_ulonglong)]
         _lib = L
@@ -96,6 +99,34 @@ def to_glm(R):
 
 def from_glm(flat):
     return np.asarray(flat, dtype=np.float32).reshape(3, 3).T.copy()
+
+
+CONVENTION_DEFAULTS = dict(fma_matvec=1, fma_dist=1, fma_rot_sub=0, fma_trans_sub=0, tex_weight=0, tex_blend=0, sum_mode=0, sin_ulps=0,
+                           svd_r2_two_sided=0)
+
+
+def set_conventions(**kw):
+    """Flip conventions the oracle CHOOSES (goicp_oracle.hpp: Conventions); process-global.  Returns the previous values."""
+    old = {}
+    for name, value in kw.items():
+        prev = C.c_int()
+        if lib().orc_convention(name.encode(), int(value), C.byref(prev)) != 0:
+            raise KeyError(name)
+        old[name] = prev.value
+    return old
+
+
+def get_conventions():
+    out = {}
+    for name in CONVENTION_DEFAULTS:
+        prev = C.c_int()
+        lib().orc_convention(name.encode(), -1000, C.byref(prev))
+        out[name] = prev.value
+    return out
+
+
+def reset_conventions():
+    lib().orc_conventions_reset()
 
 
 def rotation(x, y, z):
@@ -210,6 +241,10 @@ class FastGoICP:
         if getattr(self, "_h", None):
             lib().orc_goicp_destroy(self._h)
             self._h = None
+
+    def use_grid(self, on=True):
+        """exact nearest neighbours through the uniform grid instead of the O(ns*nt) loops (same results, bit for bit)"""
+        lib().orc_goicp_use_grid(self._h, int(bool(on)))
 
     def preproc(self):
         offs = np.empty(6, np.float32); scale = C.c_float(); bounds = np.empty(6, np.float32)

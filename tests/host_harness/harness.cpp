@@ -167,7 +167,7 @@ void harness_closest_orthogonal(const float* ABt9, float* R9) {
 void harness_svd3(const double* A9, double* U9, double* S3, double* V9) {
     double A[3][3], U[3][3], V[3][3];
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) A[i][j] = A9[3 * i + j];
-    svd3_hestenes(A, U, S3, V);
+    svd3_jacobi(A, U, S3, V);
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { U9[3 * i + j] = U[i][j]; V9[3 * i + j] = V[i][j]; }
 }
 }  // extern "C"

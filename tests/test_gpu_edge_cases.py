@@ -68,16 +68,19 @@ def test_correspondence_tie_rule_compares_square_roots(fg, gpu_required):
 
 
 def test_coplanar_and_collinear_clouds(fg, oracle, gpu_required):
-    """Rank-deficient cross-covariance: the SVD-based rotation must still be a proper rotation."""
+    """Rank-deficient cross-covariance: a proper rotation, and the SAME one as the oracle's — both sides follow Eigen's JacobiSVD
+    algorithm (icp3d.cu:118-121), whose null-space vectors decide R here (tests/test_gpu_rank_deficient.py has the ICP runs)."""
     rng = np.random.default_rng(4)
     plane = np.concatenate([rng.uniform(-0.8, 0.8, (200, 2)), np.full((200, 1), 0.1)], 1).astype(f32)
     bounds = np.array([[-1, 1], [-1, 1], [-0.2, 0.4]], f32)
     Rh, Ro = _cmp_ops(fg, oracle, plane, plane[:150].copy(), bounds, 0.1)
+    assert np.allclose(Rh, Ro, atol=1e-5)
     for R in (Rh, Ro):
         assert np.allclose(R @ R.T, np.eye(3), atol=1e-4) and np.linalg.det(R.astype(np.float64)) == pytest.approx(1.0, abs=1e-4)
     line = np.stack([np.linspace(-0.8, 0.8, 120), np.full(120, 0.05), np.full(120, -0.05)], 1).astype(f32)
     bounds = np.array([[-1, 1], [-0.2, 0.2], [-0.2, 0.2]], f32)
     Rh, Ro = _cmp_ops(fg, oracle, line, line[10:90].copy(), bounds, 0.05)
+    assert np.allclose(Rh, Ro, atol=1e-5)
     assert np.allclose(Rh @ Rh.T, np.eye(3), atol=1e-4) and np.linalg.det(Rh.astype(np.float64)) == pytest.approx(1.0, abs=1e-4)
 
 

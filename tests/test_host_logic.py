@@ -40,23 +40,25 @@ def test_python_node_types_match_oracle(oracle, fg):
 
 
 def test_product_svd_and_procrustes_rotation(oracle):
+    """csrc/host/math3.hpp restates Eigen's JacobiSVD algorithm independently of oracle/ (flat code for n = 3 against the
+    oracle's rotation objects): U, S, V and the Procrustes rotation must agree BIT FOR BIT on every rank — on rank-deficient H the
+    null-space columns are the algorithm's choice, and round 2's Hestenes SVD chose differently (fuzz seed 7, cases 103 / 505)."""
+    from tests.test_oracle_kat import _rank_deficient_family
     rng = np.random.default_rng(2)
-    for trial in range(40):
-        H = rng.normal(size=(3, 3))
-        if trial % 4 == 1:
-            H[:, 1] = 2 * H[:, 0]                       # rank 2
-        if trial % 4 == 2:
-            H = np.outer(rng.normal(size=3), rng.normal(size=3))  # rank 1
-        if trial % 4 == 3:
-            H = H @ np.diag([1, 1, -1])                 # det < 0: needs the diag(1,1,det) fix
+    for trial in range(800):
+        H = _rank_deficient_family(rng, trial)
         U, S, V = hh.svd3(H)
-        assert np.allclose(U @ np.diag(S) @ V.T, H, atol=1e-12) and np.all(np.diff(S) <= 1e-15)
-        assert np.allclose(U.T @ U, np.eye(3), atol=1e-10) and np.allclose(V.T @ V, np.eye(3), atol=1e-12)
+        Uo, So, Vo = oracle.svd3(H)
+        assert np.array_equal(U, Uo) and np.array_equal(S, So) and np.array_equal(V, Vo), trial
+        scale = max(np.abs(H).max(), 1e-300)
+        assert np.allclose(U @ np.diag(S) @ V.T, H, atol=1e-14 * scale) and np.all(np.diff(S) <= 0)
+        assert np.allclose(U.T @ U, np.eye(3), atol=1e-13) and np.allclose(V.T @ V, np.eye(3), atol=1e-13)
         ABt = H.T.reshape(9).astype(f32)
-        got = hh.closest_orthogonal(ABt).reshape(3, 3).T
+        got = hh.closest_orthogonal(ABt)
+        assert np.array_equal(got.view(np.uint32), oracle.closest_orthogonal(ABt).view(np.uint32)), trial
+        got = got.reshape(3, 3).T
         assert np.allclose(got @ got.T, np.eye(3), atol=1e-5) and np.linalg.det(got.astype(np.float64)) == pytest.approx(1, abs=1e-5)
-        if trial % 4 in (0, 3):  # full rank: unique answer, must agree with the oracle's independent SVD
-            assert np.allclose(got, oracle.closest_orthogonal(ABt).reshape(3, 3).T, atol=1e-6)
+        if S[2] > 1e-3 * S[0]:  # full rank: unique answer, numpy's LAPACK SVD gives it too
             Un, Sn, Vtn = np.linalg.svd(H)
             want = Vtn.T @ np.diag([1, 1, np.linalg.det(Vtn.T @ Un.T)]) @ Un.T
             assert np.allclose(got, want, atol=1e-5)

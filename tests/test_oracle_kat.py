@@ -197,6 +197,91 @@ def test_closest_orthogonal_matches_numpy_svd(oracle):
     assert np.allclose(U @ np.diag(S) @ V.T, H, atol=1e-12) and np.all(np.diff(S) <= 0)
 
 
+def _rank_deficient_family(rng, trial):
+    """3x3 cross-covariances of every rank, as fp32 values (what icp3d.cu:166 hands to the SVD)"""
+    H = rng.normal(size=(3, 3)) * 10.0 ** rng.uniform(-9, 2)
+    k = trial % 8
+    if k == 1:
+        H[:, 1] = 2 * H[:, 0]                                                   # rank 2, exactly
+    if k == 2:
+        H = np.outer(rng.normal(size=3), rng.normal(size=3))                    # rank 1 up to the fp32 rounding of its entries
+    if k == 3:
+        H = H @ np.diag([1, 1, -1])                                             # det < 0: needs diag(1, 1, det)
+    if k == 4:
+        H = np.zeros((3, 3))                                                    # every correspondence on one target point
+    if k == 5:
+        H = np.outer(rng.normal(size=3), rng.normal(size=3)) + 1e-9 * rng.normal(size=(3, 3))
+    if k == 6:
+        H = np.diag(rng.normal(size=3))
+    if k == 7:
+        H = np.outer(rng.normal(size=3), [1.0, 0.0, 0.0]) * 1e-12               # rank 1, tiny
+    return H.astype(f32).astype(np.float64)
+
+
+def test_svd_follows_eigens_jacobi_algorithm(oracle):
+    """icp3d.cu:118-121 calls Eigen::JacobiSVD<Matrix3d>.  Known answers of THAT algorithm which a different SVD would not give
+    (they decide R on rank-deficient input): no rotation is applied to a diagonal matrix, so U and V stay (signed, permuted) unit
+    vectors; the sort swaps with the first maximum of the tail; a negative diagonal entry negates U's column, not V's; the zero
+    matrix returns identities.  Then the scalar restatement against the numpy matrix-form one on every rank."""
+    from oracle import np_restatement as npr
+    I = np.eye(3)
+    U, S, V = oracle.svd3(np.zeros((3, 3)))
+    assert np.array_equal(U, I) and np.array_equal(V, I) and np.array_equal(S, [0, 0, 0])
+    assert np.array_equal(oracle.closest_orthogonal(np.zeros(9, f32)).reshape(3, 3), I)      # R = I, not a noise rotation
+    U, S, V = oracle.svd3(np.diag([3.0, 2.0, 1.0]))
+    assert np.array_equal(U, I) and np.array_equal(V, I) and np.array_equal(S, [3, 2, 1])
+    U, S, V = oracle.svd3(np.diag([1.0, 2.0, 3.0]))     # i=0 swaps with column 2 (the maximum); then (2, 1) is in order
+    assert np.array_equal(S, [3, 2, 1]) and np.array_equal(U, I[:, [2, 1, 0]]) and np.array_equal(V, I[:, [2, 1, 0]])
+    U, S, V = oracle.svd3(np.diag([2.0, 2.0, 5.0]))     # equal values: the FIRST maximum of the tail is taken -> no second swap
+    assert np.array_equal(S, [5, 2, 2]) and np.array_equal(U, I[:, [2, 1, 0]])
+    U, S, V = oracle.svd3(np.diag([2.0, -5.0, 1.0]))
+    assert np.array_equal(S, [5, 2, 1]) and np.array_equal(V, I[:, [1, 0, 2]]) and np.array_equal(U, np.array([[0, 1, 0], [-1, 0, 0], [0, 0, 1.0]]))
+    U, S, V = oracle.svd3(np.diag([4.0, 0.0, 0.0]))     # the sort stops at the first zero
+    assert np.array_equal(U, I) and np.array_equal(V, I)
+    # one 2x2 block, by hand: H = [[0, 1], [-1, 0]] (+) 1 is a rotation by -90 deg: d = m10 - m01 with the LARGER index first
+    H = np.array([[0.0, 1.0, 0.0], [-1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    U, S, V = oracle.svd3(H)
+    assert np.allclose(U @ np.diag(S) @ V.T, H, atol=1e-15) and np.allclose(S, 1)
+    R = oracle.closest_orthogonal(H.T.reshape(9).astype(f32)).reshape(3, 3).T
+    assert np.allclose(R, H.T, atol=1e-7)               # R = V U^T = H^T for an orthogonal H
+    rng = np.random.default_rng(12)
+    for trial in range(400):
+        H = _rank_deficient_family(rng, trial)
+        U, S, V = oracle.svd3(H)
+        scale = max(np.abs(H).max(), 1e-300)
+        assert np.allclose(U @ np.diag(S) @ V.T, H, atol=1e-14 * scale) and np.all(np.diff(S) <= 0) and np.all(S >= 0)
+        assert np.allclose(U.T @ U, I, atol=1e-13) and np.allclose(V.T @ V, I, atol=1e-13)
+        R = oracle.closest_orthogonal(H.T.reshape(9).astype(f32)).reshape(3, 3).T
+        if trial % 8 != 7:  # exact zero columns: the scalar form keeps exact zeros where the matrix form leaves 1e-17 noise, and the
+            #                   sign of that noise picks the null-space vectors — only a scalar statement can follow Eigen there
+            Rn = npr.closest_orthogonal(H)
+            assert np.allclose(R, Rn, atol=2e-7), (trial, R, Rn)  # the same member of the solution family, on every other rank
+        assert np.linalg.det(R.astype(np.float64)) == pytest.approx(1.0, abs=1e-5)
+
+
+def test_svd_choice_only_matters_on_rank_deficient_input(oracle):
+    """The convention flip `svd_r2_two_sided` (round 2's own Jacobi): same R on full-rank H, a different member of the family on
+    rank-deficient H — which is why both sides now restate Eigen's algorithm (fuzz seed 7, cases 103 and 505)."""
+    rng = np.random.default_rng(13)
+    differs = 0
+    try:
+        for trial in range(200):
+            H = _rank_deficient_family(rng, trial)
+            ABt = H.T.reshape(9).astype(f32)
+            a = oracle.closest_orthogonal(ABt)
+            oracle.set_conventions(svd_r2_two_sided=1)
+            b = oracle.closest_orthogonal(ABt)
+            oracle.reset_conventions()
+            S = np.linalg.svd(H, compute_uv=False)
+            if S[0] > 0 and S[1] > 1e-3 * S[0]:      # rank >= 2 and well conditioned: R is unique
+                assert np.allclose(a, b, atol=1e-4 if S[2] < 1e-6 * S[0] else 2e-6), trial
+            elif not np.allclose(a, b, atol=1e-3):
+                differs += 1
+    finally:
+        oracle.reset_conventions()
+    assert differs > 10
+
+
 def test_procrustes_recovers_known_motion(oracle, fg):
     rng = np.random.default_rng(6)
     tgt = rng.uniform(-1, 1, (400, 3)).astype(f32)

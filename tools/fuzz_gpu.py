@@ -34,7 +34,10 @@ def make_cloud(rng, n, box, kind):
 SCALE = int(os.environ.get("FUZZ_SCALE", "1"))  # > 1: clouds SCALE times larger (several windows per tick, long rows)
 
 
-def one_case(rng, idx):
+def gen_case(rng, idx):
+    """Every random draw of one operator case, in the campaign's order.  Pure numpy (no GPU, no oracle): `case_inputs(seed, idx)`
+    replays a campaign up to a case so that anything it found can be rebuilt anywhere — round 2's cases 103 and 505 of seed 1
+    (tests/test_gpu_edge_cases.py, tests/test_oracle_kat.py)."""
     nt = int(rng.choice([1, 2, 31, 32, 33, 64, 100, 255, 257, 1000, 2049, 6000])) if rng.random() < 0.5 else int(rng.integers(1, 4000))
     ns = int(rng.choice([1, 2, 3, 63, 64, 65, 255, 256, 257, 511, 1025, 4097])) if rng.random() < 0.5 else int(rng.integers(1, 5000))
     if SCALE > 1:
@@ -50,24 +53,46 @@ def one_case(rng, idx):
     trim = rng.random() < 0.3 and ns >= 8
     k = int(rng.integers(max(1, ns // 4), ns)) if trim else 0
     desc = f"case {idx}: nt={nt} ns={ns} res={res:.4g} dims~{np.ceil((hi - lo) / res).astype(int).tolist()} trim_k={k}"
+    # whole-tick path: G rotation nodes, UB and LB groups of the same node share translation nodes (twins)
+    G = int(rng.integers(1, 40))
+    Rs, spans, fixes, groups = [], [], [], []
+    while len(Rs) < 2 * G:
+        v = rng.uniform(-0.6, 0.6, 3)
+        node = fg.RotNode(*v, float(rng.choice([0.5, 0.25, 0.125, 0.0625])))
+        nb = int(rng.integers(1, 49))
+        tn = np.concatenate([rng.uniform(-0.6, 0.6, (nb, 3)), rng.choice([1.0, 0.5, 0.25, 0.0625], (nb, 1))], 1).astype(f32)
+        other = tn[rng.random(nb) < 0.6]
+        tn_lb = np.concatenate([other, np.concatenate([rng.uniform(-0.6, 0.6, (3, 3)), np.full((3, 1), 0.125)], 1)]).astype(f32)
+        for fix, t in ((True, tn), (False, tn_lb)):
+            Rs.append(node.q.R); spans.append(node.span); fixes.append(fix); groups.append(t)
+    batch_tn = np.concatenate([rng.uniform(-0.5, 0.5, (9, 3)), rng.choice([1.0, 0.25, 0.0625], (9, 1))], 1).astype(f32)
+    R = fg.synth.random_rotation(rng, 40.0).astype(f32)
+    t = rng.uniform(-0.2, 0.2, 3).astype(f32)
+    return dict(desc=desc, tgt=tgt, src=src, bounds=bounds, res=res, k=k, Rs=Rs, spans=spans, fixes=fixes, groups=groups,
+                batch_tn=batch_tn, R=R, t=t)
+
+
+def case_inputs(seed, idx):
+    """The inputs of case `idx` of the operator campaign with seed `seed` (replays the draws of the cases before it)."""
+    rng = np.random.default_rng(seed)
+    for i in range(idx):
+        gen_case(rng, i)
+    return gen_case(rng, idx)
+
+
+ICP_ITERS, ICP_THR = 12, 0.005
+
+
+def check_case(c):
+    """One generated case through the HIP operators and the oracle; None, or a description of the first difference."""
+    tgt, src, bounds, res, k, desc = c["tgt"], c["src"], c["bounds"], c["res"], c["k"], c["desc"]
+    Rs, spans, fixes, groups = c["Rs"], c["spans"], c["fixes"], c["groups"]
     hip = fg.Registration(tgt, src, bounds, res)
     orc = oracle.Registration(tgt, src, bounds, res)
     try:
         assert np.array_equal(hip.lut_read().view(np.uint32), orc.lut_get().view(np.uint32)), "LUT bits"
         if k:
             hip.set_inliers(k); orc.set_inliers(k)
-        # whole-tick path: G rotation nodes, UB and LB groups of the same node share translation nodes (twins)
-        G = int(rng.integers(1, 40))
-        Rs, spans, fixes, groups = [], [], [], []
-        while len(Rs) < 2 * G:
-            v = rng.uniform(-0.6, 0.6, 3)
-            node = fg.RotNode(*v, float(rng.choice([0.5, 0.25, 0.125, 0.0625])))
-            nb = int(rng.integers(1, 49))
-            tn = np.concatenate([rng.uniform(-0.6, 0.6, (nb, 3)), rng.choice([1.0, 0.5, 0.25, 0.0625], (nb, 1))], 1).astype(f32)
-            other = tn[rng.random(nb) < 0.6]
-            tn_lb = np.concatenate([other, np.concatenate([rng.uniform(-0.6, 0.6, (3, 3)), np.full((3, 1), 0.125)], 1)]).astype(f32)
-            for fix, t in ((True, tn), (False, tn_lb)):
-                Rs.append(node.q.R); spans.append(node.span); fixes.append(fix); groups.append(t)
         out = hip.compute_bounds_multi(Rs, spans, fixes, groups)
         for g in range(len(Rs)):
             lbo, ubo = orc.compute_bounds(Rs[g], spans[g], groups[g], fixes[g])
@@ -75,14 +100,13 @@ def one_case(rng, idx):
             scale = max(float(np.abs(ubo).max()), 1e-12)
             assert np.allclose(ub, ubo, rtol=2e-6, atol=1e-6 * scale) and np.allclose(lb, lbo, rtol=2e-6, atol=1e-6 * scale), f"tick bounds, group {g} (fix_rot={fixes[g]})"
         rn = fg.RotNode(0.2, -0.1, 0.3, 0.25)
-        tn = np.concatenate([rng.uniform(-0.5, 0.5, (9, 3)), rng.choice([1.0, 0.25, 0.0625], (9, 1))], 1).astype(f32)
+        tn = c["batch_tn"]
         for fix in (True, False):
             lb, ub = hip.compute_sse_error(rn, tn, fix)
             lbo, ubo = orc.compute_bounds(rn.q.R, rn.span, tn, fix)
             scale = max(float(np.abs(ubo).max()), 1e-12)
             assert np.allclose(ub, ubo, rtol=2e-6, atol=1e-6 * scale) and np.allclose(lb, lbo, rtol=2e-6, atol=1e-6 * scale), "batch bounds"
-        R = fg.synth.random_rotation(rng, 40.0).astype(f32)
-        t = rng.uniform(-0.2, 0.2, 3).astype(f32)
+        R, t = c["R"], c["t"]
         a, b = float(hip.compute_sse_error(R, t)), float(orc.compute_sse_error(R, t))
         assert abs(a - b) <= 2e-6 * max(abs(b), 1e-12) + 1e-12, f"sse {a} vs {b}"
         if not k:
@@ -91,8 +115,8 @@ def one_case(rng, idx):
             _, _, ceno, _, ixo = orc.procrustes(w)
             assert np.array_equal(ix, ixo), "correspondence indices"
             assert np.allclose(cen, ceno, rtol=1e-6, atol=1e-7), "centroids"
-        sse, Ri, ti = fg.IterativeClosestPoint3D(hip, None, None, 12, 0.005, R, t).run()
-        sse_o, Ri_o, ti_o, it_o = orc.icp(R, t, 12, 0.005)
+        sse, Ri, ti = fg.IterativeClosestPoint3D(hip, None, None, ICP_ITERS, ICP_THR, R, t).run()
+        sse_o, Ri_o, ti_o, it_o = orc.icp(R, t, ICP_ITERS, ICP_THR)
         assert abs(float(sse) - float(sse_o)) <= 2e-5 * max(abs(float(sse_o)), 1e-10) + 1e-10, f"icp {sse} vs {sse_o}"
     except AssertionError as e:
         return desc + " -> " + str(e)
@@ -101,6 +125,10 @@ def one_case(rng, idx):
     finally:
         hip.close()
     return None
+
+
+def one_case(rng, idx):
+    return check_case(gen_case(rng, idx))
 
 
 def run_case(rng, idx):
