@@ -337,12 +337,47 @@ int ctx_bounds_multi(fgoicp_ctx* c, int G, const float* R9, const float* rot_spa
     return FGOICP_OK;
 }
 
+// ---- host-side final folds of the fused reductions (small clouds) -----------------------------------------------------------------
+// The device reduces in three levels: the shuffle tree of a wave (kernels.hip wave_sum: v[i] += v[i + off], off = 32 .. 1), the four
+// waves of a block in order, then sum_partials_kernel / icp_centroids_kernel over the blocks (lane-strided partial sums + the same
+// tree).  With the first level done in the scan's epilogue, the rest are a few hundred additions: done here, in the device's
+// order, on values the kernels wrote straight into pinned memory — the same bits, two launches less per pass.
+static double tree64(double (&v)[64]) {
+    for (int off = 32; off > 0; off >>= 1)
+        for (int i = 0; i < off; ++i) v[i] += v[i + off];
+    return v[0];
+}
+static double fold_blocks(const double* bp, int nblocks, int width, int k) {  // sum_partials_kernel
+    double lane[64] = {0};
+    for (int b = 0; b < nblocks; ++b) lane[b & 63] += bp[(size_t)b * width + k];
+    return tree64(lane);
+}
+static double fold_wave_sums(const double* w, int nwaves) {  // block_sum<1> of sum_f32_kernel over the waves, then sum_partials_kernel
+    double lane[64] = {0};
+    const int nblocks = (nwaves + 3) / 4;
+    for (int b = 0; b < nblocks; ++b) {
+        double blk = w[4 * b];
+        for (int k = 1; k < 4; ++k) blk += 4 * b + k < nwaves ? w[4 * b + k] : 0.0;
+        lane[b & 63] += blk;
+    }
+    return tree64(lane);
+}
+static bool icp_fused(const fgoicp_ctx* c) { return c->icp_fuse && !c->brute_force_nn && !c->inliers && c->ns <= 262144; }
+
 // float Registration::compute_sse_error(glm::mat3, glm::vec3) — registration.cu:62-86.  Enqueue only: the result lands in
 // pinned memory (sse_result) once `st` has drained.
 // `part`: 0 = everything, 1 = the search only, 2 = the sum only (the ICP loop interleaves the launches of its two streams: both long
 // scans first — a launch costs the submitting thread ~5 us, and whatever is enqueued last starts that much later).
 static int sse_enqueue(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R9, const float* t3, const uint32_t* seed_idx, hipStream_t st, int part = 0) {
     const int ns = (int)c->ns;
+    if (icp_fused(c)) {  // one launch: the scan leaves the wave-level sums of its minima in pinned memory, sse_result() folds them
+        if (part != 2) launch_nn_scan(c->d_src, ns, c->bvh_tgt.view(), c->d_lut, c->geom, R9, t3, 1, 0, c->d_tgt, (int)c->nt, seed_idx, nullptr, nullptr, L.d_min_bits, st,
+                                      nullptr, nullptr, nullptr, L.hd_wsse);
+        L.sse_on_host = true;
+        HIPCHK(hipGetLastError());
+        return FGOICP_OK;
+    }
+    L.sse_on_host = false;
     if (part == 2) {
     } else if (c->brute_force_nn) {
         launch_fill_u32(L.d_min_bits, 0x501502F9u /* bits(1e10f) */, c->ns, st);
@@ -369,7 +404,10 @@ static int sse_enqueue(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R9, c
     HIPCHK(hipGetLastError());
     return FGOICP_OK;
 }
-static float sse_result(const fgoicp_ctx* c, const fgoicp_ctx::IcpLane& L) { return c->inliers ? L.h_trim[0] : (float)L.h_sums[12]; }
+static float sse_result(const fgoicp_ctx* c, const fgoicp_ctx::IcpLane& L) {
+    if (L.sse_on_host) return (float)fold_wave_sums(L.h_wsse, (int)((c->ns + 63) / 64));
+    return c->inliers ? L.h_trim[0] : (float)L.h_sums[12];
+}
 
 static int lane_sse(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R9, const float* t3, float* sse_out, const uint32_t* seed_idx) {
     int rc = sse_enqueue(c, L, R9, t3, seed_idx, L.stream);
@@ -391,6 +429,18 @@ int ctx_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out, con
 static int procrustes_enqueue(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const uint32_t* seed_idx, uint32_t* idx, uint32_t* wide, hipStream_t st,
                               const float* move9 = nullptr, const float* move3 = nullptr, int part = 0) {
     const int ns = (int)c->ns, nt = (int)c->nt;
+    if (icp_fused(c)) {  // two launches: scan (+ move, + wave-level sums of points and correspondences), covariance (+ centroids) into pinned memory
+        const int nb = reduce_blocks_for(ns);
+        if (part != 2)
+            launch_nn_scan(L.d_work, ns, c->bvh_tgt.view(), c->d_lut, c->geom, move9, move3, move9 ? 1 : 0, 1, c->d_tgt, nt, seed_idx, nullptr, nullptr, idx, st,
+                           move9 ? L.d_work : nullptr, nullptr, nullptr, L.d_wsum);
+        if (part != 1) launch_icp_cov_cen(L.d_work, c->d_tgt, idx, ns, nt, L.d_wsum, nb, (ns + 63) / 64, L.hd_cen, L.hd_covbp, nb, st);
+        L.cov_on_host = true;
+        L.cov_blocks = nb;
+        HIPCHK(hipGetLastError());
+        return FGOICP_OK;
+    }
+    L.cov_on_host = false;
     if (part != 2) {
         static const bool fold_move = [] { const char* e = std::getenv("FGOICP_ICP_FOLD_MOVE"); return !e || std::atoi(e) != 0; }();  // tuning knob / A-B
         const bool fold = move9 && fold_move && !c->brute_force_nn && !(c->inliers && c->trim_skip);
@@ -438,7 +488,7 @@ static void procrustes_finish(const fgoicp_ctx::IcpLane& L, Mat3f* R_out, Vec3f*
     float cen[6];
     std::memcpy(cen, L.h_cen, sizeof(cen));
     Mat3f ABt;
-    for (int k = 0; k < 9; ++k) ABt.m[k] = (float)L.h_sums[k];
+    for (int k = 0; k < 9; ++k) ABt.m[k] = L.cov_on_host ? (float)fold_blocks(L.h_covbp, L.cov_blocks, 9, k) : (float)L.h_sums[k];
     const Mat3f Rn = closest_orthogonal_approximation(ABt);  // icp3d.cu:168
     const Vec3f sc{cen[0], cen[1], cen[2]}, cc{cen[3], cen[4], cen[5]};
     *R_out = Rn;
@@ -461,8 +511,11 @@ int ctx_procrustes_device(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, Mat3f* R_out, V
 // iteration k, so they run next to each other — both are latency chains that fill half the device at 40k points.  The pass of
 // iteration k+1 is speculative (the loop may end on the SSE of iteration k); it is drained before returning.  Same kernels,
 // same arithmetic, same order of every sum as the one-stream loop (FGOICP_ICP_OVERLAP=0).
+static int lane_icp_device(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9,
+                           float* t_out3, int* iters_out);
 static int lane_icp(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3,
                     int* iters_out) {
+    if (c->icp_device && c->icp_overlap && !c->brute_force_nn && !c->inliers) return lane_icp_device(c, L, R0, t0, max_iter, thr, sse_out, R_out9, t_out3, iters_out);
     HIPCHK(hipSetDevice(c->device));  // per host thread
     const int ns = (int)c->ns;
     const bool overlap = c->icp_overlap && !c->brute_force_nn;
@@ -545,6 +598,88 @@ static int lane_icp(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0, cons
     std::memcpy(R_out9, Ro.m, sizeof(Ro.m));
     t_out3[0] = to.x; t_out3[1] = to.y; t_out3[2] = to.z;
     if (iters_out) *iters_out = iters;
+    return FGOICP_OK;
+}
+
+// The same loop advanced ON THE DEVICE (kernels.hip, icp_step_kernel): no host round trip inside the loop.  Per iteration j the
+// host enqueues, without waiting for anything,
+//   stream B:  step_j   (waits for the SSE partials of iteration j-1: loop test of :94, then SVD, compose -> state)
+//   stream A:  E_j      exact SSE of the composed (R, t) of the state on the pristine source   (scan + block sums)
+//   stream B:  P_{j+1}  correspondences of the working cloud moved by the state's (R_, t_) (+ write-back), sums, covariance
+// and paces itself by the progress word the step kernel leaves in pinned memory (`icp_ahead` iterations ahead at most).  Once a
+// step kernel has ended the loop everything enqueued behind it returns at once.  Same kernels, same sums in the same order as the
+// host loop: bit-identical (sse, R, t, iterations) (tests/test_gpu_ops.py).  Untrimmed tree path only.
+static int lane_icp_device(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9,
+                           float* t_out3, int* iters_out) {
+    HIPCHK(hipSetDevice(c->device));
+    const int ns = (int)c->ns, nt = (int)c->nt;
+    const int nb = reduce_blocks_for(ns);
+    const int mi = (int)std::min<size_t>(max_iter, (size_t)1 << 30);
+    constexpr int kRing = fgoicp_ctx::IcpLane::kRing;
+    hipStream_t A = L.stream, B = L.icp_stream;
+    const bool seeding = c->icp_seeding;
+    uint32_t* idx[2] = {L.d_first_idx, L.d_first_idx2};
+    const float* st_f = reinterpret_cast<const float*>(L.d_icp);
+    const int* done = &L.d_icp->done;
+    volatile IcpHostResult* res = L.h_res;
+    res->done = 0;
+    res->iters_done = 0;
+    launch_icp_init(L.d_icp, R0, t0, mi, thr, L.hd_res, A);
+    HIPCHK(hipEventRecord(L.icp_ev_w, A));
+    HIPCHK(hipStreamWaitEvent(B, L.icp_ev_w, 0));
+    // P_1: the pristine source moved by (R0, t0) becomes the working cloud (icp3d.cu:85) inside the first correspondence scan
+    launch_nn_scan(c->d_src, ns, c->bvh_tgt.view(), c->d_lut, c->geom, R0, t0, 1, 1, c->d_tgt, nt, nullptr, nullptr, nullptr, idx[0], B, L.d_work);
+    launch_icp_sums(L.d_work, c->d_tgt, idx[0], ns, nt, nullptr, L.d_bp, nb, B);
+    launch_icp_cov_cen(L.d_work, c->d_tgt, idx[0], ns, nt, L.d_bp, nb, 0, L.d_cen, L.d_bp2, nb, B);
+    int cur = 0, enq = 0;
+    for (int j = 1; j <= mi; ++j) {
+        // pace: at most icp_ahead iterations ahead of the step kernels that have run.  The progress word is only a pacing hint;
+        // if it does not move for 20 ms (it always has), the host falls back to draining the stream — never a hang.
+        if (!res->done && j - res->iters_done > c->icp_ahead) {
+            const auto t_spin = std::chrono::steady_clock::now();
+            unsigned spins = 0;
+            while (!res->done && j - res->iters_done > c->icp_ahead) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+                if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(20)) {
+                    HIPCHK(hipStreamSynchronize(B));
+                    break;
+                }
+            }
+        }
+        if (res->done) break;
+        if (j > 1) HIPCHK(hipStreamWaitEvent(B, L.ev_sse[(j - 1) % kRing], 0));
+        launch_icp_step(L.d_icp, L.d_bp2, nb, L.d_bp3, nb, L.d_cen, L.hd_res, B);
+        HIPCHK(hipEventRecord(L.ev_step[j % kRing], B));
+        const uint32_t* seed = seeding ? idx[cur] : nullptr;
+        // P_{j+1} first: it is the head of the next iteration's critical chain (scan -> sums -> covariance -> step)
+        if (j < mi) {
+            launch_nn_scan(L.d_work, ns, c->bvh_tgt.view(), c->d_lut, c->geom, nullptr, nullptr, 1, 1, c->d_tgt, nt, seed, nullptr, nullptr, idx[cur ^ 1], B, L.d_work,
+                           st_f + 12, done);
+        }
+        HIPCHK(hipStreamWaitEvent(A, L.ev_step[j % kRing], 0));
+        launch_nn_scan(c->d_src, ns, c->bvh_tgt.view(), c->d_lut, c->geom, nullptr, nullptr, 1, 0, c->d_tgt, nt, seed, nullptr, nullptr, L.d_min_bits, A, nullptr, st_f, done);
+        if (j < mi) {
+            launch_icp_sums(L.d_work, c->d_tgt, idx[cur ^ 1], ns, nt, nullptr, L.d_bp, nb, B, done);
+            launch_icp_cov_cen(L.d_work, c->d_tgt, idx[cur ^ 1], ns, nt, L.d_bp, nb, 0, L.d_cen, L.d_bp2, nb, B, done);
+            cur ^= 1;
+        }
+        launch_sum_f32_as_f64(L.d_min_bits, ns, L.d_bp3, nb, A, done);
+        HIPCHK(hipEventRecord(L.ev_sse[j % kRing], A));
+        enq = j;
+    }
+    // the deciding step: behind the last SSE (returns at once if an earlier step already ended the loop)
+    if (enq > 0) HIPCHK(hipStreamWaitEvent(B, L.ev_sse[enq % kRing], 0));
+    launch_icp_step(L.d_icp, L.d_bp2, nb, L.d_bp3, nb, L.d_cen, L.hd_res, B);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(B));
+    HIPCHK(hipStreamSynchronize(A));  // passes enqueued ahead of the decision: drained (they return at once)
+    if (!res->done) { set_error("device-resident ICP loop ended without a result"); return FGOICP_ERR_HIP; }
+    *sse_out = res->sse;
+    for (int k = 0; k < 9; ++k) R_out9[k] = res->R[k];
+    for (int k = 0; k < 3; ++k) t_out3[k] = res->t[k];
+    if (iters_out) *iters_out = res->iters;
     return FGOICP_OK;
 }
 
@@ -880,6 +1015,9 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
         int nl = 4;  // concurrent ICP runs (ctx_icp_batch); lane 0 shares the context's main stream
         if (const char* e = std::getenv("FGOICP_ICP_LANES")) nl = std::max(1, std::min(16, std::atoi(e)));  // tuning knob
         if (const char* e = std::getenv("FGOICP_ICP_OVERLAP")) c->icp_overlap = std::atoi(e) != 0;       // tuning knob
+        if (const char* e = std::getenv("FGOICP_ICP_DEVICE")) c->icp_device = std::atoi(e) != 0;         // tuning knob / A-B: 1 = loop advanced on the device (measured slower)
+        if (const char* e = std::getenv("FGOICP_ICP_FUSE")) c->icp_fuse = std::atoi(e) != 0;             // tuning knob / A-B: 0 = separate reduction kernels
+        if (const char* e = std::getenv("FGOICP_ICP_AHEAD")) c->icp_ahead = std::max(1, std::min(6, std::atoi(e)));  // tuning knob
         c->lanes.resize((size_t)nl);
         for (int l = 0; l < nl; ++l) {
             fgoicp_ctx::IcpLane& L = c->lanes[(size_t)l];
@@ -901,6 +1039,18 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
             CHK(hipHostGetDevicePointer((void**)&L.hd_cen, L.h_cen, 0));
             CHK(hipHostMalloc((void**)&L.h_sums, sizeof(double) * 16, hipHostMallocMapped));
             CHK(hipHostGetDevicePointer((void**)&L.hd_sums, L.h_sums, 0));
+            CHK(hipMalloc(&L.d_wsum, sizeof(double) * 4096 * 6));
+            CHK(hipHostMalloc((void**)&L.h_wsse, sizeof(double) * 4096, hipHostMallocMapped));
+            CHK(hipHostGetDevicePointer((void**)&L.hd_wsse, L.h_wsse, 0));
+            CHK(hipHostMalloc((void**)&L.h_covbp, sizeof(double) * 1024 * 9, hipHostMallocMapped));
+            CHK(hipHostGetDevicePointer((void**)&L.hd_covbp, L.h_covbp, 0));
+            CHK(hipMalloc(&L.d_icp, sizeof(IcpDevState)));
+            CHK(hipHostMalloc((void**)&L.h_res, sizeof(IcpHostResult), hipHostMallocMapped));
+            CHK(hipHostGetDevicePointer((void**)&L.hd_res, L.h_res, 0));
+            for (int k = 0; k < fgoicp_ctx::IcpLane::kRing; ++k) {
+                CHK(hipEventCreateWithFlags(&L.ev_step[k], hipEventDisableTiming));
+                CHK(hipEventCreateWithFlags(&L.ev_sse[k], hipEventDisableTiming));
+            }
         }
     }
 #undef CHK
@@ -933,6 +1083,15 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
         if (L.icp_stream) { (void)hipStreamSynchronize(L.icp_stream); (void)hipStreamDestroy(L.icp_stream); }
         if (L.icp_ev_w) (void)hipEventDestroy(L.icp_ev_w);
         if (L.icp_ev_b) (void)hipEventDestroy(L.icp_ev_b);
+        for (int k = 0; k < fgoicp_ctx::IcpLane::kRing; ++k) {
+            if (L.ev_step[k]) (void)hipEventDestroy(L.ev_step[k]);
+            if (L.ev_sse[k]) (void)hipEventDestroy(L.ev_sse[k]);
+        }
+        (void)hipFree(L.d_icp);
+        (void)hipFree(L.d_wsum);
+        if (L.h_wsse) (void)hipHostFree(L.h_wsse);
+        if (L.h_covbp) (void)hipHostFree(L.h_covbp);
+        if (L.h_res) (void)hipHostFree(L.h_res);
         (void)hipFree(L.d_work); (void)hipFree(L.d_min_bits); (void)hipFree(L.d_thr_bits); (void)hipFree(L.d_first_idx); (void)hipFree(L.d_first_idx2);
         (void)hipFree(L.d_bp); (void)hipFree(L.d_bp2); (void)hipFree(L.d_bp3); (void)hipFree(L.d_cen);
         (void)hipFree(L.d_d2); (void)hipFree(L.d_nn_lb); (void)hipFree(L.d_nn_ub); (void)hipFree(L.d_nn_lb2); (void)hipFree(L.d_nn_ub2);

@@ -101,9 +101,23 @@ struct fgoicp_ctx {
         uint32_t *d_sel = nullptr, *d_eq = nullptr, *d_sel_wide = nullptr, *d_sel_wide2 = nullptr;
         unsigned char* d_use = nullptr;          // inlier mask of the current Procrustes step
         float *h_trim = nullptr, *hd_trim = nullptr;   // pinned trimmed SSE
+        // fused reductions of small clouds (ns <= 262144; ctx.hip icp_fused): wave sums from the scans' epilogues, final folds on the host
+        double* d_wsum = nullptr;                // [groups][6] wave-level sums {query xyz, correspondence xyz} of the last correspondence scan
+        double *h_wsse = nullptr, *hd_wsse = nullptr;     // pinned: [groups] wave-level sums of the last SSE scan
+        double *h_covbp = nullptr, *hd_covbp = nullptr;   // pinned: [blocks][9] block partials of the covariance
+        bool cov_on_host = false, sse_on_host = false;    // where the result of the last enqueued pass lands
+        int cov_blocks = 0;
+        // device-resident ICP loop (ctx.hip lane_icp_device)
+        fgoicp::IcpDevState* d_icp = nullptr;    // loop state in device memory
+        fgoicp::IcpHostResult *h_res = nullptr, *hd_res = nullptr;   // pinned result + progress words
+        static constexpr int kRing = 8;
+        hipEvent_t ev_step[kRing] = {}, ev_sse[kRing] = {};   // step kernel j done (stream B) / SSE partials of iteration j ready (stream A)
     };
     std::vector<IcpLane> lanes;
     bool icp_overlap = true;
+    bool icp_fuse = true;                    // small clouds: reductions started in the scans' epilogues, folded on the host (FGOICP_ICP_FUSE=0: separate kernels)
+    bool icp_device = false;                 // ICP loop advanced on the device (FGOICP_ICP_DEVICE=0: the host loop, for A/B and as the bit reference)
+    int icp_ahead = 2;                       // iterations the host may enqueue ahead of the device's progress
 
     // HIP-event profile of the bounds kernel
     std::vector<hipEvent_t> ev_start, ev_stop, ev_sel_start, ev_sel_stop;   // bounds kernel / trimmed selection kernel of the same window

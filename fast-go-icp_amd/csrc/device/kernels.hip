@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include "../host/math3.hpp"
 #include "bvh.hpp"
 
 namespace fgoicp {
@@ -1500,7 +1501,15 @@ template <int WANT_INDEX>
 __global__ __launch_bounds__(64 * kMaxParts) void nn_scan_kernel(const float4* pts, int n, BvhView t, const float* __restrict__ lut,
                                                                  LutGeom g, Rt rt, int apply, const float4* __restrict__ tgt, int nt,
                                                                  const uint32_t* seed_idx, const float* __restrict__ skip_lb, const uint32_t* __restrict__ skip_u, uint32_t* out,
-                                                                 float4* writeback) {
+                                                                 float4* writeback, const float* __restrict__ rt_dev, const int* __restrict__ done,
+                                                                 double* __restrict__ wsum) {
+    if (done && *done) return;  // device-resident ICP loop: the run has ended, this pass was enqueued ahead of the decision
+    if (rt_dev) {               // ... and the motion is the one the step kernel left in device memory (12 floats: R, t)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) rt.R[k] = rt_dev[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rt.t[k] = rt_dev[9 + k];
+    }
     __shared__ uint32_t comb[kMaxParts][64];
     __shared__ uint32_t comb_i[WANT_INDEX ? kMaxParts : 1][64];
     __shared__ uint32_t comb_2[WANT_INDEX ? kMaxParts : 1][64];
@@ -1612,6 +1621,27 @@ __global__ __launch_bounds__(64 * kMaxParts) void nn_scan_kernel(const float4* p
     // folded into the pass that needs its result first; the moved points go back to the cloud (`writeback` may be `pts`: every
     // wave of the block read its point before the barriers above, only wave 0 writes).
     if (writeback && part == 0 && i < n) writeback[i] = make_float4(qx, qy, qz, p.w);
+    // The reductions that follow a scan, started here (small clouds: one launch less on the ICP iteration's chain).  These 64 queries
+    // are one wave of icp_sums_kernel / sum_f32_kernel when every thread of those kernels holds at most one point (n <= gridDim *
+    // 256 there), so the shuffle tree below is THEIR first reduction level with the same operands: wsum[group] is the value they
+    // would park in LDS, and whoever folds four consecutive groups in order, then the blocks, gets their bits (icp_cov_cen_kernel,
+    // fold_wave_sums on the host).
+    if (wsum && part == 0) {
+        if (WANT_INDEX) {
+            float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < n) c = tgt[min(result, (uint32_t)(nt - 1))];
+            const double v[6] = {i < n ? (double)qx : 0.0, i < n ? (double)qy : 0.0, i < n ? (double)qz : 0.0,
+                                 i < n ? (double)c.x : 0.0, i < n ? (double)c.y : 0.0, i < n ? (double)c.z : 0.0};
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const double r = wave_sum(v[k]);
+                if (lane == 0) wsum[(size_t)blockIdx.x * 6 + k] = r;
+            }
+        } else {
+            const double r = wave_sum(i < n ? (double)__uint_as_float(result) : 0.0);
+            if (lane == 0) wsum[blockIdx.x] = r;
+        }
+    }
 }
 
 // buildLUTKernel (registration.cu:258-278) through the box scan of the shifted targets, coarse to fine:
@@ -1662,7 +1692,8 @@ __global__ __launch_bounds__(kBlock) void fill_u32_kernel(uint32_t* p, uint32_t 
 // ---------------------------------------------------------------------------------------------
 // Deterministic fp64 sums (stand-ins for thrust::reduce at registration.cu:79-80, icp3d.cu:152-166)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void sum_f32_kernel(const uint32_t* __restrict__ bits, int n, double* __restrict__ bp) {
+__global__ __launch_bounds__(kBlock) void sum_f32_kernel(const uint32_t* __restrict__ bits, int n, double* __restrict__ bp, const int* __restrict__ done) {
+    if (done && *done) return;
     __shared__ double red[4];
     double acc[1] = {0.0};
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) acc[0] += (double)__uint_as_float(bits[i]);
@@ -1697,7 +1728,8 @@ __global__ __launch_bounds__(kBlock) void transform_inplace_kernel(float4* __res
 // Sum of the working cloud and of its correspondences (icp3d.cu:152-153).
 __global__ __launch_bounds__(kBlock) void icp_sums_kernel(const float4* __restrict__ work, const float4* __restrict__ tgt,
                                                           const uint32_t* __restrict__ idx, int n, int nt, const unsigned char* __restrict__ use,
-                                                          double* __restrict__ bp) {
+                                                          double* __restrict__ bp, const int* __restrict__ done) {
+    if (done && *done) return;
     __shared__ double red[24];
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
@@ -1732,6 +1764,132 @@ __global__ __launch_bounds__(kBlock) void icp_cov_kernel(const float4* __restric
     }
     const double r = block_sum<9>(acc, red);
     if (threadIdx.x < 9) bp[(size_t)blockIdx.x * 9 + threadIdx.x] = r;
+}
+
+// The same with icp_centroids_kernel folded in (device-resident ICP loop: one launch less on the iteration's chain): every block
+// reduces the block partials of icp_sums_kernel itself — per component one wave, lane-strided partial sums + the shuffle tree,
+// rounded to fp32, divided by float(ns): the arithmetic and order of icp_centroids_kernel, hence the same bits — and block 0
+// leaves the centroids in device memory for the step kernel.
+__global__ __launch_bounds__(kBlock) void icp_cov_cen_kernel(const float4* __restrict__ work, const float4* __restrict__ tgt,
+                                                             const uint32_t* __restrict__ idx, int n, int nt, const double* __restrict__ sums_bp,
+                                                             int sums_nblocks, int from_waves, float* __restrict__ cen_out, double* __restrict__ bp,
+                                                             const int* __restrict__ done) {
+    if (done && *done) return;
+    __shared__ double red[36];
+    __shared__ float cen[6];
+    {
+        // from_waves: sums_bp holds the per-WAVE sums the correspondence scan left (nn_scan_kernel's epilogue), `from_waves` of them;
+        // a block partial of icp_sums_kernel is its four waves in order
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (int k = wave; k < 6; k += kBlock / 64) {
+            double sacc = 0.0;
+            for (int b = lane; b < sums_nblocks; b += 64) {
+                if (from_waves) {
+                    double blk = sums_bp[(size_t)(4 * b) * 6 + k];
+#pragma unroll
+                    for (int w = 1; w < 4; ++w) blk += 4 * b + w < from_waves ? sums_bp[(size_t)(4 * b + w) * 6 + k] : 0.0;
+                    sacc += blk;
+                } else {
+                    sacc += sums_bp[(size_t)b * 6 + k];
+                }
+            }
+            sacc = wave_sum(sacc);
+            if (lane == 0) cen[k] = (float)sacc / (float)n;
+        }
+        __syncthreads();
+        if (blockIdx.x == 0 && threadIdx.x < 6) cen_out[threadIdx.x] = cen[threadIdx.x];
+    }
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const float4 p = work[i];
+        const float4 q = tgt[min(idx[i], (uint32_t)(nt - 1))];
+        const float a[3] = {p.x - cen[0], p.y - cen[1], p.z - cen[2]};
+        const float b[3] = {q.x - cen[3], q.y - cen[4], q.z - cen[5]};
+#pragma unroll
+        for (int col = 0; col < 3; ++col)
+#pragma unroll
+            for (int row = 0; row < 3; ++row) acc[col * 3 + row] += (double)(a[row] * b[col]);
+    }
+    const double r = block_sum<9>(acc, red);
+    if (threadIdx.x < 9) bp[(size_t)blockIdx.x * 9 + threadIdx.x] = r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device-resident ICP loop (IterativeClosestPoint3D::run, icp3d.cu:88-107).  The host loop needs the covariance on the host for
+// the 3x3 SVD and the SSE for the loop test — two host round trips per iteration, 18 us of a 90-us iteration at 40k points.
+// Here the state of the loop lives in device memory (IcpDevState) and ONE thread advances it:
+//   step j  =  [loop test of icp3d.cu:94 with the SSE of iteration j-1]  +  [Procrustes finish of iteration j: cross-covariance
+//               from the block partials, closest_orthogonal_approximation (math3.hpp, the host's source compiled for the device),
+//               t_ = c_corr - R_ c_src, R = R_ R, t = R_ t + t_]
+// so the passes of iteration j+1 can be enqueued before iteration j has been decided: every kernel of the loop returns at once
+// when `done` is set, and the scans take their motion from the state instead of the kernarg segment.  Sums are folded exactly
+// as sum_partials_kernel folds them (one wave per component, lane-strided, shuffle tree), so (sse, R, t, iterations) are the bits
+// of the host loop (FGOICP_ICP_DEVICE=0; tests/test_gpu_ops.py).
+// ---------------------------------------------------------------------------------------------
+__global__ void icp_init_kernel(IcpDevState* __restrict__ st, Rt rt0, int max_iter, float thr, IcpHostResult* __restrict__ res) {
+    if (threadIdx.x != 0) return;
+    for (int k = 0; k < 9; ++k) { st->R[k] = rt0.R[k]; st->Rn[k] = rt0.R[k]; st->last_R[k] = (k % 4 == 0) ? 1.0f : 0.0f; }
+    for (int k = 0; k < 3; ++k) { st->t[k] = rt0.t[k]; st->tn[k] = rt0.t[k]; st->last_t[k] = 0.0f; }
+    st->sse = kInf;                 // icp3d.cu:89-90
+    st->last_sse = 2.0f * kInf;
+    st->iters = 0;
+    st->done = 0;
+    st->max_iter = max_iter;
+    st->thr = thr;
+    res->iters_done = 0;
+    res->done = 0;
+}
+
+__global__ __launch_bounds__(640) void icp_step_kernel(IcpDevState* __restrict__ st, const double* __restrict__ bp_cov, int nb_cov,
+                                                       const double* __restrict__ bp_sse, int nb_sse, const float* __restrict__ cen,
+                                                       IcpHostResult* __restrict__ res) {
+    if (st->done) return;
+    __shared__ double red[10];
+    {   // sum_partials_kernel's fold: wave k < 9 the covariance component k, wave 9 the SSE of the iteration before
+        const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const double* bp = k < 9 ? bp_cov : bp_sse;
+        const int nb = k < 9 ? nb_cov : nb_sse, width = k < 9 ? 9 : 1, col = k < 9 ? k : 0;
+        double s = 0.0;
+        for (int b = lane; b < nb; b += 64) s += bp[(size_t)b * width + col];
+        s = wave_sum(s);
+        if (lane == 0) red[k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const int it = st->iters;                       // iterations completed = `iter` of icp3d.cu:94 before its post-increment
+    float sse = st->sse, last_sse = st->last_sse;
+    if (it > 0) sse = (float)red[9];                // sse = reg.compute_sse_error(R, t) of iteration `it` (:103)
+    Mat3f R = Mat3f::from(st->R);
+    Vec3f t{st->t[0], st->t[1], st->t[2]};
+    const bool go_on = it < st->max_iter && (last_sse - sse) > st->thr * last_sse;   // :94
+    if (!go_on) {
+        const bool cur_best = sse < last_sse;       // :106-107
+        res->sse = cur_best ? sse : last_sse;
+        for (int k = 0; k < 9; ++k) res->R[k] = cur_best ? R.m[k] : st->last_R[k];
+        for (int k = 0; k < 3; ++k) res->t[k] = cur_best ? st->t[k] : st->last_t[k];
+        res->iters = it;
+        st->sse = sse;
+        st->done = 1;
+        __threadfence_system();
+        *(volatile int*)&res->done = 1;
+        return;
+    }
+    for (int k = 0; k < 9; ++k) st->last_R[k] = R.m[k];   // :96-98
+    for (int k = 0; k < 3; ++k) st->last_t[k] = st->t[k];
+    st->last_sse = sse;
+    st->sse = sse;
+    Mat3f ABt;
+    for (int k = 0; k < 9; ++k) ABt.m[k] = (float)red[k];
+    const Mat3f Rn = closest_orthogonal_approximation(ABt);  // :168
+    const Vec3f sc{cen[0], cen[1], cen[2]}, cc{cen[3], cen[4], cen[5]};
+    const Vec3f tn = cc - Rn * sc;                             // :169
+    R = Rn * R;                                                // :101
+    t = Rn * t + tn;                                           // :102
+    for (int k = 0; k < 9; ++k) { st->R[k] = R.m[k]; st->Rn[k] = Rn.m[k]; }
+    st->t[0] = t.x; st->t[1] = t.y; st->t[2] = t.z;
+    st->tn[0] = tn.x; st->tn[1] = tn.y; st->tn[2] = tn.z;
+    st->iters = it + 1;
+    *(volatile int*)&res->iters_done = it + 1;  // progress hint for the host's look-ahead (no ordering needed: the host only paces itself by it)
 }
 
 // Centroids on the device (icp3d.cu:152-156): ordered fp64 sum of the block partials, rounded to fp32,
@@ -1928,7 +2086,7 @@ void launch_nn_first_index(const float4* pts, int n, const float4* tgt, int nt, 
 
 void launch_nn_scan(const float4* pts, int n, const BvhView& t, const float* lut, const LutGeom& g, const float* R9, const float* t3, int apply,
                     int want_index, const float4* tgt, int nt, const uint32_t* seed_idx, const float* skip_lb, const uint32_t* skip_u, uint32_t* out, hipStream_t s,
-                    float4* writeback) {
+                    float4* writeback, const float* rt_dev, const int* done, double* wsum) {
     const int groups = (n + 63) / 64;
     // waves per 64 queries.  The scan is a chain of dependent steps per wave (boxes -> leaf boxes -> points), so its run time is
     // that chain's latency: splitting the candidate leaves of a query group over 4-8 waves shortens the chain even when the
@@ -1937,8 +2095,8 @@ void launch_nn_scan(const float4* pts, int n, const BvhView& t, const float* lut
     while (nparts < 8 && groups * nparts < 4096) nparts <<= 1;
     static const int forced = [] { const char* e = std::getenv("FGOICP_NN_PARTS"); const int v = e ? std::atoi(e) : 0; return v; }();  // tuning knob
     if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16) nparts = forced;
-    if (want_index) hipLaunchKernelGGL(nn_scan_kernel<1>, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, skip_lb, skip_u, out, writeback);
-    else hipLaunchKernelGGL(nn_scan_kernel<0>, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, skip_lb, skip_u, out, writeback);
+    if (want_index) hipLaunchKernelGGL(nn_scan_kernel<1>, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, skip_lb, skip_u, out, writeback, rt_dev, done, wsum);
+    else hipLaunchKernelGGL(nn_scan_kernel<0>, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, skip_lb, skip_u, out, writeback, rt_dev, done, wsum);
 }
 
 void launch_nn_prep(const float4* pts, int n, const float* lut, const LutGeom& g, const float* R9, const float* t3, int apply, const float4* tgt, int nt,
@@ -1963,8 +2121,8 @@ int reduce_blocks_for(int n) {
     return b > 1024 ? 1024 : b;
 }
 
-void launch_sum_f32_as_f64(const uint32_t* bits, int n, double* bp, int nblocks, hipStream_t s) {
-    hipLaunchKernelGGL(sum_f32_kernel, dim3(nblocks), dim3(kBlock), 0, s, bits, n, bp);
+void launch_sum_f32_as_f64(const uint32_t* bits, int n, double* bp, int nblocks, hipStream_t s, const int* done) {
+    hipLaunchKernelGGL(sum_f32_kernel, dim3(nblocks), dim3(kBlock), 0, s, bits, n, bp, done);
 }
 
 void launch_sum_partials(const double* bp, int nblocks, int width, double* out, hipStream_t s) {
@@ -1976,8 +2134,8 @@ void launch_transform_inplace(float4* pts, int n, const float* R9, const float* 
 }
 
 void launch_icp_sums(const float4* work, const float4* tgt, const uint32_t* idx, int n, int nt, const unsigned char* use, double* bp, int nblocks,
-                     hipStream_t s) {
-    hipLaunchKernelGGL(icp_sums_kernel, dim3(nblocks), dim3(kBlock), 0, s, work, tgt, idx, n, nt, use, bp);
+                     hipStream_t s, const int* done) {
+    hipLaunchKernelGGL(icp_sums_kernel, dim3(nblocks), dim3(kBlock), 0, s, work, tgt, idx, n, nt, use, bp, done);
 }
 
 void launch_icp_centroids(const double* bp, int nblocks, int ns, float* cen_dev, float* cen_host, hipStream_t s) {
@@ -1987,6 +2145,19 @@ void launch_icp_centroids(const double* bp, int nblocks, int ns, float* cen_dev,
 void launch_icp_cov(const float4* work, const float4* tgt, const uint32_t* idx, int n, int nt, const float* cen_dev, const unsigned char* use,
                     double* bp, int nblocks, hipStream_t s) {
     hipLaunchKernelGGL(icp_cov_kernel, dim3(nblocks), dim3(kBlock), 0, s, work, tgt, idx, n, nt, cen_dev, use, bp);
+}
+
+void launch_icp_cov_cen(const float4* work, const float4* tgt, const uint32_t* idx, int n, int nt, const double* sums_bp, int sums_nblocks, int from_waves,
+                        float* cen_out, double* bp, int nblocks, hipStream_t s, const int* done) {
+    hipLaunchKernelGGL(icp_cov_cen_kernel, dim3(nblocks), dim3(kBlock), 0, s, work, tgt, idx, n, nt, sums_bp, sums_nblocks, from_waves, cen_out, bp, done);
+}
+
+void launch_icp_init(IcpDevState* st, const float* R9, const float* t3, int max_iter, float thr, IcpHostResult* res, hipStream_t s) {
+    hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(64), 0, s, st, make_rt(R9, t3), max_iter, thr, res);
+}
+
+void launch_icp_step(IcpDevState* st, const double* bp_cov, int nb_cov, const double* bp_sse, int nb_sse, const float* cen, IcpHostResult* res, hipStream_t s) {
+    hipLaunchKernelGGL(icp_step_kernel, dim3(1), dim3(640), 0, s, st, bp_cov, nb_cov, bp_sse, nb_sse, cen, res);
 }
 
 // trimmed bounds of a window: out_ub[row] / out_lb[row] from the row's k smallest e (trim_rows_kernel)

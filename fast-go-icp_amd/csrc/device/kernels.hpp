@@ -112,7 +112,11 @@ void launch_nn_first_index(const float4* pts, int n, const float4* tgt, int nt, 
 void launch_nn_scan(const float4* pts, int n, const BvhView& t, const float* lut, const LutGeom& g, const float* R9, const float* t3, int apply,
                     int want_index, const float4* tgt, int nt, const uint32_t* seed_idx,
                     const float* skip_lb /* optional (trimmed): queries with skip_lb[i] > float(skip_u[0]) are left out */, const uint32_t* skip_u, uint32_t* out, hipStream_t s,
-                    float4* writeback = nullptr /* optional, with apply: the moved queries are stored here (may be `pts`: kernRotateTranslateInplace folded in) */);
+                    float4* writeback = nullptr /* optional, with apply: the moved queries are stored here (may be `pts`: kernRotateTranslateInplace folded in) */,
+                    const float* rt_dev = nullptr /* optional: the motion (R[9], t[3]) is read from device memory instead of R9 / t3 */,
+                    const int* done = nullptr /* optional: the kernel returns at once when *done != 0 */,
+                    double* wsum = nullptr /* optional, n <= 262144: per group of 64 queries the wave-level sums of the reduction that follows the scan —
+                                              index mode {sum query xyz, sum correspondence xyz} (6), distance mode the sum of the minima (1) */);
 // EXTENSION (trimmed Go-ICP): per query a rigorous bracket [lb, ub] of its nearest squared distance from the LUT (kernels.hip, nn_prep_kernel);
 // box6 = the target's bounding box {minx,maxx,miny,maxy,minz,maxz}
 void launch_nn_prep(const float4* pts, int n, const float* lut, const LutGeom& g, const float* R9, const float* t3, int apply, const float4* tgt, int nt,
@@ -120,16 +124,40 @@ void launch_nn_prep(const float4* pts, int n, const float* lut, const LutGeom& g
 void launch_lut_build_scan(const BvhView& shifted_targets, const LutGeom& g, float* scratch_padded, float* lut_padded, hipStream_t s);
 
 // deterministic double sums: out[k] = sum_i vals[i*stride + k]  (k < width <= 16)
-void launch_sum_f32_as_f64(const uint32_t* bits, int n, double* block_partials, int nblocks, hipStream_t s);
+void launch_sum_f32_as_f64(const uint32_t* bits, int n, double* block_partials, int nblocks, hipStream_t s, const int* done = nullptr);
 void launch_sum_partials(const double* block_partials, int nblocks, int width, double* out, hipStream_t s);
 
 // ICP pieces (fgoicp/icp3d.cu:30-52)
 void launch_transform_inplace(float4* pts, int n, const float* R9, const float* t3, hipStream_t s);
 void launch_icp_sums(const float4* work, const float4* tgt, const uint32_t* idx, int n, int nt, const unsigned char* use_or_null,
-                     double* block_partials, int nblocks, hipStream_t s);  // width 6: sum src xyz, sum corr xyz
+                     double* block_partials, int nblocks, hipStream_t s, const int* done = nullptr);  // width 6: sum src xyz, sum corr xyz
 void launch_icp_centroids(const double* block_partials, int nblocks, int ns, float* cen_dev, float* cen_host, hipStream_t s);
 void launch_icp_cov(const float4* work, const float4* tgt, const uint32_t* idx, int n, int nt, const float* cen_dev, const unsigned char* use_or_null,
                     double* block_partials, int nblocks, hipStream_t s);  // width 9: glm mat3 order
+
+
+// Device-resident ICP loop (kernels.hip): the loop state of IterativeClosestPoint3D::run (icp3d.cu:88-107) in device memory,
+// advanced by icp_step_kernel; the scans read their motion from it (R/t at float offset 0, Rn/tn at 12).
+struct IcpDevState {
+    float R[9], t[3];            // composed transform of the current iteration (icp3d.cu:101-102)
+    float Rn[9], tn[3];          // (R_, t_) of the last Procrustes step: the move of the working cloud (:100)
+    float last_R[9], last_t[3];  // :97-98
+    float sse, last_sse;
+    int iters, done, max_iter;
+    float thr;
+};
+struct IcpHostResult {           // pinned, written by the step kernel
+    float sse, R[9], t[3];
+    int iters;
+    int iters_done;              // progress: iterations whose Procrustes step has run
+    int done;                    // set after everything above
+};
+void launch_icp_init(IcpDevState* st, const float* R9, const float* t3, int max_iter, float thr, IcpHostResult* res, hipStream_t s);
+void launch_icp_step(IcpDevState* st, const double* bp_cov, int nb_cov, const double* bp_sse, int nb_sse, const float* cen, IcpHostResult* res, hipStream_t s);
+// icp_cov with the centroid kernel folded in (same bits); cen_out receives the six centroid components
+// sums_bp: block partials of icp_sums_kernel (from_waves = 0) or the per-wave sums of the scan's epilogue (from_waves = their count)
+void launch_icp_cov_cen(const float4* work, const float4* tgt, const uint32_t* idx, int n, int nt, const double* sums_bp, int sums_nblocks, int from_waves,
+                        float* cen_out, double* block_partials, int nblocks, hipStream_t s, const int* done = nullptr);
 
 int reduce_blocks_for(int n);
 
