@@ -103,6 +103,7 @@ class Env:
         self.red_dev = "cuda"
         self.ex = None
         self.transport = None
+        self.comm_ranks = None
         if self.world > 1:
             import torch.distributed as dist
             self.dist = dist
@@ -134,6 +135,10 @@ class Env:
                     self.ex = TorchExchange()
                     self.transport = "torch.distributed nccl through ctypes callbacks (fallback)"
             self.ex.warmup()  # communicator setup is not part of a registration run
+            try:  # what the communicator itself says about its size (ncclCommCount): a scaling record shows whether RCCL really joined N ranks
+                self.comm_ranks = int(self.ex.comm_count) if hasattr(self.ex, "comm_count") else None
+            except Exception:
+                self.comm_ranks = None
 
     def barrier(self):
         self.torch.cuda.synchronize()
@@ -177,7 +182,9 @@ def run_leg(env, fg, tgt, src, res, mse, sched, K, steps, warmup, trim=0.0):
     prof = reg.profile(reset=True)
     reg.set_profile(False)
     sums, maxes = env.sum_max([sub, elapsed])
-    out = dict(solver=solver, reg=reg, R=R, t=t, stats=stats, prof=prof, elapsed=maxes[1], subcubes=sums[0], subcubes_rank=sub, steps=steps, setup_s=setup_s,
+    if stats is not None and steps > 1:  # ICP figures over all timed steps (stats() describes the last run only)
+        stats = dict(stats)
+    out = dict(solver=solver, reg=reg, R=R, t=t, stats=stats, prof=prof, elapsed=maxes[1], subcubes=sums[0], subcubes_rank=sub, steps=steps, setup_s=setup_s, trim=trim,
                best_sse=float(solver.get_best_error()), ns=reg.ns, nt=reg.nt, lut_dims=list(reg.lut_dims()))
     return out
 
@@ -298,6 +305,32 @@ def cpu_baseline(fg, reg, tgt, src, res, mse, sched_id, K, seconds, gpu_leg):
             "nearest_neighbour": "uniform grid over the target (oracle/goicp_oracle.cpp GridNN; exact, identical to the O(n*m) loops)"}
 
 
+def icp_latency(leg):
+    """The ICP path of a leg (IterativeClosestPoint3D::run, icp3d.cu:80-108; exact SSE registration.cu:62-86) is a chain of dependent
+    passes, not a bandwidth kernel: per iteration one correspondence scan of the working cloud (+ the move of the cloud and the
+    wave-level sums of points and correspondences in its epilogue), one covariance pass (+ centroids), one exact-SSE scan of the
+    pristine cloud next to them on a second stream, two host syncs (3x3 SVD; loop test).  Reported as a latency object: what an
+    iteration costs against what its bytes would cost at the HBM roof."""
+    st = leg["stats"]
+    it, runs, sec = int(st["icp_iters"]), int(st["icp_runs"]), float(st["seconds_icp"])
+    if it <= 0:
+        return None
+    ns, nt = leg["ns"], leg["nt"]
+    fused = ns <= 262144 and not leg.get("trim")
+    # bytes one iteration has to move at least: correspondence pass reads the working cloud (16 B) and the seed index (4), writes the
+    # moved cloud (16) and the index (4); covariance pass reads cloud (16), index (4) and the correspondence (16); SSE pass reads the
+    # pristine cloud (16) and the seed (4), writes the minima (4); both scans walk the target once at least (2 x 16 B per target point)
+    bytes_it = ns * (16 + 4 + 16 + 4 + 16 + 4 + 16 + 16 + 4 + 4) + 2 * nt * 16
+    us = sec / it * 1e6
+    floor_us = bytes_it / (HBM_PEAK_GBS * 1e9) * 1e6
+    return {"bound": "latency", "kernel": "nn_scan_kernel<1> -> icp_cov_cen_kernel | nn_scan_kernel<0>", "iterations": it, "icp_runs": runs, "seconds_icp": sec,
+            "us_per_iteration": us, "launches_per_iteration": 3 if fused else 9, "host_syncs_per_iteration": 2,
+            "algorithmic_bytes_per_iteration": bytes_it, "hbm_floor_us_per_iteration": floor_us, "frac_of_hbm_floor": floor_us / us,
+            "note": "seconds_icp / iterations over the leg's timed steps (every ICP run of FastGoICP::run: initial, triggered, final); iterations far from "
+                    "convergence scan many target leaves (the exact search must visit every leaf closer than the current best), converged ones few: "
+                    "tools/icp_bench.py isolates one run (profiles/r03_icp_*)"}
+
+
 def leg_summary(leg, R_gt, t_gt, what):
     st = leg["stats"]
     return {"workload": what, "subcubes_per_s": leg["subcubes"] / leg["elapsed"], "wall_clock_to_optimum_s": leg["elapsed"] / leg["steps"],
@@ -333,7 +366,7 @@ def main():
                      "config": {"workload": f"{a.workload}-shape synthetic pair (nt={len(tgt)}, ns={len(src)}), lut_resolution={a.lut_resolution}, "
                                             f"mse_threshold={a.mse_threshold}, full FastGoICP::run() per step",
                                 "schedule": a.schedule, "round_width": K if K > 0 else "adaptive (32 per rank, doubled after each round that leaves the incumbent standing)",
-                                "lut_dims": head["lut_dims"], "parallelism": f"rotation cubes sharded over {world} rank(s), one allreduce(min) + one allgather per round" + (f"; transport: {env.transport}" if env.transport else "")},
+                                "lut_dims": head["lut_dims"], "transport": env.transport, "rccl_comm_count": env.comm_ranks, "parallelism": f"rotation cubes sharded over {world} rank(s), one allreduce(min) + one allgather per round" + (f"; transport: {env.transport}" if env.transport else "")},
                      "wall_clock_to_optimum_s": head["elapsed"] / a.steps, "subcubes_per_step": head["subcubes"] / a.steps})
         s = leg_summary(head, R_gt, t_gt, "headline")
         line.update({k: s[k] for k in ("rot_cubes_rank0", "icp_runs_rank0", "rounds", "seconds_bnb_rank0", "seconds_icp_rank0", "setup_s_upload_plus_lut_build")})
@@ -355,6 +388,7 @@ def main():
         line["default_threshold_ms_per_step"] = s["wall_clock_to_optimum_s"] * 1e3
         line["default_threshold_subcubes_per_s"] = s["subcubes_per_s"]
         line["default_threshold_subcubes_per_step"] = s["subcubes_per_step"]
+        line["icp_latency"] = icp_latency(dflt)
 
     # the reference's own exploration order (the drop-in classes' default schedule)
     if want("serial") and not a.no_serial and world == 1:

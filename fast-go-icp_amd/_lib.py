@@ -62,6 +62,7 @@ _SIGS = {
     "fgoicp_lut_nodes": (C.c_int, [C.c_void_p, c_int_p, C.c_size_t, c_float_p]),
     "fgoicp_bounds_point_distances": (C.c_int, [C.c_void_p, c_float_p, C.c_float, c_float_p, C.c_int, c_float_p]),
     "fgoicp_ctx_sort_fallbacks": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "fgoicp_ctx_test_sort_fault": (C.c_int, [C.c_void_p, C.c_int]),
     "fgoicp_bounds_batch": (C.c_int, [C.c_void_p, c_float_p, C.c_float, c_float_p, C.c_int, C.c_int, c_float_p, c_float_p]),
     "fgoicp_bounds_multi": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_int_p, c_int_p, c_float_p, c_float_p,
                                       c_float_p]),
@@ -95,6 +96,7 @@ _SIGS = {
     "fgoicp_rccl_exchange": (C.c_int, [C.c_void_p, C.POINTER(Exchange)]),
     "fgoicp_rccl_calls": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "fgoicp_rccl_abort": (C.c_int, [C.c_void_p]),
+    "fgoicp_rccl_comm_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "fgoicp_rccl_destroy": (None, [C.c_void_p]),
     "fgoicp_multi_create": (C.c_int, [c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_float, C.c_float, C.POINTER(SolverOpts), c_int_p, C.c_int, C.c_int,
                                       C.POINTER(C.c_void_p)]),
@@ -104,6 +106,7 @@ _SIGS = {
     "fgoicp_multi_solver": (C.c_void_p, [C.c_void_p, C.c_int]),
     "fgoicp_multi_seconds": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     "fgoicp_multi_set_record": (C.c_int, [C.c_void_p, C.c_int]),
+    "fgoicp_multi_test_fault": (C.c_int, [C.c_void_p, C.c_int, C.c_long]),
     "fgoicp_multi_replay_rank": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
 }
 TRANSPORT_RCCL = 0

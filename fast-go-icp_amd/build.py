@@ -53,13 +53,15 @@ def build(force=False, verbose=False):
     os.makedirs(LIB_DIR, exist_ok=True)
     deps = [CSRC, os.path.join(REPO, "include")]
     srcs = [s for s in SOURCES if os.path.exists(s)]
+    rebuilt = False
     if force or not _newer(LIB_PATH, deps):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-x", "hip", *COMMON_FLAGS, "-shared", "-o", LIB_PATH, *srcs, "-lrccl"]
+        rebuilt = True
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-x", "hip", *COMMON_FLAGS, "-shared", "-o", LIB_PATH, *srcs, "-ldl"]  # RCCL is dlopen'ed on first use (csrc/host/multi.cpp)
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
     cli_srcs = [s for s in CLI_SOURCES if os.path.exists(s)]
-    if cli_srcs and (force or not _newer(CLI_PATH, deps)):
+    if cli_srcs and (force or rebuilt or not _newer(CLI_PATH, deps)):  # the CLI goes with the library it was built against
         cmd = [_hipcc(), "--offload-arch=gfx950", "-x", "hip", *COMMON_FLAGS, "-o", CLI_PATH, *cli_srcs,
                "-L" + LIB_DIR, "-lfgoicp_amd", "-Wl,-rpath,$ORIGIN"]
         if verbose:

@@ -75,7 +75,9 @@ static int tick_launch_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
     // A small tick (the tail of a round: a few long-running tasks left, or one of many ranks) is pure latency: its bounds
     // kernel reads the descriptors straight from the pinned staging buffers and takes the items in submission order —
     // two copies and four sort launches fewer on the critical path.  Results do not depend on the item order.
-    const bool small = (size_t)neval * c->nchunk1 <= (size_t)c->small_tick_items;
+    const int um = sl.win_units > 0 ? c->unit_m : 1;
+    const size_t nitems = (size_t)(neval - sl.win_units * (um - 1)) * c->nchunk1;
+    const bool small = nitems <= (size_t)c->small_tick_items;
     const TickGroup* dev_groups = small ? sl.hd_groups : sl.d_groups;
     const TickSub* dev_subs = small ? sl.hd_subs : sl.d_subs;
     *sl.h_sort_err = 0u;
@@ -91,7 +93,7 @@ static int tick_launch_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
         ++c->sorted_ticks;
         const int fault = c->sort_fault_tick && c->sorted_ticks == (uint64_t)c->sort_fault_tick;
         launch_tick_sort(c->geom, c->d_chunk_cen, c->nchunk1, sl.d_groups, sl.d_subs, neval, c->cell_shift, sl.d_keys, sl.d_ranks, sl.d_hist, sl.d_hist_xcd, sl.d_xoff, sl.d_block_sums, sl.d_cursor, sl.d_sorted,
-                         c->sort_xcd ? 1 : 0, c->sort_check ? sl.hd_sort_err : nullptr, fault, sl.sort_stream);
+                         c->sort_xcd ? 1 : 0, c->sort_check ? sl.hd_sort_err : nullptr, fault, sl.sort_stream, sl.win_units, um);
         HIPCHK(hipEventRecord(sl.sorted_ev, sl.sort_stream));
         HIPCHK(hipStreamWaitEvent(sl.stream, sl.sorted_ev, 0));
     }
@@ -112,7 +114,7 @@ static int tick_launch_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
         c->prof_evals += neval;  // a twin pair is two subcubes and one evaluation
     }
     launch_bounds_sorted(c->d_src, (int)c->ns, c->d_lut, c->d_lut_zp, c->lut_layout, c->geom, c->nchunk1, c->chunk_pts, dev_groups, dev_subs, neval, small ? nullptr : sl.d_sorted, sl.d_partials,
-                         c->inliers ? sl.d_evals : nullptr, c->erow, e0, e1, sl.stream);
+                         c->inliers ? sl.d_evals : nullptr, c->erow, e0, e1, sl.stream, sl.win_units, um);
     // the per-subcube sums run on the slot's side stream, so the main stream holds nothing but bounds kernels back to back
     hipStream_t fin = c->finalize_on_side ? sl.sort_stream : sl.stream;
     if (fin != sl.stream) {
@@ -190,6 +192,56 @@ static int tick_enqueue_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl, int G, c
         ts.dual = 0;
     }
     for (int k = 0; k < ng; ++k) sl.h_groups[k].pad_ = 0;
+    // Sibling units (bounds_units_kernel): the eight children of a translation node carry one queue key (fgoicp.cpp:157-168), so the
+    // inner BnB pops them together and they sit next to each other here.  A run of 8 evaluations of one group, one span and one
+    // kind whose centres are the 8 corners of a cube of side 2 * span is taken as an octet (checked, not assumed) and moved to
+    // the front of the descriptor list, as 8 / unit_m units; everything else follows as one-sibling items.
+    sl.win_units = 0;
+    if (c->unit_m > 1 && neval >= 8) {
+        const int M = c->unit_m;
+        std::vector<TickSub>& tmp = sl.sub_tmp;
+        tmp.assign(sl.h_subs, sl.h_subs + neval);
+        std::vector<int>& mark = sl.unit_of;
+        mark.assign((size_t)neval, 0);
+        int nocts = 0;
+        for (int i = 0; i + 8 <= neval;) {
+            const TickSub& a = tmp[(size_t)i];
+            bool ok = c->inliers || !a.dual;   // the untrimmed kernel keeps its accumulators for single-kind, non-dual units
+            float lo[3] = {a.tx, a.ty, a.tz}, hi[3] = {a.tx, a.ty, a.tz};
+            for (int j = 1; j < 8 && ok; ++j) {
+                const TickSub& b = tmp[(size_t)(i + j)];
+                ok = b.group == a.group && b.span == a.span && b.dual == a.dual;
+                lo[0] = std::min(lo[0], b.tx); lo[1] = std::min(lo[1], b.ty); lo[2] = std::min(lo[2], b.tz);
+                hi[0] = std::max(hi[0], b.tx); hi[1] = std::max(hi[1], b.ty); hi[2] = std::max(hi[2], b.tz);
+            }
+            unsigned corners = 0;
+            for (int j = 0; j < 8 && ok; ++j) {
+                const TickSub& b = tmp[(size_t)(i + j)];
+                const float v[3] = {b.tx, b.ty, b.tz};
+                unsigned bits = 0;
+                for (int ax = 0; ax < 3; ++ax) {
+                    ok = ok && hi[ax] - lo[ax] == 2.0f * a.span && (v[ax] == lo[ax] || v[ax] == hi[ax]);
+                    bits |= (v[ax] == hi[ax] ? 1u : 0u) << ax;
+                }
+                corners |= 1u << bits;
+            }
+            if (ok && corners == 0xFFu) {
+                for (int j = 0; j < 8; ++j) mark[(size_t)(i + j)] = 1;
+                ++nocts;
+                i += 8;
+            } else {
+                ++i;
+            }
+        }
+        if (nocts > 0) {
+            int w = 0;
+            for (int i = 0; i < neval; ++i) if (mark[(size_t)i]) sl.h_subs[w++] = tmp[(size_t)i];
+            for (int i = 0; i < neval; ++i) if (!mark[(size_t)i]) sl.h_subs[w++] = tmp[(size_t)i];
+            sl.win_units = nocts * (8 / M);
+        }
+        c->unit_evals += (uint64_t)nocts * 8;
+    }
+    c->unit_total += (uint64_t)neval;
     const double t1 = g_tt.on ? now_s() : 0;
     sl.win_pos = pos;
     sl.win_rows = rows;
@@ -386,7 +438,7 @@ static int sse_enqueue(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R9, c
         const float* skip_lb = nullptr;
         const uint32_t* skip_u = nullptr;
         if (c->inliers && c->trim_skip) {  // trimmed: queries provably beyond the k-th smallest distance are left out of the exact search
-            launch_nn_prep(c->d_src, ns, c->d_lut, c->geom, R9, t3, 1, c->d_tgt, (int)c->nt, seed_idx, c->bounds6, L.d_nn_ub, L.d_nn_lb, st);
+            launch_nn_prep(c->d_src, ns, c->d_lut, c->geom, R9, t3, 1, c->d_tgt, (int)c->nt, seed_idx, c->tgt_box6, L.d_nn_ub, L.d_nn_lb, st);
             launch_trim_select(L.d_nn_ub, ns, (int)c->inliers, nullptr, L.d_sel + 8, L.d_sel_wide, st);
             skip_lb = L.d_nn_lb;
             skip_u = L.d_sel + 8;
@@ -456,7 +508,7 @@ static int procrustes_enqueue(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const uint3
             const float* skip_lb = nullptr;
             const uint32_t* skip_u = nullptr;
             if (c->inliers && c->trim_skip) {  // trimmed: points provably outside the inlier set get no correspondence
-                launch_nn_prep(L.d_work, ns, c->d_lut, c->geom, nullptr, nullptr, 0, c->d_tgt, nt, seed_idx, c->bounds6, L.d_nn_ub2, L.d_nn_lb2, st);
+                launch_nn_prep(L.d_work, ns, c->d_lut, c->geom, nullptr, nullptr, 0, c->d_tgt, nt, seed_idx, c->tgt_box6, L.d_nn_ub2, L.d_nn_lb2, st);
                 launch_trim_select(L.d_nn_ub2, ns, (int)c->inliers, nullptr, L.d_sel + 4, wide, st);
                 skip_lb = L.d_nn_lb2;
                 skip_u = L.d_sel + 4;
@@ -687,6 +739,14 @@ int ctx_icp(fgoicp_ctx* c, const float* R0, const float* t0, size_t max_iter, fl
     return lane_icp(c, c->lanes[0], R0, t0, max_iter, thr, sse_out, R_out9, t_out3, iters_out);
 }
 
+// One ICP run on a lane of its own (lane >= 1: own scratch, own two streams — nothing of it queues on the context's main stream,
+// where the bounds kernels run): the late-joining refinement of the ROUND schedule (driver.hpp) calls this from a background
+// host thread while the main thread keeps submitting bounds ticks.  Same kernels and sums as ctx_icp.
+int ctx_icp_lane(fgoicp_ctx* c, int lane, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3, int* iters_out) {
+    if (lane < 0 || lane >= (int)c->lanes.size() || c->brute_force_nn) lane = 0;  // the brute-force kernels keep their scratch on lane 0
+    return lane_icp(c, c->lanes[(size_t)lane], R0, t0, max_iter, thr, sse_out, R_out9, t_out3, iters_out);
+}
+
 // Several ICP runs at once (the triggers of one expansion round, driver.hpp): run i goes to lane i % lanes, every lane has its
 // own scratch and streams and a host thread of its own (an ICP iteration is a chain of small kernels with two host syncs — at
 // 40k points one run fills a fraction of the device).  Each run is exactly the run ctx_icp would do: same kernels, same sums.
@@ -798,10 +858,19 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
     c->profile = (flags & FGOICP_FLAG_PROFILE) != 0;
     c->brute_force_nn = (flags & FGOICP_FLAG_BRUTE_FORCE_NN) != 0;
     std::memcpy(c->bounds6, bounds6, sizeof(c->bounds6));
+    // The trimmed search drops queries whose distance to the target's box already exceeds the cut (nn_prep_kernel): that box is taken
+    // from the DATA, not from the caller's `bounds6` — the reference's Registration accepts any target_bounds (they only place the
+    // LUT, registration.hpp:68), and with cropped bounds "every target point lies inside the box" would be false.
+    for (int a = 0; a < 3; ++a) { c->tgt_box6[2 * a] = tgt_xyz[a]; c->tgt_box6[2 * a + 1] = tgt_xyz[a]; }
+    for (size_t i = 1; i < nt; ++i)
+        for (int a = 0; a < 3; ++a) {
+            const float v = tgt_xyz[3 * i + a];
+            c->tgt_box6[2 * a] = std::min(c->tgt_box6[2 * a], v);
+            c->tgt_box6[2 * a + 1] = std::max(c->tgt_box6[2 * a + 1], v);
+        }
     if (const char* e = std::getenv("FGOICP_TRIM_SKIP")) c->trim_skip = std::atoi(e) != 0;        // tuning knob
     if (const char* e = std::getenv("FGOICP_SORT_XCD")) c->sort_xcd = std::atoi(e) != 0;          // tuning knob
     if (const char* e = std::getenv("FGOICP_SORT_CHECK")) c->sort_check = std::atoi(e) != 0;      // tuning knob: 0 = no permutation check of the tick sort
-    if (const char* e = std::getenv("FGOICP_SORT_FAULT_TICK")) c->sort_fault_tick = std::atoi(e); // test hook: spoil the n-th sorted tick
     auto fail = [&](int rc) { fgoicp_ctx_destroy(c); return rc; };
 #define CHK(expr) do { hipError_t e2_ = (expr); if (e2_ != hipSuccess) { set_error(std::string(#expr) + " failed: " + hipGetErrorString(e2_)); return fail(e2_ == hipErrorOutOfMemory ? FGOICP_ERR_OOM : FGOICP_ERR_HIP); } } while (0)
     CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -950,6 +1019,7 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
         c->max_groups = std::max(512, c->max_subcubes / 8);
         if (const char* e = std::getenv("FGOICP_FINALIZE_SIDE")) c->finalize_on_side = std::atoi(e) != 0;  // tuning knob
         if (const char* e = std::getenv("FGOICP_ICP_SEED")) c->icp_seeding = std::atoi(e) != 0;             // tuning knob
+        if (const char* e = std::getenv("FGOICP_UNITS")) { const int v = std::atoi(e); c->unit_m = (v == 4 || v == 8) ? v : 0; }  // tuning knob: siblings per work item
         if (const char* e = std::getenv("FGOICP_SMALL_TICK")) c->small_tick_items = std::max(0, std::atoi(e));  // tuning knob: items
         int maxd = std::max(g.dx, std::max(g.dy, g.dz));
         c->cell_shift = 0;
@@ -1070,6 +1140,9 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
                      1e6 * g_tt.pack / g_tt.ticks, 1e6 * g_tt.enqueue / g_tt.ticks, 1e6 * g_tt.wait / g_tt.ticks, 1e6 * g_tt.copyout / g_tt.ticks);
         g_tt = TickTiming{};
     }
+    if (c->unit_m > 1 && std::getenv("FGOICP_UNITS_STATS"))
+        std::fprintf(stderr, "[fgoicp units] M = %d: %llu of %llu evaluations in sibling units (%.1f %%)\n", c->unit_m, (unsigned long long)c->unit_evals,
+                     (unsigned long long)c->unit_total, c->unit_total ? 100.0 * (double)c->unit_evals / (double)c->unit_total : 0.0);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& e : c->ev_start) if (e) (void)hipEventDestroy(e);
@@ -1139,7 +1212,12 @@ int fgoicp_ctx_get_info(const fgoicp_ctx* c, fgoicp_ctx_info* out) {
     out->lut_layout = c->d_lut_zp ? c->lut_layout : 0;
     out->lut_nodes = (uint64_t)g.dx * g.dy * g.dz;
     const uint64_t padded = (uint64_t)g.px * g.py * g.pz;
-    out->lut_bytes = padded * sizeof(float) + (c->d_lut_zp ? padded * (c->lut_layout == 2 ? sizeof(float4) : sizeof(float2)) : 0);
+    size_t packed = 0;  // the bricked yz-quad copy (layout 3) holds whole 4 x 4 x 4 bricks of float4
+    if (c->d_lut_zp) {
+        if (c->lut_layout == 3) packed = (size_t)((c->geom.px + 3) / 4) * ((c->geom.py + 3) / 4) * ((c->geom.pz + 3) / 4) * 64 * sizeof(float4);
+        else packed = padded * (c->lut_layout == 2 ? sizeof(float4) : sizeof(float2));
+    }
+    out->lut_bytes = padded * sizeof(float) + packed;
     out->source_points_per_face_voxel = (double)c->ns / ((double)g.dx * g.dy + (double)g.dy * g.dz + (double)g.dx * g.dz);
     out->points_per_item = c->chunk_pts;
     out->items_per_evaluation = c->nchunk1;
@@ -1244,6 +1322,14 @@ int fgoicp_bounds_point_distances(fgoicp_ctx* c, const float* R9, float rot_span
     std::vector<float> row(c->ns);
     HIPCHK(hipMemcpy(row.data(), c->slots[0].d_evals, sizeof(float) * c->ns, hipMemcpyDeviceToHost));  // row 0 of the window just collected
     for (size_t i = 0; i < c->ns; ++i) e_out[c->perm[i]] = row[i];
+    return FGOICP_OK;
+}
+
+// TEST HOOK (tests/test_gpu_fullsize.py): the n-th sorted tick from now on gets a slot of `sorted` spoiled, so that the on-device
+// permutation check has something to find.  Nothing in the product calls it.
+int fgoicp_ctx_test_sort_fault(fgoicp_ctx* c, int nth_tick) {
+    if (!c || nth_tick < 0) return FGOICP_ERR_INVALID_ARG;
+    c->sort_fault_tick = nth_tick ? (int)c->sorted_ticks + nth_tick : 0;
     return FGOICP_OK;
 }
 

@@ -56,6 +56,9 @@ struct fgoicp_ctx {
         float *h_row_span = nullptr, *hd_row_span = nullptr;   // translation span of every output row of the window (pinned)
         unsigned *h_sort_err = nullptr, *hd_sort_err = nullptr; // pinned: set by tick_check_kernel when `sorted` is no permutation
         int win_groups = 0, win_evals = 0;       // the window in flight: groups and evaluations in the staging buffers
+        int win_units = 0;                       // ... of which the first win_units * unit_m evaluations are sibling units (bounds_units_kernel)
+        std::vector<fgoicp::TickSub> sub_tmp;    // packing scratch of the unit detection
+        std::vector<int> unit_of;
         std::vector<float> lb, ub;
         std::vector<int> row_group;              // window-local group of every output row (packing scratch)               // results of the whole submission
         int total = 0, win_pos = 0, win_rows = 0;
@@ -68,6 +71,8 @@ struct fgoicp_ctx {
     uint64_t sorted_ticks = 0, sort_fallbacks = 0;
     int nchunk1 = 0, max_groups = 0, cell_shift = 4;
     int chunk_pts = 256;                     // points per (subcube, chunk) work item of the sorted path
+    int unit_m = 0;                          // siblings per work item (0 / 1 = off): the children of one translation node share the point loads and the rotation
+    uint64_t unit_evals = 0, unit_total = 0; // evaluations that went into units / all evaluations (statistics)
     bool finalize_on_side = true;
     int small_tick_items = 4096;             // ticks of at most this many items skip the descriptor copies and the locality sort
     bool icp_seeding = true;                 // ICP passes seed their exact NN search with the previous pass's correspondences
@@ -80,7 +85,8 @@ struct fgoicp_ctx {
     size_t erow = 0;                         // floats per row of d_evals (ns rounded up to a multiple of 4)
     bool trim_ready = false;                 // trimmed-mode buffers allocated
     bool trim_skip = true;                   // exact NN only for queries that can be among the k smallest (nn_prep_kernel)
-    float bounds6[6] = {0, 0, 0, 0, 0, 0};   // the target's bounding box as passed to fgoicp_ctx_create
+    float bounds6[6] = {0, 0, 0, 0, 0, 0};   // target_bounds as passed to fgoicp_ctx_create (they place the LUT)
+    float tgt_box6[6] = {0, 0, 0, 0, 0, 0};  // the target's bounding box computed from the points (trimmed search: nn_prep_kernel)
     uint32_t* d_orig_of_slot = nullptr;      // caller index of every device slot (ties at the inlier cut)
 
     // exact-NN / ICP scratch, one set per lane: ICP runs on different lanes may be in flight together (ctx_icp_batch).  Lane 0 is
@@ -140,6 +146,8 @@ int ctx_set_inliers(fgoicp_ctx* c, size_t k);
 int ctx_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out, const uint32_t* seed_idx = nullptr);
 int ctx_icp(fgoicp_ctx* c, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3,
             int* iters_out);
+int ctx_icp_lane(fgoicp_ctx* c, int lane, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3,
+                 int* iters_out);
 int ctx_icp_batch(fgoicp_ctx* c, int n, const float* R0s, const float* t0s, size_t max_iter, float thr, float* sse_out, float* R_out9s, float* t_out3s,
                   int* iters_out);
 }  // namespace fgoicp

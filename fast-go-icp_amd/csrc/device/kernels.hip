@@ -11,6 +11,7 @@
 #include "kernels.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "../host/math3.hpp"
@@ -358,12 +359,28 @@ template <int HILBERT, int XCD>
 __global__ __launch_bounds__(64) void tick_keys_kernel(const float4* __restrict__ chunk_cen, int nchunk, const TickGroup* __restrict__ groups,
                                                            const TickSub* __restrict__ subs, int nsub, LutGeom g, int cell_shift,
                                                            unsigned short* __restrict__ keys, unsigned* __restrict__ ranks, unsigned* __restrict__ hist,
-                                                           unsigned* __restrict__ prefill /* optional: `sorted`, filled with 0xFFFFFFFF for tick_check_kernel */) {
-    const size_t nitems = (size_t)nsub * nchunk;
+                                                           unsigned* __restrict__ prefill /* optional: `sorted`, filled with 0xFFFFFFFF for tick_check_kernel */,
+                                                           int nunits, int unit_m /* sibling units: the first nunits * unit_m evaluations, unit_m per item */) {
+    const size_t unit_items = (size_t)nunits * nchunk;
+    const size_t nitems = unit_items + (size_t)(nsub - nunits * unit_m) * nchunk;
     for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < nitems; i += (size_t)gridDim.x * 64) {
         if (prefill) prefill[i] = 0xFFFFFFFFu;
-        const int s = (int)(i / nchunk), c = (int)(i - (size_t)s * nchunk);
-        const TickSub sb = subs[s];
+        int s, c;
+        TickSub sb;
+        if (i < unit_items) {  // a sibling unit is keyed by the mean of its translation nodes (the parent's centre for a whole octet)
+            const int u = (int)(i / nchunk);
+            c = (int)(i - (size_t)u * nchunk);
+            s = u * unit_m;
+            sb = subs[s];
+            for (int j = 1; j < unit_m; ++j) { const TickSub o = subs[s + j]; sb.tx += o.tx; sb.ty += o.ty; sb.tz += o.tz; }
+            const float inv = 1.0f / (float)unit_m;
+            sb.tx *= inv; sb.ty *= inv; sb.tz *= inv;
+        } else {
+            const size_t r = i - unit_items;
+            s = nunits * unit_m + (int)(r / nchunk);
+            c = (int)(r - (size_t)(s - nunits * unit_m) * nchunk);
+            sb = subs[s];
+        }
         const TickGroup& gr = groups[sb.group];
         const float4 cc = chunk_cen[c];
         float rx, ry, rz;
@@ -654,6 +671,303 @@ __global__ __launch_bounds__(THREADS * WPG) void bounds_sorted_kernel(const floa
             double* out = reinterpret_cast<double*>(partials + ((size_t)sb.out0 * nchunk + chunk));
             if (threadIdx.x < 2) out[threadIdx.x] = r;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sibling units (round 3; dense clouds).  The inner BnB (fgoicp.cpp:157-168) pushes the eight children of a translation node with
+// one key, so they are popped together: almost every evaluation of a tick has its seven siblings next to it — the same rotation,
+// the same points, translations 2 * span apart.  bounds_sorted_kernel re-loads and re-rotates the chunk's points for each of them
+// (16 B per point-evaluation against the 0.375 B of SURVEY 8d; at 1M points the cloud is 16 MB and no L2 holds it).  Here an item is
+// (unit of M siblings, chunk): the wave loads and rotates its 4 points per lane ONCE per pass (the reference's TODO.md:11, "avoid
+// repeated rotation computation") and walks the M translations with them — per sibling the same lookups, the same per-point
+// expressions and the same per-lane accumulation order as bounds_sorted_kernel, one partial per (subcube, chunk) as before, so
+// every sum keeps its bits.  Items are keyed by the unit's mean translation (tick_keys_kernel); evaluations that are not in a
+// unit follow as one-sibling items.  M = 8 for the trimmed kernel (no accumulators), 4 or 8 otherwise (2 fp64 sums per sibling in
+// registers).  Dual (twin) evaluations are grouped only in the trimmed kernel.
+// ---------------------------------------------------------------------------------------------
+template <int ZPAIR /* 0 plain, 1 z-pair, 2 yz-quad (lane-paired) */, int TRIM, int M>
+__global__ __launch_bounds__(64) void bounds_units_kernel(const float4* __restrict__ src, int ns, const float* __restrict__ lut, const float2* __restrict__ zp, LutGeom g,
+                                                          const TickGroup* __restrict__ groups, const TickSub* __restrict__ subs, const unsigned* __restrict__ sorted,
+                                                          int nchunk, int chunk_pts, double2* __restrict__ partials, float* __restrict__ evals, size_t erow,
+                                                          unsigned nitems, int nunits) {
+    constexpr int P = 4;
+    const unsigned slot = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned item = sorted ? sorted[slot] : slot;
+    if (item >= nitems) return;
+    const unsigned unit_items = (unsigned)nunits * (unsigned)nchunk;
+    int s0, chunk, count;
+    if (item < unit_items) {
+        const int u = (int)(item / (unsigned)nchunk);
+        chunk = (int)(item - (unsigned)u * (unsigned)nchunk);
+        s0 = u * M;
+        count = M;
+    } else {
+        const unsigned r = item - unit_items;
+        const int q = (int)(r / (unsigned)nchunk);
+        chunk = (int)(r - (unsigned)q * (unsigned)nchunk);
+        s0 = nunits * M + q;
+        count = 1;
+    }
+    const int tix = (int)threadIdx.x;
+    const TickSub sb0 = subs[s0];
+    const TickGroup& gr = groups[sb0.group];  // one rotation node per unit
+    const bool dual = sb0.dual != 0;           // ... and one kind (the host groups only evaluations of the same kind)
+    const size_t sy = (size_t)g.px, sz = (size_t)g.px * g.py;
+    double acc[TRIM ? 1 : 2 * M];
+#pragma unroll
+    for (int k = 0; k < (TRIM ? 1 : 2 * M); ++k) acc[k] = 0.0;
+    double accd[4] = {0.0, 0.0, 0.0, 0.0};  // a dual one-sibling item of the untrimmed kernel (as bounds_sorted_kernel)
+    const int odd = tix & 1;
+    for (int pass = 0; pass < chunk_pts; pass += 64 * P) {
+        float4 p[P];
+        float rx[P], ry[P], rz[P];
+        const int first = chunk * chunk_pts + pass + tix;
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const int i = first + k * 64;
+            p[k] = src[i < ns ? i : ns - 1];
+            rotate(gr.R, p[k].x, p[k].y, p[k].z, rx[k], ry[k], rz[k]);
+        }
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            if (j >= count) break;  // wave-uniform
+            const TickSub sb = subs[s0 + j];
+            const float trans_uncertain_radius = kSqrt3 * sb.span;  // registration.cu:33
+            TexAddr ta[P];
+            float2u v00[P], v10[P], v01[P], v11[P];
+#pragma unroll
+            for (int k = 0; k < P; ++k) ta[k] = lut_address(g, rx[k] + sb.tx, ry[k] + sb.ty, rz[k] + sb.tz);  // :34, :323-325
+            if (ZPAIR == 2) {
+                QuadPairLoads qp[P];
+#pragma unroll
+                for (int k = 0; k < P; ++k) qp[k] = quad_pair_issue(reinterpret_cast<const float4*>(zp), ta[k], odd);
+#pragma unroll
+                for (int k = 0; k < P; ++k) quad_pair_finish(qp[k], odd, v00[k], v10[k], v01[k], v11[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < P; ++k) {
+                    if (ZPAIR == 1) {
+                        zpair_gather(zp, g, ta[k], v00[k], v10[k], v01[k], v11[k]);
+                    } else {
+                        const float* q = lut + ta[k].o;
+                        v00[k] = *(const float2u*)(q);
+                        v10[k] = *(const float2u*)(q + sy);
+                        v01[k] = *(const float2u*)(q + sz);
+                        v11[k] = *(const float2u*)(q + sz + sy);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const float dsq = lut_blend(ta[k], v00[k], v10[k], v01[k], v11[k]);  // :46
+                float d = sqrtf(dsq);                                                 // :48
+                const int i = first + k * 64;
+                const bool valid = i < ns;
+                if (TRIM) {
+                    if (valid) {
+                        if (dual) {
+                            evals[(size_t)sb.out0 * erow + i] = d > 0.0f ? d : 0.0f;
+                            d -= 2.0f * p[k].w * gr.sin_half;
+                            evals[(size_t)sb.out1 * erow + i] = d > 0.0f ? d : 0.0f;
+                        } else {
+                            if (!gr.fix_rot) d -= 2.0f * p[k].w * gr.sin_half;
+                            evals[(size_t)sb.out0 * erow + i] = d > 0.0f ? d : 0.0f;
+                        }
+                    }
+                    continue;
+                }
+                if (dual) {  // wave-uniform; one-sibling items only (the host does not group dual evaluations for this kernel)
+                    const float ub1 = d > 0.0f ? d * d : 0.0f;                        // fix_rot = 1: :54
+                    const float l1 = d - trans_uncertain_radius;                      // :57
+                    const float lb1 = l1 > 0.0f ? l1 * l1 : 0.0f;                     // :58
+                    d -= 2.0f * p[k].w * gr.sin_half;                                 // fix_rot = 0: :39-43, :49-52
+                    const float ub0 = d > 0.0f ? d * d : 0.0f;
+                    const float l0 = d - trans_uncertain_radius;
+                    const float lb0 = l0 > 0.0f ? l0 * l0 : 0.0f;
+                    accd[0] += valid ? (double)ub1 : 0.0;
+                    accd[1] += valid ? (double)lb1 : 0.0;
+                    accd[2] += valid ? (double)ub0 : 0.0;
+                    accd[3] += valid ? (double)lb0 : 0.0;
+                    continue;
+                }
+                if (!gr.fix_rot) d -= 2.0f * p[k].w * gr.sin_half;                    // :39-43, :49-52
+                const float ubv = d > 0.0f ? d * d : 0.0f;                            // :54
+                const float l = d - trans_uncertain_radius;                           // :57
+                const float lbv = l > 0.0f ? l * l : 0.0f;                            // :58
+                acc[TRIM ? 0 : 2 * j] += valid ? (double)ubv : 0.0;
+                acc[TRIM ? 0 : 2 * j + 1] += valid ? (double)lbv : 0.0;
+            }
+        }
+    }
+    if (TRIM) return;
+    if (dual) {  // count == 1
+        const double r0 = wave_sum(accd[0]), r1 = wave_sum(accd[1]), r2 = wave_sum(accd[2]), r3 = wave_sum(accd[3]);
+        if (tix == 0) {
+            partials[(size_t)sb0.out0 * nchunk + chunk] = make_double2(r0, r1);
+            partials[(size_t)sb0.out1 * nchunk + chunk] = make_double2(r2, r3);
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        if (j >= count) break;
+        const double r0 = wave_sum(acc[TRIM ? 0 : 2 * j]), r1 = wave_sum(acc[TRIM ? 0 : 2 * j + 1]);
+        if (tix == 0) partials[(size_t)subs[s0 + j].out0 * nchunk + chunk] = make_double2(r0, r1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-staged LUT tiles (round 3; north_star names them, the reference wished for them: TODO.md:12).  One wave per item as in
+// bounds_sorted_kernel (64 x 4).  Per pass of 256 Hilbert-consecutive points the wave
+//   1. computes the points' first texels and takes their bounding brick (wave min / max of the three padded indices),
+//   2. if the brick is at most 16 nodes wide and ROWS rows (y x z) high, copies it from the plain fp32 LUT into LDS — 16 lanes per
+//      row, four rows per load instruction, rows padded to 16 floats, so the staging loads are row-coalesced —
+//   3. and reads the 2 x 2 x 2 footprints of its points from LDS (four 8-byte reads per point) instead of gathering them from
+//      global memory; a pass whose brick does not fit gathers from the plain LUT as before.
+// Same texels, same blend, same per-lane accumulation order: bit-identical sums (tests).  Whether it pays is a question of how
+// many lookups share a staged node: 256 points of a surface patch touch a brick of (patch extent + 2)^2 x depth nodes.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+    return v;
+}
+template <int TRIM, int ROWS>
+__global__ __launch_bounds__(64) void bounds_lds_kernel(const float4* __restrict__ src, int ns, const float* __restrict__ lut, LutGeom g,
+                                                        const TickGroup* __restrict__ groups, const TickSub* __restrict__ subs, const unsigned* __restrict__ sorted,
+                                                        int nchunk, int chunk_pts, double2* __restrict__ partials, float* __restrict__ evals, size_t erow,
+                                                        unsigned nitems, unsigned* __restrict__ stat /* optional: [0] staged passes, [1] all passes */) {
+    constexpr int P = 4;
+    __shared__ float tile[ROWS * 16];
+    const unsigned slot = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned item = sorted ? sorted[slot] : slot;
+    if (item >= nitems) return;
+    const int s = (int)(item / (unsigned)nchunk);
+    const int chunk = (int)(item - (unsigned)s * (unsigned)nchunk);
+    const int tix = (int)threadIdx.x;
+    const TickSub sb = subs[s];
+    const TickGroup& gr = groups[sb.group];
+    const float trans_uncertain_radius = kSqrt3 * sb.span;  // registration.cu:33
+    const bool dual = sb.dual != 0;
+    const size_t sy = (size_t)g.px, sz = (size_t)g.px * g.py;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    unsigned staged_passes = 0, all_passes = 0;
+    for (int pass = 0; pass < chunk_pts; pass += 64 * P) {
+        float4 p[P];
+        TexAddr ta[P];
+        float2u v00[P], v10[P], v01[P], v11[P];
+        const int first = chunk * chunk_pts + pass + tix;
+        int lo[3] = {1 << 20, 1 << 20, 1 << 20}, hi[3] = {0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const int i = first + k * 64;
+            p[k] = src[i < ns ? i : ns - 1];
+            float rx, ry, rz;
+            rotate(gr.R, p[k].x, p[k].y, p[k].z, rx, ry, rz);
+            ta[k] = lut_address(g, rx + sb.tx, ry + sb.ty, rz + sb.tz);  // :34, :323-325
+            const int ix = (int)(ta[k].pk & 1023u), iy = (int)((ta[k].pk >> 10) & 1023u), iz = (int)(ta[k].pk >> 20);
+            lo[0] = min(lo[0], ix); lo[1] = min(lo[1], iy); lo[2] = min(lo[2], iz);
+            hi[0] = max(hi[0], ix); hi[1] = max(hi[1], iy); hi[2] = max(hi[2], iz);
+        }
+        // the pass's brick: [lo, hi + 1] per axis (wave-uniform after the reductions)
+        int bx, by, bz;
+        {
+            const int x0 = wave_min_i(lo[0]), y0 = wave_min_i(lo[1]), z0 = wave_min_i(lo[2]);
+            bx = wave_max_i(hi[0]) - x0 + 2; by = wave_max_i(hi[1]) - y0 + 2; bz = wave_max_i(hi[2]) - z0 + 2;
+            lo[0] = x0; lo[1] = y0; lo[2] = z0;
+        }
+        const int rows = by * bz;
+        const bool fits = bx <= 16 && rows <= ROWS && g.px < 1024 && g.py < 1024 && g.pz < 1024;  // `pk` holds 10 bits per index
+        ++all_passes;
+        if (fits) {  // wave-uniform
+            ++staged_passes;
+            const int sub = tix >> 4, xl = tix & 15;
+            int y = sub % by, z = sub / by;  // row r = y + by * z, rows r0 + sub for r0 = 0, 4, 8, ...
+            const int xg = min(lo[0] + xl, g.px - 1);  // lanes beyond the brick's width copy in-range neighbours nobody reads
+            for (int r = sub; r < rows; r += 4) {
+                tile[r * 16 + xl] = lut[((size_t)(lo[2] + z) * g.py + (size_t)(lo[1] + y)) * g.px + (size_t)xg];
+                y += 4;
+                while (y >= by) { y -= by; ++z; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const int ix = (int)(ta[k].pk & 1023u) - lo[0], iy = (int)((ta[k].pk >> 10) & 1023u) - lo[1], iz = (int)(ta[k].pk >> 20) - lo[2];
+                const float* t0 = tile + ((iz * by + iy) * 16 + ix);
+                v00[k] = float2u{t0[0], t0[1]};                       // (x0, x1) at (y0, z0)
+                v10[k] = float2u{t0[16], t0[17]};                     // (y1, z0)
+                v01[k] = float2u{t0[by * 16], t0[by * 16 + 1]};       // (y0, z1)
+                v11[k] = float2u{t0[by * 16 + 16], t0[by * 16 + 17]}; // (y1, z1)
+            }
+            __syncthreads();  // the next pass overwrites the tile
+        } else {
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const float* q = lut + ta[k].o;
+                v00[k] = *(const float2u*)(q);
+                v10[k] = *(const float2u*)(q + sy);
+                v01[k] = *(const float2u*)(q + sz);
+                v11[k] = *(const float2u*)(q + sz + sy);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const float dsq = lut_blend(ta[k], v00[k], v10[k], v01[k], v11[k]);  // :46
+            float d = sqrtf(dsq);                                                 // :48
+            const int i = first + k * 64;
+            const bool valid = i < ns;
+            if (TRIM) {
+                if (valid) {
+                    if (dual) {
+                        evals[(size_t)sb.out0 * erow + i] = d > 0.0f ? d : 0.0f;
+                        d -= 2.0f * p[k].w * gr.sin_half;
+                        evals[(size_t)sb.out1 * erow + i] = d > 0.0f ? d : 0.0f;
+                    } else {
+                        if (!gr.fix_rot) d -= 2.0f * p[k].w * gr.sin_half;
+                        evals[(size_t)sb.out0 * erow + i] = d > 0.0f ? d : 0.0f;
+                    }
+                }
+                continue;
+            }
+            if (dual) {
+                const float ub1 = d > 0.0f ? d * d : 0.0f;
+                const float l1 = d - trans_uncertain_radius;
+                const float lb1 = l1 > 0.0f ? l1 * l1 : 0.0f;
+                d -= 2.0f * p[k].w * gr.sin_half;
+                const float ub0 = d > 0.0f ? d * d : 0.0f;
+                const float l0 = d - trans_uncertain_radius;
+                const float lb0 = l0 > 0.0f ? l0 * l0 : 0.0f;
+                acc[0] += valid ? (double)ub1 : 0.0;
+                acc[1] += valid ? (double)lb1 : 0.0;
+                acc[2] += valid ? (double)ub0 : 0.0;
+                acc[3] += valid ? (double)lb0 : 0.0;
+                continue;
+            }
+            if (!gr.fix_rot) d -= 2.0f * p[k].w * gr.sin_half;
+            const float ubv = d > 0.0f ? d * d : 0.0f;
+            const float l = d - trans_uncertain_radius;
+            const float lbv = l > 0.0f ? l * l : 0.0f;
+            acc[0] += valid ? (double)ubv : 0.0;
+            acc[1] += valid ? (double)lbv : 0.0;
+        }
+    }
+    if (stat && tix == 0) { atomicAdd(&stat[0], staged_passes); atomicAdd(&stat[1], all_passes); }
+    if (TRIM) return;
+    const double r0 = wave_sum(acc[0]), r1 = wave_sum(acc[1]);
+    if (dual) {
+        const double r2 = wave_sum(acc[2]), r3 = wave_sum(acc[3]);
+        if (tix == 0) {
+            partials[(size_t)sb.out0 * nchunk + chunk] = make_double2(r0, r1);
+            partials[(size_t)sb.out1 * nchunk + chunk] = make_double2(r2, r3);
+        }
+    } else if (tix == 0) {
+        partials[(size_t)sb.out0 * nchunk + chunk] = make_double2(r0, r1);
     }
 }
 
@@ -1943,19 +2257,19 @@ void launch_bounds(const float4* src, int ns, const float* lut, const LutGeom& g
 // The locality sort of one tick (descriptors must already be on the device): keys + histogram, scan, scatter.
 void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, const TickGroup* groups, const TickSub* subs, int nsub, int cell_shift,
                       unsigned short* keys, unsigned* ranks, unsigned* hist, unsigned* hist_xcd, unsigned* xoff, unsigned* block_sums, unsigned* cursor, unsigned* sorted,
-                      int allow_xcd, unsigned* check_err, int inject_fault, hipStream_t s) {
-    const size_t nitems = (size_t)nsub * nchunk;
+                      int allow_xcd, unsigned* check_err, int inject_fault, hipStream_t s, int nunits, int unit_m) {
+    const size_t nitems = (size_t)(nsub - nunits * (unit_m - 1)) * nchunk;
     const unsigned kb = (unsigned)std::min<size_t>((nitems + 63) / 64, 8192);  // `hist` / `hist_xcd` are zero here: the scan / fold kernels re-zero them
     static const int hilbert = [] { const char* e = std::getenv("FGOICP_SORT_CURVE"); return e ? std::atoi(e) : 1; }();  // tuning knob: 1 = Hilbert (default), 0 = Z-order
     static const int use_ranks = [] { const char* e = std::getenv("FGOICP_SORT_RANKS"); return e ? std::atoi(e) : 1; }();  // tuning knob
     const bool xcd = allow_xcd && use_ranks && hist_xcd && xoff;  // allow_xcd: FGOICP_SORT_XCD per context, cleared by a failed permutation check
     if (xcd) {
-        if (hilbert) hipLaunchKernelGGL((tick_keys_kernel<1, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd, check_err ? sorted : nullptr);
-        else hipLaunchKernelGGL((tick_keys_kernel<0, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd, check_err ? sorted : nullptr);
+        if (hilbert) hipLaunchKernelGGL((tick_keys_kernel<1, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd, check_err ? sorted : nullptr, nunits, unit_m);
+        else hipLaunchKernelGGL((tick_keys_kernel<0, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd, check_err ? sorted : nullptr, nunits, unit_m);
         hipLaunchKernelGGL(tick_fold_sums_kernel, dim3(kScanBlocks), dim3(64), 0, s, hist_xcd, xoff, hist, block_sums);
     } else {
-        if (hilbert) hipLaunchKernelGGL((tick_keys_kernel<1, 0>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist, check_err ? sorted : nullptr);
-        else hipLaunchKernelGGL((tick_keys_kernel<0, 0>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist, check_err ? sorted : nullptr);
+        if (hilbert) hipLaunchKernelGGL((tick_keys_kernel<1, 0>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist, check_err ? sorted : nullptr, nunits, unit_m);
+        else hipLaunchKernelGGL((tick_keys_kernel<0, 0>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist, check_err ? sorted : nullptr, nunits, unit_m);
     }
     if (!xcd) hipLaunchKernelGGL(tick_scan_sums_kernel, dim3(kScanBlocks), dim3(64), 0, s, hist, block_sums);
     hipLaunchKernelGGL(tick_scan_apply_kernel, dim3(kScanBlocks), dim3(64), 0, s, hist, block_sums, cursor);
@@ -1968,8 +2282,49 @@ void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, con
 
 void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* zp, int layout, const LutGeom& g, int nchunk, int chunk_pts,
                           const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials, float* evals, size_t erow,
-                          hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s) {
-    const size_t nitems = (size_t)nsub * nchunk;
+                          hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s, int nunits, int unit_m) {
+    const size_t nitems = (size_t)(nsub - nunits * (unit_m - 1)) * nchunk;
+    const int lds_rows = [] { const char* e = std::getenv("FGOICP_LDS_TILES"); return e ? std::atoi(e) : 0; }();  // tuning knob / A-B (read per launch: tests toggle it): 128 or 192 rows of 16 floats per wave
+    if (nunits == 0 && (lds_rows == 128 || lds_rows == 192) && lut) {
+        static unsigned* d_stat = [] { unsigned* p = nullptr; if (std::getenv("FGOICP_LDS_STATS")) { (void)hipMalloc(&p, 8); (void)hipMemset(p, 0, 8); } return p; }();
+        if (ev_start) (void)hipEventRecord(ev_start, s);
+        const dim3 lgrid((unsigned)nitems);
+        if (evals) {
+            if (lds_rows == 128) hipLaunchKernelGGL((bounds_lds_kernel<1, 128>), lgrid, dim3(64), 0, s, src, ns, lut, g, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, (unsigned)nitems, d_stat);
+            else hipLaunchKernelGGL((bounds_lds_kernel<1, 192>), lgrid, dim3(64), 0, s, src, ns, lut, g, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, (unsigned)nitems, d_stat);
+        } else {
+            if (lds_rows == 128) hipLaunchKernelGGL((bounds_lds_kernel<0, 128>), lgrid, dim3(64), 0, s, src, ns, lut, g, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, (unsigned)nitems, d_stat);
+            else hipLaunchKernelGGL((bounds_lds_kernel<0, 192>), lgrid, dim3(64), 0, s, src, ns, lut, g, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, (unsigned)nitems, d_stat);
+        }
+        if (ev_stop) (void)hipEventRecord(ev_stop, s);
+        if (d_stat) {
+            static int calls = 0;
+            if ((++calls & 63) == 0) {
+                unsigned h[2] = {0, 0};
+                (void)hipStreamSynchronize(s);
+                (void)hipMemcpy(h, d_stat, 8, hipMemcpyDeviceToHost);
+                std::fprintf(stderr, "[fgoicp lds tiles] %u of %u passes staged (%.1f %%)\n", h[0], h[1], h[1] ? 100.0 * h[0] / h[1] : 0.0);
+            }
+        }
+        return;
+    }
+    if (nunits > 0) {  // sibling units (dense clouds): the z-pair or plain layouts, one wave per item, 4 points per lane
+        if (ev_start) (void)hipEventRecord(ev_start, s);
+        const dim3 ugrid((unsigned)nitems);
+#define FGOICP_LAUNCH_UNITS(Z, TR, M) \
+        hipLaunchKernelGGL((bounds_units_kernel<Z, TR, M>), ugrid, dim3(64), 0, s, src, ns, lut, zp, g, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, (unsigned)nitems, nunits)
+        const int z = (zp && layout == 2) ? 2 : zp ? 1 : 0;
+        if (evals) {
+            if (unit_m == 8) { if (z == 2) FGOICP_LAUNCH_UNITS(2, 1, 8); else if (z == 1) FGOICP_LAUNCH_UNITS(1, 1, 8); else FGOICP_LAUNCH_UNITS(0, 1, 8); }
+            else { if (z == 2) FGOICP_LAUNCH_UNITS(2, 1, 4); else if (z == 1) FGOICP_LAUNCH_UNITS(1, 1, 4); else FGOICP_LAUNCH_UNITS(0, 1, 4); }
+        } else {
+            if (unit_m == 8) { if (z == 2) FGOICP_LAUNCH_UNITS(2, 0, 8); else if (z == 1) FGOICP_LAUNCH_UNITS(1, 0, 8); else FGOICP_LAUNCH_UNITS(0, 0, 8); }
+            else { if (z == 2) FGOICP_LAUNCH_UNITS(2, 0, 4); else if (z == 1) FGOICP_LAUNCH_UNITS(1, 0, 4); else FGOICP_LAUNCH_UNITS(0, 0, 4); }
+        }
+#undef FGOICP_LAUNCH_UNITS
+        if (ev_stop) (void)hipEventRecord(ev_stop, s);
+        return;
+    }
     const TickGroup* gp = groups;
     const TickSub* sp = subs;
     if (ev_start) (void)hipEventRecord(ev_start, s);

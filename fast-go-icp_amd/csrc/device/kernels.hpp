@@ -66,13 +66,14 @@ void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, con
                       unsigned* hist_xcd /* 16 x kTickNumKeys, zero on entry and on exit (optional) */, unsigned* xoff /* 16 x kTickNumKeys (optional) */,
                       unsigned* block_sums /* 64 */, unsigned* cursor, unsigned* sorted,
                       int allow_xcd /* 0: device-scope histogram atomics */, unsigned* check_err /* optional, host-visible: set to 1 unless `sorted` is a permutation */,
-                      int inject_fault /* test hook */, hipStream_t s);
+                      int inject_fault /* test hook */, hipStream_t s,
+                      int nunits = 0, int unit_m = 1 /* sibling units: the first nunits * unit_m evaluations form nunits items per chunk (bounds_units_kernel) */);
 // descriptors of a tick: pinned staging (device-visible addresses) -> device arrays, one launch
 void launch_tick_upload(const TickGroup* hd_groups, TickGroup* d_groups, int ngroups, const TickSub* hd_subs, TickSub* d_subs, int nsubs, hipStream_t s);
 void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* packed_or_null, int layout /* 1 z-pair, 2 yz-quad */, const LutGeom& g, int nchunk,
                           int chunk_pts /* 256 .. 2048 points per item */, const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials,
                           float* evals_or_null /* trimmed mode: row r = the per-point e = max(d, 0) of output row r */, size_t erow /* floats per row, multiple of 4 */,
-                          hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s);
+                          hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s, int nunits = 0, int unit_m = 1);
 // EXTENSION (trimmed Go-ICP): per output row the sums of ub = e*e and lb = max(e - sqrt3*span, 0)^2 over the row's k smallest e
 // (one exact selection per row, kernels.hip trim_rows_kernel); row_span[r] = translation span of row r (device-readable)
 void launch_trim_rows(const float* evals, size_t erow, int n, int k, int rows, const float* row_span, float* out_ub, float* out_lb, hipStream_t s);

@@ -31,6 +31,7 @@
 #include <iterator>
 #include <map>
 #include <thread>
+#include <tuple>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -264,7 +265,7 @@ public:
         {
             std::lock_guard<std::mutex> g(m_);
             stop_ = true;
-            generation_.fetch_add(1, std::memory_order_release);
+            generation_.fetch_add(1, std::memory_order_seq_cst);
         }
         cv_start_.notify_all();
         for (auto& t : threads_) t.join();
@@ -278,8 +279,8 @@ public:
         fn_ = &f;
         n_ = n;
         active_.store(threads_.size(), std::memory_order_relaxed);
-        generation_.fetch_add(1, std::memory_order_release);  // publishes the job to spinning workers
-        if (sleepers_.load(std::memory_order_acquire) > 0) {
+        generation_.fetch_add(1, std::memory_order_seq_cst);  // publishes the job to spinning workers
+        if (sleepers_.load(std::memory_order_seq_cst) > 0) {
             std::lock_guard<std::mutex> g(m_);  // pairs with the sleeper's predicate check: no lost wake-up
             cv_start_.notify_all();
         }
@@ -303,18 +304,18 @@ private:
         for (;;) {
             bool got = false;
             for (int spin = 0; spin < spin_budget_; ++spin) {  // ~50-100 us of polling before going to sleep
-                if (generation_.load(std::memory_order_acquire) != seen) { got = true; break; }
+                if (generation_.load(std::memory_order_seq_cst) != seen) { got = true; break; }
 #if defined(__x86_64__) || defined(__i386__)
                 __builtin_ia32_pause();
 #endif
             }
             if (!got) {
                 std::unique_lock<std::mutex> lk(m_);
-                sleepers_.fetch_add(1, std::memory_order_release);
-                cv_start_.wait(lk, [&] { return generation_.load(std::memory_order_acquire) != seen; });
-                sleepers_.fetch_sub(1, std::memory_order_release);
+                sleepers_.fetch_add(1, std::memory_order_seq_cst);  // store-buffering pair with the poster's (generation_++, sleepers_ load): both sides sequentially consistent, or a wake-up can be lost
+                cv_start_.wait(lk, [&] { return generation_.load(std::memory_order_seq_cst) != seen; });
+                sleepers_.fetch_sub(1, std::memory_order_seq_cst);
             }
-            seen = generation_.load(std::memory_order_acquire);
+            seen = generation_.load(std::memory_order_seq_cst);
             if (stop_) return;
             drain(id);
             active_.fetch_sub(1, std::memory_order_release);
@@ -329,7 +330,7 @@ private:
     std::atomic<uint64_t> generation_{0};
     std::atomic<int> sleepers_{0};
     const int spin_budget_ = [] { const char* e = std::getenv("FGOICP_HOST_SPIN"); return e ? std::atoi(e) : 20000; }();  // tuning knob: 0 = workers sleep at once
-    bool stop_ = false;
+    std::atomic<bool> stop_{false};
 };
 
 template <class Ops>
@@ -403,12 +404,12 @@ private:
     using clock = std::chrono::steady_clock;
     static double seconds_since(clock::time_point t0) { return std::chrono::duration<double>(clock::now() - t0).count(); }
 
-    int icp(const Mat3f& R0, const Vec3f& t0, float thr, float& sse, Mat3f& R, Vec3f& t) {
+    int icp(const Mat3f& R0, const Vec3f& t0, float thr, float& sse, Mat3f& R, Vec3f& t, bool background = false) {
         const auto t_icp = clock::now();
         const float t03[3] = {t0.x, t0.y, t0.z};
         float t3[3];
         int iters = 0;
-        int rc = ops_.icp(R0.m, t03, 100, thr, &sse, R.m, t3, &iters);
+        int rc = background ? ops_.icp_background(R0.m, t03, 100, thr, &sse, R.m, t3, &iters) : ops_.icp(R0.m, t03, 100, thr, &sse, R.m, t3, &iters);
         t = Vec3f{t3[0], t3[1], t3[2]};
         stats_.icp_runs++;
         stats_.icp_iters += (uint64_t)iters;
@@ -576,6 +577,31 @@ private:
         rcand.push(RotCube(0.f, 0.f, 0.f, 1.0f, 0.f, best_sse()));
         const int rank = ex_.rank, world = ex_.world < 1 ? 1 : ex_.world;
         std::vector<RotCube> children;
+        // LATE-JOINING REFINEMENT (FGOICP_LATE_ICP; default on for world > 1).  The ICP runs a round triggers (fgoicp.cpp:74-88) fall on
+        // the ranks whose children trigger them — one or two single runs of tens of milliseconds per round, on ONE rank, while the
+        // others wait in the exchange (the named serial term of the 8-rank estimate).  With this on, a round's
+        // triggers run in the background (own host thread, own ICP lane and streams of the context) while the rank goes on to the
+        // exchange and to the NEXT round's bounds work; their result enters the exchange one round late.  Price: one round of weaker
+        // pruning (tasks and pushes of round r+1 see the incumbent without round r's refinements).  The replicated state stays
+        // identical on all ranks — refinements enter it only through exchanges, a last exchange after the loop collects the final
+        // round's — and the result is an epsilon-optimal solution as before, reached through a different sequence of incumbents.
+        struct LateJob {
+            std::thread th;
+            std::vector<std::tuple<Mat3f, Vec3f, float>> cands;  // (rotation, best translation, ub) in child order
+            float sse = 0.f; Mat3f R{}; Vec3f t{0, 0, 0};
+            int rc = kDriverOk;
+            bool active = false;
+            ~LateJob() { if (th.joinable()) th.join(); }
+        } late;
+        // folds a finished background job into (loc_sse, loc_R, loc_t)
+        auto join_late = [&](float& ls, Mat3f& lR, Vec3f& lt) -> int {
+            if (!late.active) return kDriverOk;
+            late.th.join();
+            late.active = false;
+            if (late.rc) return late.rc;
+            if (late.sse < ls) { ls = late.sse; lR = late.R; lt = late.t; }
+            return kDriverOk;
+        };
         // round_width 0 = adaptive: start at 32 cubes per rank, double after every round that leaves the incumbent
         // standing (the search is certifying: every cube below the threshold gap has to be expanded anyway, wide rounds
         // waste nothing and feed the device bigger ticks), fall back to the base width when the incumbent improves.
@@ -635,6 +661,29 @@ private:
             // candidates the rule would have skipped, and its length is that of its longest run.)
             float loc_sse; Mat3f loc_R; Vec3f loc_t;
             { std::lock_guard<std::mutex> g(mu_); loc_sse = best_sse_; loc_R = best_R_; loc_t = best_t_; }
+            if (late_icp_ > 0 && (world > 1 || late_icp_ > 1)) {
+                rc = join_late(loc_sse, loc_R, loc_t);  // the refinements of the round before: they join THIS exchange
+                if (rc) return rc;
+                late.cands.clear();
+                for (size_t k = 0; k < mine.size(); ++k) {
+                    const RotCube& ch = children[mine[k]];
+                    set_last(ch.q.R, boxes[2 * k].best_t);
+                    if (boxes[2 * k].best_ub < loc_sse * 1.8) late.cands.emplace_back(ch.q.R, boxes[2 * k].best_t, boxes[2 * k].best_ub);  // could trigger at all
+                }
+                if (!late.cands.empty()) {
+                    late.sse = loc_sse; late.R = loc_R; late.t = loc_t; late.rc = kDriverOk;
+                    late.active = true;
+                    late.th = std::thread([this, &late] {  // the rule of fgoicp.cpp:74-88, in child order against the job's running best
+                        for (const auto& c : late.cands) {
+                            if (!(std::get<2>(c) < late.sse * 1.8)) continue;
+                            float sse; Mat3f R; Vec3f t;
+                            const int r = icp(std::get<0>(c), std::get<1>(c), 0.005f, sse, R, t, true);
+                            if (r) { late.rc = r; return; }
+                            if (sse < late.sse) { late.sse = sse; late.R = R; late.t = t; }
+                        }
+                    });
+                }
+            } else
             for (size_t k = 0; k < mine.size(); ++k) {
                 const RotCube& ch = children[mine[k]];
                 const float ub = boxes[2 * k].best_ub;
@@ -698,6 +747,36 @@ private:
                 children[i].lb = lbs[i];
                 children[i].ub = ubs[i];
                 rcand.push(children[i]);
+            }
+        }
+        if (late_icp_ > 0 && (world > 1 || late_icp_ > 1)) {
+            // the last round's refinements: joined and agreed on by one more exchange (every rank gets here after the same round —
+            // the loop's decisions depend on the replicated state only)
+            float loc_sse; Mat3f loc_R; Vec3f loc_t;
+            { std::lock_guard<std::mutex> g(mu_); loc_sse = best_sse_; loc_R = best_R_; loc_t = best_t_; }
+            int rc = join_late(loc_sse, loc_R, loc_t);
+            if (rc) return rc;
+            if (world > 1) {
+                float gmin = loc_sse;
+                if (ex_.allreduce_min(&gmin, 1, ex_.user)) return kDriverExchangeFailed;
+                std::vector<float> send(13, 0.f), recv((size_t)13 * world, 0.f);
+                send[0] = loc_sse;
+                std::memcpy(&send[1], loc_R.m, sizeof(float) * 9);
+                send[10] = loc_t.x; send[11] = loc_t.y; send[12] = loc_t.z;
+                if (ex_.allgather(send.data(), recv.data(), 13, ex_.user)) return kDriverExchangeFailed;
+                for (int r = 0; r < world; ++r) {
+                    const float* p = &recv[(size_t)13 * r];
+                    if (p[0] == gmin && gmin < best_sse()) {
+                        std::lock_guard<std::mutex> g(mu_);
+                        best_sse_ = gmin;
+                        std::memcpy(best_R_.m, p + 1, sizeof(float) * 9);
+                        best_t_ = Vec3f{p[10], p[11], p[12]};
+                        break;
+                    }
+                }
+            } else if (loc_sse < best_sse()) {
+                std::lock_guard<std::mutex> g(mu_);
+                best_sse_ = loc_sse; best_R_ = loc_R; best_t_ = loc_t;
             }
         }
         return kDriverOk;
@@ -880,8 +959,11 @@ private:
     // Advance a set of inner tasks to completion.  Every submission carries the current batch of every
     // live task of a half in ONE operator call (G groups).  With an asynchronous backend the tasks are
     // split into two halves on two slots: while the device evaluates one half, the host consumes the
-    // results of the other and pops its next batches.  A task's own sequence of batches is the same
-    // either way, so results do not depend on the mode.
+    // results of the other and pops its next batches.  With the tail batches OFF (FGOICP_TAIL_BATCH=0) a task's own sequence of
+    // batches is the same either way, so results do not depend on the mode.  With them on (ROUND's default) a task's batch size
+    // depends on how many tasks share its half — on the mode, the rebalancing, the world size, the memo: the inner BnB stops on
+    // `best_error - top.lb < threshold` (fgoicp.cpp:120), so best_ub, the counters and the accepted incumbent may then differ WITHIN
+    // THE THRESHOLD between configurations (same epsilon-optimal answer, not the same bits).
     void overlap_report(std::vector<Task*>& tasks, const std::vector<const RotCube*>& cubes) {
         for (size_t i = 0; i + 1 < tasks.size(); i += 2) {
             if (cubes[i] != cubes[i + 1]) continue;
@@ -957,6 +1039,7 @@ private:
     double t_pop_ = 0, t_ops_ = 0, t_push_ = 0;
     double t_prep_[3] = {0, 0, 0};  // FGOICP_TIMING: pops / pair matching / packing inside prepare_half
     const bool timing_ = std::getenv("FGOICP_TIMING") != nullptr;  // host-side timing lines on stderr
+    const int late_icp_ = [] { const char* e = std::getenv("FGOICP_LATE_ICP"); return e ? std::atoi(e) : 1; }();  // tuning knob (ROUND): 0 = off, 1 = with an exchange (world > 1), 2 = always
     bool use_twins_ = [] { const char* e = std::getenv("FGOICP_TWINS"); return !e || std::atoi(e) != 0; }();  // tuning knob
     const size_t round_batch_ = [] { const char* e = std::getenv("FGOICP_ROUND_BATCH"); const int v = e ? std::atoi(e) : 48; return (size_t)(v >= 8 && v <= 64 ? v : 48); }();  // tuning knob (ROUND only; SERIAL keeps the reference's 32)
     const size_t tail_batch_ = [] { const char* e = std::getenv("FGOICP_TAIL_BATCH"); const int v = e ? std::atoi(e) : 128; return (size_t)(v >= 8 && v <= 128 ? v : 0); }();  // tuning knob (ROUND): batch of a half with few tasks left (0 = off)

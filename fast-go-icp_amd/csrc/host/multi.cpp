@@ -10,7 +10,8 @@
 //
 // The reference is single-GPU (no NCCL/MPI call sites); nothing here replaces reference code.
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is loaded on first use (RcclApi below), not linked
+#include <dlfcn.h>
 
 #include <atomic>
 #include <chrono>
@@ -23,6 +24,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../../include/fgoicp_amd.h"
@@ -43,10 +45,52 @@ struct fgoicp_rccl {
     size_t cap = 0;                               // floats per rank the buffers hold
     int rank = 0, world = 1, device = 0;
     uint64_t calls = 0;
-    std::atomic<bool> dead{false};                // communicator aborted (fgoicp_rccl_abort): every later collective fails at once
+    // Failure handling.  `dead` may be set by ANY thread (fgoicp_rccl_abort: another rank has failed); the communicator itself is only
+    // ever touched by its owner — the thread that runs this rank's collectives — which polls `dead` while it waits for a collective
+    // and then calls ncclCommAbort itself (`released`).  (Round 2 aborted from the peer's thread: ncclCommAbort frees the
+    // communicator, and the owner could be between its check and its ncclAllReduce — a use after free.)
+    std::atomic<bool> dead{false};
+    bool released = false;                        // owner only: the communicator has been aborted / destroyed
 };
 
 namespace {
+
+// RCCL is needed by the multi-GPU entry points only, so libfgoicp_amd.so does not link it: a single-GPU installation without
+// RCCL loads and runs; the first fgoicp_rccl_* call resolves the handful of entry points it uses.
+struct RcclApi {
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitRankConfig) CommInitRankConfig = nullptr;
+    decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+    bool ok = false;
+};
+const RcclApi& rccl_api() {
+    static const RcclApi api = [] {
+        RcclApi a;
+        void* h = nullptr;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        if (!h) { a.error = std::string("RCCL is not installed (dlopen librccl.so.1: ") + dlerror() + ")"; return a; }
+        bool all = true;
+        auto sym = [&](auto& fn, const char* name) { fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(h, name)); all = all && fn != nullptr; };
+        sym(a.GetUniqueId, "ncclGetUniqueId"); sym(a.CommInitRank, "ncclCommInitRank"); sym(a.CommInitRankConfig, "ncclCommInitRankConfig");
+        sym(a.CommGetAsyncError, "ncclCommGetAsyncError"); sym(a.CommDestroy, "ncclCommDestroy"); sym(a.CommAbort, "ncclCommAbort");
+        sym(a.CommCount, "ncclCommCount"); sym(a.AllReduce, "ncclAllReduce"); sym(a.AllGather, "ncclAllGather"); sym(a.GetErrorString, "ncclGetErrorString");
+        if (!all) { a.error = "librccl.so lacks an entry point this library uses"; return a; }
+        a.ok = true;
+        return a;
+    }();
+    return api;
+}
 
 #define RCCL_HIP(expr)                                                                                     \
     do {                                                                                                   \
@@ -56,7 +100,7 @@ namespace {
 #define RCCL_NCCL(expr)                                                                                    \
     do {                                                                                                   \
         ncclResult_t r_ = (expr);                                                                          \
-        if (r_ != ncclSuccess) { set_error(std::string(#expr) + " failed: " + ncclGetErrorString(r_)); return 1; } \
+        if (r_ != ncclSuccess) { set_error(std::string(#expr) + " failed: " + rccl_api().GetErrorString(r_)); return 1; } \
     } while (0)
 
 int rccl_reserve(fgoicp_rccl* x, size_t n) {
@@ -74,17 +118,48 @@ int rccl_reserve(fgoicp_rccl* x, size_t n) {
     return 0;
 }
 
+// Owner only: give the communicator up (idempotent).  After it every collective of this rank fails at once.
+void rccl_release(fgoicp_rccl* x) {
+    if (x->released) return;
+    x->released = true;
+    if (x->comm) (void)rccl_api().CommAbort(x->comm);
+    x->comm = nullptr;
+}
+int rccl_dead(fgoicp_rccl* x) {
+    rccl_release(x);
+    set_error("exchange aborted: another rank failed");
+    return 1;
+}
+// Waits for the stream without blocking in the runtime: the collective of a rank whose peer has died never completes, so the
+// owner polls — stream, `dead`, the communicator's asynchronous error — and aborts its own communicator when it has to.
+int rccl_wait(fgoicp_rccl* x) {
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t q = hipStreamQuery(x->stream);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) { set_error(std::string("hipStreamQuery failed: ") + hipGetErrorString(q)); rccl_release(x); return 1; }
+        if (x->dead.load(std::memory_order_acquire)) return rccl_dead(x);
+        if ((spins & 255u) == 255u) {
+            ncclResult_t async = ncclSuccess;
+            if (rccl_api().CommGetAsyncError(x->comm, &async) != ncclSuccess || (async != ncclSuccess && async != ncclInProgress)) {
+                set_error(std::string("RCCL reported an asynchronous error: ") + rccl_api().GetErrorString(async));
+                rccl_release(x);
+                return 1;
+            }
+            std::this_thread::yield();
+        }
+    }
+}
+
 int rccl_allreduce_min(float* buf, size_t n, void* user) {
     fgoicp_rccl* x = static_cast<fgoicp_rccl*>(user);
-    if (x->dead.load()) { set_error("exchange aborted: another rank failed"); return 1; }
+    if (x->released || x->dead.load(std::memory_order_acquire)) return rccl_dead(x);
     RCCL_HIP(hipSetDevice(x->device));
     if (rccl_reserve(x, n)) return 1;
     std::memcpy(x->h_pin, buf, sizeof(float) * n);
     RCCL_HIP(hipMemcpyAsync(x->d_send, x->h_pin, sizeof(float) * n, hipMemcpyHostToDevice, x->stream));
-    RCCL_NCCL(ncclAllReduce(x->d_send, x->d_recv, n, ncclFloat, ncclMin, x->comm, x->stream));
+    RCCL_NCCL(rccl_api().AllReduce(x->d_send, x->d_recv, n, ncclFloat, ncclMin, x->comm, x->stream));
     RCCL_HIP(hipMemcpyAsync(x->h_pin, x->d_recv, sizeof(float) * n, hipMemcpyDeviceToHost, x->stream));
-    RCCL_HIP(hipStreamSynchronize(x->stream));
-    if (x->dead.load()) { set_error("exchange aborted: another rank failed"); return 1; }
+    if (rccl_wait(x)) return 1;
     std::memcpy(buf, x->h_pin, sizeof(float) * n);
     x->calls++;
     return 0;
@@ -92,15 +167,14 @@ int rccl_allreduce_min(float* buf, size_t n, void* user) {
 
 int rccl_allgather(const float* send, float* recv, size_t n, void* user) {
     fgoicp_rccl* x = static_cast<fgoicp_rccl*>(user);
-    if (x->dead.load()) { set_error("exchange aborted: another rank failed"); return 1; }
+    if (x->released || x->dead.load(std::memory_order_acquire)) return rccl_dead(x);
     RCCL_HIP(hipSetDevice(x->device));
     if (rccl_reserve(x, n)) return 1;
     std::memcpy(x->h_pin, send, sizeof(float) * n);
     RCCL_HIP(hipMemcpyAsync(x->d_send, x->h_pin, sizeof(float) * n, hipMemcpyHostToDevice, x->stream));
-    RCCL_NCCL(ncclAllGather(x->d_send, x->d_recv, n, ncclFloat, x->comm, x->stream));
+    RCCL_NCCL(rccl_api().AllGather(x->d_send, x->d_recv, n, ncclFloat, x->comm, x->stream));
     RCCL_HIP(hipMemcpyAsync(x->h_pin + x->cap, x->d_recv, sizeof(float) * n * x->world, hipMemcpyDeviceToHost, x->stream));
-    RCCL_HIP(hipStreamSynchronize(x->stream));
-    if (x->dead.load()) { set_error("exchange aborted: another rank failed"); return 1; }
+    if (rccl_wait(x)) return 1;
     std::memcpy(recv, x->h_pin + x->cap, sizeof(float) * n * x->world);
     x->calls++;
     return 0;
@@ -113,9 +187,10 @@ extern "C" {
 int fgoicp_rccl_unique_id(unsigned char* id128) {
     if (!id128) return FGOICP_ERR_INVALID_ARG;
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    if (!rccl_api().ok) { set_error(rccl_api().error); return FGOICP_ERR_EXCHANGE; }
     ncclUniqueId id;
-    ncclResult_t r = ncclGetUniqueId(&id);
-    if (r != ncclSuccess) { set_error(std::string("ncclGetUniqueId failed: ") + ncclGetErrorString(r)); return FGOICP_ERR_EXCHANGE; }
+    ncclResult_t r = rccl_api().GetUniqueId(&id);
+    if (r != ncclSuccess) { set_error(std::string("ncclGetUniqueId failed: ") + rccl_api().GetErrorString(r)); return FGOICP_ERR_EXCHANGE; }
     std::memcpy(id128, &id, 128);
     return FGOICP_OK;
 }
@@ -123,18 +198,24 @@ int fgoicp_rccl_unique_id(unsigned char* id128) {
 void fgoicp_rccl_destroy(fgoicp_rccl* x) {
     if (!x) return;
     (void)hipSetDevice(x->device);
-    if (x->stream && !x->dead.load()) (void)hipStreamSynchronize(x->stream);
-    if (x->comm && !x->dead.load()) (void)ncclCommDestroy(x->comm);  // an aborted communicator is already released
+    // the caller is the owner now (no collective of this rank is running): a communicator marked dead by a peer and not yet given
+    // up is aborted here, a healthy one is drained and destroyed
+    if (x->dead.load() && !x->released) rccl_release(x);
+    if (x->stream && !x->released) (void)hipStreamSynchronize(x->stream);
+    if (x->comm && !x->released) (void)rccl_api().CommDestroy(x->comm);
     (void)hipFree(x->d_send); (void)hipFree(x->d_recv);
     if (x->h_pin) (void)hipHostFree(x->h_pin);
     if (x->stream) (void)hipStreamDestroy(x->stream);
     delete x;
 }
 
-int fgoicp_rccl_create(int rank, int world, const unsigned char* id128, int device, fgoicp_rccl** out) {
-    if (!out) return FGOICP_ERR_INVALID_ARG;
+// Everything of a rank's transport that can fail WITHOUT its peers: device, stream, buffers.  fgoicp_multi_create runs this for all
+// ranks before any of them enters ncclCommInitRank (which blocks until every rank has joined), so a rank that cannot even set
+// itself up does not leave the others waiting for it.
+static int rccl_prepare(int rank, int world, int device, fgoicp_rccl** out) {
     *out = nullptr;
-    if (!id128 || world < 1 || rank < 0 || rank >= world) { set_error("fgoicp_rccl_create: invalid argument"); return FGOICP_ERR_INVALID_ARG; }
+    if (!rccl_api().ok) { set_error(rccl_api().error); return FGOICP_ERR_EXCHANGE; }
+    if (world < 1 || rank < 0 || rank >= world) { set_error("fgoicp_rccl_create: invalid argument"); return FGOICP_ERR_INVALID_ARG; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { set_error("fgoicp_rccl_create: no such HIP device"); return FGOICP_ERR_NO_DEVICE; }
     auto x = std::make_unique<fgoicp_rccl>();
@@ -143,25 +224,68 @@ int fgoicp_rccl_create(int rank, int world, const unsigned char* id128, int devi
         set_error("fgoicp_rccl_create: stream creation failed");
         return FGOICP_ERR_HIP;
     }
-    ncclUniqueId id;
-    std::memcpy(&id, id128, 128);
-    ncclResult_t r = ncclCommInitRank(&x->comm, world, id, rank);
-    if (r != ncclSuccess) {
-        set_error(std::string("ncclCommInitRank failed: ") + ncclGetErrorString(r));
-        x->comm = nullptr;
-        fgoicp_rccl_destroy(x.release());
-        return FGOICP_ERR_EXCHANGE;
-    }
     if (rccl_reserve(x.get(), 64)) { fgoicp_rccl_destroy(x.release()); return FGOICP_ERR_HIP; }
     *out = x.release();
     return FGOICP_OK;
 }
+// ... and the part that needs all ranks: the communicator.  `give_up` (optional) is polled while the non-blocking initialisation is
+// in progress — set by the caller when another rank of the same process has failed.
+static int rccl_join(fgoicp_rccl* x, const unsigned char* id128, const std::atomic<bool>* give_up) {
+    ncclUniqueId id;
+    std::memcpy(&id, id128, 128);
+    if (hipSetDevice(x->device) != hipSuccess) { set_error("fgoicp_rccl_create: hipSetDevice failed"); return FGOICP_ERR_HIP; }
+    ncclResult_t r;
+    if (give_up) {
+        ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+        cfg.blocking = 0;
+        r = rccl_api().CommInitRankConfig(&x->comm, x->world, id, x->rank, &cfg);
+        while (r == ncclInProgress || r == ncclSuccess) {
+            ncclResult_t st = ncclSuccess;
+            if (!x->comm || rccl_api().CommGetAsyncError(x->comm, &st) != ncclSuccess) { r = ncclInternalError; break; }
+            if (st != ncclInProgress) { r = st; break; }
+            if (give_up->load(std::memory_order_acquire)) { r = ncclInvalidUsage; set_error("communicator set-up abandoned: another rank failed"); break; }
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+    } else {
+        r = rccl_api().CommInitRank(&x->comm, x->world, id, x->rank);
+    }
+    if (r != ncclSuccess) {
+        if (!(give_up && give_up->load())) set_error(std::string("ncclCommInitRank failed: ") + rccl_api().GetErrorString(r));
+        if (x->comm) rccl_release(x);
+        x->released = true;
+        return FGOICP_ERR_EXCHANGE;
+    }
+    return FGOICP_OK;
+}
 
-// Ends every collective in flight on this communicator and fails all later ones: what a rank's owner calls when ANOTHER rank has
-// failed, so that this one does not wait for it for ever.  Callable from any thread, once or more.
+int fgoicp_rccl_create(int rank, int world, const unsigned char* id128, int device, fgoicp_rccl** out) {
+    if (!out) return FGOICP_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!id128) { set_error("fgoicp_rccl_create: invalid argument"); return FGOICP_ERR_INVALID_ARG; }
+    fgoicp_rccl* x = nullptr;
+    int rc = rccl_prepare(rank, world, device, &x);  // one process per GPU: a rank that fails here is its launcher's to report
+    if (rc) return rc;
+    rc = rccl_join(x, id128, nullptr);
+    if (rc) { fgoicp_rccl_destroy(x); return rc; }
+    *out = x;
+    return FGOICP_OK;
+}
+
+// Another rank has failed: every collective of this communicator that is in flight or follows must end instead of waiting for
+// it.  Callable from any thread, once or more — it only raises a flag; the communicator's owner sees it (rccl_wait polls it) and
+// aborts the communicator itself.
 int fgoicp_rccl_abort(fgoicp_rccl* x) {
     if (!x) return FGOICP_ERR_INVALID_ARG;
-    if (!x->dead.exchange(true) && x->comm) (void)ncclCommAbort(x->comm);
+    x->dead.store(true, std::memory_order_release);
+    return FGOICP_OK;
+}
+
+// Ranks the communicator itself reports (ncclCommCount): what a scaling run prints to show that RCCL really joined N ranks.
+int fgoicp_rccl_comm_count(fgoicp_rccl* x, int* count) {
+    if (!x || !count) return FGOICP_ERR_INVALID_ARG;
+    if (x->released || !x->comm) { set_error("fgoicp_rccl_comm_count: the communicator has been released"); return FGOICP_ERR_EXCHANGE; }
+    ncclResult_t r = rccl_api().CommCount(x->comm, count);
+    if (r != ncclSuccess) { set_error(std::string("ncclCommCount failed: ") + rccl_api().GetErrorString(r)); return FGOICP_ERR_EXCHANGE; }
     return FGOICP_OK;
 }
 
@@ -237,7 +361,7 @@ struct RankLink {        // what one rank's exchange callbacks see
     std::vector<std::vector<float>>* log = nullptr;   // results of every exchange, in order
     size_t replay_pos = 0;
     bool replay = false;
-    long fail_at = -1, calls = 0;                 // test hook (FGOICP_MULTI_FAULT = "rank:call"): that exchange of that rank fails
+    long fail_at = -1, calls = 0;                 // test hook (fgoicp_multi_test_fault): that exchange of that rank fails, once
 };
 
 int link_allreduce_min(float* buf, size_t n, void* user) {
@@ -247,7 +371,7 @@ int link_allreduce_min(float* buf, size_t n, void* user) {
         std::memcpy(buf, (*l->log)[l->replay_pos++].data(), sizeof(float) * n);
         return 0;
     }
-    if (l->calls++ == l->fail_at) { set_error("injected exchange fault (FGOICP_MULTI_FAULT)"); return 1; }
+    if (l->calls++ == l->fail_at) { l->fail_at = -1; set_error("injected exchange fault (fgoicp_multi_test_fault)"); return 1; }
     int rc = 0;
     if (l->rv) {
         rc = l->rv->run(n,
@@ -268,7 +392,7 @@ int link_allgather(const float* send, float* recv, size_t n, void* user) {
         std::memcpy(recv, (*l->log)[l->replay_pos++].data(), sizeof(float) * n * l->world);
         return 0;
     }
-    if (l->calls++ == l->fail_at) { set_error("injected exchange fault (FGOICP_MULTI_FAULT)"); return 1; }
+    if (l->calls++ == l->fail_at) { l->fail_at = -1; set_error("injected exchange fault (fgoicp_multi_test_fault)"); return 1; }
     int rc = 0;
     if (l->rv) {
         rc = l->rv->run(n * (size_t)l->world,
@@ -337,15 +461,22 @@ int fgoicp_multi_create(const float* tgt_xyz, size_t nt, const float* src_xyz, s
         int rc = fgoicp_rccl_unique_id(id);
         if (rc) return fail(rc);
         m->rccl.assign(ndev, nullptr);
+        for (int r = 0; r < ndev; ++r) {  // phase 1, on this thread: what a rank can fail at on its own
+            rc = rccl_prepare(r, ndev, devices[r], &m->rccl[r]);
+            if (rc) { set_error("rank " + std::to_string(r) + ": " + fgoicp_last_error()); return fail(rc); }
+        }
         std::vector<int> rcs(ndev, 0);
         std::vector<std::string> errs(ndev);
-        std::vector<std::thread> th;  // ncclCommInitRank blocks until every rank has joined: one thread per rank
+        std::atomic<bool> give_up{false};
+        std::vector<std::thread> th;  // phase 2: the communicator forms when every rank has joined — one thread per rank, non-blocking init
         for (int r = 0; r < ndev; ++r)
             th.emplace_back([&, r] {
-                rcs[r] = fgoicp_rccl_create(r, ndev, id, devices[r], &m->rccl[r]);
-                if (rcs[r]) errs[r] = fgoicp_last_error();
+                rcs[r] = rccl_join(m->rccl[r], id, &give_up);
+                if (rcs[r]) { errs[r] = fgoicp_last_error(); give_up.store(true, std::memory_order_release); }
             });
         for (auto& t : th) t.join();
+        for (int r = 0; r < ndev; ++r)
+            if (rcs[r] && errs[r].find("abandoned") == std::string::npos) { set_error("rank " + std::to_string(r) + ": " + errs[r]); return fail(rcs[r]); }
         for (int r = 0; r < ndev; ++r)
             if (rcs[r]) { set_error("rank " + std::to_string(r) + ": " + errs[r]); return fail(rcs[r]); }
     }
@@ -354,10 +485,6 @@ int fgoicp_multi_create(const float* tgt_xyz, size_t nt, const float* src_xyz, s
         l->rank = r;
         l->world = ndev;
         l->log = &m->logs[r];
-        if (const char* e = std::getenv("FGOICP_MULTI_FAULT")) {
-            int fr = -1; long fc = -1;
-            if (std::sscanf(e, "%d:%ld", &fr, &fc) == 2 && fr == r) l->fail_at = fc;
-        }
         if (ndev > 1 && transport == FGOICP_TRANSPORT_RCCL) fgoicp_rccl_exchange(m->rccl[r], &l->inner);
         else l->rv = &m->rv;
         fgoicp_exchange ex{r, ndev, link_allreduce_min, link_allgather, l.get()};
@@ -366,6 +493,13 @@ int fgoicp_multi_create(const float* tgt_xyz, size_t nt, const float* src_xyz, s
         m->links.push_back(std::move(l));
     }
     *out = m.release();
+    return FGOICP_OK;
+}
+
+// TEST HOOK (tests/test_gpu_multi.py): the `call`-th exchange of `rank` in the next run fails, once.  Nothing in the product calls it.
+int fgoicp_multi_test_fault(fgoicp_multi* m, int rank, long call) {
+    if (!m || rank < 0 || rank >= (int)m->links.size()) return FGOICP_ERR_INVALID_ARG;
+    m->links[(size_t)rank]->fail_at = call;
     return FGOICP_OK;
 }
 

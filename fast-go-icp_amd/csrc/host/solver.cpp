@@ -30,6 +30,10 @@ struct HipOps {
     int icp(const float* R0, const float* t0, size_t max_iter, float thr, float* sse, float* R9, float* t3, int* iters) {
         return ctx_icp(ctx, R0, t0, max_iter, thr, sse, R9, t3, iters);
     }
+    // a refinement that runs next to the bounds work (late-joining ICP of the ROUND schedule): ICP lane 1, its own streams
+    int icp_background(const float* R0, const float* t0, size_t max_iter, float thr, float* sse, float* R9, float* t3, int* iters) {
+        return ctx_icp_lane(ctx, 1, R0, t0, max_iter, thr, sse, R9, t3, iters);
+    }
     bool pipeline = std::getenv("FGOICP_PIPELINE") ? std::atoi(std::getenv("FGOICP_PIPELINE")) != 0 : true;  // tuning knob
 };
 

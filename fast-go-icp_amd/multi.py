@@ -35,8 +35,16 @@ class RcclExchange:
         _lib.check(self._lib.fgoicp_rccl_calls(self._h, C.byref(n)), "fgoicp_rccl_calls")
         return n.value
 
+    @property
+    def comm_count(self):
+        """ranks the RCCL communicator itself reports (ncclCommCount)"""
+        n = C.c_int()
+        _lib.check(self._lib.fgoicp_rccl_comm_count(self._h, C.byref(n)), "fgoicp_rccl_comm_count")
+        return n.value
+
     def abort(self):
-        """A peer rank failed: end the collective in flight here and fail every later one (fgoicp_rccl_abort)."""
+        """A peer rank failed: the collective in flight here and every later one must end (fgoicp_rccl_abort raises the flag; the
+        thread running the collectives aborts the communicator)."""
         _lib.check(self._lib.fgoicp_rccl_abort(self._h), "fgoicp_rccl_abort")
 
     def warmup(self):
@@ -85,6 +93,10 @@ class MultiGoICP:
         R = np.empty(9, np.float32); t = np.empty(3, np.float32)
         _lib.check(self._lib.fgoicp_multi_run(self._h, _fp(R), _fp(t)), "fgoicp_multi_run")
         return from_glm(R), t
+
+    def test_fault(self, rank, call):
+        """TEST HOOK: the call-th exchange of `rank` in the next run fails, once."""
+        _lib.check(self._lib.fgoicp_multi_test_fault(self._h, int(rank), int(call)), "fgoicp_multi_test_fault")
 
     def set_record(self, on=True):
         _lib.check(self._lib.fgoicp_multi_set_record(self._h, int(bool(on))), "fgoicp_multi_set_record")

@@ -168,6 +168,10 @@ class Registration:
                    "fgoicp_bounds_point_distances")
         return out
 
+    def test_sort_fault(self, nth_tick):
+        """TEST HOOK: spoil the nth sorted tick from now (0 = off) so that the on-device permutation check has something to find."""
+        _lib.check(self._lib.fgoicp_ctx_test_sort_fault(self._h, int(nth_tick)), "fgoicp_ctx_test_sort_fault")
+
     def sort_fallbacks(self):
         """(sorted ticks, ticks repeated after a failed permutation check)"""
         a = C.c_uint64(); b = C.c_uint64()

@@ -162,6 +162,9 @@ int fgoicp_bounds_point_distances(fgoicp_ctx* ctx, const float* R9, float rot_sp
 /* Sorted ticks so far and how many of them had to be repeated because the on-device check found that the locality sort had not
  * produced a permutation of the work items (then the context switches to device-scope atomics for good). */
 int fgoicp_ctx_sort_fallbacks(const fgoicp_ctx* ctx, uint64_t* sorted_ticks, uint64_t* fallbacks);
+/* TEST HOOK, not part of the drop-in surface: spoils the nth_tick-th sorted tick from now (0 = off) so that the permutation check
+ * above has something to find.  (Round 2 read this from the environment of the shipped library) */
+int fgoicp_ctx_test_sort_fault(fgoicp_ctx* ctx, int nth_tick);
 
 /* Accumulated HIP-event timing of the bounds kernel since the last reset (FGOICP_FLAG_PROFILE):
  * kernel_ms = sum of launch durations, launches = kernel launches, subcubes = (rot, trans) pairs. */
@@ -270,8 +273,11 @@ int fgoicp_rccl_unique_id(unsigned char* id128);
 int fgoicp_rccl_create(int rank, int world_size, const unsigned char* id128, int device, fgoicp_rccl** out);
 int fgoicp_rccl_exchange(fgoicp_rccl* x, fgoicp_exchange* out);   /* `out` borrows x: keep x alive while a solver uses it */
 int fgoicp_rccl_calls(const fgoicp_rccl* x, uint64_t* collectives);
-/* Ends the collective in flight on x (ncclCommAbort) and fails every later one at once.  For the owner of a rank whose PEER has
- * failed: without it this rank would wait for the peer in its next collective for ever.  Any thread; x stays valid until
+/* Ranks the communicator itself reports (ncclCommCount) — printed by bench.py so that a scaling run shows RCCL joined N ranks. */
+int fgoicp_rccl_comm_count(fgoicp_rccl* x, int* count);
+/* A PEER rank has failed: the collective in flight on x and every later one must end instead of waiting for it for ever.  Any
+ * thread, once or more — it only raises a flag; the thread that runs x's collectives polls it while it waits and aborts the
+ * communicator itself (ncclCommAbort frees it: it must not be called under a running collective's feet).  x stays valid until
  * fgoicp_rccl_destroy but cannot be used for another run. */
 int fgoicp_rccl_abort(fgoicp_rccl* x);
 void fgoicp_rccl_destroy(fgoicp_rccl* x);
@@ -294,6 +300,8 @@ int fgoicp_multi_seconds(const fgoicp_multi* m, int rank, double* seconds);   /*
 /* Scaling rehearsal on fewer GPUs than ranks: record what every exchange returned during a run, then run ONE rank alone
  * against the recording — the time that rank would need on a GPU of its own, without the collectives' latency. */
 int fgoicp_multi_set_record(fgoicp_multi* m, int on);
+/* TEST HOOK, not part of the drop-in surface: the call-th exchange of `rank` in the next run fails, once. */
+int fgoicp_multi_test_fault(fgoicp_multi* m, int rank, long call);
 int fgoicp_multi_replay_rank(fgoicp_multi* m, int rank, double* seconds_out);
 
 #ifdef __cplusplus

@@ -45,6 +45,9 @@ struct OracleOps {
         std::memcpy(ub, slot_ub[slot].data(), slot_ub[slot].size() * sizeof(float));
         return 0;
     }
+    int icp_background(const float* R0, const float* t0, size_t max_iter, float thr, float* sse, float* R9, float* t3, int* iters) {
+        return icp(R0, t0, max_iter, thr, sse, R9, t3, iters);  // the oracle's ICP object is local to the call: safe next to the bounds operator
+    }
     int icp(const float* R0, const float* t0, size_t max_iter, float thr, float* sse, float* R9, float* t3, int* iters) {
         orc::Mat3 R;
         std::memcpy(R.c, R0, sizeof(float) * 9);

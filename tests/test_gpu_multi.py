@@ -14,13 +14,18 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = np.load(os.path.join(REPO, "tests", "golden", "goicp_golden.npz"))
 
 
-def same(a, b):
+def same(a, b, tol=1e-5):
     (Ra, ta, ea), (Rb, tb, eb) = a, b
-    return abs(float(ea) - float(eb)) <= 1e-5 * float(eb) and np.allclose(Ra, Rb, atol=1e-5) and np.allclose(ta, tb, atol=1e-5 * max(1.0, float(np.abs(tb).max())))
+    return abs(float(ea) - float(eb)) <= tol * float(eb) and np.allclose(Ra, Rb, atol=max(tol, 1e-5) * 10 if tol > 1e-5 else 1e-5) and \
+        np.allclose(ta, tb, atol=(max(tol, 1e-5) * 10 if tol > 1e-5 else 1e-5) * max(1.0, float(np.abs(tb).max())))
 
 
-@pytest.mark.parametrize("world", [2, 3, 5])
-def test_ranks_on_one_gpu_reach_the_single_gpu_optimum(fg, gpu_required, world):
+@pytest.mark.parametrize("world,late", [(2, "0"), (3, "0"), (5, "0"), (2, "1"), (3, "1"), (5, "1")])
+def test_ranks_on_one_gpu_reach_the_single_gpu_optimum(fg, gpu_required, monkeypatch, world, late):
+    """late = "1" (the default with an exchange): a round's triggered ICP runs overlap the next round's bounds work on an ICP lane of
+    their own and join the exchange one round late — the same optimum through another sequence of incumbents, so the final
+    refinement (stops when an iteration improves the error by < 0.05 %, fgoicp.cpp:22-23) may end a hair elsewhere: compared at 2e-3."""
+    monkeypatch.setenv("FGOICP_LATE_ICP", late)
     tgt, src, R_gt, t_gt = fg.synth.workload("small", angle_deg=150.0, min_angle_deg=110.0)
     mse = 2e-4  # ns * mse = 1.0: below the residual, the search has to certify
     one = fg.FastGoICP(tgt, src, 0.01, mse, schedule=fg.SCHEDULE_ROUND, round_width=0)
@@ -31,7 +36,7 @@ def test_ranks_on_one_gpu_reach_the_single_gpu_optimum(fg, gpu_required, world):
     m = fg.MultiGoICP(tgt, src, 0.01, mse, devices=[0] * world, transport=fg.TRANSPORT_IN_PROCESS)
     m.set_record(True)
     R, t = m.run()
-    assert same((R, t, m.get_best_error()), ref)
+    assert same((R, t, m.get_best_error()), ref, 1e-5 if late == "0" else 2e-3)
     subs = [m.stats(r)["trans_cubes"] for r in range(world)]
     assert min(subs) > 0 and 0.5 * sub1 < sum(subs) < 2.5 * sub1  # every rank worked; the total stays in the single-GPU ballpark
     for r in range(world):
@@ -43,23 +48,23 @@ def test_ranks_on_one_gpu_reach_the_single_gpu_optimum(fg, gpu_required, world):
     m.close()
 
 
-def test_a_failing_rank_ends_the_run_for_all_ranks(fg, gpu_required, monkeypatch):
-    """One rank's exchange fails mid-run (FGOICP_MULTI_FAULT = "rank:call", a test hook): the others must not wait for it in
-    their next collective; the call returns that rank's error and the same object runs cleanly afterwards."""
+def test_a_failing_rank_ends_the_run_for_all_ranks(fg, gpu_required):
+    """One rank's exchange fails mid-run (fgoicp_multi_test_fault, a test hook of the ABI): the others must not wait for it in
+    their next collective; the call returns that rank's error and THE SAME OBJECT runs cleanly afterwards (the rendezvous is
+    reset, stale generations and accumulators do not leak into the next run)."""
     tgt, src, _, _ = fg.synth.workload("small", angle_deg=150.0, min_angle_deg=110.0)
-    monkeypatch.setenv("FGOICP_MULTI_FAULT", "1:3")
     m = fg.MultiGoICP(tgt, src, 0.01, 2e-4, devices=[0, 0, 0], transport=fg.TRANSPORT_IN_PROCESS)
-    monkeypatch.delenv("FGOICP_MULTI_FAULT")
-    with pytest.raises(fg.FgoicpError, match=r"rank 1: .*exchange callback failed"):
-        m.run()
+    for rank, call in ((1, 3), (2, 0), (0, 5)):
+        m.test_fault(rank, call)
+        with pytest.raises(fg.FgoicpError, match=rf"rank {rank}: .*exchange callback failed"):
+            m.run()
+    m.run()  # the same object, after three aborted runs
+    e = m.get_best_error()
+    assert all(m.get_best_error(r) == e for r in range(3))
     m.close()
-    ok = fg.MultiGoICP(tgt, src, 0.01, 2e-4, devices=[0, 0, 0], transport=fg.TRANSPORT_IN_PROCESS)
-    ok.run()
-    e = ok.get_best_error()
-    ok.close()
     one = fg.FastGoICP(tgt, src, 0.01, 2e-4, schedule=fg.SCHEDULE_ROUND, round_width=0)
     one.run()
-    assert abs(one.get_best_error() - e) <= 1e-5 * e
+    assert abs(one.get_best_error() - e) <= 2e-3 * e  # late-joining refinements (the default with ranks): the final ICP's stop band
     one.close()
 
 

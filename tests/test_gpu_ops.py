@@ -567,3 +567,75 @@ def test_context_reports_what_it_derived_from_the_cloud_statistics(fg, gpu_requi
     assert b["source_points_per_face_voxel"] == pytest.approx(2.0, rel=0.05) and b["lut_layout"] == 1 and b["points_per_item"] == 2048
     sparse.close(); dense.close()
 
+
+
+def _lattice_tick(fg, rng, n_groups):
+    """Groups as the inner BnB submits them (fgoicp.cpp:157-168): whole sibling octets of lattice nodes, mixed with stray nodes, some
+    octets incomplete (7 of 8) and one with a wrong span — only genuine octets may be grouped, every row must keep its bits."""
+    Rs, spans, fixes, groups = [], [], [], []
+    for gi in range(n_groups):
+        v = rng.uniform(-0.5, 0.5, 3)
+        node = fg.RotNode(*v, float(rng.choice([0.25, 0.125, 0.0625])))
+        rows = []
+        for _ in range(int(rng.integers(1, 5))):
+            span = float(rng.choice([0.25, 0.125, 0.0625]))
+            k = rng.integers(-3, 4, 3) * 2 + 1          # parent centre: odd multiples of the parent span 2 * span
+            parent = k * (2 * span) * 0.5
+            octet = [[parent[0] - span + (j & 1) * 2 * span, parent[1] - span + ((j >> 1) & 1) * 2 * span, parent[2] - span + ((j >> 2) & 1) * 2 * span, span] for j in range(8)]
+            octet = [octet[j] for j in rng.permutation(8)]  # a heap pops equal keys in any order
+            kind = rng.integers(0, 4)
+            if kind == 1:
+                octet = octet[:7]                       # incomplete
+            if kind == 2:
+                octet[3][3] = span * 2                  # one sibling with another span
+            rows += octet
+            if rng.random() < 0.5:
+                rows.append([*rng.uniform(-0.4, 0.4, 3), span])  # a stray node between octets
+        Rs.append(node.q.R); spans.append(node.span); fixes.append(bool(gi % 2)); groups.append(np.asarray(rows, np.float32) * np.float32(0.35))
+    return Rs, spans, fixes, groups
+
+
+@pytest.mark.parametrize("trim", [False, True])
+@pytest.mark.parametrize("workload,res,chunk", [("tiny", 0.05, None), ("small", 0.02, "1024")])
+def test_sibling_units_keep_every_bit(fg, gpu_required, monkeypatch, workload, res, chunk, trim):
+    """FGOICP_UNITS = 4 / 8: the children of one translation node share the point loads and the rotation (bounds_units_kernel);
+    FGOICP_LDS_TILES = 128 / 192: the LUT brick under a pass of 256 points is staged in LDS and the footprints are read from there
+    (bounds_lds_kernel).  Lookups, per-point expressions and the order of every sum are those of the one-evaluation kernel — all bounds
+    bit-identical, trimmed or not."""
+    tgt, src, R_gt, t_gt = fg.synth.workload(workload, angle_deg=30.0)
+    pct, pcs, off_t, off_s, scale, bounds = fg.synth.preprocess(tgt, src)
+    if chunk:
+        monkeypatch.setenv("FGOICP_CHUNK_PTS", chunk)
+    monkeypatch.setenv("FGOICP_SMALL_TICK", "0")  # through the sort even for this small tick
+    out = {}
+    for units in ("0", "4", "8", "lds128", "lds192"):
+        monkeypatch.setenv("FGOICP_UNITS", units if units.isdigit() else "0")
+        monkeypatch.setenv("FGOICP_LDS_TILES", units[3:] if units.startswith("lds") else "0")  # LUT tiles staged in LDS (bounds_lds_kernel)
+        reg = fg.Registration(pct, pcs, bounds, res)
+        if trim:
+            reg.set_inliers(int(0.8 * len(pcs)))
+        args = _lattice_tick(fg, np.random.default_rng(5), 24)
+        out[units] = reg.compute_bounds_multi(*args)
+        reg.close()
+    for units in ("4", "8", "lds128", "lds192"):
+        for (lb0, ub0), (lb1, ub1) in zip(out["0"], out[units]):
+            assert np.array_equal(lb0.view(np.uint32), lb1.view(np.uint32)) and np.array_equal(ub0.view(np.uint32), ub1.view(np.uint32)), units
+
+
+def test_sibling_units_whole_run(fg, gpu_required, monkeypatch):
+    """A whole FastGoICP::run() with and without sibling units: same counters, same result bits (twins and the memo included)."""
+    tgt, src, R_gt, t_gt = fg.synth.workload("small", angle_deg=150.0, min_angle_deg=110.0)
+    monkeypatch.setenv("FGOICP_CHUNK_PTS", "1024")
+    res = {}
+    for units in ("0", "4", "8"):
+        monkeypatch.setenv("FGOICP_UNITS", units)
+        for trim in (0.0, 0.2):
+            s = fg.FastGoICP(tgt, src, 0.02, 1e-4, schedule=fg.SCHEDULE_ROUND, round_width=0, trim_fraction=trim)
+            R, t = s.run()
+            st = s.stats()
+            res[(units, trim)] = (np.float32(s.get_best_error()).view(np.uint32), R.copy(), t.copy(), int(st["trans_cubes"]), int(st["rot_cubes"]))
+            s.close()
+    for units in ("4", "8"):
+        for trim in (0.0, 0.2):
+            a, b = res[("0", trim)], res[(units, trim)]
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3:] == b[3:], (units, trim, a, b)

@@ -268,3 +268,27 @@ def test_hip_trimmed_selection_paths(fg, oracle, gpu_required, shape):
     if shape == "mostly_zero":
         assert (hip.point_distances(rn.q.R, rn.span, tn[0], False) == 0).mean() > 0.3
     hip.close()
+
+
+@pytest.mark.gpu
+def test_hip_trimmed_search_with_cropped_target_bounds(fg, oracle, gpu_required):
+    """The reference's Registration takes ANY target_bounds (they only place the LUT, registration.hpp:68).  With bounds cropped to
+    a corner of the target, the trimmed search's "distance to the target's box" prune must still use the box of the POINTS
+    (taken from the caller's bounds it silently dropped queries whose nearest neighbour lay outside the crop)."""
+    tgt, src, R_gt, t_gt = outlier_pair(fg, nt=900, ns=600, frac=0.25, seed=21)
+    lo, hi = tgt.min(0), tgt.max(0)
+    crop = np.stack([lo, lo + 0.35 * (hi - lo)], 1).astype(f32)  # a third of the extent per axis: most targets lie outside
+    hip = fg.Registration(tgt, src, crop, 0.01)
+    orc = oracle.Registration(tgt, src, crop, 0.01)
+    k = int(0.7 * len(src))
+    hip.set_inliers(k); orc.set_inliers(k)
+    rng = np.random.default_rng(2)
+    for _ in range(4):
+        R = fg.synth.random_rotation(rng, 60.0).astype(f32)
+        t = rng.uniform(-0.05, 0.05, 3).astype(f32)
+        a, b = float(hip.compute_sse_error(R, t)), float(orc.compute_sse_error(R, t))
+        assert a == pytest.approx(b, rel=1e-6, abs=1e-12)
+    sse, Ri, ti = fg.IterativeClosestPoint3D(hip, None, None, 30, 0.005, R_gt.astype(f32), t_gt.astype(f32)).run()
+    sse_o, Ro, to, it = orc.icp(R_gt.astype(f32), t_gt.astype(f32), 30, 0.005)
+    assert float(sse) == pytest.approx(float(sse_o), rel=1e-5, abs=1e-10) and np.allclose(Ri, Ro, atol=1e-5)
+    hip.close()

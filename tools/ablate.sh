@@ -9,7 +9,7 @@ OUT=gpurun_out/profiles/r02_ablation_fixed_tick.txt
 for AB in 0 1 4 5; do
   LIB=/tmp/libfgoicp_ab$AB.so
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -x hip -DFGOICP_ABLATE=$AB -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -shared -o $LIB \
-     fast-go-icp_amd/csrc/device/kernels.hip fast-go-icp_amd/csrc/device/ctx.hip fast-go-icp_amd/csrc/device/bvh.hip fast-go-icp_amd/csrc/host/solver.cpp fast-go-icp_amd/csrc/host/multi.cpp -lrccl 2>/dev/null || exit 1
+     fast-go-icp_amd/csrc/device/kernels.hip fast-go-icp_amd/csrc/device/ctx.hip fast-go-icp_amd/csrc/device/bvh.hip fast-go-icp_amd/csrc/host/solver.cpp fast-go-icp_amd/csrc/host/multi.cpp -ldl 2>/dev/null || exit 1
   for WL in bunny dragon; do
     echo "ablate=$AB $(FGOICP_LIB=$LIB timeout -k 10 300 python tools/op_bench.py $WL 1024 5 2>/dev/null)" | tee -a $OUT
   done
