@@ -229,6 +229,33 @@ def roofline(leg, pmc, extra=None):
     return r
 
 
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0  # G wave64-instructions/s: 256 CUs x 4 SIMD-32, one wave64 VALU instruction per 2 cycles, 2.4 GHz max clock
+
+
+def utilisation(r, x):
+    """What binds the bounds kernel besides HBM bytes: the units the kernel keeps busy, from separate rocprofv3 --pmc passes
+    of the same deterministic step (profiles/bench_pmc_extra.json), each as achieved / peak <= 1.  The instruction count per launch carries
+    over to this run (same step, same code); rates use THIS run's launch duration, the cycle-based fractions are the profiled pass's own."""
+    if not r or not x:
+        return
+    dur = r["avg_launch_us"] * 1e-6
+    u = {"source": x.get("source")}
+    if x.get("valu_insts_per_launch"):
+        ach = x["valu_insts_per_launch"] / dur / 1e9
+        u["valu"] = {"achieved": ach, "peak": VALU_PEAK_GINST, "unit": "G wave64 VALU instructions/s", "frac": ach / VALU_PEAK_GINST,
+                     "frac_cycle_based": x.get("valu_issue_utilisation"), "insts_per_launch": x["valu_insts_per_launch"],
+                     "insts_per_point_evaluation": x["valu_insts_per_launch"] * 64.0 / (r["evaluations_per_launch"] * r["algorithmic_bytes_per_evaluation"] / 32.375)}
+    for k in ("l1_hit_rate", "l1_miss_latency_cycles", "l1_pending_stall_frac", "ta_busy_frac", "ta_addr_stalled_frac", "wave_wait_frac", "wave_issue_stall_frac"):
+        if x.get(k) is not None:
+            u[k] = x[k]
+    if x.get("l1_accesses_per_launch"):
+        u["l1_accesses_per_point_evaluation"] = x["l1_accesses_per_launch"] / (r["evaluations_per_launch"] * r["algorithmic_bytes_per_evaluation"] / 32.375)
+    r["utilisation"] = u
+    cands = {"hbm": r.get("hbm_actual_frac") or 0.0, "valu": (u.get("valu") or {}).get("frac_cycle_based") or (u.get("valu") or {}).get("frac") or 0.0, "ta": u.get("ta_busy_frac") or 0.0}
+    r["busiest_unit"] = max(cands, key=cands.get)
+    r["busiest_unit_fracs"] = cands
+
+
 def unique_line_model(fg, tgt, src, res, layout_bytes, samples=6, seed=0):
     """Dense clouds: neighbouring points share LUT texels, so 8 private texels per point over-count what a subcube needs.
     Counts, for sampled rigid motions, the distinct 128-byte lines of the packed LUT (z-pair: 8 B per node, rows y0 and y0+1;
@@ -347,9 +374,13 @@ def main():
     env = Env(a)
     world, rank = env.world, env.rank
     want = lambda name: (a.only is None or a.only == name)
-    pmc_all = {}
+    pmc_all, pmc_extra = {}, {}
     try:
         pmc_all = json.load(open(os.path.join(REPO, "profiles", "bench_pmc.json")))
+    except Exception:
+        pass
+    try:  # SQ / TA / TCP passes of the same legs (tools/pmc_extra.sh -> tools/pmc_extra_summary.py)
+        pmc_extra = json.load(open(os.path.join(REPO, "profiles", "bench_pmc_extra.json")))
     except Exception:
         pass
 
@@ -375,6 +406,7 @@ def main():
         line["roofline"] = roofline(head, pmc_all.get("headline"), {
             "limited_by": "L1-miss concurrency x L2 latency, not HBM bytes: texture addresser busy 71 %, L1 pending-stall 54 % of cycles, ~65 misses in flight per CU at 333 "
                           "cycles each (profiles/r01_bounds_kernel_pmc_extra.json); a build whose gathers all hit on chip runs 1.71x faster (profiles/r02_ablation_fixed_tick.txt)"})
+        utilisation(line["roofline"], pmc_extra.get("headline"))
 
     # BASELINE.md's parameters (mse_threshold 1e-3) on the same clouds
     dflt = None
@@ -419,10 +451,29 @@ def main():
             if r:
                 r["private_texel_model_GBps"] = r["achieved"]
                 r["unique_line_model_GBps"] = ach_u
-                r["limited_by"] = "texture addresser busy 75 %, VALU issue co-limiter (120 VALU instructions per point), L1 hit rate 75 % (profiles/r01_bounds_kernel_pmc_extra_dragon.json); not HBM"
+                utilisation(r, pmc_extra.get("dragon"))
+                u = r.get("utilisation") or {}
+                # Neither per-evaluation byte model is a roof for this kernel (both exceed the HBM peak: LUT lines are shared ACROSS the evaluations of a
+                # tick, out of the L2s): `bound` names the unit the counters show busiest, `achieved / peak` are in that unit's terms, and the HBM side
+                # is reported as what it is — measured traffic per launch / launch duration.
                 if r.get("hbm_actual_GBps"):
-                    # both per-evaluation byte models exceed the peak (lines are shared ACROSS the evaluations of a tick, out of L2), so neither is a roof:
-                    # the fraction of the HBM roof this kernel uses is its measured traffic rate
+                    r["hbm"] = {"achieved": r["hbm_actual_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["hbm_actual_frac"],
+                                "definition": "measured HBM bytes per launch (rocprofv3 PMC, FETCH_SIZE x 2 + WRITE_SIZE) / launch duration"}
+                if u.get("valu") and r.get("busiest_unit") in ("valu", "ta"):
+                    if r["busiest_unit"] == "valu":
+                        r["bound"] = "valu"
+                        r["achieved"], r["peak"], r["unit"] = u["valu"]["achieved"], u["valu"]["peak"], u["valu"]["unit"]
+                        r["frac"] = u["valu"]["frac"]
+                        r["achieved_definition"] = "SQ_INSTS_VALU per launch (profiles/bench_pmc_extra.json) / launch duration of this run, against 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction"
+                    else:
+                        r["bound"] = "ta"
+                        r["achieved"], r["peak"], r["unit"], r["frac"] = u["ta_busy_frac"], 1.0, "texture-addresser busy fraction", u["ta_busy_frac"]
+                    r.pop("frac_of_measured_copy_rate", None)
+                    r["limited_by"] = (f"VALU issue {100 * (u['valu'].get('frac_cycle_based') or u['valu']['frac']):.0f} % of the SIMDs' slots ({u['valu']['insts_per_point_evaluation']:.0f} VALU instructions per point: IEEE sqrt, "
+                                       f"1.8 fixed-point weights, fp64 accumulation are the contract), L1 hit rate {100 * u.get('l1_hit_rate', 0):.0f} %, "
+                                       f"L1 miss latency {u.get('l1_miss_latency_cycles', 0):.0f} cycles, measured HBM traffic {100 * (r.get('hbm_actual_frac') or 0):.0f} % of the peak "
+                                       "(profiles/bench_pmc_extra.json: round-3 counters of this kernel)")
+                elif r.get("hbm_actual_GBps"):
                     r["achieved"] = r["hbm_actual_GBps"]
                     r["frac"] = r["hbm_actual_frac"]
                     r["frac_of_measured_copy_rate"] = r["hbm_actual_GBps"] / HBM_COPY_GBS
@@ -432,6 +483,7 @@ def main():
                     r["frac"] = ach_u / HBM_PEAK_GBS
                     r["model_exceeds_peak"] = bool(ach_u > HBM_PEAK_GBS)
             s["roofline"] = r
+        s["icp_latency"] = icp_latency(dr)
         line["dragon_shape"] = s
         dr["solver"].close()
 
@@ -449,6 +501,8 @@ def main():
                           "selection kernel, which runs NEXT TO the bounds kernel on a side stream, reads each row twice"}
         extra["limited_by"] = "closest of the three to the HBM roof: measured traffic (LUT lines + 4 B written per point-row) at ~0.7 of the peak, ~0.9 of the measured copy rate"
         s["roofline"] = roofline(tr, pmc_all.get("trimmed"), extra)
+        utilisation(s["roofline"], pmc_extra.get("trimmed"))
+        s["icp_latency"] = icp_latency(tr)
         line["trimmed_1m_outliers"] = s
         tr["solver"].close()
 

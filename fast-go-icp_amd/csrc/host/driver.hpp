@@ -577,7 +577,10 @@ private:
         rcand.push(RotCube(0.f, 0.f, 0.f, 1.0f, 0.f, best_sse()));
         const int rank = ex_.rank, world = ex_.world < 1 ? 1 : ex_.world;
         std::vector<RotCube> children;
-        // LATE-JOINING REFINEMENT (FGOICP_LATE_ICP; default on for world > 1).  The ICP runs a round triggers (fgoicp.cpp:74-88) fall on
+        // LATE-JOINING REFINEMENT (FGOICP_LATE_ICP = 1; built in round 3, measured, OFF by default).  On the 8-rank replay it LOSES —
+        // bunny shape 5.55x -> 4.17x, dragon shape 6.12x -> 3.33x (profiles/r03_scale_replay.jsonl): a certify run has 5-8 rounds, the
+        // first of which finds the incumbent; one round of lag means round 2 prunes and triggers against the initial ICP's error
+        // (+20-25 % subcubes, 4-10x the ICP time: `ub < 1.8 best` holds for almost every child while `best` is stale).  The ICP runs a round triggers (fgoicp.cpp:74-88) fall on
         // the ranks whose children trigger them — one or two single runs of tens of milliseconds per round, on ONE rank, while the
         // others wait in the exchange (the named serial term of the 8-rank estimate).  With this on, a round's
         // triggers run in the background (own host thread, own ICP lane and streams of the context) while the rank goes on to the
@@ -1039,7 +1042,7 @@ private:
     double t_pop_ = 0, t_ops_ = 0, t_push_ = 0;
     double t_prep_[3] = {0, 0, 0};  // FGOICP_TIMING: pops / pair matching / packing inside prepare_half
     const bool timing_ = std::getenv("FGOICP_TIMING") != nullptr;  // host-side timing lines on stderr
-    const int late_icp_ = [] { const char* e = std::getenv("FGOICP_LATE_ICP"); return e ? std::atoi(e) : 1; }();  // tuning knob (ROUND): 0 = off, 1 = with an exchange (world > 1), 2 = always
+    const int late_icp_ = [] { const char* e = std::getenv("FGOICP_LATE_ICP"); return e ? std::atoi(e) : 0; }();  // tuning knob (ROUND): 0 = off (default: measured slower, see above), 1 = with an exchange (world > 1), 2 = always
     bool use_twins_ = [] { const char* e = std::getenv("FGOICP_TWINS"); return !e || std::atoi(e) != 0; }();  // tuning knob
     const size_t round_batch_ = [] { const char* e = std::getenv("FGOICP_ROUND_BATCH"); const int v = e ? std::atoi(e) : 48; return (size_t)(v >= 8 && v <= 64 ? v : 48); }();  // tuning knob (ROUND only; SERIAL keeps the reference's 32)
     const size_t tail_batch_ = [] { const char* e = std::getenv("FGOICP_TAIL_BATCH"); const int v = e ? std::atoi(e) : 128; return (size_t)(v >= 8 && v <= 128 ? v : 0); }();  // tuning knob (ROUND): batch of a half with few tasks left (0 = off)

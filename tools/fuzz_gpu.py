@@ -131,6 +131,9 @@ def one_case(rng, idx):
     return check_case(gen_case(rng, idx))
 
 
+BASINS = []  # whole-run cases in which ROUND and SERIAL ended in different basins (counted in the campaign summary, not failed)
+
+
 def run_case(rng, idx):
     """A whole FastGoICP::run(): SERIAL must walk the oracle's trajectory (every counter equal), ROUND must end within the band
     of the same optimum when the threshold certifies (below the residual), trimmed or not."""
@@ -168,6 +171,7 @@ def run_case(rng, idx):
             # below that it relies on the ICP trigger `ub < 1.8 * best` (:74) — which depends on the incumbent at the moment a cube
             # is met, i.e. on the order.  Round 2, seed 23, run 43 (23 source points, LUT at 0.02): SERIAL meets the cube of the
             # optimum with best = 0.367 (0.614 < 0.661: refined, 0.0014), ROUND with best = 0.189 (not refined).  Reported, not failed.
+            BASINS.append(desc)
             print(f"NOTE {desc}: ROUND sse {er} vs SERIAL {e} (band {band}): schedules ended in different basins", flush=True)
     except AssertionError as ex:
         return desc + " -> " + str(ex)
@@ -190,7 +194,7 @@ def main():
             print("FAIL", r, flush=True)
         if i % 10 == 9:
             print(f"[{i + 1}/{cases}] {time.time() - t0:.0f}s, {len(bad)} failures", flush=True)
-    print(f"done: {cases} cases, {len(bad)} failures")
+    print(f"done: {cases} cases, {len(bad)} failures" + (f", {len(BASINS)} runs in which ROUND ended in another basin than SERIAL (loose threshold: see README)" if mode == "run" else ""))
     return 1 if bad else 0
 
 

@@ -1,25 +1,26 @@
 # What binds the bounds kernel on a leg: SQ / TA / TCP counter passes of `bench.py --only LEG` (separate rocprofv3 --pmc passes,
-# --kernel-trace only), summed per kernel by tools/pmc_generic.py.   bash tools/pmc_extra.sh <tag> <leg> [<leg> ...]
+# --kernel-trace only), summed per kernel by tools/pmc_generic.py.   bash tools/pmc_extra.sh <tag> <passes: e.g. "1 2 3 4"> <leg> [<leg> ...]
 cd $GRAFT_REPO_ROOT
 REPO=$GRAFT_REPO_ROOT
 TAG=$1; shift
+PASSES=$1; shift
 mkdir -p $REPO/gpurun_out/profiles
 export TMPDIR=/tmp
 cd /tmp
+SET1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"
+SET2="SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"
+SET3="TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE"
+SET4="TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE"
 for LEG in "$@"; do
   DIRS=""
-  i=0
-  for SET in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" \
-             "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE" \
-             "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum GRBM_GUI_ACTIVE" \
-             "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE"; do
-    i=$((i+1))
+  for i in $PASSES; do
+    eval SET=\$SET$i
     D=/tmp/px_${LEG}_$i
     rm -rf $D
-    timeout -k 10 400 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $D -- python3 $REPO/bench.py --only $LEG --steps 1 --warmup 0 > $REPO/gpurun_out/${TAG}_px_${LEG}_$i.log 2>&1 || { echo "pass $i of $LEG failed"; tail -n 5 $REPO/gpurun_out/${TAG}_px_${LEG}_$i.log; continue; }
+    timeout -k 10 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $D -- python3 $REPO/bench.py --only $LEG --steps 1 --warmup 0 > $REPO/gpurun_out/${TAG}_px_${LEG}_$i.log 2>&1 || { echo "pass $i of $LEG failed"; tail -n 3 $REPO/gpurun_out/${TAG}_px_${LEG}_$i.log | cut -c1-300; continue; }
     DIRS="$DIRS $D"
     echo "leg $LEG pass $i done"
   done
-  python3 $REPO/tools/pmc_generic.py $REPO/gpurun_out/profiles/${TAG}_${LEG}_pmc_extra.json $DIRS > $REPO/gpurun_out/${TAG}_px_${LEG}_summary.txt 2>&1
-  grep -E "bounds_sorted_kernel|trim_rows_kernel" $REPO/gpurun_out/${TAG}_px_${LEG}_summary.txt | head -40
+  python3 $REPO/tools/pmc_generic.py $REPO/gpurun_out/profiles/${TAG}_${LEG}_pmc_extra_p$(echo $PASSES | tr -d ' ').json $DIRS > $REPO/gpurun_out/${TAG}_px_${LEG}_summary_p$(echo $PASSES | tr -d ' ').txt 2>&1
+  grep -E "bounds_sorted_kernel" $REPO/gpurun_out/${TAG}_px_${LEG}_summary_p$(echo $PASSES | tr -d ' ').txt | head -20
 done
