@@ -1595,7 +1595,12 @@ __global__ __launch_bounds__(kBlock) void nn_first_index_kernel(const float4* __
 // are bit-identical to kernComputeClosestError / kernFindNearestNeighbor / buildLUTKernel.
 // ---------------------------------------------------------------------------------------------
 constexpr float kBoxShrink = 0.999999f;  // see bvh.hpp: covers fp32 rounding of box and point distances
-constexpr int kSuperShift = 5;           // 32 leaves per super-leaf
+constexpr float kMasked = 3.4028234e38f; // the "distance" a lane sees for a leaf that cannot matter to it: beyond every bound and every initial value
+// Fan-out of the two box levels above the leaves: 2^kSuperShift leaves per super-leaf, as many super-leaves per top box.  A wave walks its
+// candidate super-leaves one after another, each a DEPENDENT load of the leaf boxes, and a scan lasts as long as its slowest wave
+// (tools/scan_stats.sh: bunny shape, far from convergence, up to 25 super-leaf steps and 16 leaf scans in one wave).  64 instead of 32 uses
+// every lane of the box tests and halves the chain.
+constexpr int kSuperShift = 6;
 
 __device__ __forceinline__ float box_d2(const float4 lo, const float4 hi, float qx, float qy, float qz) {
     const float dx = fmaxf(fmaxf(lo.x - qx, qx - hi.x), 0.0f);
@@ -1638,24 +1643,59 @@ __device__ __forceinline__ float boxbox_d2(const float4 lo, const float4 hi, con
 // and takes every nparts-th candidate leaf; the caller min-combines their results.
 // Steps 1-2 are supersets of what each query needs (box-to-region distance <= box-to-query distance,
 // wave radius >= own bound), step 3 applies the exact per-query rule, so no needed point is skipped.
+#ifdef FGOICP_SCAN_STATS   // development builds only (tools/scan_stats.sh): what a scan's waves spend their steps on
+__device__ unsigned long long g_scan_stats[8];  // walks, top candidates, super candidates, leaf candidates (dealt to this part), leaves scanned
+__device__ unsigned long long g_scan_times[4096 * 4];  // per block of the last index-mode scan: s_memtime at entry, after the seeds, after the first walk, at exit
+#define SCAN_TIME(slot) do { if (WANT_INDEX && threadIdx.x == 0 && blockIdx.x < 4096) g_scan_times[blockIdx.x * 4 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#if FGOICP_SCAN_STATS == 2   // stamps only: the counters' atomics sit inside the loops and would stretch what is being timed
+#define SCAN_STAT(i, n) do { } while (0)
+#else
+#define SCAN_STAT(i, n) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_scan_stats[i], (unsigned long long)(n)); } while (0)
+#endif
+#define SCAN_STAT_DECL unsigned stat_supers = 0, stat_scanned = 0
+#define SCAN_STAT_END do { if ((threadIdx.x & 63) == 0) { atomicMax(&g_scan_stats[5], (unsigned long long)stat_scanned); atomicMax(&g_scan_stats[6], (unsigned long long)stat_supers); \
+                            if (stat_scanned > 16) atomicAdd(&g_scan_stats[7], 1ull); } } while (0)
+#define SCAN_STAT_LOCAL(v) (++(v))
+#else
+#define SCAN_TIME(slot) do { } while (0)
+#define SCAN_STAT(i, n) do { } while (0)
+#define SCAN_STAT_DECL do { } while (0)
+#define SCAN_STAT_END do { } while (0)
+#define SCAN_STAT_LOCAL(v) do { } while (0)
+#endif
 template <class LeafFn, class BoundFn>
-__device__ __forceinline__ void box_scan(const BvhView t, float qx, float qy, float qz, bool active, int part, int nparts, LeafFn leaf, BoundFn bound) {
+__device__ __forceinline__ void box_scan(const BvhView t, float qx, float qy, float qz, bool active, int part, int nparts, LeafFn leaf, BoundFn bound,
+                                         int* claim_ctr = nullptr /* LDS word, zero on entry, when nparts > 1 */) {
     const int lane = threadIdx.x & 63;
-    int turn = 0;  // candidate leaves are dealt round-robin to the `nparts` waves that share these 64 queries
+    // The candidate leaves of these 64 queries are shared out among the `nparts` waves of the block DYNAMICALLY: every wave enumerates the
+    // same candidates in the same order (cand) and works on the one it has claimed from an LDS counter, claiming the next when it is
+    // done.  (Round 2 dealt them round-robin: a candidate the per-query test drops costs 20 instructions, one that is scanned 700, so
+    // the slowest of 8 waves carried twice the mean — tools/scan_stats.sh — and the block waits for it at the combine.)
+    // claim_ctr == nullptr: round-robin (candidate c goes to wave c mod nparts) — FGOICP_NN_CLAIM=0, the A/B.
+    int cand = 0, next_claim = part;
+    auto claim = [&]() {
+        if (!claim_ctr) return next_claim + nparts;
+        int v = 0;
+        if (lane == 0) v = atomicAdd(claim_ctr, 1);
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    if (nparts > 1 && claim_ctr) next_claim = claim();
     const float big = 3.0e38f;
     const float wl[3] = {wave_min_f(active ? qx : big), wave_min_f(active ? qy : big), wave_min_f(active ? qz : big)};
     const float wh[3] = {wave_max_f(active ? qx : -big), wave_max_f(active ? qy : -big), wave_max_f(active ? qz : -big)};
     float r2 = wave_max_f(active ? bound() : 0.0f);
     const int sdepth = t.depth > kSuperShift ? t.depth - kSuperShift : 0;
     const int nsuper = 1 << sdepth;
-    const int lps = 1 << (t.depth - sdepth);  // leaves per super-leaf (<= 32)
+    const int lps = 1 << (t.depth - sdepth);  // leaves per super-leaf (<= 64)
     const int first_super = nsuper - 1;
     // a third level above the super-leaves ("top boxes", 32 super-leaves = 1024 leaves = 32768 points each): without it every wave
     // tests every super-leaf box — 977 of them for a million targets, 16 dependent rounds before the first leaf
     const int tdepth = sdepth > kSuperShift ? sdepth - kSuperShift : 0;
     const int ntop = 1 << tdepth;
-    const int spt = 1 << (sdepth - tdepth);   // super-leaves per top box (<= 32)
+    const int spt = 1 << (sdepth - tdepth);   // super-leaves per top box (<= 64)
     const int first_top = ntop - 1;
+    SCAN_STAT(0, 1);
+    SCAN_STAT_DECL;
     for (int tb = 0; tb < ntop; tb += 64) {
         bool tc = false;
         if (tb + lane < ntop) {
@@ -1663,6 +1703,7 @@ __device__ __forceinline__ void box_scan(const BvhView t, float qx, float qy, fl
             tc = !(boxbox_d2(t.box[2 * tn], t.box[2 * tn + 1], wl, wh) * kBoxShrink > r2);
         }
         unsigned long long tmask = __ballot(tc);
+        SCAN_STAT(1, __popcll(tmask));
         while (tmask) {
             const int top = tb + __ffsll((long long)tmask) - 1;
             tmask &= tmask - 1;
@@ -1672,9 +1713,11 @@ __device__ __forceinline__ void box_scan(const BvhView t, float qx, float qy, fl
                 sc = !(boxbox_d2(t.box[2 * sn], t.box[2 * sn + 1], wl, wh) * kBoxShrink > r2);
             }
             unsigned long long smask = __ballot(sc);
+            SCAN_STAT(2, __popcll(smask));
             while (smask) {
                 const int s = top * spt + __ffsll((long long)smask) - 1;
                 smask &= smask - 1;
+                SCAN_STAT_LOCAL(stat_supers);
                 float4 llo = make_float4(big, big, big, 0.f), lhi = make_float4(-big, -big, -big, 0.f);
                 bool lc = false;
                 if (lane < lps) {
@@ -1688,25 +1731,41 @@ __device__ __forceinline__ void box_scan(const BvhView t, float qx, float qy, fl
                     const int l = __ffsll((long long)lmask) - 1;
                     lmask &= lmask - 1;
                     if (nparts > 1) {
-                        const bool mine = turn == part;
-                        turn = turn + 1 == nparts ? 0 : turn + 1;
+                        const bool mine = cand == next_claim;
+                        ++cand;
                         if (!mine) continue;
                     }
                     const float4 lo = make_float4(bcast(llo.x, l), bcast(llo.y, l), bcast(llo.z, l), 0.f);
                     const float4 hi = make_float4(bcast(lhi.x, l), bcast(lhi.y, l), bcast(lhi.z, l), 0.f);
                     const bool pl = active && !(box_d2(lo, hi, qx, qy, qz) * kBoxShrink > bound());
-                    if (!__any(pl)) continue;
-                    const float4 pp = t.pts[(size_t)(s * lps + l) * kBvhLeaf + (lane & (kBvhLeaf - 1))];
-#pragma unroll
+                    SCAN_STAT(3, 1);
+                    if (!__any(pl)) {
+                        if (nparts > 1) next_claim = claim();
+                        continue;
+                    }
+                    SCAN_STAT(4, 1);
+                    SCAN_STAT_LOCAL(stat_scanned);
+                    // The leaf's 32 points have a wave-uniform address: read through the scalar unit (s_load, 512 B) instead of one vector
+                    // load + 128 v_readlane broadcasts; `leaf` takes the lane's flag and stays branch-free (a lane the leaf cannot
+                    // matter to sees a distance beyond every bound).  Round 3: the far-from-converged ICP scan 62 -> NN us at 40k points.
+                    // (constant address space: the tree is read-only for the kernel's lifetime, and a uniform constant-space address is what
+                    // the backend selects s_load for)
+                    typedef float v4f_c __attribute__((ext_vector_type(4)));
+                    const __attribute__((address_space(4))) v4f_c* lp =
+                        (const __attribute__((address_space(4))) v4f_c*)(t.pts + (size_t)__builtin_amdgcn_readfirstlane(s * lps + l) * kBvhLeaf);
+#pragma unroll 4   // 4 points in flight keep the index-mode kernel at 61 VGPRs = 8 waves per SIMD (16: 91 VGPRs, 5 waves — the scan
+                    // lives on resident waves hiding each other's dependent loads; measured slower)
                     for (int k = 0; k < kBvhLeaf; ++k) {
-                        const float4 c = make_float4(bcast(pp.x, k), bcast(pp.y, k), bcast(pp.z, k), bcast(pp.w, k));
-                        if (pl) leaf(c);
+                        const v4f_c c = lp[k];
+                        leaf(make_float4(c.x, c.y, c.z, c.w), pl);
                     }
                     if (nparts == 1) r2 = wave_max_f(active ? bound() : 0.0f);  // the wave radius only shrinks
+                    else next_claim = claim();
                 }
             }
         }
     }
+    SCAN_STAT_END;
 }
 
 // Minimum squared distance.  `ub` is any value >= the true minimum (or +huge): it only seeds the
@@ -1717,8 +1776,8 @@ __device__ __forceinline__ float scan_min_d2(const BvhView t, float qx, float qy
     float best = ub < init ? ub : init;
     float found = init;
     box_scan(t, qx, qy, qz, active, 0, 1,
-             [&](const float4 p) {
-                 const float d = dist_sq(qx, qy, qz, p.x, p.y, p.z);
+             [&](const float4 p, bool on) {
+                 const float d = on ? dist_sq(qx, qy, qz, p.x, p.y, p.z) : kMasked;
                  found = d < found ? d : found;
                  best = d < best ? d : best;
              },
@@ -1727,8 +1786,8 @@ __device__ __forceinline__ float scan_min_d2(const BvhView t, float qx, float qy
     if (__any(redo)) {
         if (redo) found = init;
         box_scan(t, qx, qy, qz, redo, 0, 1,
-                 [&](const float4 p) {
-                     const float d = dist_sq(qx, qy, qz, p.x, p.y, p.z);
+                 [&](const float4 p, bool on) {
+                     const float d = on ? dist_sq(qx, qy, qz, p.x, p.y, p.z) : kMasked;
                      found = d < found ? d : found;
                  },
                  [&]() { return found; });
@@ -1816,7 +1875,7 @@ __global__ __launch_bounds__(64 * kMaxParts) void nn_scan_kernel(const float4* p
                                                                  LutGeom g, Rt rt, int apply, const float4* __restrict__ tgt, int nt,
                                                                  const uint32_t* seed_idx, const float* __restrict__ skip_lb, const uint32_t* __restrict__ skip_u, uint32_t* out,
                                                                  float4* writeback, const float* __restrict__ rt_dev, const int* __restrict__ done,
-                                                                 double* __restrict__ wsum) {
+                                                                 double* __restrict__ wsum, int dynamic_claim) {
     if (done && *done) return;  // device-resident ICP loop: the run has ended, this pass was enqueued ahead of the decision
     if (rt_dev) {               // ... and the motion is the one the step kernel left in device memory (12 floats: R, t)
 #pragma unroll
@@ -1824,6 +1883,9 @@ __global__ __launch_bounds__(64 * kMaxParts) void nn_scan_kernel(const float4* p
 #pragma unroll
         for (int k = 0; k < 3; ++k) rt.t[k] = rt_dev[9 + k];
     }
+    SCAN_TIME(0);
+    __shared__ int claim_ctr[3];  // one per walk (first, redo, tie): zeroed here, used once each
+    if (threadIdx.x < 3) claim_ctr[threadIdx.x] = 0;
     __shared__ uint32_t comb[kMaxParts][64];
     __shared__ uint32_t comb_i[WANT_INDEX ? kMaxParts : 1][64];
     __shared__ uint32_t comb_2[WANT_INDEX ? kMaxParts : 1][64];
@@ -1857,19 +1919,26 @@ __global__ __launch_bounds__(64 * kMaxParts) void nn_scan_kernel(const float4* p
     // distances — i1 is the answer and the second walk below is skipped.
     float second = kInf;
     uint32_t i1 = 0x7fffffffu;
+    SCAN_TIME(1);
+    if (nparts > 1) __syncthreads();  // the claim counters are zero for every wave
     box_scan(t, qx, qy, qz, active, part, nparts,
-             [&](const float4 c) {
-                 const float d = dist_sq(qx, qy, qz, c.x, c.y, c.z);
+             [&](const float4 c, bool on) {
+                 const float d = on ? dist_sq(qx, qy, qz, c.x, c.y, c.z) : kMasked;
                  if (WANT_INDEX) {
+                     // branch-free form of:  d < found: second = found, i1 = j;  d == found: i1 = min(i1, j);  else second = min(second, d)
+                     // (`second` > `found` always, so min(second, max(found, d)) covers both outer cases)
                      const uint32_t j = __float_as_uint(c.w);
                      const bool lt = d < found, eq = d == found;
-                     second = lt ? found : (!eq && d < second ? d : second);
-                     i1 = lt ? j : (eq ? min(i1, j) : i1);
+                     const float s2 = fminf(second, fmaxf(found, d));
+                     second = eq ? second : s2;
+                     const uint32_t cand = d <= found ? j : 0x7fffffffu;
+                     i1 = lt ? j : min(i1, cand);
                  }
-                 found = d < found ? d : found;
-                 best = d < best ? d : best;
+                 found = fminf(found, d);
+                 best = fminf(best, d);
              },
-             [&]() { return WANT_INDEX ? best * 1.0000015f : best; });
+             [&]() { return WANT_INDEX ? best * 1.0000015f : best; }, dynamic_claim ? &claim_ctr[0] : nullptr);
+    SCAN_TIME(2);
     if (nparts > 1) {
         comb[part][lane] = __float_as_uint(found);  // non-negative floats order like their bit patterns
         __syncthreads();
@@ -1892,11 +1961,11 @@ __global__ __launch_bounds__(64 * kMaxParts) void nn_scan_kernel(const float4* p
     if (__syncthreads_or(redo)) {
         float f2 = kInf;
         box_scan(t, qx, qy, qz, redo, part, nparts,
-                 [&](const float4 c) {
-                     const float d = dist_sq(qx, qy, qz, c.x, c.y, c.z);
+                 [&](const float4 c, bool on) {
+                     const float d = on ? dist_sq(qx, qy, qz, c.x, c.y, c.z) : kMasked;
                      f2 = d < f2 ? d : f2;
                  },
-                 [&]() { return f2; });
+                 [&]() { return f2; }, dynamic_claim ? &claim_ctr[1] : nullptr);
         if (nparts > 1) {
             comb[part][lane] = __float_as_uint(f2);
             __syncthreads();
@@ -1916,11 +1985,11 @@ __global__ __launch_bounds__(64 * kMaxParts) void nn_scan_kernel(const float4* p
         if (__syncthreads_or(again)) {
             uint32_t idx2 = 0x7fffffffu;
             box_scan(t, qx, qy, qz, again, part, nparts,
-                     [&](const float4 c) {
-                         const float d = dist_sq(qx, qy, qz, c.x, c.y, c.z);
+                     [&](const float4 c, bool on) {
+                         const float d = on ? dist_sq(qx, qy, qz, c.x, c.y, c.z) : kMasked;
                          idx2 = min(idx2, d <= thr ? __float_as_uint(c.w) : 0x7fffffffu);
                      },
-                     [&]() { return thr; });
+                     [&]() { return thr; }, dynamic_claim ? &claim_ctr[2] : nullptr);
             if (nparts > 1) {
                 comb[part][lane] = idx2;
                 __syncthreads();
@@ -1935,6 +2004,7 @@ __global__ __launch_bounds__(64 * kMaxParts) void nn_scan_kernel(const float4* p
     // folded into the pass that needs its result first; the moved points go back to the cloud (`writeback` may be `pts`: every
     // wave of the block read its point before the barriers above, only wave 0 writes).
     if (writeback && part == 0 && i < n) writeback[i] = make_float4(qx, qy, qz, p.w);
+    SCAN_TIME(3);
     // The reductions that follow a scan, started here (small clouds: one launch less on the ICP iteration's chain).  These 64 queries
     // are one wave of icp_sums_kernel / sum_f32_kernel when every thread of those kernels holds at most one point (n <= gridDim *
     // 256 there), so the shuffle tree below is THEIR first reduction level with the same operands: wsum[group] is the value they
@@ -2450,8 +2520,12 @@ void launch_nn_scan(const float4* pts, int n, const BvhView& t, const float* lut
     while (nparts < 8 && groups * nparts < 4096) nparts <<= 1;
     static const int forced = [] { const char* e = std::getenv("FGOICP_NN_PARTS"); const int v = e ? std::atoi(e) : 0; return v; }();  // tuning knob
     if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16) nparts = forced;
-    if (want_index) hipLaunchKernelGGL(nn_scan_kernel<1>, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, skip_lb, skip_u, out, writeback, rt_dev, done, wsum);
-    else hipLaunchKernelGGL(nn_scan_kernel<0>, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, skip_lb, skip_u, out, writeback, rt_dev, done, wsum);
+    // candidate leaves claimed dynamically by the waves of a block while the grid does not fill the device (the scan then lasts as long as its
+    // slowest block: 40k points, -3 %), dealt round-robin when it does (437k / 1M points: the LDS claims cost 1-2 % and buy nothing)
+    static const int dyn_env = [] { const char* e = std::getenv("FGOICP_NN_CLAIM"); return e ? std::atoi(e) : -1; }();  // tuning knob / A-B: 0 / 1 force
+    const int dyn = dyn_env >= 0 ? dyn_env : (groups * nparts <= 8192 ? 1 : 0);
+    if (want_index) hipLaunchKernelGGL(nn_scan_kernel<1>, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, skip_lb, skip_u, out, writeback, rt_dev, done, wsum, dyn);
+    else hipLaunchKernelGGL(nn_scan_kernel<0>, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, skip_lb, skip_u, out, writeback, rt_dev, done, wsum, dyn);
 }
 
 void launch_nn_prep(const float4* pts, int n, const float* lut, const LutGeom& g, const float* R9, const float* t3, int apply, const float4* tgt, int nt,
@@ -2469,6 +2543,21 @@ void launch_lut_build_scan(const BvhView& t, const LutGeom& g, float* scratch, f
     const size_t waves = cdiv(g.px, 4) * cdiv(g.py, 4) * cdiv(g.pz, 4);
     hipLaunchKernelGGL(lut_build_scan_kernel, dim3((unsigned)cdiv(waves, kBlock / 64)), dim3(kBlock), 0, s, t, g, scratch, lut_padded);
 }
+
+#ifdef FGOICP_SCAN_STATS
+}  // namespace fgoicp
+extern "C" int fgoicp_debug_scan_times(unsigned long long* out, int nblocks) {
+    using namespace fgoicp;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_times), sizeof(unsigned long long) * 4 * (size_t)nblocks) != hipSuccess;
+}
+extern "C" int fgoicp_debug_scan_stats(unsigned long long* out8, int reset) {
+    using namespace fgoicp;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_scan_stats), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_scan_stats), z, sizeof(z)); }
+    return 0;
+}
+namespace fgoicp {
+#endif
 
 int reduce_blocks_for(int n) {
     int b = (n + kBlock - 1) / kBlock;
