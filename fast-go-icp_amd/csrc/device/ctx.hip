@@ -565,9 +565,16 @@ int ctx_procrustes_device(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, Mat3f* R_out, V
 // same arithmetic, same order of every sum as the one-stream loop (FGOICP_ICP_OVERLAP=0).
 static int lane_icp_device(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9,
                            float* t_out3, int* iters_out);
+static int lane_icp_dual(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9,
+                         float* t_out3, int* iters_out);
 static int lane_icp(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3,
                     int* iters_out) {
     if (c->icp_device && c->icp_overlap && !c->brute_force_nn && !c->inliers) return lane_icp_device(c, L, R0, t0, max_iter, thr, sse_out, R_out9, t_out3, iters_out);
+    // one walk for both scans where the device is full anyway (clouds beyond 262 144 points, trimmed runs: -3 ... -5 % of the ICP time); below
+    // that the two scans of an iteration overlap on two streams and a wave carrying both query sets only lengthens the chain (40k points:
+    // 51-53 -> 55-56 us per iteration) — FGOICP_ICP_DUAL = 1 / 0 forces either
+    const bool dual = c->icp_dual_env >= 0 ? c->icp_dual_env != 0 : !icp_fused(c);
+    if (dual && c->icp_overlap && !c->brute_force_nn) return lane_icp_dual(c, L, R0, t0, max_iter, thr, sse_out, R_out9, t_out3, iters_out);
     HIPCHK(hipSetDevice(c->device));  // per host thread
     const int ns = (int)c->ns;
     const bool overlap = c->icp_overlap && !c->brute_force_nn;
@@ -737,6 +744,90 @@ static int lane_icp_device(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R
 
 int ctx_icp(fgoicp_ctx* c, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3, int* iters_out) {
     return lane_icp(c, c->lanes[0], R0, t0, max_iter, thr, sse_out, R_out9, t_out3, iters_out);
+}
+
+// The loop with ONE walk per iteration (kernels.hip nn_scan_dual_kernel; default).  Once the host has (R_, t_) of iteration k, the exact
+// SSE of iteration k and the correspondences of iteration k+1 are two query sets of the same walk, so the lane needs one stream and the
+// host one sync per iteration: [trimmed: move, LUT brackets and cuts of both sets] -> dual scan -> inlier cut / sums / covariance of pass
+// k+1 -> sum (or trimmed selection) of the SSE -> sync.  Pass k+1 is speculative as before (the loop may end on the SSE of iteration
+// k).  Same per-query results, same sums in the same order: the bits of the two-stream loop (FGOICP_ICP_DUAL=0; tests).
+static int lane_icp_dual(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9,
+                         float* t_out3, int* iters_out) {
+    HIPCHK(hipSetDevice(c->device));
+    const int ns = (int)c->ns, nt = (int)c->nt;
+    const bool seeding = c->icp_seeding, fused = icp_fused(c), trimmed = c->inliers != 0, skip = trimmed && c->trim_skip;
+    hipStream_t S = L.stream;
+    uint32_t* idx[2] = {L.d_first_idx, L.d_first_idx2};
+    int cur = 0;
+    HIPCHK(hipMemcpyAsync(L.d_work, c->d_src, sizeof(float4) * c->ns, hipMemcpyDeviceToDevice, S));
+    launch_transform_inplace(L.d_work, ns, R0, t0, S);  // icp3d.cu:85
+    Mat3f R = Mat3f::from(R0);
+    Vec3f t{t0[0], t0[1], t0[2]};
+    size_t iter = 0;
+    float sse = kInf, last_sse = 2.0f * kInf;
+    Mat3f last_R = Mat3f::identity();
+    Vec3f last_t{0, 0, 0};
+    int iters = 0;
+    bool pending = false;
+    if (max_iter > 0) {
+        int rc = procrustes_enqueue(c, L, nullptr, idx[0], L.d_sel_wide2, S);
+        if (rc) return rc;
+        pending = true;
+    }
+    while (iter++ < max_iter && (last_sse - sse) > thr * last_sse) {  // icp3d.cu:94
+        last_sse = sse;
+        last_R = R;
+        last_t = t;
+        HIPCHK(hipStreamSynchronize(S));  // first iteration: pass 1; later: a no-op (the SSE's sync below drained the stream)
+        pending = false;
+        Mat3f Rn;
+        Vec3f tn;
+        procrustes_finish(L, &Rn, &tn, nullptr, nullptr);
+        const float tn3[3] = {tn.x, tn.y, tn.z};
+        R = Rn * R;                                              // :101
+        t = Rn * t + tn;                                         // :102
+        const float t3[3] = {t.x, t.y, t.z};
+        const uint32_t* seed = seeding ? idx[cur] : nullptr;
+        const bool next = iter < max_iter;
+        int rc = FGOICP_OK;
+        if (next) {
+            const float *lbA = nullptr, *lbB = nullptr;
+            const uint32_t *uA = nullptr, *uB = nullptr;
+            if (skip) {  // trimmed: the brackets need the moved cloud, so the move is its own kernel here (as in the two-stream loop)
+                launch_transform_inplace(L.d_work, ns, Rn.m, tn3, S);  // :100
+                launch_nn_prep(L.d_work, ns, c->d_lut, c->geom, nullptr, nullptr, 0, c->d_tgt, nt, seed, c->tgt_box6, L.d_nn_ub2, L.d_nn_lb2, S);
+                launch_nn_prep(c->d_src, ns, c->d_lut, c->geom, R.m, t3, 1, c->d_tgt, nt, seed, c->tgt_box6, L.d_nn_ub, L.d_nn_lb, S);
+                launch_trim_select(L.d_nn_ub2, ns, (int)c->inliers, nullptr, L.d_sel + 4, L.d_sel_wide2, S);
+                launch_trim_select(L.d_nn_ub, ns, (int)c->inliers, nullptr, L.d_sel + 8, L.d_sel_wide, S);
+                lbA = L.d_nn_lb2; uA = L.d_sel + 4; lbB = L.d_nn_lb; uB = L.d_sel + 8;
+            }
+            launch_nn_scan_dual(L.d_work, skip ? nullptr : Rn.m, skip ? nullptr : tn3, skip ? 0 : 1, c->d_src, R.m, t3, ns, c->bvh_tgt.view(), c->d_lut, c->geom, c->d_tgt, nt, seed,
+                                lbA, uA, lbB, uB, idx[cur ^ 1], L.d_min_bits, skip ? nullptr : L.d_work, fused ? L.d_wsum : nullptr, fused ? L.hd_wsse : nullptr, S);
+            rc = procrustes_enqueue(c, L, seed, idx[cur ^ 1], L.d_sel_wide2, S, nullptr, nullptr, 2);  // inlier cut, sums, covariance of pass k+1
+            if (rc) return rc;
+            rc = sse_enqueue(c, L, R.m, t3, seed, S, 2);                                                // sum / trimmed selection of the SSE
+            if (rc) return rc;
+            cur ^= 1;
+            pending = true;
+        } else {  // the last iteration the loop can make: no pass rides along
+            launch_transform_inplace(L.d_work, ns, Rn.m, tn3, S);  // :100
+            rc = sse_enqueue(c, L, R.m, t3, seed, S);              // :103
+            if (rc) return rc;
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(S));
+        sse = sse_result(c, L);
+        ++iters;
+    }
+    if (pending) HIPCHK(hipStreamSynchronize(S));  // the speculative pass: drained, not used
+    const bool cur_best = sse < last_sse;  // :106-107
+    *sse_out = cur_best ? sse : last_sse;
+    const Mat3f& Ro = cur_best ? R : last_R;
+    const Vec3f& to = cur_best ? t : last_t;
+    std::memcpy(R_out9, Ro.m, sizeof(Ro.m));
+    t_out3[0] = to.x; t_out3[1] = to.y; t_out3[2] = to.z;
+    if (iters_out) *iters_out = iters;
+    return FGOICP_OK;
 }
 
 // One ICP run on a lane of its own (lane >= 1: own scratch, own two streams — nothing of it queues on the context's main stream,
@@ -1086,6 +1177,7 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
         if (const char* e = std::getenv("FGOICP_ICP_LANES")) nl = std::max(1, std::min(16, std::atoi(e)));  // tuning knob
         if (const char* e = std::getenv("FGOICP_ICP_OVERLAP")) c->icp_overlap = std::atoi(e) != 0;       // tuning knob
         if (const char* e = std::getenv("FGOICP_ICP_DEVICE")) c->icp_device = std::atoi(e) != 0;         // tuning knob / A-B: 1 = loop advanced on the device (measured slower)
+        if (const char* e = std::getenv("FGOICP_ICP_DUAL")) c->icp_dual_env = std::atoi(e) != 0 ? 1 : 0; // tuning knob / A-B: 1 = one walk for both scans of an iteration, 0 = two scans on two streams
         if (const char* e = std::getenv("FGOICP_ICP_FUSE")) c->icp_fuse = std::atoi(e) != 0;             // tuning knob / A-B: 0 = separate reduction kernels
         if (const char* e = std::getenv("FGOICP_ICP_AHEAD")) c->icp_ahead = std::max(1, std::min(6, std::atoi(e)));  // tuning knob
         c->lanes.resize((size_t)nl);

@@ -122,6 +122,7 @@ struct fgoicp_ctx {
     std::vector<IcpLane> lanes;
     bool icp_overlap = true;
     bool icp_fuse = true;                    // small clouds: reductions started in the scans' epilogues, folded on the host (FGOICP_ICP_FUSE=0: separate kernels)
+    int icp_dual_env = -1;                   // FGOICP_ICP_DUAL: one walk serves the two scans of an ICP iteration (nn_scan_dual_kernel); -1 = by cloud size
     bool icp_device = false;                 // ICP loop advanced on the device (FGOICP_ICP_DEVICE=0: the host loop, for A/B and as the bit reference)
     int icp_ahead = 2;                       // iterations the host may enqueue ahead of the device's progress
 

@@ -1663,9 +1663,12 @@ __device__ unsigned long long g_scan_times[4096 * 4];  // per block of the last 
 #define SCAN_STAT_END do { } while (0)
 #define SCAN_STAT_LOCAL(v) do { } while (0)
 #endif
-template <class LeafFn, class BoundFn>
-__device__ __forceinline__ void box_scan(const BvhView t, float qx, float qy, float qz, bool active, int part, int nparts, LeafFn leaf, BoundFn bound,
-                                         int* claim_ctr = nullptr /* LDS word, zero on entry, when nparts > 1 */) {
+// The walk itself, independent of what a lane asks of a leaf: `wl` / `wh` = the wave's query region, radius() = the wave-uniform squared
+// pruning radius (re-evaluated after every leaf when one wave holds the queries alone), test(lo, hi) = the lane's flags for a leaf box
+// (0: the leaf cannot matter to this lane), leaf(point, flags) = what to do with each of the leaf's points.
+template <class RadiusFn, class TestFn, class LeafFn>
+__device__ __forceinline__ void box_walk(const BvhView t, const float (&wl)[3], const float (&wh)[3], int part, int nparts, RadiusFn radius, TestFn test, LeafFn leaf,
+                                         int* claim_ctr /* LDS word, zero on entry, when nparts > 1 (nullptr: round-robin) */) {
     const int lane = threadIdx.x & 63;
     // The candidate leaves of these 64 queries are shared out among the `nparts` waves of the block DYNAMICALLY: every wave enumerates the
     // same candidates in the same order (cand) and works on the one it has claimed from an LDS counter, claiming the next when it is
@@ -1681,15 +1684,13 @@ __device__ __forceinline__ void box_scan(const BvhView t, float qx, float qy, fl
     };
     if (nparts > 1 && claim_ctr) next_claim = claim();
     const float big = 3.0e38f;
-    const float wl[3] = {wave_min_f(active ? qx : big), wave_min_f(active ? qy : big), wave_min_f(active ? qz : big)};
-    const float wh[3] = {wave_max_f(active ? qx : -big), wave_max_f(active ? qy : -big), wave_max_f(active ? qz : -big)};
-    float r2 = wave_max_f(active ? bound() : 0.0f);
+    float r2 = radius();
     const int sdepth = t.depth > kSuperShift ? t.depth - kSuperShift : 0;
     const int nsuper = 1 << sdepth;
     const int lps = 1 << (t.depth - sdepth);  // leaves per super-leaf (<= 64)
     const int first_super = nsuper - 1;
-    // a third level above the super-leaves ("top boxes", 32 super-leaves = 1024 leaves = 32768 points each): without it every wave
-    // tests every super-leaf box — 977 of them for a million targets, 16 dependent rounds before the first leaf
+    // a third level above the super-leaves ("top boxes"): without it every wave tests every super-leaf box — 977 of them for a
+    // million targets (at 32 per level), 16 dependent rounds before the first leaf
     const int tdepth = sdepth > kSuperShift ? sdepth - kSuperShift : 0;
     const int ntop = 1 << tdepth;
     const int spt = 1 << (sdepth - tdepth);   // super-leaves per top box (<= 64)
@@ -1737,17 +1738,17 @@ __device__ __forceinline__ void box_scan(const BvhView t, float qx, float qy, fl
                     }
                     const float4 lo = make_float4(bcast(llo.x, l), bcast(llo.y, l), bcast(llo.z, l), 0.f);
                     const float4 hi = make_float4(bcast(lhi.x, l), bcast(lhi.y, l), bcast(lhi.z, l), 0.f);
-                    const bool pl = active && !(box_d2(lo, hi, qx, qy, qz) * kBoxShrink > bound());
+                    const int pl = test(lo, hi);
                     SCAN_STAT(3, 1);
-                    if (!__any(pl)) {
+                    if (!__any(pl != 0)) {
                         if (nparts > 1) next_claim = claim();
                         continue;
                     }
                     SCAN_STAT(4, 1);
                     SCAN_STAT_LOCAL(stat_scanned);
                     // The leaf's 32 points have a wave-uniform address: read through the scalar unit (s_load, 512 B) instead of one vector
-                    // load + 128 v_readlane broadcasts; `leaf` takes the lane's flag and stays branch-free (a lane the leaf cannot
-                    // matter to sees a distance beyond every bound).  Round 3: the far-from-converged ICP scan 62 -> NN us at 40k points.
+                    // load + 128 v_readlane broadcasts; `leaf` takes the lane's flags and stays branch-free (a lane the leaf cannot
+                    // matter to sees a distance beyond every bound).
                     // (constant address space: the tree is read-only for the kernel's lifetime, and a uniform constant-space address is what
                     // the backend selects s_load for)
                     typedef float v4f_c __attribute__((ext_vector_type(4)));
@@ -1759,13 +1760,24 @@ __device__ __forceinline__ void box_scan(const BvhView t, float qx, float qy, fl
                         const v4f_c c = lp[k];
                         leaf(make_float4(c.x, c.y, c.z, c.w), pl);
                     }
-                    if (nparts == 1) r2 = wave_max_f(active ? bound() : 0.0f);  // the wave radius only shrinks
+                    if (nparts == 1) r2 = radius();  // the wave radius only shrinks
                     else next_claim = claim();
                 }
             }
         }
     }
     SCAN_STAT_END;
+}
+
+template <class LeafFn, class BoundFn>
+__device__ __forceinline__ void box_scan(const BvhView t, float qx, float qy, float qz, bool active, int part, int nparts, LeafFn leaf, BoundFn bound,
+                                         int* claim_ctr = nullptr /* LDS word, zero on entry, when nparts > 1 */) {
+    const float big = 3.0e38f;
+    const float wl[3] = {wave_min_f(active ? qx : big), wave_min_f(active ? qy : big), wave_min_f(active ? qz : big)};
+    const float wh[3] = {wave_max_f(active ? qx : -big), wave_max_f(active ? qy : -big), wave_max_f(active ? qz : -big)};
+    box_walk(t, wl, wh, part, nparts, [&]() { return wave_max_f(active ? bound() : 0.0f); },
+             [&](const float4 lo, const float4 hi) { return (int)(active && !(box_d2(lo, hi, qx, qy, qz) * kBoxShrink > bound())); },
+             [&](const float4 c, int pl) { leaf(c, pl != 0); }, claim_ctr);
 }
 
 // Minimum squared distance.  `ub` is any value >= the true minimum (or +huge): it only seeds the
@@ -2025,6 +2037,182 @@ __global__ __launch_bounds__(64 * kMaxParts) void nn_scan_kernel(const float4* p
             const double r = wave_sum(i < n ? (double)__uint_as_float(result) : 0.0);
             if (lane == 0) wsum[blockIdx.x] = r;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ONE walk for the two scans of an ICP iteration (round 3).  Iteration k needs, once its (R_, t_) is known, the correspondences of the
+// working cloud moved by (R_, t_) (kernFindNearestNeighbor for iteration k+1, icp3d.cu:146 after :100) and the exact SSE of the pristine
+// source under the composed (R, t) (registration.cu:62-86 for :103).  Query i of the one is query i of the other up to the fp32 error
+// the in-place moves have accumulated (~1e-6): the same region, the same candidate leaves.  Round 2 ran them as two kernels on two streams
+// — 10 000 waves on 8 192 slots at 40k points, twice the box loads and leaf reads; here every lane carries BOTH queries through one
+// walk (set A: index rule, set B: minimum), so the traversal is paid once.  Each set keeps its own exact rule (own seeds, own bounds,
+// own skip list in trimmed mode, own combine), and the results are those of nn_scan_kernel<1> / <0> bit for bit (tests).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * kMaxParts) void nn_scan_dual_kernel(const float4* ptsA, Rt rtA, int applyA, const float4* __restrict__ ptsB, Rt rtB, int n, BvhView t,
+                                                                      const float* __restrict__ lut, LutGeom g, const float4* __restrict__ tgt, int nt, const uint32_t* seed_idx,
+                                                                      const float* __restrict__ skip_lbA, const uint32_t* __restrict__ skip_uA,
+                                                                      const float* __restrict__ skip_lbB, const uint32_t* __restrict__ skip_uB, uint32_t* out_idx,
+                                                                      uint32_t* __restrict__ out_min, float4* writeback, double* __restrict__ wsumA, double* __restrict__ wsumB,
+                                                                      int dynamic_claim) {
+    __shared__ int claim_ctr[3];
+    if (threadIdx.x < 3) claim_ctr[threadIdx.x] = 0;
+    __shared__ uint32_t comb[kMaxParts][64];     // set A: minimum
+    __shared__ uint32_t comb_i[kMaxParts][64];   //        index
+    __shared__ uint32_t comb_2[kMaxParts][64];   //        second distance
+    __shared__ uint32_t comb_b[kMaxParts][64];   // set B: minimum
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6, nparts = blockDim.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    bool actA = i < n, actB = i < n;
+    if (skip_lbA && actA && skip_lbA[i] > __uint_as_float(skip_uA[0])) {  // trimmed: provably beyond the k-th smallest distance (nn_prep_kernel)
+        actA = false;
+        if (part == 0) out_idx[i] = 0x7fffffffu;
+    }
+    if (skip_lbB && actB && skip_lbB[i] > __uint_as_float(skip_uB[0])) {
+        actB = false;
+        if (part == 0) out_min[i] = __float_as_uint(skip_lbB[i]);
+    }
+    const float4 pA = ptsA[i < n ? i : n - 1], pB = ptsB[i < n ? i : n - 1];
+    float ax = pA.x, ay = pA.y, az = pA.z, bx, by, bz;
+    if (applyA) {
+        rotate(rtA.R, pA.x, pA.y, pA.z, ax, ay, az);
+        ax += rtA.t[0]; ay += rtA.t[1]; az += rtA.t[2];
+    }
+    rotate(rtB.R, pB.x, pB.y, pB.z, bx, by, bz);
+    bx += rtB.t[0]; by += rtB.t[1]; bz += rtB.t[2];
+    float ubA = lut_upper_bound_d2(lut, g, ax, ay, az), ubB = lut_upper_bound_d2(lut, g, bx, by, bz);
+    if (seed_idx) {
+        const uint32_t j = seed_idx[i < n ? i : n - 1];
+        if (j < (uint32_t)nt) {
+            const float4 c = tgt[j];
+            const float dA = dist_sq(ax, ay, az, c.x, c.y, c.z), dB = dist_sq(bx, by, bz, c.x, c.y, c.z);
+            ubA = dA < ubA ? dA : ubA;
+            ubB = dB < ubB ? dB : ubB;
+        }
+    }
+    float bestA = ubA < kInf ? ubA : kInf, foundA = kInf, secondA = kInf;
+    uint32_t i1 = 0x7fffffffu;
+    float bestB = ubB < kInf ? ubB : kInf, foundB = kInf;
+    const float big = 3.0e38f;
+    const bool any_act = actA || actB;
+    // the wave's region: both query sets (an inactive set contributes nothing)
+    auto lo3 = [&](float a, float b) { return wave_min_f(fminf(actA ? a : big, actB ? b : big)); };
+    auto hi3 = [&](float a, float b) { return wave_max_f(fmaxf(actA ? a : -big, actB ? b : -big)); };
+    const float wl[3] = {lo3(ax, bx), lo3(ay, by), lo3(az, bz)};
+    const float wh[3] = {hi3(ax, bx), hi3(ay, by), hi3(az, bz)};
+    if (nparts > 1) __syncthreads();  // the claim counters are zero for every wave
+    box_walk(t, wl, wh, part, nparts,
+             [&]() { return wave_max_f(fmaxf(actA ? bestA * 1.0000015f : 0.0f, actB ? bestB : 0.0f)); },
+             [&](const float4 lo, const float4 hi) {
+                 const int fa = actA && !(box_d2(lo, hi, ax, ay, az) * kBoxShrink > bestA * 1.0000015f);
+                 const int fb = actB && !(box_d2(lo, hi, bx, by, bz) * kBoxShrink > bestB);
+                 return fa | (fb << 1);
+             },
+             [&](const float4 c, int fl) {
+                 const float dA = (fl & 1) ? dist_sq(ax, ay, az, c.x, c.y, c.z) : kMasked;
+                 const float dB = (fl & 2) ? dist_sq(bx, by, bz, c.x, c.y, c.z) : kMasked;
+                 const uint32_t j = __float_as_uint(c.w);
+                 const bool lt = dA < foundA, eq = dA == foundA;
+                 const float s2 = fminf(secondA, fmaxf(foundA, dA));
+                 secondA = eq ? secondA : s2;
+                 const uint32_t cnd = dA <= foundA ? j : 0x7fffffffu;
+                 i1 = lt ? j : min(i1, cnd);
+                 foundA = fminf(foundA, dA);
+                 bestA = fminf(bestA, dA);
+                 foundB = fminf(foundB, dB);
+                 bestB = fminf(bestB, dB);
+             },
+             dynamic_claim ? &claim_ctr[0] : nullptr);
+    (void)any_act;
+    if (nparts > 1) {
+        comb[part][lane] = __float_as_uint(foundA);
+        comb_b[part][lane] = __float_as_uint(foundB);
+        __syncthreads();
+        uint32_t m = comb[0][lane], mb = comb_b[0][lane];
+        for (int k = 1; k < nparts; ++k) { m = min(m, comb[k][lane]); mb = min(mb, comb_b[k][lane]); }
+        const float gm = __uint_as_float(m);
+        comb_i[part][lane] = foundA == gm ? i1 : 0x7fffffffu;
+        comb_2[part][lane] = __float_as_uint(foundA > gm ? foundA : secondA);
+        __syncthreads();
+        uint32_t mi = comb_i[0][lane], m2 = comb_2[0][lane];
+        for (int k = 1; k < nparts; ++k) { mi = min(mi, comb_i[k][lane]); m2 = min(m2, comb_2[k][lane]); }
+        i1 = mi;
+        secondA = __uint_as_float(m2);
+        foundA = gm;
+        foundB = __uint_as_float(mb);
+        __syncthreads();
+    }
+    // seed too small by rounding (cannot happen: stay exact): the lanes concerned walk again unseeded, each set on its own
+    const bool redoA = actA && foundA > (ubA < kInf ? ubA : kInf), redoB = actB && foundB > (ubB < kInf ? ubB : kInf);
+    if (__syncthreads_or(redoA || redoB)) {
+        float fA = kInf, fB = kInf;
+        const float rl[3] = {wave_min_f(fminf(redoA ? ax : big, redoB ? bx : big)), wave_min_f(fminf(redoA ? ay : big, redoB ? by : big)), wave_min_f(fminf(redoA ? az : big, redoB ? bz : big))};
+        const float rh[3] = {wave_max_f(fmaxf(redoA ? ax : -big, redoB ? bx : -big)), wave_max_f(fmaxf(redoA ? ay : -big, redoB ? by : -big)), wave_max_f(fmaxf(redoA ? az : -big, redoB ? bz : -big))};
+        box_walk(t, rl, rh, part, nparts, [&]() { return wave_max_f(fmaxf(redoA ? fA : 0.0f, redoB ? fB : 0.0f)); },
+                 [&](const float4 lo, const float4 hi) {
+                     const int fa = redoA && !(box_d2(lo, hi, ax, ay, az) * kBoxShrink > fA);
+                     const int fb = redoB && !(box_d2(lo, hi, bx, by, bz) * kBoxShrink > fB);
+                     return fa | (fb << 1);
+                 },
+                 [&](const float4 c, int fl) {
+                     const float dA = (fl & 1) ? dist_sq(ax, ay, az, c.x, c.y, c.z) : kMasked;
+                     const float dB = (fl & 2) ? dist_sq(bx, by, bz, c.x, c.y, c.z) : kMasked;
+                     fA = fminf(fA, dA);
+                     fB = fminf(fB, dB);
+                 },
+                 dynamic_claim ? &claim_ctr[1] : nullptr);
+        if (nparts > 1) {
+            comb[part][lane] = __float_as_uint(fA);
+            comb_b[part][lane] = __float_as_uint(fB);
+            __syncthreads();
+            uint32_t m = comb[0][lane], mb = comb_b[0][lane];
+            for (int k = 1; k < nparts; ++k) { m = min(m, comb[k][lane]); mb = min(mb, comb_b[k][lane]); }
+            fA = __uint_as_float(m);
+            fB = __uint_as_float(mb);
+            __syncthreads();
+        }
+        if (redoA) foundA = fA;
+        if (redoB) foundB = fB;
+    }
+    // set A: the lowest index inside the sqrt-tie set of the minimum (icp3d.cu:20-25), as nn_scan_kernel<1>
+    const float thr = tie_threshold(foundA);
+    const bool again = actA && (redoA || !(secondA > thr));
+    uint32_t idx = i1;
+    if (__syncthreads_or(again)) {
+        uint32_t idx2 = 0x7fffffffu;
+        box_scan(t, ax, ay, az, again, part, nparts,
+                 [&](const float4 c, bool on) {
+                     const float d = on ? dist_sq(ax, ay, az, c.x, c.y, c.z) : kMasked;
+                     idx2 = min(idx2, d <= thr ? __float_as_uint(c.w) : 0x7fffffffu);
+                 },
+                 [&]() { return thr; }, dynamic_claim ? &claim_ctr[2] : nullptr);
+        if (nparts > 1) {
+            comb[part][lane] = idx2;
+            __syncthreads();
+            for (int k = 0; k < nparts; ++k) idx2 = min(idx2, comb[k][lane]);
+        }
+        if (again) idx = idx2;
+    }
+    if (part == 0) {
+        if (actA) out_idx[i] = idx;
+        if (actB) out_min[i] = __float_as_uint(foundB);
+        if (writeback && i < n) writeback[i] = make_float4(ax, ay, az, pA.w);
+    }
+    // the first level of the reductions that follow (see nn_scan_kernel): wave sums of {moved point, correspondence} and of the minima
+    if (part == 0 && wsumA) {
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n) c = tgt[min(idx, (uint32_t)(nt - 1))];
+        const double v[6] = {i < n ? (double)ax : 0.0, i < n ? (double)ay : 0.0, i < n ? (double)az : 0.0,
+                             i < n ? (double)c.x : 0.0, i < n ? (double)c.y : 0.0, i < n ? (double)c.z : 0.0};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double r = wave_sum(v[k]);
+            if (lane == 0) wsumA[(size_t)blockIdx.x * 6 + k] = r;
+        }
+    }
+    if (part == 0 && wsumB) {
+        const double r = wave_sum(i < n ? (double)foundB : 0.0);
+        if (lane == 0) wsumB[blockIdx.x] = r;
     }
 }
 
@@ -2526,6 +2714,20 @@ void launch_nn_scan(const float4* pts, int n, const BvhView& t, const float* lut
     const int dyn = dyn_env >= 0 ? dyn_env : (groups * nparts <= 8192 ? 1 : 0);
     if (want_index) hipLaunchKernelGGL(nn_scan_kernel<1>, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, skip_lb, skip_u, out, writeback, rt_dev, done, wsum, dyn);
     else hipLaunchKernelGGL(nn_scan_kernel<0>, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, skip_lb, skip_u, out, writeback, rt_dev, done, wsum, dyn);
+}
+
+void launch_nn_scan_dual(const float4* ptsA, const float* RA9, const float* tA3, int applyA, const float4* ptsB, const float* RB9, const float* tB3, int n, const BvhView& t,
+                         const float* lut, const LutGeom& g, const float4* tgt, int nt, const uint32_t* seed_idx, const float* skip_lbA, const uint32_t* skip_uA,
+                         const float* skip_lbB, const uint32_t* skip_uB, uint32_t* out_idx, uint32_t* out_min, float4* writeback, double* wsumA, double* wsumB, hipStream_t s) {
+    const int groups = (n + 63) / 64;
+    int nparts = 4;
+    while (nparts < 8 && groups * nparts < 4096) nparts <<= 1;
+    static const int forced = [] { const char* e = std::getenv("FGOICP_NN_PARTS"); const int v = e ? std::atoi(e) : 0; return v; }();  // tuning knob
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16) nparts = forced;
+    static const int dyn_env = [] { const char* e = std::getenv("FGOICP_NN_CLAIM"); return e ? std::atoi(e) : -1; }();  // tuning knob / A-B
+    const int dyn = dyn_env >= 0 ? dyn_env : (groups * nparts <= 8192 ? 1 : 0);
+    hipLaunchKernelGGL(nn_scan_dual_kernel, dim3(groups), dim3(64 * nparts), 0, s, ptsA, make_rt(RA9, tA3), applyA, ptsB, make_rt(RB9, tB3), n, t, lut, g, tgt, nt, seed_idx,
+                       skip_lbA, skip_uA, skip_lbB, skip_uB, out_idx, out_min, writeback, wsumA, wsumB, dyn);
 }
 
 void launch_nn_prep(const float4* pts, int n, const float* lut, const LutGeom& g, const float* R9, const float* t3, int apply, const float4* tgt, int nt,

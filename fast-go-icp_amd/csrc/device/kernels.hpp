@@ -118,6 +118,12 @@ void launch_nn_scan(const float4* pts, int n, const BvhView& t, const float* lut
                     const int* done = nullptr /* optional: the kernel returns at once when *done != 0 */,
                     double* wsum = nullptr /* optional, n <= 262144: per group of 64 queries the wave-level sums of the reduction that follows the scan —
                                               index mode {sum query xyz, sum correspondence xyz} (6), distance mode the sum of the minima (1) */);
+// The two scans of an ICP iteration in ONE walk (kernels.hip nn_scan_dual_kernel): set A = ptsA (moved by (RA, tA) when applyA; written back to
+// `writeback`) -> lowest index of the sqrt-tie set in out_idx; set B = ptsB under (RB, tB) -> bits of the minimum in out_min.  Same results as
+// launch_nn_scan with want_index = 1 / 0.  skip_*: trimmed mode, per set.  wsumA / wsumB: as launch_nn_scan's wsum.
+void launch_nn_scan_dual(const float4* ptsA, const float* RA9, const float* tA3, int applyA, const float4* ptsB, const float* RB9, const float* tB3, int n, const BvhView& t,
+                         const float* lut, const LutGeom& g, const float4* tgt, int nt, const uint32_t* seed_idx, const float* skip_lbA, const uint32_t* skip_uA,
+                         const float* skip_lbB, const uint32_t* skip_uB, uint32_t* out_idx, uint32_t* out_min, float4* writeback, double* wsumA, double* wsumB, hipStream_t s);
 // EXTENSION (trimmed Go-ICP): per query a rigorous bracket [lb, ub] of its nearest squared distance from the LUT (kernels.hip, nn_prep_kernel);
 // box6 = the target's bounding box {minx,maxx,miny,maxy,minz,maxz}
 void launch_nn_prep(const float4* pts, int n, const float* lut, const LutGeom& g, const float* R9, const float* t3, int apply, const float4* tgt, int nt,

@@ -47,7 +47,7 @@ def test_world_size_2_round_schedule(tmp_path, case, K):
     assert np.allclose(a["t"], G[case + "t"], atol=1e-5 * max(1.0, float(np.abs(G[case + "t"]).max())))
 
 
-@pytest.mark.parametrize("case,K,world", [("runsyn_", 1, 2), ("runbun_", 0, 2), ("runsyn_", 1, 3), ("runbun_", 2, 3)])
+@pytest.mark.parametrize("case,K,world", [("runbun_", 0, 2), ("runsyn_", 1, 3)])
 def test_late_joining_refinement_keeps_the_ranks_identical_and_the_optimum(tmp_path, case, K, world):
     """FGOICP_LATE_ICP=1 (a knob; measured slower on the 8-rank replay and off by default): a round's triggered ICP runs overlap the next round's bounds work and enter the
     exchange one round late; one more exchange after the loop collects the last round's.  The replicated state must stay identical on

@@ -315,9 +315,12 @@ def test_small_tick_path_equals_sorted_path(fg, oracle, tiny_case, gpu_required,
 @pytest.mark.parametrize("workload,res", [("tiny", 0.05), ("bunny", 0.02)])
 def test_icp_loop_variants_are_bit_identical(fg, gpu_required, monkeypatch, workload, res):
     """Ways to run IterativeClosestPoint3D::run (icp3d.cu:88-107), all on the same kernels' arithmetic:
-      default    host loop on two streams (exact SSE of iteration k next to the correspondence pass of iteration k+1), the reductions
-                 that follow a scan started in the scan's epilogue and folded on the host in the device's order (small clouds);
-      unfused    the same loop with separate reduction kernels (FGOICP_ICP_FUSE=0);
+      "1"        ONE walk per iteration serves the exact SSE of iteration k and the correspondence pass of iteration k+1 (nn_scan_dual_kernel:
+                 the default beyond 262 144 points and in trimmed runs), the reductions that follow started in its epilogue and folded on the
+                 host in the device's order;
+      dual_unfused  the same with separate reduction kernels;
+      two_scans  two scans on two streams (FGOICP_ICP_DUAL=0; the default up to 262 144 points), fused reductions;
+      unfused    two scans, separate reduction kernels (FGOICP_ICP_FUSE=0);
       sequential one stream, separate kernels (FGOICP_ICP_OVERLAP=0);
       device     the loop advanced ON THE DEVICE (FGOICP_ICP_DEVICE=1: SVD, compose and loop test in a one-thread kernel — the host's
                  SVD source compiled for the device —, passes enqueued ahead; measured slower, kept as a knob).
@@ -326,10 +329,11 @@ def test_icp_loop_variants_are_bit_identical(fg, gpu_required, monkeypatch, work
     pct, pcs, off_t, off_s, scale, bounds = fg.synth.preprocess(tgt, src)
     rng = np.random.default_rng(3)
     out = {}
-    for mode in ("1", "unfused", "device", "0"):
+    for mode in ("1", "dual_unfused", "two_scans", "unfused", "device", "0"):
         monkeypatch.setenv("FGOICP_ICP_OVERLAP", "0" if mode == "0" else "1")
         monkeypatch.setenv("FGOICP_ICP_DEVICE", "1" if mode == "device" else "0")
-        monkeypatch.setenv("FGOICP_ICP_FUSE", "0" if mode in ("unfused", "0") else "1")
+        monkeypatch.setenv("FGOICP_ICP_DUAL", "1" if mode in ("1", "dual_unfused") else "0")
+        monkeypatch.setenv("FGOICP_ICP_FUSE", "0" if mode in ("unfused", "dual_unfused", "0") else "1")
         reg = fg.Registration(pct, pcs, bounds, res)
         runs = []
         for thr, ang, max_iter in ((0.05, 40.0, 100), (0.005, 15.0, 100), (0.0005, 3.0, 100), (0.0, 25.0, 3), (0.005, 20.0, 1), (1e-7, 2.0, 40)):  # 4th, 5th, 6th end on max_iter
@@ -344,7 +348,7 @@ def test_icp_loop_variants_are_bit_identical(fg, gpu_required, monkeypatch, work
         runs.append(np.float32(reg.compute_sse_error(R, t)).view(np.uint32))
         out[mode] = runs
         reg.close()
-    for other in ("unfused", "device", "0"):
+    for other in ("dual_unfused", "two_scans", "unfused", "device", "0"):
         for a, b in zip(out["1"][:6], out[other][:6]):
             assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3], (other, a, b)
         assert np.array_equal(out["1"][6], out[other][6]) and out["1"][7] == out[other][7]

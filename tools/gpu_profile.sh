@@ -15,7 +15,7 @@ if [ -z "$3" ]; then
 fi
 cd /tmp
 SPECS=""
-for LEG in headline dragon trimmed; do
+for LEG in headline dragon trimmed default_threshold; do
   rm -rf /tmp/st_$LEG /tmp/pf_$LEG /tmp/pw_$LEG
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$LEG -- python3 $REPO/bench.py --only $LEG --steps 3 --warmup 1 > $REPO/gpurun_out/${TAG}_stats_$LEG.log 2>&1 || exit 1
   cp /tmp/st_$LEG/*/*kernel_stats.csv $OUT/${TAG}_${LEG}_kernel_stats.csv

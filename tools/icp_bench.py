@@ -10,8 +10,8 @@ import time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
-VARIANTS = {"default_fused_two_streams": {}, "unfused_two_streams": {"FGOICP_ICP_FUSE": "0"}, "device_loop": {"FGOICP_ICP_DEVICE": "1"},
-            "one_stream_unfused": {"FGOICP_ICP_FUSE": "0", "FGOICP_ICP_OVERLAP": "0"}}
+VARIANTS = {"default": {}, "dual_walk_fused": {"FGOICP_ICP_DUAL": "1"}, "two_scans_two_streams_fused": {"FGOICP_ICP_DUAL": "0"}, "two_scans_unfused": {"FGOICP_ICP_DUAL": "0", "FGOICP_ICP_FUSE": "0"}, "device_loop": {"FGOICP_ICP_DEVICE": "1"},
+            "one_stream_unfused": {"FGOICP_ICP_DUAL": "0", "FGOICP_ICP_FUSE": "0", "FGOICP_ICP_OVERLAP": "0"}}
 
 
 def child(name, repeats):
