@@ -350,7 +350,9 @@ def icp_latency(leg):
     bytes_it = ns * (16 + 4 + 16 + 4 + 16 + 4 + 16 + 16 + 4 + 4) + 2 * nt * 16
     us = sec / it * 1e6
     floor_us = bytes_it / (HBM_PEAK_GBS * 1e9) * 1e6
-    return {"bound": "latency", "kernel": "nn_scan_kernel<1> -> icp_cov_cen_kernel | nn_scan_kernel<0>", "iterations": it, "icp_runs": runs, "seconds_icp": sec,
+    kern = ("nn_scan_kernel<1> -> icp_cov_cen_kernel | nn_scan_kernel<0> (two streams)" if fused else
+            "nn_scan_dual_kernel (one walk for both scans) -> " + ("icp_inliers, " if leg.get("trim") else "") + "icp_sums, icp_centroids, icp_cov, sums")
+    return {"bound": "latency", "kernel": kern, "iterations": it, "icp_runs": runs, "seconds_icp": sec,
             "us_per_iteration": us, "launches_per_iteration": 3 if fused else 9, "host_syncs_per_iteration": 2,
             "algorithmic_bytes_per_iteration": bytes_it, "hbm_floor_us_per_iteration": floor_us, "frac_of_hbm_floor": floor_us / us,
             "note": "seconds_icp / iterations over the leg's timed steps (every ICP run of FastGoICP::run: initial, triggered, final); iterations far from "
@@ -404,8 +406,10 @@ def main():
         line["result"] = {"best_sse": head["best_sse"], "rotation_error_deg_vs_ground_truth": s["rotation_error_deg_vs_ground_truth"],
                           "translation_error_vs_ground_truth": s["translation_error_vs_ground_truth"]}
         line["roofline"] = roofline(head, pmc_all.get("headline"), {
-            "limited_by": "L1-miss concurrency x L2 latency, not HBM bytes: texture addresser busy 71 %, L1 pending-stall 54 % of cycles, ~65 misses in flight per CU at 333 "
-                          "cycles each (profiles/r01_bounds_kernel_pmc_extra.json); a build whose gathers all hit on chip runs 1.71x faster (profiles/r02_ablation_fixed_tick.txt)"})
+            "limited_by": "L1-miss concurrency x L2 latency, not HBM bytes (round-3 counters of this kernel, profiles/bench_pmc_extra.json [headline]: L1 hit rate 41 %, the L1 "
+                          "in pending-stall 55 % of its cycles, 320 cycles per L1 miss, VALU issue 37 %); a build whose gathers all hit on chip runs 1.71x faster "
+                          "(profiles/r02_ablation_fixed_tick.txt); the plain LUT that fits the Infinity Cache moves 37 % fewer bytes and is 1.58x slower "
+                          "(profiles/r03_ab_lut_layout_final_ticks.txt)"})
         utilisation(line["roofline"], pmc_extra.get("headline"))
 
     # BASELINE.md's parameters (mse_threshold 1e-3) on the same clouds
