@@ -1668,7 +1668,8 @@ __device__ unsigned long long g_scan_times[4096 * 4];  // per block of the last 
 // (0: the leaf cannot matter to this lane), leaf(point, flags) = what to do with each of the leaf's points.
 template <class RadiusFn, class TestFn, class LeafFn>
 __device__ __forceinline__ void box_walk(const BvhView t, const float (&wl)[3], const float (&wh)[3], int part, int nparts, RadiusFn radius, TestFn test, LeafFn leaf,
-                                         int* claim_ctr /* LDS word, zero on entry, when nparts > 1 (nullptr: round-robin) */) {
+                                         int* claim_ctr /* LDS word, zero on entry, when nparts > 1 (nullptr: round-robin) */,
+                                         unsigned long long* flat_mask = nullptr /* LDS, 32 words: every wave of the block holds the SAME queries (nn_scan kernels) */) {
     const int lane = threadIdx.x & 63;
     // The candidate leaves of these 64 queries are shared out among the `nparts` waves of the block DYNAMICALLY: every wave enumerates the
     // same candidates in the same order (cand) and works on the one it has claimed from an LDS counter, claiming the next when it is
@@ -1685,6 +1686,69 @@ __device__ __forceinline__ void box_walk(const BvhView t, const float (&wl)[3], 
     if (nparts > 1 && claim_ctr) next_claim = claim();
     const float big = 3.0e38f;
     float r2 = radius();
+    SCAN_STAT(0, 1);
+    SCAN_STAT_DECL;
+    // The leaf step shared by both forms of the walk: claim, per-query test against the leaf's box, then its 32 points through the
+    // scalar unit (a wave-uniform address in the constant address space is what the backend selects s_load for; `leaf` takes the lane's
+    // flags and stays branch-free: a lane the leaf cannot matter to sees a distance beyond every bound).
+    auto visit = [&](int leaf_id, const float4 lo, const float4 hi) {
+        if (nparts > 1) {
+            const bool mine = cand == next_claim;
+            ++cand;
+            if (!mine) return;
+        }
+        const int pl = test(lo, hi);
+        SCAN_STAT(3, 1);
+        if (__any(pl != 0)) {
+            SCAN_STAT(4, 1);
+            SCAN_STAT_LOCAL(stat_scanned);
+            typedef float v4f_c __attribute__((ext_vector_type(4)));
+            const __attribute__((address_space(4))) v4f_c* lp = (const __attribute__((address_space(4))) v4f_c*)(t.pts + (size_t)__builtin_amdgcn_readfirstlane(leaf_id) * kBvhLeaf);
+#pragma unroll 4   // 4 points in flight keep the index-mode kernel at 61 VGPRs = 8 waves per SIMD (16: 91 VGPRs, 5 waves — the scan
+            // lives on resident waves hiding each other's dependent loads; measured slower)
+            for (int k = 0; k < kBvhLeaf; ++k) {
+                const v4f_c c = lp[k];
+                leaf(make_float4(c.x, c.y, c.z, c.w), pl);
+            }
+            if (nparts == 1) r2 = radius();  // the wave radius only shrinks
+        }
+        if (nparts > 1) next_claim = claim();
+    };
+    // FLAT form (FGOICP_NN_FLAT=1; built in round 3, measured SLOWER — 49-53 -> 53-58 us per ICP iteration at 40k points — and off by default;
+    // targets of at most 2048 leaves = 65 536 points, block-cooperative scans): the box levels above the leaves cost a
+    // wave one DEPENDENT load per candidate super-leaf (tools/scan_stats.sh: 6 on average, 15-25 in the slowest wave, at 40k points) — the
+    // chain the scan's duration consists of.  Here the block tests EVERY leaf box once, 64 per step, the steps dealt to its waves and
+    // independent of each other (1 258 leaves / 8 waves = 3 loads per wave, issued together), publishes the candidate masks in LDS,
+    // and every wave then walks the same candidate list, fetching a claimed leaf's box through the scalar unit.
+    if (flat_mask && t.depth <= 11) {
+        const int nleaf = 1 << t.depth, steps = (nleaf + 63) >> 6;
+        for (int j = part; j < steps; j += nparts) {
+            const int ln = j * 64 + lane;
+            bool c = false;
+            if (ln < nleaf) {
+                const int node = t.first_leaf + ln;
+                c = !(boxbox_d2(t.box[2 * node], t.box[2 * node + 1], wl, wh) * kBoxShrink > r2);
+            }
+            const unsigned long long m = __ballot(c);
+            if (lane == 0) flat_mask[j] = m;
+        }
+        __syncthreads();
+        typedef float v4f_b __attribute__((ext_vector_type(4)));
+        const __attribute__((address_space(4))) v4f_b* bx = (const __attribute__((address_space(4))) v4f_b*)t.box;
+        for (int j = 0; j < steps; ++j) {
+            const unsigned long long mv = flat_mask[j];
+            unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(mv >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(mv & 0xffffffffull));
+            while (m) {
+                const int leaf_id = j * 64 + __ffsll((long long)m) - 1;
+                m &= m - 1;
+                if (nparts > 1 && cand != next_claim) { ++cand; continue; }  // not this wave's: no box fetch
+                const v4f_b lo4 = bx[2 * (size_t)(t.first_leaf + leaf_id)], hi4 = bx[2 * (size_t)(t.first_leaf + leaf_id) + 1];
+                visit(leaf_id, make_float4(lo4.x, lo4.y, lo4.z, 0.f), make_float4(hi4.x, hi4.y, hi4.z, 0.f));
+            }
+        }
+        SCAN_STAT_END;
+        return;
+    }
     const int sdepth = t.depth > kSuperShift ? t.depth - kSuperShift : 0;
     const int nsuper = 1 << sdepth;
     const int lps = 1 << (t.depth - sdepth);  // leaves per super-leaf (<= 64)
@@ -1695,8 +1759,6 @@ __device__ __forceinline__ void box_walk(const BvhView t, const float (&wl)[3], 
     const int ntop = 1 << tdepth;
     const int spt = 1 << (sdepth - tdepth);   // super-leaves per top box (<= 64)
     const int first_top = ntop - 1;
-    SCAN_STAT(0, 1);
-    SCAN_STAT_DECL;
     for (int tb = 0; tb < ntop; tb += 64) {
         bool tc = false;
         if (tb + lane < ntop) {
@@ -1731,37 +1793,10 @@ __device__ __forceinline__ void box_walk(const BvhView t, const float (&wl)[3], 
                 while (lmask) {
                     const int l = __ffsll((long long)lmask) - 1;
                     lmask &= lmask - 1;
-                    if (nparts > 1) {
-                        const bool mine = cand == next_claim;
-                        ++cand;
-                        if (!mine) continue;
-                    }
+                    if (nparts > 1 && cand != next_claim) { ++cand; continue; }
                     const float4 lo = make_float4(bcast(llo.x, l), bcast(llo.y, l), bcast(llo.z, l), 0.f);
                     const float4 hi = make_float4(bcast(lhi.x, l), bcast(lhi.y, l), bcast(lhi.z, l), 0.f);
-                    const int pl = test(lo, hi);
-                    SCAN_STAT(3, 1);
-                    if (!__any(pl != 0)) {
-                        if (nparts > 1) next_claim = claim();
-                        continue;
-                    }
-                    SCAN_STAT(4, 1);
-                    SCAN_STAT_LOCAL(stat_scanned);
-                    // The leaf's 32 points have a wave-uniform address: read through the scalar unit (s_load, 512 B) instead of one vector
-                    // load + 128 v_readlane broadcasts; `leaf` takes the lane's flags and stays branch-free (a lane the leaf cannot
-                    // matter to sees a distance beyond every bound).
-                    // (constant address space: the tree is read-only for the kernel's lifetime, and a uniform constant-space address is what
-                    // the backend selects s_load for)
-                    typedef float v4f_c __attribute__((ext_vector_type(4)));
-                    const __attribute__((address_space(4))) v4f_c* lp =
-                        (const __attribute__((address_space(4))) v4f_c*)(t.pts + (size_t)__builtin_amdgcn_readfirstlane(s * lps + l) * kBvhLeaf);
-#pragma unroll 4   // 4 points in flight keep the index-mode kernel at 61 VGPRs = 8 waves per SIMD (16: 91 VGPRs, 5 waves — the scan
-                    // lives on resident waves hiding each other's dependent loads; measured slower)
-                    for (int k = 0; k < kBvhLeaf; ++k) {
-                        const v4f_c c = lp[k];
-                        leaf(make_float4(c.x, c.y, c.z, c.w), pl);
-                    }
-                    if (nparts == 1) r2 = radius();  // the wave radius only shrinks
-                    else next_claim = claim();
+                    visit(s * lps + l, lo, hi);
                 }
             }
         }
@@ -1771,13 +1806,13 @@ __device__ __forceinline__ void box_walk(const BvhView t, const float (&wl)[3], 
 
 template <class LeafFn, class BoundFn>
 __device__ __forceinline__ void box_scan(const BvhView t, float qx, float qy, float qz, bool active, int part, int nparts, LeafFn leaf, BoundFn bound,
-                                         int* claim_ctr = nullptr /* LDS word, zero on entry, when nparts > 1 */) {
+                                         int* claim_ctr = nullptr /* LDS word, zero on entry, when nparts > 1 */, unsigned long long* flat_mask = nullptr) {
     const float big = 3.0e38f;
     const float wl[3] = {wave_min_f(active ? qx : big), wave_min_f(active ? qy : big), wave_min_f(active ? qz : big)};
     const float wh[3] = {wave_max_f(active ? qx : -big), wave_max_f(active ? qy : -big), wave_max_f(active ? qz : -big)};
     box_walk(t, wl, wh, part, nparts, [&]() { return wave_max_f(active ? bound() : 0.0f); },
              [&](const float4 lo, const float4 hi) { return (int)(active && !(box_d2(lo, hi, qx, qy, qz) * kBoxShrink > bound())); },
-             [&](const float4 c, int pl) { leaf(c, pl != 0); }, claim_ctr);
+             [&](const float4 c, int pl) { leaf(c, pl != 0); }, claim_ctr, flat_mask);
 }
 
 // Minimum squared distance.  `ub` is any value >= the true minimum (or +huge): it only seeds the
@@ -1887,7 +1922,7 @@ __global__ __launch_bounds__(64 * kMaxParts) void nn_scan_kernel(const float4* p
                                                                  LutGeom g, Rt rt, int apply, const float4* __restrict__ tgt, int nt,
                                                                  const uint32_t* seed_idx, const float* __restrict__ skip_lb, const uint32_t* __restrict__ skip_u, uint32_t* out,
                                                                  float4* writeback, const float* __restrict__ rt_dev, const int* __restrict__ done,
-                                                                 double* __restrict__ wsum, int dynamic_claim) {
+                                                                 double* __restrict__ wsum, int dynamic_claim, int flat_walk) {
     if (done && *done) return;  // device-resident ICP loop: the run has ended, this pass was enqueued ahead of the decision
     if (rt_dev) {               // ... and the motion is the one the step kernel left in device memory (12 floats: R, t)
 #pragma unroll
@@ -1898,6 +1933,8 @@ __global__ __launch_bounds__(64 * kMaxParts) void nn_scan_kernel(const float4* p
     SCAN_TIME(0);
     __shared__ int claim_ctr[3];  // one per walk (first, redo, tie): zeroed here, used once each
     if (threadIdx.x < 3) claim_ctr[threadIdx.x] = 0;
+    __shared__ unsigned long long leaf_mask[32];  // flat form of the walk (box_walk): the block's candidate leaves
+    unsigned long long* const flat = flat_walk ? leaf_mask : nullptr;
     __shared__ uint32_t comb[kMaxParts][64];
     __shared__ uint32_t comb_i[WANT_INDEX ? kMaxParts : 1][64];
     __shared__ uint32_t comb_2[WANT_INDEX ? kMaxParts : 1][64];
@@ -1949,7 +1986,7 @@ __global__ __launch_bounds__(64 * kMaxParts) void nn_scan_kernel(const float4* p
                  found = fminf(found, d);
                  best = fminf(best, d);
              },
-             [&]() { return WANT_INDEX ? best * 1.0000015f : best; }, dynamic_claim ? &claim_ctr[0] : nullptr);
+             [&]() { return WANT_INDEX ? best * 1.0000015f : best; }, dynamic_claim ? &claim_ctr[0] : nullptr, flat);
     SCAN_TIME(2);
     if (nparts > 1) {
         comb[part][lane] = __float_as_uint(found);  // non-negative floats order like their bit patterns
@@ -1977,7 +2014,7 @@ __global__ __launch_bounds__(64 * kMaxParts) void nn_scan_kernel(const float4* p
                      const float d = on ? dist_sq(qx, qy, qz, c.x, c.y, c.z) : kMasked;
                      f2 = d < f2 ? d : f2;
                  },
-                 [&]() { return f2; }, dynamic_claim ? &claim_ctr[1] : nullptr);
+                 [&]() { return f2; }, dynamic_claim ? &claim_ctr[1] : nullptr, flat);
         if (nparts > 1) {
             comb[part][lane] = __float_as_uint(f2);
             __syncthreads();
@@ -2001,7 +2038,7 @@ __global__ __launch_bounds__(64 * kMaxParts) void nn_scan_kernel(const float4* p
                          const float d = on ? dist_sq(qx, qy, qz, c.x, c.y, c.z) : kMasked;
                          idx2 = min(idx2, d <= thr ? __float_as_uint(c.w) : 0x7fffffffu);
                      },
-                     [&]() { return thr; }, dynamic_claim ? &claim_ctr[2] : nullptr);
+                     [&]() { return thr; }, dynamic_claim ? &claim_ctr[2] : nullptr, flat);
             if (nparts > 1) {
                 comb[part][lane] = idx2;
                 __syncthreads();
@@ -2712,8 +2749,9 @@ void launch_nn_scan(const float4* pts, int n, const BvhView& t, const float* lut
     // slowest block: 40k points, -3 %), dealt round-robin when it does (437k / 1M points: the LDS claims cost 1-2 % and buy nothing)
     static const int dyn_env = [] { const char* e = std::getenv("FGOICP_NN_CLAIM"); return e ? std::atoi(e) : -1; }();  // tuning knob / A-B: 0 / 1 force
     const int dyn = dyn_env >= 0 ? dyn_env : (groups * nparts <= 8192 ? 1 : 0);
-    if (want_index) hipLaunchKernelGGL(nn_scan_kernel<1>, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, skip_lb, skip_u, out, writeback, rt_dev, done, wsum, dyn);
-    else hipLaunchKernelGGL(nn_scan_kernel<0>, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, skip_lb, skip_u, out, writeback, rt_dev, done, wsum, dyn);
+    const int flat = [] { const char* e = std::getenv("FGOICP_NN_FLAT"); return e ? std::atoi(e) : 0; }();  // tuning knob / A-B (read per launch): 1 = flat form of the walk for targets of <= 2048 leaves (measured slower: off)
+    if (want_index) hipLaunchKernelGGL(nn_scan_kernel<1>, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, skip_lb, skip_u, out, writeback, rt_dev, done, wsum, dyn, flat);
+    else hipLaunchKernelGGL(nn_scan_kernel<0>, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, skip_lb, skip_u, out, writeback, rt_dev, done, wsum, dyn, flat);
 }
 
 void launch_nn_scan_dual(const float4* ptsA, const float* RA9, const float* tA3, int applyA, const float4* ptsB, const float* RB9, const float* tB3, int n, const BvhView& t,
