@@ -567,12 +567,16 @@ static int lane_icp_device(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R
                            float* t_out3, int* iters_out);
 static int lane_icp_dual(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9,
                          float* t_out3, int* iters_out);
+static int lane_icp_gated(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9,
+                          float* t_out3, int* iters_out);
 static int lane_icp(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3,
                     int* iters_out) {
     if (c->icp_device && c->icp_overlap && !c->brute_force_nn && !c->inliers) return lane_icp_device(c, L, R0, t0, max_iter, thr, sse_out, R_out9, t_out3, iters_out);
     // one walk for both scans where the device is full anyway (clouds beyond 262 144 points, trimmed runs: -3 ... -5 % of the ICP time); below
     // that the two scans of an iteration overlap on two streams and a wave carrying both query sets only lengthens the chain (40k points:
     // 51-53 -> 55-56 us per iteration) — FGOICP_ICP_DUAL = 1 / 0 forces either
+    if (c->icp_gated && c->icp_gate_ok && c->icp_dual_env <= 0 && c->icp_overlap && icp_fused(c) && L.sig_b && L.sig_a)
+        return lane_icp_gated(c, L, R0, t0, max_iter, thr, sse_out, R_out9, t_out3, iters_out);
     const bool dual = c->icp_dual_env >= 0 ? c->icp_dual_env != 0 : !icp_fused(c);
     if (dual && c->icp_overlap && !c->brute_force_nn) return lane_icp_dual(c, L, R0, t0, max_iter, thr, sse_out, R_out9, t_out3, iters_out);
     HIPCHK(hipSetDevice(c->device));  // per host thread
@@ -820,6 +824,116 @@ static int lane_icp_dual(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0,
         ++iters;
     }
     if (pending) HIPCHK(hipStreamSynchronize(S));  // the speculative pass: drained, not used
+    const bool cur_best = sse < last_sse;  // :106-107
+    *sse_out = cur_best ? sse : last_sse;
+    const Mat3f& Ro = cur_best ? R : last_R;
+    const Vec3f& to = cur_best ? t : last_t;
+    std::memcpy(R_out9, Ro.m, sizeof(Ro.m));
+    t_out3[0] = to.x; t_out3[1] = to.y; t_out3[2] = to.z;
+    if (iters_out) *iters_out = iters;
+    return FGOICP_OK;
+}
+
+// (FGOICP_ICP_GATED=1; measured SLOWER than paying the launches — 50-53 -> 53-56 us per iteration at 40k points: the command processor's
+// wait-value poll and the two extra stream operations per iteration cost more than the launch latency they hide — so this is a knob, off by default.)
+// The two-stream loop of small clouds with the launch latency taken off the iteration's chain (round 3).  An iteration's kernels depend on the
+// host only through 24 floats (R_, t_, R, t): they are enqueued one iteration AHEAD, behind a stream wait (hipStreamWaitValue64) on a signal
+// word, and read their motion from pinned memory; when the SVD is done the host writes the motion and raises the signal — the command
+// processor releases kernels that are already queued instead of the host paying three launches (5 us each to submit, 6-8 us until the first
+// one starts) between the SVD and the scan.  Same kernels, same arithmetic as lane_icp's fused path (the scans' `rt_dev` / `done` arguments of the
+// device-resident loop are reused): bit-identical (tests).  The set enqueued behind a gate the loop never opens is released with `done` set.
+static int lane_icp_gated(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9,
+                          float* t_out3, int* iters_out) {
+    HIPCHK(hipSetDevice(c->device));
+    const int ns = (int)c->ns, nt = (int)c->nt, nb = reduce_blocks_for(ns), groups = (ns + 63) / 64;
+    constexpr int kRing = fgoicp_ctx::IcpLane::kRing;
+    hipStream_t A = L.stream, B = L.icp_stream;
+    const bool seeding = c->icp_seeding;
+    uint32_t* idx[2] = {L.d_first_idx, L.d_first_idx2};
+    const uint64_t base = L.gate_seq;  // gate j of this run opens at base + j
+    *(volatile int*)L.h_done = 0;
+    L.sse_on_host = true;              // where the gated kernels leave their results (as the fused enqueue functions would record)
+    L.cov_on_host = true;
+    L.cov_blocks = nb;
+    HIPCHK(hipMemcpyAsync(L.d_work, c->d_src, sizeof(float4) * c->ns, hipMemcpyDeviceToDevice, A));
+    launch_transform_inplace(L.d_work, ns, R0, t0, A);  // icp3d.cu:85
+    Mat3f R = Mat3f::from(R0);
+    Vec3f t{t0[0], t0[1], t0[2]};
+    size_t iter = 0;
+    float sse = kInf, last_sse = 2.0f * kInf;
+    Mat3f last_R = Mat3f::identity();
+    Vec3f last_t{0, 0, 0};
+    int iters = 0;
+    uint64_t enq = 0;     // highest gate with kernels queued behind it
+    uint64_t opened = 0;  // highest gate raised
+    // pass j+1 and the SSE of iteration j, queued behind gate j; pass j writes idx[j & 1] and is seeded by idx[(j - 1) & 1]
+    auto enqueue_gated = [&](uint64_t j) -> int {
+        const float* rt = L.hd_rt + 24 * (j & 1);
+        const uint32_t* seed = seeding ? idx[j & 1] : nullptr;
+        enq = j;  // from here on something may be waiting behind gate j: release_all() has to raise it whatever happens below
+        HIPCHK(hipStreamWaitValue64(B, L.sig_b, base + j, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull));
+        launch_nn_scan(L.d_work, ns, c->bvh_tgt.view(), c->d_lut, c->geom, nullptr, nullptr, 1, 1, c->d_tgt, nt, seed, nullptr, nullptr, idx[(j + 1) & 1], B, L.d_work, rt, L.hd_done, L.d_wsum);
+        launch_icp_cov_cen(L.d_work, c->d_tgt, idx[(j + 1) & 1], ns, nt, L.d_wsum, nb, groups, L.hd_cen, L.hd_covbp, nb, B, L.hd_done);
+        HIPCHK(hipEventRecord(L.ev_step[(j + 1) % kRing], B));
+        HIPCHK(hipStreamWaitValue64(A, L.sig_a, base + j, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull));
+        launch_nn_scan(c->d_src, ns, c->bvh_tgt.view(), c->d_lut, c->geom, nullptr, nullptr, 1, 0, c->d_tgt, nt, seed, nullptr, nullptr, L.d_min_bits, A, nullptr, rt + 12, L.hd_done, L.hd_wsse);
+        HIPCHK(hipEventRecord(L.ev_sse[j % kRing], A));
+        HIPCHK(hipGetLastError());
+        return FGOICP_OK;
+    };
+    auto open_gate = [&](uint64_t j) {
+        __atomic_store_n(L.sig_b, base + j, __ATOMIC_RELEASE);
+        __atomic_store_n(L.sig_a, base + j, __ATOMIC_RELEASE);
+        opened = j;
+    };
+    int rc = FGOICP_OK;
+    if (max_iter > 0) {
+        HIPCHK(hipEventRecord(L.icp_ev_w, A));
+        HIPCHK(hipStreamWaitEvent(B, L.icp_ev_w, 0));
+        rc = procrustes_enqueue(c, L, nullptr, idx[1], L.d_sel_wide2, B);  // pass 1 (no gate: its motion is (R0, t0), applied above)
+        if (rc == FGOICP_OK) HIPCHK(hipEventRecord(L.ev_step[1 % kRing], B));
+        if (rc == FGOICP_OK && max_iter > 1) rc = enqueue_gated(1);
+    }
+    // every exit below has to leave no kernel waiting behind a closed gate
+    auto release_all = [&]() {
+        if (enq > opened) { *(volatile int*)L.h_done = 1; __atomic_thread_fence(__ATOMIC_SEQ_CST); open_gate(enq); }
+        (void)hipStreamSynchronize(B);
+        (void)hipStreamSynchronize(A);
+        L.gate_seq = base + (enq > opened ? enq : opened) + 1;
+        *(volatile uint64_t*)L.sig_b = L.gate_seq;
+        *(volatile uint64_t*)L.sig_a = L.gate_seq;
+        *(volatile int*)L.h_done = 0;
+    };
+    if (rc) { release_all(); return rc; }
+    while (iter++ < max_iter && (last_sse - sse) > thr * last_sse) {  // icp3d.cu:94
+        last_sse = sse;
+        last_R = R;
+        last_t = t;
+        if (hipEventSynchronize(L.ev_step[iter % kRing]) != hipSuccess) { release_all(); set_error("hipEventSynchronize failed in the ICP loop"); return FGOICP_ERR_HIP; }
+        Mat3f Rn;
+        Vec3f tn;
+        procrustes_finish(L, &Rn, &tn, nullptr, nullptr);
+        const float tn3[3] = {tn.x, tn.y, tn.z};
+        R = Rn * R;                                              // :101
+        t = Rn * t + tn;                                         // :102
+        const float t3[3] = {t.x, t.y, t.z};
+        if (iter < max_iter) {
+            float* slot = L.h_rt + 24 * (iter & 1);
+            std::memcpy(slot, Rn.m, 36); std::memcpy(slot + 9, tn3, 12);
+            std::memcpy(slot + 12, R.m, 36); std::memcpy(slot + 21, t3, 12);
+            open_gate(iter);                                      // pass iter+1 and SSE iter start now: they were queued an iteration ago
+            if (iter + 1 < max_iter) { rc = enqueue_gated(iter + 1); if (rc) { release_all(); return rc; } }
+        } else {  // the last iteration the loop can make: nothing was queued for it
+            launch_transform_inplace(L.d_work, ns, Rn.m, tn3, B);  // :100
+            rc = sse_enqueue(c, L, R.m, t3, seeding ? idx[iter & 1] : nullptr, A);
+            if (rc) { release_all(); return rc; }
+            HIPCHK(hipEventRecord(L.ev_sse[iter % kRing], A));
+        }
+        if (hipEventSynchronize(L.ev_sse[iter % kRing]) != hipSuccess) { release_all(); set_error("hipEventSynchronize failed in the ICP loop"); return FGOICP_ERR_HIP; }
+        sse = sse_result(c, L);
+        ++iters;
+    }
+    release_all();  // the speculative pass (and a set behind a gate the loop never opened): drained, not used
     const bool cur_best = sse < last_sse;  // :106-107
     *sse_out = cur_best ? sse : last_sse;
     const Mat3f& Ro = cur_best ? R : last_R;
@@ -1178,6 +1292,7 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
         if (const char* e = std::getenv("FGOICP_ICP_OVERLAP")) c->icp_overlap = std::atoi(e) != 0;       // tuning knob
         if (const char* e = std::getenv("FGOICP_ICP_DEVICE")) c->icp_device = std::atoi(e) != 0;         // tuning knob / A-B: 1 = loop advanced on the device (measured slower)
         if (const char* e = std::getenv("FGOICP_ICP_DUAL")) c->icp_dual_env = std::atoi(e) != 0 ? 1 : 0; // tuning knob / A-B: 1 = one walk for both scans of an iteration, 0 = two scans on two streams
+        if (const char* e = std::getenv("FGOICP_ICP_GATED")) c->icp_gated = std::atoi(e) != 0;           // tuning knob / A-B: 1 = iterations pre-enqueued behind stream gates
         if (const char* e = std::getenv("FGOICP_ICP_FUSE")) c->icp_fuse = std::atoi(e) != 0;             // tuning knob / A-B: 0 = separate reduction kernels
         if (const char* e = std::getenv("FGOICP_ICP_AHEAD")) c->icp_ahead = std::max(1, std::min(6, std::atoi(e)));  // tuning knob
         c->lanes.resize((size_t)nl);
@@ -1206,6 +1321,15 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
             CHK(hipHostGetDevicePointer((void**)&L.hd_wsse, L.h_wsse, 0));
             CHK(hipHostMalloc((void**)&L.h_covbp, sizeof(double) * 1024 * 9, hipHostMallocMapped));
             CHK(hipHostGetDevicePointer((void**)&L.hd_covbp, L.h_covbp, 0));
+            CHK(hipHostMalloc((void**)&L.h_rt, sizeof(float) * 48, hipHostMallocMapped));
+            CHK(hipHostGetDevicePointer((void**)&L.hd_rt, L.h_rt, 0));
+            CHK(hipHostMalloc((void**)&L.h_done, sizeof(int) * 4, hipHostMallocMapped));
+            CHK(hipHostGetDevicePointer((void**)&L.hd_done, L.h_done, 0));
+            *L.h_done = 0;
+            // signal words for hipStreamWaitValue64; without them (or without the stream operation) the gated loop is simply not used
+            if (hipExtMallocWithFlags((void**)&L.sig_b, 8, hipMallocSignalMemory) != hipSuccess) L.sig_b = nullptr;
+            if (hipExtMallocWithFlags((void**)&L.sig_a, 8, hipMallocSignalMemory) != hipSuccess) L.sig_a = nullptr;
+            (void)hipGetLastError();
             CHK(hipMalloc(&L.d_icp, sizeof(IcpDevState)));
             CHK(hipHostMalloc((void**)&L.h_res, sizeof(IcpHostResult), hipHostMallocMapped));
             CHK(hipHostGetDevicePointer((void**)&L.hd_res, L.h_res, 0));
@@ -1213,6 +1337,17 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
                 CHK(hipEventCreateWithFlags(&L.ev_step[k], hipEventDisableTiming));
                 CHK(hipEventCreateWithFlags(&L.ev_sse[k], hipEventDisableTiming));
             }
+        }
+    }
+    {   // probe the stream wait-value operation once: a wait that is already satisfied, on lane 0's side stream
+        fgoicp_ctx::IcpLane& L0 = c->lanes[0];
+        c->icp_gate_ok = false;
+        if (L0.sig_b && L0.sig_a) {
+            *(volatile uint64_t*)L0.sig_b = 1;
+            if (hipStreamWaitValue64(L0.icp_stream, L0.sig_b, 1, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull) == hipSuccess && hipStreamSynchronize(L0.icp_stream) == hipSuccess)
+                c->icp_gate_ok = true;
+            (void)hipGetLastError();
+            for (auto& L : c->lanes) { if (L.sig_b) *(volatile uint64_t*)L.sig_b = 1; if (L.sig_a) *(volatile uint64_t*)L.sig_a = 1; L.gate_seq = 1; }
         }
     }
 #undef CHK
@@ -1253,6 +1388,10 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
             if (L.ev_sse[k]) (void)hipEventDestroy(L.ev_sse[k]);
         }
         (void)hipFree(L.d_icp);
+        if (L.sig_b) (void)hipFree(L.sig_b);
+        if (L.sig_a) (void)hipFree(L.sig_a);
+        if (L.h_rt) (void)hipHostFree(L.h_rt);
+        if (L.h_done) (void)hipHostFree(L.h_done);
         (void)hipFree(L.d_wsum);
         if (L.h_wsse) (void)hipHostFree(L.h_wsse);
         if (L.h_covbp) (void)hipHostFree(L.h_covbp);

@@ -113,6 +113,12 @@ struct fgoicp_ctx {
         double *h_covbp = nullptr, *hd_covbp = nullptr;   // pinned: [blocks][9] block partials of the covariance
         bool cov_on_host = false, sse_on_host = false;    // where the result of the last enqueued pass lands
         int cov_blocks = 0;
+        // gated loop (ctx.hip lane_icp_gated): the next iteration's kernels are enqueued BEFORE their motion is known, behind a stream
+        // wait on a signal word the host raises once it has written the motion into pinned memory
+        uint64_t *sig_b = nullptr, *sig_a = nullptr;   // hipMallocSignalMemory, 8 bytes each
+        uint64_t gate_seq = 0;                         // last value the gates have been raised to
+        float *h_rt = nullptr, *hd_rt = nullptr;       // pinned: 2 slots x {R_[9], t_[3], R[9], t[3]}
+        int *h_done = nullptr, *hd_done = nullptr;     // pinned: kernels enqueued behind a gate return at once when it is set
         // device-resident ICP loop (ctx.hip lane_icp_device)
         fgoicp::IcpDevState* d_icp = nullptr;    // loop state in device memory
         fgoicp::IcpHostResult *h_res = nullptr, *hd_res = nullptr;   // pinned result + progress words
@@ -122,6 +128,8 @@ struct fgoicp_ctx {
     std::vector<IcpLane> lanes;
     bool icp_overlap = true;
     bool icp_fuse = true;                    // small clouds: reductions started in the scans' epilogues, folded on the host (FGOICP_ICP_FUSE=0: separate kernels)
+    bool icp_gated = false;                  // FGOICP_ICP_GATED=1: small clouds, iterations pre-enqueued behind stream gates (built in round 3; measured slower, off)
+    bool icp_gate_ok = false;                // stream wait-value operations work on this device (probed at context creation)
     int icp_dual_env = -1;                   // FGOICP_ICP_DUAL: one walk serves the two scans of an ICP iteration (nn_scan_dual_kernel); -1 = by cloud size
     bool icp_device = false;                 // ICP loop advanced on the device (FGOICP_ICP_DEVICE=0: the host loop, for A/B and as the bit reference)
     int icp_ahead = 2;                       // iterations the host may enqueue ahead of the device's progress

@@ -319,7 +319,10 @@ def test_icp_loop_variants_are_bit_identical(fg, gpu_required, monkeypatch, work
                  the default beyond 262 144 points and in trimmed runs), the reductions that follow started in its epilogue and folded on the
                  host in the device's order;
       dual_unfused  the same with separate reduction kernels;
-      two_scans  two scans on two streams (FGOICP_ICP_DUAL=0; the default up to 262 144 points), fused reductions;
+      two_scans  two scans on two streams (FGOICP_ICP_DUAL=0), fused reductions, every iteration enqueued after its SVD — the default up to
+                 262 144 points;
+      gated      the same kernels enqueued one iteration AHEAD behind stream gates (hipStreamWaitValue64) the host opens once it has written the
+                 motion into pinned memory (FGOICP_ICP_GATED=1; measured slower, a knob);
       unfused    two scans, separate reduction kernels (FGOICP_ICP_FUSE=0);
       sequential one stream, separate kernels (FGOICP_ICP_OVERLAP=0);
       device     the loop advanced ON THE DEVICE (FGOICP_ICP_DEVICE=1: SVD, compose and loop test in a one-thread kernel — the host's
@@ -329,10 +332,11 @@ def test_icp_loop_variants_are_bit_identical(fg, gpu_required, monkeypatch, work
     pct, pcs, off_t, off_s, scale, bounds = fg.synth.preprocess(tgt, src)
     rng = np.random.default_rng(3)
     out = {}
-    for mode in ("1", "dual_unfused", "two_scans", "unfused", "device", "0"):
+    for mode in ("1", "dual_unfused", "two_scans", "gated", "unfused", "device", "0"):
+        monkeypatch.setenv("FGOICP_ICP_GATED", "1" if mode == "gated" else "0")
         monkeypatch.setenv("FGOICP_ICP_OVERLAP", "0" if mode == "0" else "1")
         monkeypatch.setenv("FGOICP_ICP_DEVICE", "1" if mode == "device" else "0")
-        monkeypatch.setenv("FGOICP_ICP_DUAL", "1" if mode in ("1", "dual_unfused") else "0")
+        monkeypatch.setenv("FGOICP_ICP_DUAL", "1" if mode in ("1", "dual_unfused") else "0")  # "gated": two scans, fused, pre-enqueued behind stream gates
         monkeypatch.setenv("FGOICP_ICP_FUSE", "0" if mode in ("unfused", "dual_unfused", "0") else "1")
         reg = fg.Registration(pct, pcs, bounds, res)
         runs = []
@@ -348,7 +352,7 @@ def test_icp_loop_variants_are_bit_identical(fg, gpu_required, monkeypatch, work
         runs.append(np.float32(reg.compute_sse_error(R, t)).view(np.uint32))
         out[mode] = runs
         reg.close()
-    for other in ("dual_unfused", "two_scans", "unfused", "device", "0"):
+    for other in ("dual_unfused", "two_scans", "gated", "unfused", "device", "0"):
         for a, b in zip(out["1"][:6], out[other][:6]):
             assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3], (other, a, b)
         assert np.array_equal(out["1"][6], out[other][6]) and out["1"][7] == out[other][7]

@@ -10,7 +10,7 @@ import time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
-VARIANTS = {"default": {}, "dual_walk_fused": {"FGOICP_ICP_DUAL": "1"}, "two_scans_two_streams_fused": {"FGOICP_ICP_DUAL": "0"}, "two_scans_unfused": {"FGOICP_ICP_DUAL": "0", "FGOICP_ICP_FUSE": "0"}, "device_loop": {"FGOICP_ICP_DEVICE": "1"},
+VARIANTS = {"default": {}, "gated_two_scans_fused": {"FGOICP_ICP_GATED": "1"}, "dual_walk_fused": {"FGOICP_ICP_DUAL": "1"}, "two_scans_unfused": {"FGOICP_ICP_GATED": "0", "FGOICP_ICP_DUAL": "0", "FGOICP_ICP_FUSE": "0"}, "device_loop": {"FGOICP_ICP_DEVICE": "1"},
             "one_stream_unfused": {"FGOICP_ICP_DUAL": "0", "FGOICP_ICP_FUSE": "0", "FGOICP_ICP_OVERLAP": "0"}}
 
 
