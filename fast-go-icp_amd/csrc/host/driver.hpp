@@ -259,9 +259,12 @@ struct Task : InnerTask {
 class WorkerPool {
 public:
     explicit WorkerPool(int nthreads) {
+        live_threads().fetch_add(nthreads, std::memory_order_relaxed);
+        nthreads_ = nthreads;
         for (int i = 1; i < nthreads; ++i) threads_.emplace_back([this, i] { worker((size_t)i); });
     }
     ~WorkerPool() {
+        live_threads().fetch_sub(nthreads_, std::memory_order_relaxed);
         {
             std::lock_guard<std::mutex> g(m_);
             stop_ = true;
@@ -303,7 +306,12 @@ private:
         uint64_t seen = 0;
         for (;;) {
             bool got = false;
-            for (int spin = 0; spin < spin_budget_; ++spin) {  // ~50-100 us of polling before going to sleep
+            // ~50-100 us of polling before going to sleep — unless the pools of this process (one per solver: N ranks of an
+            // fgoicp_multi in one process) already hold more threads than the machine has cores: spinning workers would then keep each
+            // other's solvers off the CPU, so they sleep at once
+            const int hw = (int)std::thread::hardware_concurrency();
+            const int budget = hw > 0 && live_threads().load(std::memory_order_relaxed) > hw ? 0 : spin_budget_;
+            for (int spin = 0; spin < budget; ++spin) {
                 if (generation_.load(std::memory_order_seq_cst) != seen) { got = true; break; }
 #if defined(__x86_64__) || defined(__i386__)
                 __builtin_ia32_pause();
@@ -321,6 +329,8 @@ private:
             active_.fetch_sub(1, std::memory_order_release);
         }
     }
+    static std::atomic<int>& live_threads() { static std::atomic<int> n{0}; return n; }  // pool threads alive in this process
+    int nthreads_ = 1;
     std::vector<std::thread> threads_;
     std::mutex m_;
     std::condition_variable cv_start_;
