@@ -498,10 +498,22 @@ def main():
         s = leg_summary(tr, R_gt_m, t_gt_m, f"1M-point synthetic pair, 20 % of the source replaced by uniform outliers (nt={len(tgt_m)}, ns={len(src_m)}), trim_fraction=0.2, "
                                              "mse_threshold=0.001, one step, no warm-up")
         p = tr["prof"]
-        extra = {"select_kernel": "trim_rows_kernel", "select_kernel_ms": p["select_ms"], "bounds_kernel_ms": p["kernel_ms"],
-                 "select_bytes_per_row": 2 * 4.0 * tr["ns"], "bounds_write_bytes_per_row": 4.0 * tr["ns"],
+        shift = int(os.environ.get("FGOICP_TRIM_SAMPLE", "5"))
+        sel_rows, sel_fallbacks, sel_members = tr["solver"].registration.trim_stats()
+        one_pass = shift > 0 and sel_rows > 0
+        frac_fb = sel_fallbacks / sel_rows if sel_rows else 0.0
+        samp = 1.0 / (1 << shift) if shift > 0 else 0.0
+        extra = {"select_kernel": "trim_rows_sampled_kernel" if one_pass else "trim_rows_kernel", "select_kernel_ms": p["select_ms"], "bounds_kernel_ms": p["kernel_ms"],
+                 # one pass over the row + its 1/2^shift sample (+ two more passes for a row whose bracket failed its exact check) | two passes
+                 "select_bytes_per_row": (4.0 * tr["ns"] * (1.0 + samp + 2.0 * frac_fb)) if one_pass else 2 * 4.0 * tr["ns"],
+                 "bounds_write_bytes_per_row": 4.0 * tr["ns"] * (1.0 + (samp if one_pass else 0.0)),
+                 "select_rows": sel_rows, "select_rows_done_again_in_two_passes": sel_fallbacks,
+                 "select_bracket_members_per_row": (sel_members / max(1, sel_rows - sel_fallbacks)) if one_pass else None,
                  "bnb_without_icp_GBps_algorithmic_rank0": tr["stats"]["trans_cubes"] * unit_bytes(tr["ns"]) / (tr["stats"]["seconds_total"] - tr["stats"]["seconds_icp"]) / 1e9,
-                 "model": "algorithmic bytes as for the untrimmed operator (SURVEY 8d); on top of them the trimmed path writes 4 B per point-row (e = max(d, 0)) and the "
+                 "model": "algorithmic bytes as for the untrimmed operator (SURVEY 8d); on top of them the trimmed path writes 4 B per point-row (e = max(d, 0)) plus a 1/32 "
+                          "sample of it, and the selection kernel, which runs NEXT TO the bounds kernel on a side stream, reads the sample and then the row ONCE "
+                          "(bracket from the sample, verified exactly; round 2 read every row twice)" if one_pass else
+                          "algorithmic bytes as for the untrimmed operator (SURVEY 8d); on top of them the trimmed path writes 4 B per point-row (e = max(d, 0)) and the "
                           "selection kernel, which runs NEXT TO the bounds kernel on a side stream, reads each row twice"}
         extra["limited_by"] = "closest of the three to the HBM roof: measured traffic (LUT lines + 4 B written per point-row) at ~0.7 of the peak, ~0.9 of the measured copy rate"
         s["roofline"] = roofline(tr, pmc_all.get("trimmed"), extra)

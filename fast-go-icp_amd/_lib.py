@@ -77,6 +77,7 @@ _SIGS = {
     "fgoicp_ctx_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
     "fgoicp_ctx_profile_evaluations": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "fgoicp_ctx_profile_select_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "fgoicp_ctx_trim_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]),
     "fgoicp_ctx_set_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "fgoicp_ctx_ns": (C.c_size_t, [C.c_void_p]),
     "fgoicp_ctx_nt": (C.c_size_t, [C.c_void_p]),

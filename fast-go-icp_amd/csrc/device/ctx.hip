@@ -114,7 +114,7 @@ static int tick_launch_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
         c->prof_evals += neval;  // a twin pair is two subcubes and one evaluation
     }
     launch_bounds_sorted(c->d_src, (int)c->ns, c->d_lut, c->d_lut_zp, c->lut_layout, c->geom, c->nchunk1, c->chunk_pts, dev_groups, dev_subs, neval, small ? nullptr : sl.d_sorted, sl.d_partials,
-                         c->inliers ? sl.d_evals : nullptr, c->erow, e0, e1, sl.stream, sl.win_units, um);
+                         c->inliers ? sl.d_evals : nullptr, c->erow, c->trim_samp_shift, e0, e1, sl.stream, sl.win_units, um);
     // the per-subcube sums run on the slot's side stream, so the main stream holds nothing but bounds kernels back to back
     hipStream_t fin = c->finalize_on_side ? sl.sort_stream : sl.stream;
     if (fin != sl.stream) {
@@ -124,7 +124,7 @@ static int tick_launch_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
     if (c->inliers) {  // trimmed: per row one selection of the k smallest e, both sums from it
         const int pi = e0 ? c->ev_used - 1 : -1;
         if (pi >= 0) { HIPCHK(hipEventRecord(c->ev_sel_start[pi], fin)); c->ev_has_sel[pi] = 1; }
-        launch_trim_rows(sl.d_evals, c->erow, (int)c->ns, (int)c->inliers, rows, sl.hd_row_span, sl.hd_ub, sl.hd_lb, fin);
+        launch_trim_rows(sl.d_evals, c->erow, (int)c->ns, (int)c->inliers, rows, sl.hd_row_span, sl.hd_ub, sl.hd_lb, fin, c->trim_samp_shift, c->trim_margin, c->d_trim_stat);
         if (pi >= 0) HIPCHK(hipEventRecord(c->ev_sel_stop[pi], fin));
     } else
         launch_bounds_finalize(sl.d_partials, c->nchunk1, rows, sl.hd_lb, sl.hd_ub, fin);
@@ -992,7 +992,12 @@ int ctx_set_inliers(fgoicp_ctx* c, size_t k) {
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         const size_t budget = std::max<size_t>((size_t)3 << 29, std::min<size_t>((size_t)12 << 30, free_b / 6));
+        if (const char* e = std::getenv("FGOICP_TRIM_SAMPLE")) c->trim_samp_shift = std::max(0, std::min(10, std::atoi(e)));  // tuning knob: 0 = two-pass selection, no sample
+        if (const char* e = std::getenv("FGOICP_TRIM_MARGIN")) c->trim_margin_sd = (float)std::atof(e);                          // tuning knob: bracket half-width (standard deviations)
         c->erow = (c->ns + 3) & ~(size_t)3;  // rows start 16-byte aligned
+        if (c->trim_samp_shift > 0)  // + the row's sample (trim_store); rows and samples then start on 256-byte boundaries
+            c->erow = ((c->ns + 63) & ~(size_t)63) + (((((c->ns + ((size_t)1 << c->trim_samp_shift) - 1) >> c->trim_samp_shift)) + 63) & ~(size_t)63);
+        if (!c->d_trim_stat) { HIPCHK(hipMalloc(&c->d_trim_stat, sizeof(unsigned long long) * 4)); HIPCHK(hipMemset(c->d_trim_stat, 0, sizeof(unsigned long long) * 4)); }
         size_t rows = budget / (sizeof(float) * c->erow);
         rows = std::max<size_t>(1, std::min<size_t>(rows, (size_t)c->max_subcubes));
         c->vals_rows = (int)rows;
@@ -1024,6 +1029,12 @@ int ctx_set_inliers(fgoicp_ctx* c, size_t k) {
         c->trim_ready = true;
     }
     c->inliers = k;
+    if (k && c->trim_samp_shift > 0) {
+        // the cut's rank in a sample of m points: binomial standard deviation sqrt(m p (1 - p)) if the sample were random (a systematic
+        // sample of a Hilbert-ordered surface is tighter); the bracket spans trim_margin_sd of them either side, at least 2 ranks
+        const double m = (double)((c->ns + ((size_t)1 << c->trim_samp_shift) - 1) >> c->trim_samp_shift), p = (double)k / (double)c->ns;
+        c->trim_margin = 2 + (int)std::ceil((double)c->trim_margin_sd * std::sqrt(m * p * (1.0 - p)));
+    }
     return FGOICP_OK;
 }
 
@@ -1250,7 +1261,14 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
             {
                 const char* e = std::getenv("FGOICP_SORT_STREAM");  // tuning knob: 0 = sort on the main stream
                 if (e && std::atoi(e) == 0) sl.sort_stream = c->stream;
-                else CHK(hipStreamCreateWithFlags(&sl.sort_stream, hipStreamNonBlocking));
+                else {
+                    const char* pe = std::getenv("FGOICP_SIDE_PRIORITY");  // tuning knob: -1 = the side streams (sort, finalize / selection) above the bounds kernels' stream, 1 = below
+                    const int pri = pe ? std::atoi(pe) : 0;
+                    int least = 0, greatest = 0;
+                    if (pri) CHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+                    if (pri) CHK(hipStreamCreateWithPriority(&sl.sort_stream, hipStreamNonBlocking, pri < 0 ? greatest : least));
+                    else CHK(hipStreamCreateWithFlags(&sl.sort_stream, hipStreamNonBlocking));
+                }
             }
             CHK(hipEventCreateWithFlags(&sl.sorted_ev, hipEventDisableTiming));
             CHK(hipEventCreateWithFlags(&sl.bounds_ev, hipEventDisableTiming));
@@ -1414,6 +1432,7 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
         if (sl.bounds_ev) (void)hipEventDestroy(sl.bounds_ev);
         if (sl.sort_stream && sl.sort_stream != c->stream) { (void)hipStreamSynchronize(sl.sort_stream); (void)hipStreamDestroy(sl.sort_stream); }
         (void)hipFree(sl.d_evals);
+        (void)hipFree(c->d_trim_stat); c->d_trim_stat = nullptr;
         if (sl.h_row_span) (void)hipHostFree(sl.h_row_span);
         if (sl.h_sort_err) (void)hipHostFree(sl.h_sort_err);
         (void)hipFree(sl.d_groups); (void)hipFree(sl.d_subs); (void)hipFree(sl.d_keys); (void)hipFree(sl.d_ranks); (void)hipFree(sl.d_hist);
@@ -1640,6 +1659,22 @@ int fgoicp_ctx_profile_select_ms(fgoicp_ctx* c, double* select_ms) {
         if (rc) return rc;
     }
     *select_ms = c->prof_sel_ms;
+    return FGOICP_OK;
+}
+
+int fgoicp_ctx_trim_stats(fgoicp_ctx* c, uint64_t* out3, int reset) {
+    if (!c || !out3) return FGOICP_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    if (c->d_trim_stat) {
+        unsigned long long h[4] = {0, 0, 0, 0};
+        for (auto& sl : c->slots) if (sl.inflight) { set_error("fgoicp_ctx_trim_stats: a bounds submission is in flight"); return FGOICP_ERR_INVALID_ARG; }
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(h, c->d_trim_stat, sizeof(h), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemset(c->d_trim_stat, 0, sizeof(h)));
+        for (int i = 0; i < 3; ++i) c->trim_stat_acc[i] += h[i];
+    }
+    for (int i = 0; i < 3; ++i) out3[i] = c->trim_stat_acc[i];
+    if (reset) for (auto& v : c->trim_stat_acc) v = 0;
     return FGOICP_OK;
 }
 

@@ -82,7 +82,12 @@ struct fgoicp_ctx {
     // EXTENSION: trimmed Go-ICP (sum of the `inliers` smallest per-point terms; 0 = off)
     size_t inliers = 0;
     int vals_rows = 0;                       // subcubes per window in trimmed mode (memory budget)
-    size_t erow = 0;                         // floats per row of d_evals (ns rounded up to a multiple of 4)
+    size_t erow = 0;                         // floats per row of d_evals (ns rounded up to a multiple of 4, plus the row's sample)
+    int trim_samp_shift = 5;                 // trimmed mode: every 2^shift-th point goes into the row's sample (0: none, two-pass selection)
+    float trim_margin_sd = 1.0f;             // bracket half-width in standard deviations of a binomial sample rank
+    int trim_margin = 0;                     // ... in sample ranks (set with the inlier count)
+    unsigned long long* d_trim_stat = nullptr;        // {rows selected, rows that fell back to two passes, bracket members}
+    uint64_t trim_stat_acc[3] = {0, 0, 0};
     bool trim_ready = false;                 // trimmed-mode buffers allocated
     bool trim_skip = true;                   // exact NN only for queries that can be among the k smallest (nn_prep_kernel)
     float bounds6[6] = {0, 0, 0, 0, 0, 0};   // target_bounds as passed to fgoicp_ctx_create (they place the LUT)

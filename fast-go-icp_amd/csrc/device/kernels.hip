@@ -527,13 +527,23 @@ __global__ __launch_bounds__(64) void tick_scatter_kernel(const unsigned short* 
 // on one CU at the same time and share its L1 (the XCD remap alone spreads neighbours over the 32 CUs of an XCD: they share
 // the L2 only).  NT = 1: the source points are loaded non-temporally (they stream through once per item; kept out of the L1
 // they leave it to the LUT lines).
+// Trimmed mode: the per-point e of an output row, and — samp_shift > 0 — every 2^samp_shift-th point of the (Hilbert-ordered) cloud
+// once more in a compact SAMPLE behind the row (offset: ns rounded up to 64 floats): a systematic sample of the row that the selection
+// reads first (125 KB instead of 4 MB at 1M points) to bracket the cut, so that it needs ONE pass over the row instead of two
+// (trim_rows_sampled_kernel).  The sample only steers; the selection verifies the bracket exactly and falls back if it is wrong.
+__host__ __device__ __forceinline__ size_t trim_sample_offset(int ns) { return ((size_t)ns + 63) & ~(size_t)63; }  // the sample starts on a 256-byte boundary of its row
+__device__ __forceinline__ void trim_store(float* __restrict__ evals, size_t row_base, int i, float e, int samp_shift, int ns) {
+    evals[row_base + (size_t)i] = e;
+    if (samp_shift > 0 && (i & ((1 << samp_shift) - 1)) == 0) evals[row_base + trim_sample_offset(ns) + (size_t)(i >> samp_shift)] = e;
+}
+
 typedef float v4f __attribute__((ext_vector_type(4)));
 template <int THREADS, int P, int ZPAIR, int TRIM, int WPG = 1, int NT = 0>
 __global__ __launch_bounds__(THREADS * WPG) void bounds_sorted_kernel(const float4* __restrict__ src, int ns, const float* __restrict__ lut,
                                                                 const float2* __restrict__ zp, LutGeom g,
                                                                 const TickGroup* __restrict__ groups, const TickSub* __restrict__ subs,
                                                                 const unsigned* __restrict__ sorted, int nchunk, int chunk_pts,
-                                                                double2* __restrict__ partials, float* __restrict__ evals, size_t erow, unsigned nitems) {
+                                                                double2* __restrict__ partials, float* __restrict__ evals, size_t erow, int samp_shift, unsigned nitems) {
     static_assert(THREADS % 64 == 0 && THREADS * P <= kBlock, "one pass covers THREADS * P points");
     static_assert(WPG == 1 || THREADS == 64, "several items per workgroup: one wave each");
     __shared__ double red[4 * (THREADS / 64)];
@@ -603,6 +613,7 @@ __global__ __launch_bounds__(THREADS * WPG) void bounds_sorted_kernel(const floa
                 v11[k] = *(const float2u*)(q + sz + sy);
             }
         }
+        float te0[TRIM ? P : 1], te1[TRIM ? P : 1];
 #pragma unroll
         for (int k = 0; k < P; ++k) {
             const float dsq = lut_blend(ta[k], v00[k], v10[k], v01[k], v11[k]);  // :46
@@ -612,16 +623,21 @@ __global__ __launch_bounds__(THREADS * WPG) void bounds_sorted_kernel(const floa
             if (TRIM) {
                 // trimmed Go-ICP: both bounds are non-decreasing functions of e = max(d, 0) (ub = e*e, lb = max(e - r_t, 0)^2 —
                 // the same fp32 values as :54-58), so ONE row of e per variant carries both selections (trim_rows_kernel)
-                if (valid) {
-                    if (dual) {
-                        evals[(size_t)sb.out0 * erow + i] = d > 0.0f ? d : 0.0f;
-                        d -= 2.0f * p[k].w * gr.sin_half;
-                        evals[(size_t)sb.out1 * erow + i] = d > 0.0f ? d : 0.0f;
-                    } else {
-                        if (!gr.fix_rot) d -= 2.0f * p[k].w * gr.sin_half;
-                        evals[(size_t)sb.out0 * erow + i] = d > 0.0f ? d : 0.0f;
-                    }
+                float e0, e1 = 0.0f;
+                if (dual) {
+                    e0 = d > 0.0f ? d : 0.0f;
+                    d -= 2.0f * p[k].w * gr.sin_half;
+                    e1 = d > 0.0f ? d : 0.0f;
+                } else {
+                    if (!gr.fix_rot) d -= 2.0f * p[k].w * gr.sin_half;
+                    e0 = d > 0.0f ? d : 0.0f;
                 }
+                if (valid) {
+                    evals[(size_t)sb.out0 * erow + i] = e0;
+                    if (dual) evals[(size_t)sb.out1 * erow + i] = e1;
+                }
+                te0[k] = e0;
+                te1[k] = e1;
                 continue;
             }
             if (dual) {  // wave-uniform
@@ -644,6 +660,22 @@ __global__ __launch_bounds__(THREADS * WPG) void bounds_sorted_kernel(const floa
             const float lbv = l > 0.0f ? l * l : 0.0f;                            // :58
             acc[0] += valid ? (double)ubv : 0.0;
             acc[1] += valid ? (double)lbv : 0.0;
+        }
+        if (TRIM && samp_shift > 0) {
+            // the row's sample (see trim_store): every 2^samp_shift-th point once more behind the row.  i = first + k * THREADS and
+            // first - tix is a multiple of THREADS * P, so ONE test per pass finds the lanes that can hold a sample point for some k
+            const int mask = (1 << samp_shift) - 1;
+            if (((int)tix & mask & (THREADS - 1)) == 0) {
+                const size_t off = trim_sample_offset(ns);
+#pragma unroll
+                for (int k = 0; k < P; ++k) {
+                    const int i = first + k * THREADS;
+                    if (i < ns && (i & mask) == 0) {
+                        evals[(size_t)sb.out0 * erow + off + (size_t)(i >> samp_shift)] = te0[k];
+                        if (dual) evals[(size_t)sb.out1 * erow + off + (size_t)(i >> samp_shift)] = te1[k];
+                    }
+                }
+            }
         }
     }
     if (!TRIM && WPG > 1) {  // one wave per item, several items per workgroup: the wave tree only (= block_sum with one wave), no barrier
@@ -689,7 +721,7 @@ __global__ __launch_bounds__(THREADS * WPG) void bounds_sorted_kernel(const floa
 template <int ZPAIR /* 0 plain, 1 z-pair, 2 yz-quad (lane-paired) */, int TRIM, int M>
 __global__ __launch_bounds__(64) void bounds_units_kernel(const float4* __restrict__ src, int ns, const float* __restrict__ lut, const float2* __restrict__ zp, LutGeom g,
                                                           const TickGroup* __restrict__ groups, const TickSub* __restrict__ subs, const unsigned* __restrict__ sorted,
-                                                          int nchunk, int chunk_pts, double2* __restrict__ partials, float* __restrict__ evals, size_t erow,
+                                                          int nchunk, int chunk_pts, double2* __restrict__ partials, float* __restrict__ evals, size_t erow, int samp_shift,
                                                           unsigned nitems, int nunits) {
     constexpr int P = 4;
     const unsigned slot = xcd_remap(blockIdx.x, gridDim.x);
@@ -767,12 +799,12 @@ __global__ __launch_bounds__(64) void bounds_units_kernel(const float4* __restri
                 if (TRIM) {
                     if (valid) {
                         if (dual) {
-                            evals[(size_t)sb.out0 * erow + i] = d > 0.0f ? d : 0.0f;
+                            trim_store(evals, (size_t)sb.out0 * erow, i, d > 0.0f ? d : 0.0f, samp_shift, ns);
                             d -= 2.0f * p[k].w * gr.sin_half;
-                            evals[(size_t)sb.out1 * erow + i] = d > 0.0f ? d : 0.0f;
+                            trim_store(evals, (size_t)sb.out1 * erow, i, d > 0.0f ? d : 0.0f, samp_shift, ns);
                         } else {
                             if (!gr.fix_rot) d -= 2.0f * p[k].w * gr.sin_half;
-                            evals[(size_t)sb.out0 * erow + i] = d > 0.0f ? d : 0.0f;
+                            trim_store(evals, (size_t)sb.out0 * erow, i, d > 0.0f ? d : 0.0f, samp_shift, ns);
                         }
                     }
                     continue;
@@ -841,7 +873,7 @@ __device__ __forceinline__ int wave_max_i(int v) {
 template <int TRIM, int ROWS>
 __global__ __launch_bounds__(64) void bounds_lds_kernel(const float4* __restrict__ src, int ns, const float* __restrict__ lut, LutGeom g,
                                                         const TickGroup* __restrict__ groups, const TickSub* __restrict__ subs, const unsigned* __restrict__ sorted,
-                                                        int nchunk, int chunk_pts, double2* __restrict__ partials, float* __restrict__ evals, size_t erow,
+                                                        int nchunk, int chunk_pts, double2* __restrict__ partials, float* __restrict__ evals, size_t erow, int samp_shift,
                                                         unsigned nitems, unsigned* __restrict__ stat /* optional: [0] staged passes, [1] all passes */) {
     constexpr int P = 4;
     __shared__ float tile[ROWS * 16];
@@ -925,12 +957,12 @@ __global__ __launch_bounds__(64) void bounds_lds_kernel(const float4* __restrict
             if (TRIM) {
                 if (valid) {
                     if (dual) {
-                        evals[(size_t)sb.out0 * erow + i] = d > 0.0f ? d : 0.0f;
+                        trim_store(evals, (size_t)sb.out0 * erow, i, d > 0.0f ? d : 0.0f, samp_shift, ns);
                         d -= 2.0f * p[k].w * gr.sin_half;
-                        evals[(size_t)sb.out1 * erow + i] = d > 0.0f ? d : 0.0f;
+                        trim_store(evals, (size_t)sb.out1 * erow, i, d > 0.0f ? d : 0.0f, samp_shift, ns);
                     } else {
                         if (!gr.fix_rot) d -= 2.0f * p[k].w * gr.sin_half;
-                        evals[(size_t)sb.out0 * erow + i] = d > 0.0f ? d : 0.0f;
+                        trim_store(evals, (size_t)sb.out0 * erow, i, d > 0.0f ? d : 0.0f, samp_shift, ns);
                     }
                 }
                 continue;
@@ -1045,18 +1077,13 @@ __device__ __forceinline__ void trim_for_each(const float* __restrict__ v, int n
     if (t < n) f(v[t]);
 }
 
-__global__ __launch_bounds__(kTrimThreads) void trim_rows_kernel(const float* __restrict__ evals, size_t erow, int n, int k, const float* __restrict__ row_span,
-                                                                 float* __restrict__ out_ub, float* __restrict__ out_lb) {
-    __shared__ unsigned hist[kTrimBins];
-    __shared__ unsigned list[kTrimCap];
-    __shared__ unsigned wsum[kTrimThreads / 64];
-    __shared__ unsigned s_pick[2];
-    __shared__ unsigned s_count;
-    __shared__ double red[2 * (kTrimThreads / 64)];
+template <int CAP>
+__device__ __forceinline__ void trim_row_two_pass(const float* __restrict__ v, int n, int k, float rt, unsigned* hist /* kTrimBins */, unsigned* list /* CAP */,
+                                                  unsigned* wsum, unsigned* s_pick, unsigned* s_count_p, double* red, float* __restrict__ out_ub,
+                                                  float* __restrict__ out_lb, int row) {
+    static_assert((CAP & (CAP - 1)) == 0, "the bitonic sort pads to a power of two inside the buffer");
+    unsigned& s_count = *s_count_p;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row = blockIdx.x;
-    const float* v = evals + (size_t)row * erow;
-    const float rt = kSqrt3 * row_span[row];  // registration.cu:33
 
     // pass 1: zeros counted, the rest into the level-0 histogram
     for (int b = tid; b < kTrimBins; b += kTrimThreads) hist[b] = 0;
@@ -1085,7 +1112,7 @@ __global__ __launch_bounds__(kTrimThreads) void trim_rows_kernel(const float* __
     unsigned long long b = bin == kTrimBins - 1 ? 0x100000000ull : (unsigned long long)kTrimLo + ((unsigned long long)(bin + 1) << 14);
     __syncthreads();
     // refinement (rare): more members than the gather buffer holds
-    while (cnt > (unsigned)kTrimCap && b - a > 1ull) {
+    while (cnt > (unsigned)CAP && b - a > 1ull) {
         int sh = 0;
         while (((b - a - 1ull) >> sh) >= (unsigned long long)kTrimBins) ++sh;
         for (int q = tid; q < kTrimBins; q += kTrimThreads) hist[q] = 0;
@@ -1107,7 +1134,7 @@ __global__ __launch_bounds__(kTrimThreads) void trim_rows_kernel(const float* __
         __syncthreads();
     }
     // pass 2: sums below the range, members of the range into LDS
-    const bool gather = cnt <= (unsigned)kTrimCap;
+    const bool gather = cnt <= (unsigned)CAP;
     if (tid == 0) s_count = 0;
     __syncthreads();
     double acc[2] = {0.0, 0.0};
@@ -1158,6 +1185,225 @@ __global__ __launch_bounds__(kTrimThreads) void trim_rows_kernel(const float* __
             const float l = x - rt;
             extra = (double)m * (double)(tid == 0 ? x * x : (l > 0.0f ? l * l : 0.0f));
         }
+        (tid == 0 ? out_ub : out_lb)[row] = (float)(r + extra);
+    }
+}
+
+
+__global__ __launch_bounds__(kTrimThreads) void trim_rows_kernel(const float* __restrict__ evals, size_t erow, int n, int k, const float* __restrict__ row_span,
+                                                                 float* __restrict__ out_ub, float* __restrict__ out_lb) {
+    __shared__ unsigned hist[kTrimBins];
+    __shared__ unsigned list[kTrimCap];
+    __shared__ unsigned wsum[kTrimThreads / 64];
+    __shared__ unsigned s_pick[2];
+    __shared__ unsigned s_count;
+    __shared__ double red[2 * (kTrimThreads / 64)];
+    const int row = blockIdx.x;
+    trim_row_two_pass<kTrimCap>(evals + (size_t)row * erow, n, k, kSqrt3 * row_span[row] /* registration.cu:33 */, hist, list, wsum, s_pick, &s_count, red, out_ub, out_lb, row);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One pass per row (round 3).  trim_rows_kernel reads a row twice (histogram, then sums) = 8 B per point-row on top of the 4 B the
+// bounds kernel wrote.  Here the bounds kernel also leaves a systematic SAMPLE of the row behind it (trim_store: every 2^samp_shift-th
+// point of the Hilbert-ordered cloud, 1/32 of the row), and the selection
+//   (0) histograms the sample (level-0 bins) and takes the values at sample ranks r -+ margin around the cut's expected rank as a
+//       BRACKET [a, bmax] of bit patterns;
+//   (1) streams the row ONCE: zeros counted, everything below a summed (fp64, per thread) and counted, the members of the bracket
+//       compacted into LDS — per wave in a segment of its own, in the order (load slot, lane), so the list does not depend on timing;
+//   (2) verifies the bracket EXACTLY: with z zeros and c elements in (0, a), the k-th smallest lies in the bracket iff
+//       1 <= k - z - c <= members, and no segment overflowed.  If not (a poor sample, a wide bracket), the row is done again by
+//       the two-pass algorithm — the sample steers, it never decides;
+//   (3) radix-selects the (k - z - c)-th smallest member in LDS (8 bits per round over the bracket's width) and adds the members
+//       below it in list order plus the needed copies of it.
+// Every sum has a fixed order (thread-strided row, own segment lane-strided, wave tree, waves in order): bit-reproducible.  The
+// value can differ from trim_rows_kernel's in the last bits of the fp64 sum (other grouping of the same terms): tests compare both
+// with the oracle at 1e-6.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTrimSegCap = 960;                       // members per wave segment: 16 x 960 x 4 B = 60 KB of LDS
+constexpr int kTrimFallbackCap = 4096;                 // gather buffer of the in-kernel fallback (hist 32 KB + list 16 KB share that LDS)
+
+__global__ __launch_bounds__(kTrimThreads) void trim_rows_sampled_kernel(const float* __restrict__ evals, size_t erow, int n, int k, int samp_shift, int margin,
+                                                                         const float* __restrict__ row_span, float* __restrict__ out_ub, float* __restrict__ out_lb,
+                                                                         unsigned long long* __restrict__ stat /* optional: [0] rows, [1] fallbacks, [2] members */) {
+    constexpr int kWaves = kTrimThreads / 64;
+    __shared__ unsigned buf[kWaves * kTrimSegCap];  // sample histogram (8192 bins), then the member segments; fallback: hist + list
+    static_assert(kWaves * kTrimSegCap >= kTrimBins + kTrimFallbackCap, "the fallback's histogram and gather buffer live in the same LDS");
+    __shared__ unsigned h256[256];
+    __shared__ unsigned wsum[kWaves];
+    __shared__ unsigned wcount[kWaves];
+    __shared__ unsigned s_pick[2];
+    __shared__ unsigned s_count;
+    __shared__ unsigned s_tot[4];
+    __shared__ double red[2 * kWaves];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = blockIdx.x;
+    const float* v = evals + (size_t)row * erow;
+    const float rt = kSqrt3 * row_span[row];  // registration.cu:33
+    const int nsamp = (n + (1 << samp_shift) - 1) >> samp_shift;
+    const float* sv = v + trim_sample_offset(n);
+
+    // (0) the sample: zeros counted, the rest into the level-0 histogram
+    unsigned* hist = buf;
+    for (int b = tid; b < kTrimBins; b += kTrimThreads) hist[b] = 0;
+    __syncthreads();
+    unsigned nzs = 0;
+    for (int j = tid; j < nsamp; j += kTrimThreads) {
+        const unsigned u = __float_as_uint(sv[j]);
+        if (u == 0u) ++nzs; else atomicAdd(&hist[trim_bin0(u)], 1u);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nzs += __shfl_xor(nzs, off, 64);
+    if (lane == 0) wsum[wave] = nzs;
+    __syncthreads();
+    unsigned zeros_s = 0;
+    for (int w = 0; w < kWaves; ++w) zeros_s += wsum[w];
+    __syncthreads();
+    const unsigned pos_s = (unsigned)nsamp - zeros_s;  // positive sample values
+    unsigned a = 1u, bmax = 0xFFFFFFFFu;               // the bracket, inclusive, in bit patterns (a >= 1: zeros are never members)
+    if (pos_s > 0u) {
+        const long long r = ((long long)k * nsamp + n - 1) / n;  // the cut's expected rank in the sample
+        long long lo_p = r - margin - (long long)zeros_s, hi_p = r + margin - (long long)zeros_s;
+        if (hi_p < 1) hi_p = 1;
+        unsigned bin, before;
+        if (lo_p >= 1) {
+            if (lo_p > (long long)pos_s) lo_p = pos_s;
+            trim_pick(hist, (unsigned)lo_p, wsum, s_pick, bin, before);
+            a = bin == 0 ? 1u : kTrimLo + (bin << 14);
+        }
+        if (hi_p <= (long long)pos_s) {
+            trim_pick(hist, (unsigned)hi_p, wsum, s_pick, bin, before);
+            if (bin != kTrimBins - 1) bmax = kTrimLo + ((bin + 1u) << 14) - 1u;
+        }
+    }
+    __syncthreads();  // the histogram is dead: its LDS becomes the segments
+
+    // (1) one pass over the row
+    unsigned* seg = buf + wave * kTrimSegCap;
+    unsigned nz = 0, nbelow = 0, wcnt = 0;  // wcnt: wave-uniform
+    double acc[2] = {0.0, 0.0};
+    auto below_a = [&](float x, unsigned u, bool valid) {
+        const bool zero = valid && u == 0u, low = valid && u != 0u && u < a;
+        nz += zero ? 1u : 0u;  // branch-free counters (as `if / else if` the compiler turned the two into a scratch array indexed by the case)
+        nbelow += low ? 1u : 0u;
+        if (low) {
+            const float l = x - rt;
+            acc[0] += (double)(x * x);
+            acc[1] += (double)(l > 0.0f ? l * l : 0.0f);
+        }
+    };
+    auto member = [&](unsigned u, bool in) {  // wave-level compaction in the order (call, lane)
+        const unsigned long long m = __ballot(in);
+        if (in) {
+            const unsigned pos = wcnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (pos < (unsigned)kTrimSegCap) seg[pos] = u;
+        }
+        wcnt += (unsigned)__popcll(m);
+    };
+    auto visit4 = [&](const float4& p, bool valid) {
+        const unsigned u0 = __float_as_uint(p.x), u1 = __float_as_uint(p.y), u2 = __float_as_uint(p.z), u3 = __float_as_uint(p.w);
+        below_a(p.x, u0, valid); below_a(p.y, u1, valid); below_a(p.z, u2, valid); below_a(p.w, u3, valid);
+        const bool i0 = valid && u0 >= a && u0 <= bmax, i1 = valid && u1 >= a && u1 <= bmax, i2 = valid && u2 >= a && u2 <= bmax, i3 = valid && u3 >= a && u3 <= bmax;
+        if (__ballot(i0 | i1 | i2 | i3)) {  // rare: a few per cent of the row lie in the bracket
+            member(u0, i0); member(u1, i1); member(u2, i2); member(u3, i3);
+        }
+    };
+    {
+        const int n4 = n >> 2;
+        const float4* v4 = reinterpret_cast<const float4*>(v);
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int base = 0; base < n4; base += 4 * kTrimThreads) {  // every lane of a wave runs the same trips (the ballots need that)
+            const int i0 = base + tid, i1 = i0 + kTrimThreads, i2 = i1 + kTrimThreads, i3 = i2 + kTrimThreads;
+            const bool ok0 = i0 < n4, ok1 = i1 < n4, ok2 = i2 < n4, ok3 = i3 < n4;
+            const float4 p0 = ok0 ? v4[i0] : zero4, p1 = ok1 ? v4[i1] : zero4, p2 = ok2 ? v4[i2] : zero4, p3 = ok3 ? v4[i3] : zero4;  // four 16-byte loads in flight per lane
+            visit4(p0, ok0); visit4(p1, ok1); visit4(p2, ok2); visit4(p3, ok3);
+        }
+        const int t = (n4 << 2) + tid;
+        if (wave == 0) {  // the row's last n % 4 elements
+            const bool ok = t < n;
+            const float x = ok ? v[t] : 0.f;
+            const unsigned u = __float_as_uint(x);
+            below_a(x, u, ok);
+            member(u, ok && u >= a && u <= bmax);
+        }
+    }
+    // totals
+    unsigned t0 = nz, t1 = nbelow;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { t0 += __shfl_xor(t0, off, 64); t1 += __shfl_xor(t1, off, 64); }
+    if (lane == 0) { wsum[wave] = t0; wcount[wave] = wcnt; h256[wave] = t1; }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned z = 0, c = 0, mem = 0, over = 0;
+        for (int w = 0; w < kWaves; ++w) { z += wsum[w]; c += h256[w]; mem += wcount[w]; over |= wcount[w] > (unsigned)kTrimSegCap ? 1u : 0u; }
+        s_tot[0] = z; s_tot[1] = c; s_tot[2] = mem; s_tot[3] = over;
+    }
+    __syncthreads();
+    const unsigned zeros = s_tot[0], below = s_tot[0] + s_tot[1], members = s_tot[2], over = s_tot[3];
+    const unsigned mycnt = wcount[wave] < (unsigned)kTrimSegCap ? wcount[wave] : (unsigned)kTrimSegCap;
+    __syncthreads();
+    if ((unsigned)k <= zeros) {  // the k smallest terms are all zero
+        if (tid == 0) { out_ub[row] = 0.0f; out_lb[row] = 0.0f; if (stat) atomicAdd(&stat[0], 1ull); }
+        return;
+    }
+    // (2) the exact check of the bracket
+    if (over || (unsigned)k <= below || (unsigned)k - below > members) {
+        if (tid == 0 && stat) { atomicAdd(&stat[0], 1ull); atomicAdd(&stat[1], 1ull); }
+        trim_row_two_pass<kTrimFallbackCap>(v, n, k, rt, buf, buf + kTrimBins, wsum, s_pick, &s_count, red, out_ub, out_lb, row);
+        return;
+    }
+    if (tid == 0 && stat) { atomicAdd(&stat[0], 1ull); atomicAdd(&stat[2], (unsigned long long)members); }
+    // (3) the need-th smallest member: radix select on w = u - a, 8 bits per round
+    unsigned need = (unsigned)k - below;  // 1 <= need <= members
+    const unsigned width = bmax - a;      // w in [0, width]
+    int nbits = 32 - __clz(width | 1u);
+    int shift = ((nbits + 7) / 8) * 8 - 8;
+    unsigned prefix = 0;                  // the bits of the answer above shift + 8
+    for (; shift >= 0; shift -= 8) {
+        if (tid < 256) h256[tid] = 0;
+        __syncthreads();
+        for (unsigned j = lane; j < mycnt; j += 64) {
+            const unsigned w = seg[j] - a;
+            if (shift + 8 >= 32 || (w >> (shift + 8)) == prefix) atomicAdd(&h256[(w >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        unsigned mine = 0, incl = 0;
+        if (tid < 256) {  // waves 0..3: which digit holds rank `need`
+            mine = h256[tid];
+            incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned u = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += u;
+            }
+            if (lane == 63) wsum[wave] = incl;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            unsigned base = 0;
+            for (int w = 0; w < wave; ++w) base += wsum[w];
+            const unsigned excl = base + incl - mine;
+            if (excl < need && need <= excl + mine) { s_pick[0] = (unsigned)tid; s_pick[1] = excl; }  // exactly one thread
+        }
+        __syncthreads();
+        prefix = (prefix << 8) | s_pick[0];
+        need -= s_pick[1];
+        __syncthreads();
+    }
+    const unsigned wk = prefix;  // w of the need-th smallest member; `need` is now its rank among its copies: that many copies count
+    for (unsigned j = lane; j < mycnt; j += 64) {
+        const unsigned u = seg[j];
+        if (u - a < wk) {
+            const float x = __uint_as_float(u);
+            const float l = x - rt;
+            acc[0] += (double)(x * x);
+            acc[1] += (double)(l > 0.0f ? l * l : 0.0f);
+        }
+    }
+    const double r = block_sum<2, kWaves>(acc, red);
+    if (tid < 2) {
+        const float x = __uint_as_float(a + wk);
+        const float l = x - rt;
+        const double extra = (double)need * (double)(tid == 0 ? x * x : (l > 0.0f ? l * l : 0.0f));
         (tid == 0 ? out_ub : out_lb)[row] = (float)(r + extra);
     }
 }
@@ -2576,7 +2822,7 @@ void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, con
 }
 
 void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* zp, int layout, const LutGeom& g, int nchunk, int chunk_pts,
-                          const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials, float* evals, size_t erow,
+                          const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials, float* evals, size_t erow, int samp_shift,
                           hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s, int nunits, int unit_m) {
     const size_t nitems = (size_t)(nsub - nunits * (unit_m - 1)) * nchunk;
     const int lds_rows = [] { const char* e = std::getenv("FGOICP_LDS_TILES"); return e ? std::atoi(e) : 0; }();  // tuning knob / A-B (read per launch: tests toggle it): 128 or 192 rows of 16 floats per wave
@@ -2585,11 +2831,11 @@ void launch_bounds_sorted(const float4* src, int ns, const float* lut, const flo
         if (ev_start) (void)hipEventRecord(ev_start, s);
         const dim3 lgrid((unsigned)nitems);
         if (evals) {
-            if (lds_rows == 128) hipLaunchKernelGGL((bounds_lds_kernel<1, 128>), lgrid, dim3(64), 0, s, src, ns, lut, g, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, (unsigned)nitems, d_stat);
-            else hipLaunchKernelGGL((bounds_lds_kernel<1, 192>), lgrid, dim3(64), 0, s, src, ns, lut, g, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, (unsigned)nitems, d_stat);
+            if (lds_rows == 128) hipLaunchKernelGGL((bounds_lds_kernel<1, 128>), lgrid, dim3(64), 0, s, src, ns, lut, g, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, d_stat);
+            else hipLaunchKernelGGL((bounds_lds_kernel<1, 192>), lgrid, dim3(64), 0, s, src, ns, lut, g, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, d_stat);
         } else {
-            if (lds_rows == 128) hipLaunchKernelGGL((bounds_lds_kernel<0, 128>), lgrid, dim3(64), 0, s, src, ns, lut, g, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, (unsigned)nitems, d_stat);
-            else hipLaunchKernelGGL((bounds_lds_kernel<0, 192>), lgrid, dim3(64), 0, s, src, ns, lut, g, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, (unsigned)nitems, d_stat);
+            if (lds_rows == 128) hipLaunchKernelGGL((bounds_lds_kernel<0, 128>), lgrid, dim3(64), 0, s, src, ns, lut, g, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, d_stat);
+            else hipLaunchKernelGGL((bounds_lds_kernel<0, 192>), lgrid, dim3(64), 0, s, src, ns, lut, g, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, d_stat);
         }
         if (ev_stop) (void)hipEventRecord(ev_stop, s);
         if (d_stat) {
@@ -2607,7 +2853,7 @@ void launch_bounds_sorted(const float4* src, int ns, const float* lut, const flo
         if (ev_start) (void)hipEventRecord(ev_start, s);
         const dim3 ugrid((unsigned)nitems);
 #define FGOICP_LAUNCH_UNITS(Z, TR, M) \
-        hipLaunchKernelGGL((bounds_units_kernel<Z, TR, M>), ugrid, dim3(64), 0, s, src, ns, lut, zp, g, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, (unsigned)nitems, nunits)
+        hipLaunchKernelGGL((bounds_units_kernel<Z, TR, M>), ugrid, dim3(64), 0, s, src, ns, lut, zp, g, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, nunits)
         const int z = (zp && layout == 2) ? 2 : zp ? 1 : 0;
         if (evals) {
             if (unit_m == 8) { if (z == 2) FGOICP_LAUNCH_UNITS(2, 1, 8); else if (z == 1) FGOICP_LAUNCH_UNITS(1, 1, 8); else FGOICP_LAUNCH_UNITS(0, 1, 8); }
@@ -2629,9 +2875,9 @@ void launch_bounds_sorted(const float4* src, int ns, const float* lut, const flo
     static const int nt_src = [] { const char* e = std::getenv("FGOICP_NT_SOURCE"); return e ? std::atoi(e) : 0; }();   // tuning knob: non-temporal source loads
     static const unsigned lds_pad = [] { const char* e = std::getenv("FGOICP_LDS_PAD"); return e ? (unsigned)std::atoi(e) : 0u; }();  // tuning knob: unused dynamic LDS per workgroup = fewer resident waves per CU
 #define FGOICP_LAUNCH_SORTED(T, PP, Z, TR) \
-    hipLaunchKernelGGL((bounds_sorted_kernel<T, PP, Z, TR>), grid, dim3(T), lds_pad, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, chunk_pts, partials, evals, erow, (unsigned)nitems)
+    hipLaunchKernelGGL((bounds_sorted_kernel<T, PP, Z, TR>), grid, dim3(T), lds_pad, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems)
 #define FGOICP_LAUNCH_WPG(Z, W, N) \
-    hipLaunchKernelGGL((bounds_sorted_kernel<64, 4, Z, 0, W, N>), dim3((unsigned)((nitems + W - 1) / W)), dim3(64 * W), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, chunk_pts, partials, evals, erow, (unsigned)nitems)
+    hipLaunchKernelGGL((bounds_sorted_kernel<64, 4, Z, 0, W, N>), dim3((unsigned)((nitems + W - 1) / W)), dim3(64 * W), 0, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems)
     if (!evals && variant == 2 && (wpg > 1 || nt_src)) {  // experimental variants of the default 64 x 4 kernel
         const int z = (zp && layout == 2) ? 3 : zp ? 1 : 0;
         bool done = true;
@@ -2845,8 +3091,12 @@ void launch_icp_step(IcpDevState* st, const double* bp_cov, int nb_cov, const do
 }
 
 // trimmed bounds of a window: out_ub[row] / out_lb[row] from the row's k smallest e (trim_rows_kernel)
-void launch_trim_rows(const float* evals, size_t erow, int n, int k, int rows, const float* row_span, float* out_ub, float* out_lb, hipStream_t s) {
-    hipLaunchKernelGGL(trim_rows_kernel, dim3(rows), dim3(kTrimThreads), 0, s, evals, erow, n, k, row_span, out_ub, out_lb);
+void launch_trim_rows(const float* evals, size_t erow, int n, int k, int rows, const float* row_span, float* out_ub, float* out_lb, hipStream_t s,
+                      int samp_shift, int margin, unsigned long long* stat) {
+    if (samp_shift > 0)  // one pass per row, steered by the sample the bounds kernel left behind each row (trim_store)
+        hipLaunchKernelGGL(trim_rows_sampled_kernel, dim3(rows), dim3(kTrimThreads), 0, s, evals, erow, n, k, samp_shift, margin, row_span, out_ub, out_lb, stat);
+    else
+        hipLaunchKernelGGL(trim_rows_kernel, dim3(rows), dim3(kTrimThreads), 0, s, evals, erow, n, k, row_span, out_ub, out_lb);
 }
 
 // ONE row: out[0] = sum of the k smallest of vals[0..n), sel_info = {bits of the k-th smallest, copies of it among the k}

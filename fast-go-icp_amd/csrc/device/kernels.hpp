@@ -73,10 +73,14 @@ void launch_tick_upload(const TickGroup* hd_groups, TickGroup* d_groups, int ngr
 void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* packed_or_null, int layout /* 1 z-pair, 2 yz-quad */, const LutGeom& g, int nchunk,
                           int chunk_pts /* 256 .. 2048 points per item */, const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials,
                           float* evals_or_null /* trimmed mode: row r = the per-point e = max(d, 0) of output row r */, size_t erow /* floats per row, multiple of 4 */,
+                          int samp_shift /* trimmed mode: > 0 = every 2^samp_shift-th point once more in the sample behind the row (offset: ns rounded up to 64 floats) */,
                           hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s, int nunits = 0, int unit_m = 1);
 // EXTENSION (trimmed Go-ICP): per output row the sums of ub = e*e and lb = max(e - sqrt3*span, 0)^2 over the row's k smallest e
 // (one exact selection per row, kernels.hip trim_rows_kernel); row_span[r] = translation span of row r (device-readable)
-void launch_trim_rows(const float* evals, size_t erow, int n, int k, int rows, const float* row_span, float* out_ub, float* out_lb, hipStream_t s);
+// samp_shift > 0: one pass per row (trim_rows_sampled_kernel) — the bracket of the cut comes from the row's sample, `margin` sample ranks
+// either side of the expected rank, verified exactly, two-pass fallback inside the kernel; stat (optional): {rows, fallbacks, members}
+void launch_trim_rows(const float* evals, size_t erow, int n, int k, int rows, const float* row_span, float* out_ub, float* out_lb, hipStream_t s,
+                      int samp_shift = 0, int margin = 0, unsigned long long* stat = nullptr);
 // one row: out[0] (optional) = sum of the k smallest of vals[0..n), sel_info (optional) = {bits of the k-th smallest, copies of it needed}
 void launch_trim_select(const float* vals, int n, int k, float* out, uint32_t* sel_info,
                         uint32_t* wide_scratch /* 64 KiB, optional: rows of n >= 32768 are then selected by the whole device */, hipStream_t s);

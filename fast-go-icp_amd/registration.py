@@ -178,6 +178,12 @@ class Registration:
         _lib.check(self._lib.fgoicp_ctx_sort_fallbacks(self._h, C.byref(a), C.byref(b)), "fgoicp_ctx_sort_fallbacks")
         return a.value, b.value
 
+    def trim_stats(self, reset=False):
+        """trimmed bounds: (rows selected, rows done again in two passes after the sampled bracket failed its check, bracket members)"""
+        out = (C.c_uint64 * 3)()
+        _lib.check(self._lib.fgoicp_ctx_trim_stats(self._h, out, int(reset)), "fgoicp_ctx_trim_stats")
+        return int(out[0]), int(out[1]), int(out[2])
+
     def set_profile(self, enabled):
         _lib.check(self._lib.fgoicp_ctx_set_profile(self._h, int(bool(enabled))), "fgoicp_ctx_set_profile")
 

@@ -175,6 +175,10 @@ int fgoicp_ctx_profile_evaluations(fgoicp_ctx* ctx, uint64_t* evaluations);
 /* Trimmed mode: accumulated duration of the selection kernel (one launch per window, next to the bounds kernel) since the last
  * reset by fgoicp_ctx_profile — read it before that call. */
 int fgoicp_ctx_profile_select_ms(fgoicp_ctx* ctx, double* select_ms);
+/* Trimmed mode (EXTENSION): how the per-row selections of the bounds went since the last reset — out3 = {rows selected, rows whose
+ * sampled bracket failed its exact check and that were done again in two passes, bracket members gathered}.  No submission may
+ * be in flight. */
+int fgoicp_ctx_trim_stats(fgoicp_ctx* ctx, uint64_t* out3, int reset);
 /* Turns the HIP-event bracketing on or off at run time (events are created on first use). */
 int fgoicp_ctx_set_profile(fgoicp_ctx* ctx, int enabled);
 size_t fgoicp_ctx_ns(const fgoicp_ctx* ctx);

@@ -100,6 +100,7 @@ def test_invalid_arguments_are_refused_before_any_device_work(fg):
     assert lib.fgoicp_bounds_point_distances(None, None, 0.0, None, 0, None) == 1
     assert lib.fgoicp_ctx_sort_fallbacks(None, None, None) == 1
     assert lib.fgoicp_ctx_profile_select_ms(None, None) == 1
+    assert lib.fgoicp_ctx_trim_stats(None, None, 0) == 1
     assert lib.fgoicp_icp_batch(None, 1, None, None, 10, 0.1, None, None, None, None) == 1
     assert lib.fgoicp_bounds_collect(None, 0, None, None) == 1
     assert lib.fgoicp_rccl_unique_id(None) == 1

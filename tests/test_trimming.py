@@ -241,11 +241,14 @@ def test_hip_trimmed_bounds_across_several_windows(fg, oracle, tiny_case, gpu_re
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sample", ["5", "0"])
 @pytest.mark.parametrize("shape", ["cluster", "identical", "mostly_zero"])
-def test_hip_trimmed_selection_paths(fg, oracle, gpu_required, shape):
-    """The rare paths of trim_rows_kernel against the oracle: a histogram bin with more members than the gather buffer holds
+def test_hip_trimmed_selection_paths(fg, oracle, gpu_required, shape, sample, monkeypatch):
+    """The rare paths of the per-row selection against the oracle: a histogram bin with more members than the gather buffer holds
     (20 000 source points in a 1e-5 cluster: distinct values within one 1/512-octave bin -> refinement passes), all values equal
-    (identical points: the cut's range shrinks to one bit pattern, no gather), and rows whose k smallest are all zero."""
+    (identical points: the cut's range shrinks to one bit pattern, no gather), and rows whose k smallest are all zero.  Under the
+    one-pass selection (sample = 5) the first two are rows whose bracket overflows the member segments: the in-kernel fallback."""
+    monkeypatch.setenv("FGOICP_TRIM_SAMPLE", sample)
     rng = np.random.default_rng(31)
     tgt = rng.uniform(-0.8, 0.8, (400, 3)).astype(f32)
     bounds = np.array([[tgt[:, a].min(), tgt[:, a].max()] for a in range(3)], f32)
@@ -267,7 +270,66 @@ def test_hip_trimmed_selection_paths(fg, oracle, gpu_required, shape):
             assert np.allclose(ub, ubo, rtol=1e-6, atol=1e-12) and np.allclose(lb, lbo, rtol=1e-6, atol=1e-6 * max(float(ubo.max()), 1e-12)), (shape, k, fix)
     if shape == "mostly_zero":
         assert (hip.point_distances(rn.q.R, rn.span, tn[0], False) == 0).mean() > 0.3
+    rows, fallbacks, members = hip.trim_stats()
+    if sample == "0":
+        assert rows == 0  # the two-pass kernel keeps no statistics
+    else:
+        assert rows >= 3 * 2 * len(tn) and (fallbacks > 0 if shape in ("cluster", "identical") else True)  # + the row point_distances submitted
     hip.close()
+
+
+@pytest.mark.gpu
+def test_hip_one_pass_selection_equals_the_two_pass_selection(fg, oracle, gpu_required, monkeypatch):
+    """The sampled one-pass selection (trim_rows_sampled_kernel: bracket from the row's 1/32 sample, exact check, LDS radix select)
+    against the two-pass kernel and the oracle on a surface cloud with 20 % outliers: same bounds to 1e-6 whatever the bracket
+    does — default margin (few or no fallbacks), a margin of zero standard deviations (the bracket misses often: fallbacks), a
+    huge margin (everything is a member: segment overflow -> fallback) and a denser sample."""
+    tgt, src, R_gt, t_gt = fg.synth.make_pair(4000, 30001, (0.156, 0.152, 0.118), seed=12)
+    rng = np.random.default_rng(13)
+    bad = rng.choice(len(src), len(src) // 5, replace=False)
+    src = src.copy()
+    src[bad] = rng.uniform(-0.12, 0.12, (len(bad), 3)).astype(f32)  # 20 % uniform outliers
+    pct, pcs, *_, bounds = fg.synth.preprocess(tgt, src)
+    orc = oracle.Registration(pct, pcs, bounds, 0.05)
+    rng = np.random.default_rng(8)
+    rn = fg.RotNode(0.2, -0.1, 0.3, 0.0625)
+    tn = np.concatenate([rng.uniform(-0.4, 0.4, (24, 3)), rng.choice([0.5, 0.125, 0.03125], (24, 1))], 1).astype(f32)
+    ks = (int(0.8 * len(pcs)), int(0.3 * len(pcs)), len(pcs) - 1, 2)
+    want = {}
+    for k in ks:
+        orc.set_inliers(k)
+        for fix in (True, False):
+            want[k, fix] = orc.compute_bounds(rn.q.R, rn.span, tn, fix)
+    got = {}
+    for mode, env in {"two_pass": {"FGOICP_TRIM_SAMPLE": "0"}, "default": {}, "margin0": {"FGOICP_TRIM_MARGIN": "0"},
+                      "wide": {"FGOICP_TRIM_MARGIN": "1000"}, "dense": {"FGOICP_TRIM_SAMPLE": "3"}}.items():
+        for name in ("FGOICP_TRIM_SAMPLE", "FGOICP_TRIM_MARGIN"):
+            monkeypatch.delenv(name, raising=False)
+        for name, val in env.items():
+            monkeypatch.setenv(name, val)
+        hip = fg.Registration(pct, pcs, bounds, 0.05)
+        for k in ks:
+            hip.set_inliers(k)
+            for fix in (True, False):
+                lb, ub = hip.compute_sse_error(rn, tn, fix)
+                lbo, ubo = want[k, fix]
+                assert np.allclose(ub, ubo, rtol=1e-6, atol=1e-12) and np.allclose(lb, lbo, rtol=1e-6, atol=1e-6 * max(float(ubo.max()), 1e-12)), (mode, k, fix)
+                got[mode, k, fix] = (lb.copy(), ub.copy())
+        st = hip.trim_stats()
+        hip.close()
+        if mode == "two_pass":
+            assert st[0] == 0
+        else:
+            assert st[0] == len(ks) * 2 * len(tn)
+            if mode == "default":
+                assert st[1] <= st[0] // 10, st   # the bracket holds on a surface cloud
+            if mode in ("margin0", "wide"):
+                assert st[1] > 0, (mode, st)      # ... and these two exercise the fallback
+    for mode in ("default", "margin0", "wide", "dense"):
+        for k in ks:
+            for fix in (True, False):
+                assert np.allclose(got[mode, k, fix][1], got["two_pass", k, fix][1], rtol=3e-7, atol=0) and \
+                       np.allclose(got[mode, k, fix][0], got["two_pass", k, fix][0], rtol=3e-7, atol=1e-7 * float(got["two_pass", k, fix][1].max()))
 
 
 @pytest.mark.gpu
