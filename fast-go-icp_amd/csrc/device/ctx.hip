@@ -1164,10 +1164,21 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
         // is chosen by the number of source points per voxel of the LUT's projected faces.
         const double face_voxels = (double)g.dx * g.dy + (double)g.dy * g.dz + (double)g.dx * g.dz;
         int layout = ((double)ns / face_voxels < 0.5 && total * sizeof(float4) <= ((size_t)16 << 30)) ? 2 : 1;
+        // sparse clouds, round 3: the apron-bricked quads (kernels.hip apron_index: every lookup inside one line, a line serves a 3 x 2
+        // patch of base voxels; 21.3 instead of 16 B per node) — bounds kernel -1.1 % on the bunny shape, three A/B pairs
+        const size_t apron_bytes = (size_t)((g.px + 2) / 3) * ((g.py + 1) / 2) * g.pz * 8 * sizeof(float4);
+        if (layout == 2 && apron_bytes <= ((size_t)16 << 30)) layout = 4;
         if (const char* e = std::getenv("FGOICP_LUT_ZPAIR")) layout = std::atoi(e);  // tuning knob
+        const char* units_env = std::getenv("FGOICP_UNITS");
+        const bool units_on = units_env && (std::atoi(units_env) == 4 || std::atoi(units_env) == 8);
         if (layout == 3 && (g.px > 1023 || g.py > 1023 || g.pz > 1023 || c->inliers)) layout = 2;  // the bricked copy packs indices in 10 bits
+        if (layout == 4 && (g.px > 1023 || g.py > 1023 || g.pz > 1023 || units_on)) layout = 2;     // the apron copy too; no sibling-unit kernel for it
         c->lut_layout = layout;
-        if (layout == 3) {
+        if (layout == 4) {
+            const size_t lines = (size_t)((g.px + 2) / 3) * ((g.py + 1) / 2) * g.pz;
+            CHK(hipMalloc(&c->d_lut_zp, lines * 8 * sizeof(float4)));
+            launch_lut_quad_apron(c->d_lut, g, reinterpret_cast<float4*>(c->d_lut_zp), c->stream);
+        } else if (layout == 3) {
             const size_t bricks = (size_t)((g.px + 3) / 4) * ((g.py + 3) / 4) * ((g.pz + 3) / 4);
             CHK(hipMalloc(&c->d_lut_zp, bricks * 64 * sizeof(float4)));
             launch_lut_quad_bricked(c->d_lut, g, reinterpret_cast<float4*>(c->d_lut_zp), c->stream);
@@ -1236,11 +1247,12 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
         if (const char* e = std::getenv("FGOICP_FINALIZE_SIDE")) c->finalize_on_side = std::atoi(e) != 0;  // tuning knob
         if (const char* e = std::getenv("FGOICP_ICP_SEED")) c->icp_seeding = std::atoi(e) != 0;             // tuning knob
         if (const char* e = std::getenv("FGOICP_UNITS")) { const int v = std::atoi(e); c->unit_m = (v == 4 || v == 8) ? v : 0; }  // tuning knob: siblings per work item
+        if (c->lut_layout == 4) c->unit_m = 0;  // the apron layout has no sibling-unit kernel
         if (const char* e = std::getenv("FGOICP_SMALL_TICK")) c->small_tick_items = std::max(0, std::atoi(e));  // tuning knob: items
         int maxd = std::max(g.dx, std::max(g.dy, g.dz));
         c->cell_shift = 0;
         while ((maxd >> c->cell_shift) > 32) ++c->cell_shift;  // 5 bits per axis
-        std::vector<float4> cen(c->nchunk1);
+        std::vector<float4> cen(2 * (size_t)c->nchunk1);  // [0, nchunk): patch centres; [nchunk, 2 nchunk): patch normals (direction of least variance)
         for (int k = 0; k < c->nchunk1; ++k) {
             double sx = 0, sy = 0, sz = 0;
             const size_t a = (size_t)k * c->chunk_pts, b = std::min(ns, a + (size_t)c->chunk_pts);
@@ -1249,10 +1261,19 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
                 sx += p[0]; sy += p[1]; sz += p[2];
             }
             const double inv = 1.0 / (double)(b - a);
-            cen[k] = make_float4((float)(sx * inv), (float)(sy * inv), (float)(sz * inv), 0.f);
+            const double m[3] = {sx * inv, sy * inv, sz * inv};
+            cen[k] = make_float4((float)m[0], (float)m[1], (float)m[2], 0.f);
+            double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, U[3][3], S[3], V[3][3];
+            for (size_t i = a; i < b; ++i) {
+                const float* p = src_xyz + 3 * (size_t)c->perm[i];
+                const double d[3] = {p[0] - m[0], p[1] - m[1], p[2] - m[2]};
+                for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) H[r][q] += d[r] * d[q];
+            }
+            svd3_jacobi(H, U, S, V);  // symmetric positive semi-definite: the last column belongs to the smallest eigenvalue
+            cen[(size_t)c->nchunk1 + k] = make_float4((float)V[0][2], (float)V[1][2], (float)V[2][2], 0.f);
         }
-        CHK(hipMalloc(&c->d_chunk_cen, sizeof(float4) * c->nchunk1));
-        CHK(hipMemcpy(c->d_chunk_cen, cen.data(), sizeof(float4) * c->nchunk1, hipMemcpyHostToDevice));
+        CHK(hipMalloc(&c->d_chunk_cen, sizeof(float4) * cen.size()));
+        CHK(hipMemcpy(c->d_chunk_cen, cen.data(), sizeof(float4) * cen.size(), hipMemcpyHostToDevice));
         const size_t max_items = (size_t)c->max_subcubes * c->nchunk1;
         for (int k = 0; k < 2; ++k) {
             fgoicp_ctx::TickSlot& sl = c->slots[k];
@@ -1464,7 +1485,8 @@ int fgoicp_ctx_get_info(const fgoicp_ctx* c, fgoicp_ctx_info* out) {
     const uint64_t padded = (uint64_t)g.px * g.py * g.pz;
     size_t packed = 0;  // the bricked yz-quad copy (layout 3) holds whole 4 x 4 x 4 bricks of float4
     if (c->d_lut_zp) {
-        if (c->lut_layout == 3) packed = (size_t)((c->geom.px + 3) / 4) * ((c->geom.py + 3) / 4) * ((c->geom.pz + 3) / 4) * 64 * sizeof(float4);
+        if (c->lut_layout == 4) packed = (size_t)((c->geom.px + 2) / 3) * ((c->geom.py + 1) / 2) * c->geom.pz * 8 * sizeof(float4);
+        else if (c->lut_layout == 3) packed = (size_t)((c->geom.px + 3) / 4) * ((c->geom.py + 3) / 4) * ((c->geom.pz + 3) / 4) * 64 * sizeof(float4);
         else packed = padded * (c->lut_layout == 2 ? sizeof(float4) : sizeof(float2));
     }
     out->lut_bytes = padded * sizeof(float) + packed;

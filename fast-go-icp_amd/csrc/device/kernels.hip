@@ -223,6 +223,44 @@ __global__ __launch_bounds__(kBlock) void lut_quad_bricked_kernel(const float* _
     }
 }
 
+// Apron-bricked yz-quad copy (round 3, FGOICP_LUT_ZPAIR=4): a 128-byte line holds the quads of 4 consecutive x at 2 consecutive y
+// (one z), and consecutive lines OVERLAP by one x: line (xb, yb, z) = quads x in [3 xb, 3 xb + 3], y in {2 yb, 2 yb + 1}.  A lookup
+// with base voxel (x0, y0, z0) needs the quads at x0 and x0 + 1 of row y0: slots s, s + 1 of line (x0 / 3, y0 / 2, z0) with
+// s = (y0 & 1) * 4 + x0 % 3 — ALWAYS one line (the x-run layout straddles two lines when x0 % 8 == 7, the 2 x 2 x 2 brick for every odd
+// x0), and a line serves a 3 x 2 patch of base voxels instead of a run of 8: a surface of any orientation crosses
+// (|nx| + |ny| + |nz|) / (|nx| / 3 + |ny| / 2 + |nz|) = 1.6 base voxels of a line it touches against 1.4 / 1.125 lines per lookup for the
+// run.  21.3 B per node (the run: 16).  Same texels, same 32 contiguous bytes per lookup, same blend: bit-identical values.
+__device__ __forceinline__ unsigned apron_index(unsigned pk /* x | y << 10 | z << 20 */, unsigned nbx3, unsigned nby2) {
+    const unsigned x = pk & 1023u, y = (pk >> 10) & 1023u, z = pk >> 20;
+    const unsigned q = (x * 43691u) >> 17;  // x / 3 (x < 1024)
+    return ((z * nby2 + (y >> 1)) * nbx3 + q) * 8u + ((y & 1u) << 2) + (x - 3u * q);
+}
+__device__ __forceinline__ QuadPairLoads quad_pair_issue_apron(const float4* __restrict__ qd, const TexAddr& t, int odd, unsigned nbx3, unsigned nby2) {
+    const int own = (int)apron_index(t.pk, nbx3, nby2), other = swap_lane_pair(own);
+    const int o_even = odd ? other : own, o_odd = odd ? own : other;
+    QuadPairLoads q;
+    q.r1 = *(const float4a*)(qd + (size_t)(o_even + odd));
+    q.r2 = *(const float4a*)(qd + (size_t)(o_odd + odd));
+    return q;
+}
+__global__ __launch_bounds__(kBlock) void lut_quad_apron_kernel(const float* __restrict__ lut, LutGeom g, float4* __restrict__ qd) {
+    const unsigned nbx3 = (unsigned)(g.px + 2) / 3u, nby2 = (unsigned)(g.py + 1) >> 1;
+    const size_t slots = (size_t)nbx3 * nby2 * g.pz * 8, total = (size_t)g.px * g.py * g.pz, sy = (size_t)g.px, sz = (size_t)g.px * g.py;
+    for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < slots; e += (size_t)gridDim.x * kBlock) {
+        const unsigned s = (unsigned)(e & 7u);
+        const size_t line = e >> 3;
+        const unsigned xb = (unsigned)(line % nbx3), yb = (unsigned)((line / nbx3) % nby2), z = (unsigned)(line / ((size_t)nbx3 * nby2));
+        const unsigned x = 3u * xb + (s & 3u), y = 2u * yb + (s >> 2);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (x < (unsigned)g.px && y < (unsigned)g.py) {
+            const size_t n = ((size_t)z * g.py + y) * g.px + x;
+            const size_t nz = n + sz < total ? n + sz : n, ny = n + sy < total ? n + sy : n, nyz = n + sy + sz < total ? n + sy + sz : n;
+            v = make_float4(lut[n], lut[nz], lut[ny], lut[nyz]);
+        }
+        qd[e] = v;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void lut_quad_kernel(const float* __restrict__ lut, LutGeom g, float4* __restrict__ qd) {
     const size_t total = (size_t)g.px * g.py * g.pz, sy = (size_t)g.px, sz = (size_t)g.px * g.py;
     for (size_t n = (size_t)blockIdx.x * kBlock + threadIdx.x; n < total; n += (size_t)gridDim.x * kBlock) {
@@ -360,7 +398,8 @@ __global__ __launch_bounds__(64) void tick_keys_kernel(const float4* __restrict_
                                                            const TickSub* __restrict__ subs, int nsub, LutGeom g, int cell_shift,
                                                            unsigned short* __restrict__ keys, unsigned* __restrict__ ranks, unsigned* __restrict__ hist,
                                                            unsigned* __restrict__ prefill /* optional: `sorted`, filled with 0xFFFFFFFF for tick_check_kernel */,
-                                                           int nunits, int unit_m /* sibling units: the first nunits * unit_m evaluations, unit_m per item */) {
+                                                           int nunits, int unit_m /* sibling units: the first nunits * unit_m evaluations, unit_m per item */,
+                                                           int orient /* experimental: 1 = 12-bit cell index + 3 bits of the rotated patch normal (chunk_cen[nchunk + c]) */) {
     const size_t unit_items = (size_t)nunits * nchunk;
     const size_t nitems = unit_items + (size_t)(nsub - nunits * unit_m) * nchunk;
     for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < nitems; i += (size_t)gridDim.x * 64) {
@@ -388,8 +427,18 @@ __global__ __launch_bounds__(64) void tick_keys_kernel(const float4* __restrict_
         const int vx = (int)fminf(fmaxf((rx + sb.tx + g.off_x) * g.scale, 0.0f), (float)(g.dx - 1)) >> cell_shift;
         const int vy = (int)fminf(fmaxf((ry + sb.ty + g.off_y) * g.scale, 0.0f), (float)(g.dy - 1)) >> cell_shift;
         const int vz = (int)fminf(fmaxf((rz + sb.tz + g.off_z) * g.scale, 0.0f), (float)(g.dz - 1)) >> cell_shift;
-        const unsigned key = HILBERT ? hilbert15((unsigned)vx, (unsigned)vy, (unsigned)vz)
-                                     : part1by2_5((unsigned)vx) | (part1by2_5((unsigned)vy) << 1) | (part1by2_5((unsigned)vz) << 2);
+        unsigned key = HILBERT ? hilbert15((unsigned)vx, (unsigned)vy, (unsigned)vz)
+                               : part1by2_5((unsigned)vx) | (part1by2_5((unsigned)vy) << 1) | (part1by2_5((unsigned)vz) << 2);
+        if (orient) {
+            // two patches around the same LUT cell share lines only if they lie in (nearly) the same plane: cells twice as wide, and
+            // inside a cell the items grouped by the direction of the rotated patch normal (hemisphere: 4 quadrants x {pole cap, rim})
+            const float4 nn = chunk_cen[nchunk + c];
+            float nx, ny, nz;
+            rotate(gr.R, nn.x, nn.y, nn.z, nx, ny, nz);
+            if (nz < 0.0f) { nx = -nx; ny = -ny; }
+            const unsigned oc = (nx >= 0.0f ? 1u : 0u) | (ny >= 0.0f ? 2u : 0u) | (nz * nz > 0.5f ? 4u : 0u);
+            key = (hilbert15((unsigned)vx >> 1, (unsigned)vy >> 1, (unsigned)vz >> 1) << 3) | oc;
+        }
         keys[i] = (unsigned short)key;
         if (XCD) {
             const unsigned x = __builtin_amdgcn_s_getreg(20 /* HW_REG_XCC_ID */ | (0 << 6) | ((4 - 1) << 11));
@@ -587,20 +636,22 @@ __global__ __launch_bounds__(THREADS * WPG) void bounds_sorted_kernel(const floa
             ta[k].o &= (size_t)4095;
 #endif
         }
-        QuadPairLoads qp[(ZPAIR == 3 || ZPAIR == 4) ? P : 1];
+        QuadPairLoads qp[(ZPAIR == 3 || ZPAIR == 4 || ZPAIR == 5) ? P : 1];
         const int odd = (int)tix & 1;
-        if (ZPAIR == 3 || ZPAIR == 4) {
+        if (ZPAIR == 3 || ZPAIR == 4 || ZPAIR == 5) {
             const unsigned nbx = (unsigned)(g.px + 3) >> 2, nby = (unsigned)(g.py + 3) >> 2;
+            const unsigned nbx3 = (unsigned)(g.px + 2) / 3u, nby2 = (unsigned)(g.py + 1) >> 1;
 #pragma unroll
             for (int k = 0; k < P; ++k)
                 qp[k] = ZPAIR == 4 ? quad_pair_issue_bricked(reinterpret_cast<const float4*>(zp), ta[k], odd, nbx, nby)
+                      : ZPAIR == 5 ? quad_pair_issue_apron(reinterpret_cast<const float4*>(zp), ta[k], odd, nbx3, nby2)
                                    : quad_pair_issue(reinterpret_cast<const float4*>(zp), ta[k], odd);
 #pragma unroll
             for (int k = 0; k < P; ++k) quad_pair_finish(qp[k], odd, v00[k], v10[k], v01[k], v11[k]);
         }
 #pragma unroll
         for (int k = 0; k < P; ++k) {
-            if (ZPAIR == 3 || ZPAIR == 4) {
+            if (ZPAIR == 3 || ZPAIR == 4 || ZPAIR == 5) {
             } else if (ZPAIR == 2) {
                 quad_gather(reinterpret_cast<const float4*>(zp), ta[k], v00[k], v10[k], v01[k], v11[k]);
             } else if (ZPAIR == 1) {
@@ -2803,14 +2854,15 @@ void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, con
     const unsigned kb = (unsigned)std::min<size_t>((nitems + 63) / 64, 8192);  // `hist` / `hist_xcd` are zero here: the scan / fold kernels re-zero them
     static const int hilbert = [] { const char* e = std::getenv("FGOICP_SORT_CURVE"); return e ? std::atoi(e) : 1; }();  // tuning knob: 1 = Hilbert (default), 0 = Z-order
     static const int use_ranks = [] { const char* e = std::getenv("FGOICP_SORT_RANKS"); return e ? std::atoi(e) : 1; }();  // tuning knob
+    static const int orient = [] { const char* e = std::getenv("FGOICP_SORT_ORIENT"); return e ? std::atoi(e) : 0; }();  // tuning knob (experimental): orientation bits in the sort key
     const bool xcd = allow_xcd && use_ranks && hist_xcd && xoff;  // allow_xcd: FGOICP_SORT_XCD per context, cleared by a failed permutation check
     if (xcd) {
-        if (hilbert) hipLaunchKernelGGL((tick_keys_kernel<1, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd, check_err ? sorted : nullptr, nunits, unit_m);
-        else hipLaunchKernelGGL((tick_keys_kernel<0, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd, check_err ? sorted : nullptr, nunits, unit_m);
+        if (hilbert) hipLaunchKernelGGL((tick_keys_kernel<1, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd, check_err ? sorted : nullptr, nunits, unit_m, orient);
+        else hipLaunchKernelGGL((tick_keys_kernel<0, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd, check_err ? sorted : nullptr, nunits, unit_m, orient);
         hipLaunchKernelGGL(tick_fold_sums_kernel, dim3(kScanBlocks), dim3(64), 0, s, hist_xcd, xoff, hist, block_sums);
     } else {
-        if (hilbert) hipLaunchKernelGGL((tick_keys_kernel<1, 0>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist, check_err ? sorted : nullptr, nunits, unit_m);
-        else hipLaunchKernelGGL((tick_keys_kernel<0, 0>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist, check_err ? sorted : nullptr, nunits, unit_m);
+        if (hilbert) hipLaunchKernelGGL((tick_keys_kernel<1, 0>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist, check_err ? sorted : nullptr, nunits, unit_m, orient);
+        else hipLaunchKernelGGL((tick_keys_kernel<0, 0>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist, check_err ? sorted : nullptr, nunits, unit_m, orient);
     }
     if (!xcd) hipLaunchKernelGGL(tick_scan_sums_kernel, dim3(kScanBlocks), dim3(64), 0, s, hist, block_sums);
     hipLaunchKernelGGL(tick_scan_apply_kernel, dim3(kScanBlocks), dim3(64), 0, s, hist, block_sums, cursor);
@@ -2889,10 +2941,13 @@ void launch_bounds_sorted(const float4* src, int ns, const float* lut, const flo
     if (evals) {
         static const int trim_variant = [] { const char* e = std::getenv("FGOICP_TRIM_VARIANT"); return e ? std::atoi(e) : 2; }();  // tuning knob (2 = 64x4, default)
         if (trim_variant == 2) {
+            if (zp && layout == 4) FGOICP_LAUNCH_SORTED(64, 4, 5, 1); else
             if (zp && layout == 2) FGOICP_LAUNCH_SORTED(64, 4, 3, 1); else if (zp) FGOICP_LAUNCH_SORTED(64, 4, 1, 1); else FGOICP_LAUNCH_SORTED(64, 4, 0, 1);
         } else if (zp && layout == 2) FGOICP_LAUNCH_SORTED(128, 2, 2, 1); else if (zp) FGOICP_LAUNCH_SORTED(128, 2, 1, 1); else FGOICP_LAUNCH_SORTED(128, 2, 0, 1);
     } else if (zp && layout == 3) {
         FGOICP_LAUNCH_SORTED(64, 4, 4, 0);
+    } else if (zp && layout == 4) {
+        FGOICP_LAUNCH_SORTED(64, 4, 5, 0);
     } else if (zp && layout == 2) {
         static const int paired = [] { const char* e = std::getenv("FGOICP_QUAD_PAIRED"); return e ? std::atoi(e) : 1; }();  // tuning knob (1 = default)
         if (variant == 2 && paired) FGOICP_LAUNCH_SORTED(64, 4, 3, 0); else
@@ -2931,6 +2986,9 @@ void launch_lut_quad_bricked(const float* lut_padded, const LutGeom& g, float4* 
     hipLaunchKernelGGL(lut_quad_bricked_kernel, dim3(8192), dim3(kBlock), 0, s, lut_padded, g, qd);
 }
 
+void launch_lut_quad_apron(const float* lut_padded, const LutGeom& g, float4* qd, hipStream_t s) {
+    hipLaunchKernelGGL(lut_quad_apron_kernel, dim3(4096), dim3(kBlock), 0, s, lut_padded, g, qd);
+}
 void launch_lut_quad(const float* lut_padded, const LutGeom& g, float4* qd, hipStream_t s) {
     hipLaunchKernelGGL(lut_quad_kernel, dim3(8192), dim3(kBlock), 0, s, lut_padded, g, qd);
 }

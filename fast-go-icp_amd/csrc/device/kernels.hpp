@@ -93,6 +93,7 @@ void launch_lut_build(const float4* tgt_shifted, int nt, const LutGeom& g, float
 // zp[o] = {lut[o], lut[o + one z-slice]}: the z-paired copy the sorted bounds kernel gathers from (kernels.hip)
 void launch_lut_zpair(const float* lut_padded, const LutGeom& g, float2* zp, hipStream_t s);
 void launch_lut_quad(const float* lut_padded, const LutGeom& g, float4* qd, hipStream_t s);
+void launch_lut_quad_apron(const float* lut_padded, const LutGeom& g, float4* qd /* ceil(px/3)*ceil(py/2)*pz*8 quads */, hipStream_t s);
 void launch_lut_quad_bricked(const float* lut_padded, const LutGeom& g, float4* qd /* ceil(px/4)*ceil(py/4)*ceil(pz/4)*64 quads */, hipStream_t s);
 void launch_lut_unpad(const float* lut_padded, const LutGeom& g, float* out, hipStream_t s);
 void launch_lut_search(const float* lut, const LutGeom& g, const float* q_xyz, size_t n, float* out, hipStream_t s);

@@ -72,7 +72,7 @@ int fgoicp_lut_read(fgoicp_ctx* ctx, float* out, size_t capacity_floats);
  * faces (the density that picks the packed layout and the points per work item), work items per evaluation. */
 typedef struct fgoicp_ctx_info {
     int lut_dims[3];
-    int lut_layout;              /* 1 = z-pair copy (8 B per node), 2 = yz-quad copy (16 B per node) next to the plain fp32 LUT */
+    int lut_layout;              /* next to the plain fp32 LUT: 1 = z-pair copy (8 B per node), 2 = yz-quad copy (16 B per node), 4 = apron-bricked yz-quad copy (21.3 B per node) */
     uint64_t lut_nodes;
     uint64_t lut_bytes;          /* plain LUT (padded) + packed copy, device memory */
     double source_points_per_face_voxel;

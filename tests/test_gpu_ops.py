@@ -559,7 +559,7 @@ def test_icp_batch_equals_single_runs(fg, gpu_required, trim):
 
 
 def test_context_reports_what_it_derived_from_the_cloud_statistics(fg, gpu_required):
-    """fgoicp_ctx_get_info: a sparse cloud (few source points per voxel of the LUT's faces) gets the yz-quad LUT copy and 256-point
+    """fgoicp_ctx_get_info: a sparse cloud (few source points per voxel of the LUT's faces) gets the (apron-bricked) yz-quad LUT copy and 256-point
     items, a dense one the z-pair copy and bigger items (measured crossovers)."""
     rng = np.random.default_rng(2)
     bounds = np.array([[-1, 1]] * 3, np.float32)
@@ -570,8 +570,8 @@ def test_context_reports_what_it_derived_from_the_cloud_statistics(fg, gpu_requi
     for i, reg in ((a, sparse), (b, dense)):
         assert i["lut_dims"] == reg.lut_dims() and i["lut_nodes"] == int(np.prod(i["lut_dims"]))
         assert i["items_per_evaluation"] == -(-reg.ns // i["points_per_item"]) and i["max_subcubes_per_window"] >= 32
-        assert i["lut_bytes"] >= i["lut_nodes"] * 4 * (1 + (4 if i["lut_layout"] == 2 else 2))
-    assert a["source_points_per_face_voxel"] == pytest.approx(3000 / 3e4, rel=0.05) and a["lut_layout"] == 2 and a["points_per_item"] == 256
+        assert i["lut_bytes"] >= i["lut_nodes"] * 4 * (1 + (4 if i["lut_layout"] in (2, 4) else 2))
+    assert a["source_points_per_face_voxel"] == pytest.approx(3000 / 3e4, rel=0.05) and a["lut_layout"] == 4 and a["points_per_item"] == 256
     assert b["source_points_per_face_voxel"] == pytest.approx(2.0, rel=0.05) and b["lut_layout"] == 1 and b["points_per_item"] == 2048
     sparse.close(); dense.close()
 
@@ -628,6 +628,35 @@ def test_sibling_units_keep_every_bit(fg, gpu_required, monkeypatch, workload, r
     for units in ("4", "8", "lds128", "lds192"):
         for (lb0, ub0), (lb1, ub1) in zip(out["0"], out[units]):
             assert np.array_equal(lb0.view(np.uint32), lb1.view(np.uint32)) and np.array_equal(ub0.view(np.uint32), ub1.view(np.uint32)), units
+
+
+@pytest.mark.parametrize("trim", [False, True])
+@pytest.mark.parametrize("workload,res", [("tiny", 0.05), ("small", 0.02), ("small", 0.013)])
+def test_packed_lut_layouts_keep_every_bit(fg, gpu_required, monkeypatch, workload, res, trim):
+    """FGOICP_LUT_ZPAIR = 0 plain / 1 z-pair / 2 yz-quad runs / 3 2x2x2 quad bricks / 4 apron-bricked quads (4 x 2 quads per line,
+    lines overlapping by one x): the same texels in the same blend order under every layout — all bounds bit-identical, trimmed or
+    not (the bricked layouts have no trimmed kernel and fall back to the runs there; the apron layout has one).  LUT dims that are
+    and are not multiples of the brick sizes."""
+    tgt, src, R_gt, t_gt = fg.synth.workload(workload, angle_deg=30.0)
+    pct, pcs, off_t, off_s, scale, bounds = fg.synth.preprocess(tgt, src)
+    monkeypatch.setenv("FGOICP_SMALL_TICK", "0")  # through the sort even for this small tick
+    out = {}
+    for layout in ("2", "0", "1", "3", "4"):
+        monkeypatch.setenv("FGOICP_LUT_ZPAIR", layout)
+        reg = fg.Registration(pct, pcs, bounds, res)
+        if layout == "4":
+            assert reg.info()["lut_layout"] == 4
+        if trim:
+            if layout == "3":
+                reg.close()
+                continue
+            reg.set_inliers(int(0.8 * len(pcs)))
+        args = _lattice_tick(fg, np.random.default_rng(5), 24)
+        out[layout] = reg.compute_bounds_multi(*args)
+        reg.close()
+    for layout in out:
+        for (lb0, ub0), (lb1, ub1) in zip(out["2"], out[layout]):
+            assert np.array_equal(lb0.view(np.uint32), lb1.view(np.uint32)) and np.array_equal(ub0.view(np.uint32), ub1.view(np.uint32)), layout
 
 
 def test_sibling_units_whole_run(fg, gpu_required, monkeypatch):
