@@ -23,8 +23,9 @@ class CloudStats(C.Structure):
 class Exchange(C.Structure):
     ALLREDUCE_MIN = C.CFUNCTYPE(C.c_int, c_float_p, C.c_size_t, C.c_void_p)
     ALLGATHER = C.CFUNCTYPE(C.c_int, c_float_p, c_float_p, C.c_size_t, C.c_void_p)
+    ALLGATHER_DEVICE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
     _fields_ = [("rank", C.c_int), ("world_size", C.c_int), ("allreduce_min", ALLREDUCE_MIN),
-                ("allgather", ALLGATHER), ("user", C.c_void_p)]
+                ("allgather", ALLGATHER), ("user", C.c_void_p), ("allgather_device", ALLGATHER_DEVICE)]  # the last one optional (NULL: no cooperative ICP)
 
 
 class SolverOpts(C.Structure):
@@ -103,6 +104,7 @@ _SIGS = {
                                       C.POINTER(C.c_void_p)]),
     "fgoicp_multi_destroy": (None, [C.c_void_p]),
     "fgoicp_multi_run": (C.c_int, [C.c_void_p, c_float_p, c_float_p]),
+    "fgoicp_multi_icp": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_size_t, C.c_float, c_float_p, c_float_p, c_float_p, c_int_p]),
     "fgoicp_multi_world": (C.c_int, [C.c_void_p]),
     "fgoicp_multi_solver": (C.c_void_p, [C.c_void_p, C.c_int]),
     "fgoicp_multi_seconds": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),

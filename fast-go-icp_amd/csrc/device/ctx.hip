@@ -750,6 +750,96 @@ int ctx_icp(fgoicp_ctx* c, const float* R0, const float* t0, size_t max_iter, fl
     return lane_icp(c, c->lanes[0], R0, t0, max_iter, thr, sse_out, R_out9, t_out3, iters_out);
 }
 
+// COOPERATIVE ICP (round 3): `world` ranks that hold the same clouds run ONE IterativeClosestPoint3D::run() (icp3d.cu:80-108)
+// together.  The two exact scans of an iteration — what an ICP run consists of (600-1900 us per iteration at 437k points) — are
+// split by query range: rank r scans the Hilbert-consecutive queries [r * per, (r + 1) * per), `gather` all-gathers the results
+// (correspondence indices / bits of the minima: 4 B per query) IN PLACE on device memory, and every rank then runs the cheap
+// reductions (sums, centroids, covariance, SSE) over the WHOLE cloud with the single-GPU kernels and the 3x3 SVD on its host.  A
+// query's nearest neighbour does not depend on which queries are scanned next to it and the reductions see the same arrays in the
+// same order on every rank, so (sse, R, t, iterations) are the single-GPU loop's bits on every rank — no result needs to be
+// exchanged, and an N-rank run refines exactly like a one-rank run.  Trimmed and brute-force contexts run the whole loop on every
+// rank instead (replicated: same bits, no speed-up).  `gather(buf, bytes_per_rank, user)`: the caller's stream is idle when it is
+// called; on return chunk r of buf holds rank r's results, for every r.
+int ctx_icp_coop(fgoicp_ctx* c, int rank, int world, int (*gather)(void* dev_buf, size_t bytes_per_rank, void* user), void* user, const float* R0,
+                 const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3, int* iters_out) {
+    if (world <= 1 || !gather || c->inliers || c->brute_force_nn) return ctx_icp(c, R0, t0, max_iter, thr, sse_out, R_out9, t_out3, iters_out);
+    if (rank < 0 || rank >= world) { set_error("ctx_icp_coop: rank out of range"); return FGOICP_ERR_INVALID_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    fgoicp_ctx::IcpLane& L = c->lanes[0];
+    const int ns = (int)c->ns, nt = (int)c->nt;
+    const size_t per = ((((size_t)ns + world - 1) / world) + 255) & ~(size_t)255;  // whole 256-query blocks per rank
+    if (c->coop_cap < per * world) {
+        (void)hipFree(c->d_coop);
+        c->d_coop = nullptr;
+        c->coop_cap = 0;
+        HIPCHK(hipMalloc(&c->d_coop, sizeof(uint32_t) * 2 * per * world));
+        HIPCHK(hipMemset(c->d_coop, 0, sizeof(uint32_t) * 2 * per * world));
+        c->coop_cap = per * world;
+    }
+    uint32_t* idx = c->d_coop;
+    uint32_t* mins = c->d_coop + c->coop_cap;
+    const int qb = (int)std::min<size_t>((size_t)ns, per * rank), nq = (int)std::min<size_t>((size_t)ns, per * (rank + 1)) - qb;
+    const bool seeding = c->icp_seeding;
+    hipStream_t S = L.stream;
+    const int nb = reduce_blocks_for(ns);
+    HIPCHK(hipMemcpyAsync(L.d_work, c->d_src, sizeof(float4) * c->ns, hipMemcpyDeviceToDevice, S));
+    launch_transform_inplace(L.d_work, ns, R0, t0, S);  // icp3d.cu:85
+    Mat3f R = Mat3f::from(R0);
+    Vec3f t{t0[0], t0[1], t0[2]};
+    size_t iter = 0;
+    float sse = kInf, last_sse = 2.0f * kInf;
+    Mat3f last_R = Mat3f::identity();
+    Vec3f last_t{0, 0, 0};
+    int iters = 0;
+    while (iter++ < max_iter && (last_sse - sse) > thr * last_sse) {  // icp3d.cu:94
+        last_sse = sse;
+        last_R = R;
+        last_t = t;
+        // procrustes (icp3d.cu:140-172): correspondences of my share, gathered; sums over everything
+        if (nq > 0)
+            launch_nn_scan(L.d_work + qb, nq, c->bvh_tgt.view(), c->d_lut, c->geom, nullptr, nullptr, 0, 1, c->d_tgt, nt, iters > 0 && seeding ? idx + qb : nullptr, nullptr,
+                           nullptr, idx + qb, S);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(S));
+        if (gather(idx, sizeof(uint32_t) * per, user)) return FGOICP_ERR_EXCHANGE;
+        launch_icp_sums(L.d_work, c->d_tgt, idx, ns, nt, nullptr, L.d_bp, nb, S);
+        launch_icp_centroids(L.d_bp, nb, ns, L.d_cen, L.hd_cen, S);
+        launch_icp_cov(L.d_work, c->d_tgt, idx, ns, nt, L.d_cen, nullptr, L.d_bp2, nb, S);
+        launch_sum_partials(L.d_bp2, nb, 9, L.hd_sums, S);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(S));
+        L.cov_on_host = false;
+        Mat3f Rn;
+        Vec3f tn;
+        procrustes_finish(L, &Rn, &tn, nullptr, nullptr);
+        const float tn3[3] = {tn.x, tn.y, tn.z};
+        R = Rn * R;                                              // :101
+        t = Rn * t + tn;                                         // :102
+        const float t3[3] = {t.x, t.y, t.z};
+        launch_transform_inplace(L.d_work, ns, Rn.m, tn3, S);    // :100
+        // compute_sse_error(R, t) (:103): minima of my share, gathered; one sum over everything
+        if (nq > 0)
+            launch_nn_scan(c->d_src + qb, nq, c->bvh_tgt.view(), c->d_lut, c->geom, R.m, t3, 1, 0, c->d_tgt, nt, seeding ? idx + qb : nullptr, nullptr, nullptr, mins + qb, S);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(S));
+        if (gather(mins, sizeof(uint32_t) * per, user)) return FGOICP_ERR_EXCHANGE;
+        launch_sum_f32_as_f64(mins, ns, L.d_bp3, nb, S);
+        launch_sum_partials(L.d_bp3, nb, 1, L.hd_sums + 12, S);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(S));
+        sse = (float)L.h_sums[12];
+        ++iters;
+    }
+    const bool cur_best = sse < last_sse;  // :106-107
+    *sse_out = cur_best ? sse : last_sse;
+    const Mat3f& Ro = cur_best ? R : last_R;
+    const Vec3f& to = cur_best ? t : last_t;
+    std::memcpy(R_out9, Ro.m, sizeof(Ro.m));
+    t_out3[0] = to.x; t_out3[1] = to.y; t_out3[2] = to.z;
+    if (iters_out) *iters_out = iters;
+    return FGOICP_OK;
+}
+
 // The loop with ONE walk per iteration (kernels.hip nn_scan_dual_kernel; default).  Once the host has (R_, t_) of iteration k, the exact
 // SSE of iteration k and the correspondences of iteration k+1 are two query sets of the same walk, so the lane needs one stream and the
 // host one sync per iteration: [trimmed: move, LUT brackets and cuts of both sets] -> dual scan -> inlier cut / sums / covariance of pass
@@ -1454,6 +1544,7 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
         if (sl.sort_stream && sl.sort_stream != c->stream) { (void)hipStreamSynchronize(sl.sort_stream); (void)hipStreamDestroy(sl.sort_stream); }
         (void)hipFree(sl.d_evals);
         (void)hipFree(c->d_trim_stat); c->d_trim_stat = nullptr;
+        (void)hipFree(c->d_coop); c->d_coop = nullptr; c->coop_cap = 0;
         if (sl.h_row_span) (void)hipHostFree(sl.h_row_span);
         if (sl.h_sort_err) (void)hipHostFree(sl.h_sort_err);
         (void)hipFree(sl.d_groups); (void)hipFree(sl.d_subs); (void)hipFree(sl.d_keys); (void)hipFree(sl.d_ranks); (void)hipFree(sl.d_hist);

@@ -86,6 +86,8 @@ struct fgoicp_ctx {
     int trim_samp_shift = 5;                 // trimmed mode: every 2^shift-th point goes into the row's sample (0: none, two-pass selection)
     float trim_margin_sd = 1.0f;             // bracket half-width in standard deviations of a binomial sample rank
     int trim_margin = 0;                     // ... in sample ranks (set with the inlier count)
+    uint32_t* d_coop = nullptr;              // cooperative ICP: {correspondence indices | bits of the minima}, coop_cap entries each (all ranks' shares)
+    size_t coop_cap = 0;
     unsigned long long* d_trim_stat = nullptr;        // {rows selected, rows that fell back to two passes, bracket members}
     uint64_t trim_stat_acc[3] = {0, 0, 0};
     bool trim_ready = false;                 // trimmed-mode buffers allocated
@@ -160,6 +162,8 @@ int ctx_set_inliers(fgoicp_ctx* c, size_t k);
 int ctx_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out, const uint32_t* seed_idx = nullptr);
 int ctx_icp(fgoicp_ctx* c, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3,
             int* iters_out);
+int ctx_icp_coop(fgoicp_ctx* c, int rank, int world, int (*gather)(void* dev_buf, size_t bytes_per_rank, void* user), void* user, const float* R0,
+                 const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3, int* iters_out);
 int ctx_icp_lane(fgoicp_ctx* c, int lane, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3,
                  int* iters_out);
 int ctx_icp_batch(fgoicp_ctx* c, int n, const float* R0s, const float* t0s, size_t max_iter, float thr, float* sse_out, float* R_out9s, float* t_out3s,

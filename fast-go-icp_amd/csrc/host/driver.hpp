@@ -121,6 +121,7 @@ struct Exchange {
     int (*allreduce_min)(float*, size_t, void*) = nullptr;
     int (*allgather)(const float*, float*, size_t, void*) = nullptr;
     void* user = nullptr;
+    int (*allgather_device)(void*, size_t, void*) = nullptr;  // optional: in-place all-gather on device memory -> cooperative refinements
 };
 
 struct DriverStats {
@@ -419,7 +420,9 @@ private:
         const float t03[3] = {t0.x, t0.y, t0.z};
         float t3[3];
         int iters = 0;
-        int rc = background ? ops_.icp_background(R0.m, t03, 100, thr, &sse, R.m, t3, &iters) : ops_.icp(R0.m, t03, 100, thr, &sse, R.m, t3, &iters);
+        int rc = background ? ops_.icp_background(R0.m, t03, 100, thr, &sse, R.m, t3, &iters)
+               : coop()     ? ops_.icp_coop(ex_.rank, ex_.world, ex_.allgather_device, ex_.user, R0.m, t03, 100, thr, &sse, R.m, t3, &iters)
+                            : ops_.icp(R0.m, t03, 100, thr, &sse, R.m, t3, &iters);
         t = Vec3f{t3[0], t3[1], t3[2]};
         stats_.icp_runs++;
         stats_.icp_iters += (uint64_t)iters;
@@ -427,6 +430,10 @@ private:
         if (timing_) std::fprintf(stderr, "[fgoicp timing] icp thr %g: %d iterations, %.3f ms, sse %g\n", (double)thr, iters, seconds_since(t_icp) * 1e3, (double)sse);
         return rc;
     }
+    // Cooperative refinements (world > 1 and the exchange can all-gather device memory): EVERY ICP of a run — the initial one, a
+    // round's triggers, the final refinement — is then one run that all ranks execute together (Ops::icp_coop), at the same points of
+    // the replicated control flow.  FGOICP_COOP_ICP=0: the round-2 flow (a rank refines its own children alone).
+    bool coop() const { return coop_icp_ && ex_.world > 1 && ex_.allgather_device != nullptr; }
     void set_best_sse_only(float sse) { std::lock_guard<std::mutex> g(mu_); best_sse_ = sse; }
     void set_last(const Mat3f& R, const Vec3f& t) { std::lock_guard<std::mutex> g(mu_); last_R_ = R; last_t_ = t; }
 
@@ -674,6 +681,39 @@ private:
             // candidates the rule would have skipped, and its length is that of its longest run.)
             float loc_sse; Mat3f loc_R; Vec3f loc_t;
             { std::lock_guard<std::mutex> g(mu_); loc_sse = best_sse_; loc_R = best_R_; loc_t = best_t_; }
+            std::vector<float> lbs(nchild), ubs(nchild);
+            if (coop()) {
+                // COOPERATIVE ROUND (round 3): the bounds are exchanged FIRST — {lb, ub, best translation} per child, one all-gather —, then
+                // every rank applies the trigger rule to ALL children in the single-GPU child order against the same running best, and
+                // each triggered refinement is one ICP run that all ranks execute together (ctx_icp_coop: every rank scans 1 / world of
+                // the source, results identical on every rank).  No rank waits for another rank's private ICP (the serial term of the
+                // round-2 flow: one 35-40 ms run on one of eight ranks), no candidate needs to be exchanged, and the sequence of
+                // incumbents is the one-rank run's.
+                const size_t per = 5 * slots;
+                std::vector<float> send(per, 0.f), recv(per * world, 0.f);
+                for (size_t k = 0; k < mine.size(); ++k) {
+                    float* p = &send[5 * k];
+                    p[0] = boxes[2 * k + 1].best_ub;  // LB pass: its best_ub is the cube's lower bound (:90)
+                    p[1] = boxes[2 * k].best_ub;      // UB pass
+                    p[2] = boxes[2 * k].best_t.x; p[3] = boxes[2 * k].best_t.y; p[4] = boxes[2 * k].best_t.z;
+                }
+                if (!ex_.allgather) return kDriverExchangeFailed;
+                if (nchild > 0 && ex_.allgather(send.data(), recv.data(), per, ex_.user)) return kDriverExchangeFailed;  // (a round may consist of cubes pushed unevaluated)
+                for (size_t i = 0; i < nchild; ++i) {
+                    const float* p = &recv[per * (i % world)] + 5 * (i / world);
+                    lbs[i] = p[0];
+                    ubs[i] = p[1];
+                    const Vec3f bt{p[2], p[3], p[4]};
+                    set_last(children[i].q.R, bt);
+                    if (ubs[i] < loc_sse * 1.8) {  // fgoicp.cpp:74
+                        float sse; Mat3f R; Vec3f t;
+                        rc = icp(children[i].q.R, bt, 0.005f, sse, R, t);
+                        if (rc) return rc;
+                        if (sse < loc_sse) { loc_sse = sse; loc_R = R; loc_t = t; }
+                    }
+                }
+                if (loc_sse < best_sse()) { std::lock_guard<std::mutex> g(mu_); best_sse_ = loc_sse; best_R_ = loc_R; best_t_ = loc_t; }
+            } else {
             if (late_icp_ > 0 && (world > 1 || late_icp_ > 1)) {
                 rc = join_late(loc_sse, loc_R, loc_t);  // the refinements of the round before: they join THIS exchange
                 if (rc) return rc;
@@ -711,7 +751,6 @@ private:
             }
 
             // exchange: best error (min-all-reduce) + {candidate transform, child bounds} (all-gather)
-            std::vector<float> lbs(nchild), ubs(nchild);
             if (world > 1) {
                 float gmin = loc_sse;
                 if (!ex_.allreduce_min || !ex_.allgather) return kDriverExchangeFailed;
@@ -748,6 +787,7 @@ private:
                     ubs[mine[k]] = boxes[2 * k].best_ub;
                 }
             }
+            }  // !coop()
             const float now = best_sse();
             if (timing_)
                 std::fprintf(stderr, "[fgoicp timing] round %llu: popped %d, children %zu (mine %zu), submissions %llu, subcubes %llu, tasks %.3f ms, icp %.3f ms, round %.3f ms, setup %.3f ms\n",
@@ -762,7 +802,7 @@ private:
                 rcand.push(children[i]);
             }
         }
-        if (late_icp_ > 0 && (world > 1 || late_icp_ > 1)) {
+        if (!coop() && late_icp_ > 0 && (world > 1 || late_icp_ > 1)) {
             // the last round's refinements: joined and agreed on by one more exchange (every rank gets here after the same round —
             // the loop's decisions depend on the replicated state only)
             float loc_sse; Mat3f loc_R; Vec3f loc_t;
@@ -1052,6 +1092,7 @@ private:
     double t_pop_ = 0, t_ops_ = 0, t_push_ = 0;
     double t_prep_[3] = {0, 0, 0};  // FGOICP_TIMING: pops / pair matching / packing inside prepare_half
     const bool timing_ = std::getenv("FGOICP_TIMING") != nullptr;  // host-side timing lines on stderr
+    const bool coop_icp_ = [] { const char* e = std::getenv("FGOICP_COOP_ICP"); return !e || std::atoi(e) != 0; }();  // tuning knob / A-B: 0 = every rank refines its own children alone
     const int late_icp_ = [] { const char* e = std::getenv("FGOICP_LATE_ICP"); return e ? std::atoi(e) : 0; }();  // tuning knob (ROUND): 0 = off (default: measured slower, see above), 1 = with an exchange (world > 1), 2 = always
     bool use_twins_ = [] { const char* e = std::getenv("FGOICP_TWINS"); return !e || std::atoi(e) != 0; }();  // tuning knob
     const size_t round_batch_ = [] { const char* e = std::getenv("FGOICP_ROUND_BATCH"); const int v = e ? std::atoi(e) : 48; return (size_t)(v >= 8 && v <= 64 ? v : 48); }();  // tuning knob (ROUND only; SERIAL keeps the reference's 32)

@@ -31,6 +31,8 @@
 
 namespace fgoicp {
 void set_error(const std::string& s);
+int ctx_icp_coop(fgoicp_ctx* c, int rank, int world, int (*gather)(void* dev_buf, size_t bytes_per_rank, void* user), void* user, const float* R0,
+                 const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3, int* iters_out);  // csrc/device/ctx.hip
 }
 using fgoicp::set_error;
 
@@ -180,6 +182,18 @@ int rccl_allgather(const float* send, float* recv, size_t n, void* user) {
     return 0;
 }
 
+// In place on the caller's device memory (cooperative ICP: 4 B per source point, twice per iteration): chunk `rank` of buf is this
+// rank's contribution.  The caller's stream is idle; ours is waited for before returning.
+int rccl_allgather_device(void* buf, size_t bytes, void* user) {
+    fgoicp_rccl* x = static_cast<fgoicp_rccl*>(user);
+    if (x->released || x->dead.load(std::memory_order_acquire)) return rccl_dead(x);
+    RCCL_HIP(hipSetDevice(x->device));
+    RCCL_NCCL(rccl_api().AllGather(static_cast<char*>(buf) + bytes * (size_t)x->rank, buf, bytes, ncclInt8, x->comm, x->stream));
+    if (rccl_wait(x)) return 1;
+    x->calls++;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -296,6 +310,7 @@ int fgoicp_rccl_exchange(fgoicp_rccl* x, fgoicp_exchange* out) {
     out->allreduce_min = rccl_allreduce_min;
     out->allgather = rccl_allgather;
     out->user = x;
+    out->allgather_device = rccl_allgather_device;
     return FGOICP_OK;
 }
 
@@ -353,9 +368,18 @@ struct Rendezvous {
     }
 };
 
+struct DeviceGather {    // in-process all-gather on device memory: where every rank's buffer lives (written before the first barrier)
+    std::vector<void*> ptr;
+    std::vector<int> device;
+    std::vector<std::vector<unsigned char>> log;  // recorded gathers (whole buffers, written by rank 0): what a replayed rank receives
+};
+
 struct RankLink {        // what one rank's exchange callbacks see
     int rank = 0, world = 1;
     Rendezvous* rv = nullptr;
+    DeviceGather* dg = nullptr;
+    int device = 0;
+    size_t dev_replay_pos = 0;
     fgoicp_exchange inner{};                      // transport underneath (RCCL) when rv == nullptr
     bool record = false;
     std::vector<std::vector<float>>* log = nullptr;   // results of every exchange, in order
@@ -406,6 +430,49 @@ int link_allgather(const float* send, float* recv, size_t n, void* user) {
     return rc;
 }
 
+// Cooperative ICP's all-gather.  In process: every rank publishes its buffer, waits for the others, copies their chunks into its
+// own buffer (peer copies between devices, plain copies when the ranks share one), and waits again before anybody overwrites its
+// chunk.  Recording keeps the gathered buffer (rank 0's copy; they are equal); a replayed rank, alone on the device, computes its own
+// chunk and takes the others from the recording — the upload stands in for the transfer of the collective.
+int link_allgather_device(void* buf, size_t bytes, void* user) {
+    RankLink* l = static_cast<RankLink*>(user);
+    const size_t total = bytes * (size_t)l->world;
+    if (l->replay) {
+        if (!l->dg || l->dev_replay_pos >= l->dg->log.size() || l->dg->log[l->dev_replay_pos].size() != total) return 1;
+        const std::vector<unsigned char>& rec = l->dg->log[l->dev_replay_pos++];
+        for (int p = 0; p < l->world; ++p)
+            if (p != l->rank && hipMemcpy(static_cast<char*>(buf) + bytes * p, rec.data() + bytes * p, bytes, hipMemcpyHostToDevice) != hipSuccess) return 1;
+        return 0;
+    }
+    if (l->calls++ == l->fail_at) { l->fail_at = -1; set_error("injected exchange fault (fgoicp_multi_test_fault)"); return 1; }
+    int rc = 0;
+    if (l->rv) {
+        auto barrier = [&] { return l->rv->run(0, [](std::vector<float>&, bool) {}, [](const std::vector<float>&) {}); };
+        l->dg->ptr[l->rank] = buf;
+        l->dg->device[l->rank] = l->device;
+        if (!barrier()) { set_error("exchange aborted: another rank failed"); return 1; }
+        for (int p = 0; p < l->world && !rc; ++p) {
+            if (p == l->rank) continue;
+            char* dst = static_cast<char*>(buf) + bytes * p;
+            const char* src = static_cast<const char*>(l->dg->ptr[p]) + bytes * p;
+            const hipError_t e = l->dg->device[p] == l->device ? hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice) : hipMemcpyPeer(dst, l->device, src, l->dg->device[p], bytes);
+            if (e != hipSuccess) { set_error(std::string("in-process device all-gather: ") + hipGetErrorString(e)); rc = 1; }
+        }
+        // device-to-device copies may return before they have landed, and the contexts' streams do not wait for the null stream
+        if (!rc && hipStreamSynchronize(nullptr) != hipSuccess) { set_error("in-process device all-gather: hipStreamSynchronize failed"); rc = 1; }
+        if (!barrier() && !rc) { set_error("exchange aborted: another rank failed"); rc = 1; }
+    } else {
+        if (!l->inner.allgather_device) { set_error("the transport has no device all-gather"); return 1; }
+        rc = l->inner.allgather_device(buf, bytes, l->inner.user);
+    }
+    if (!rc && l->record && l->rank == 0 && l->dg) {
+        std::vector<unsigned char> rec(total);
+        if (hipMemcpy(rec.data(), buf, total, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+        l->dg->log.push_back(std::move(rec));
+    }
+    return rc;
+}
+
 }  // namespace
 
 struct fgoicp_multi {
@@ -415,6 +482,7 @@ struct fgoicp_multi {
     std::vector<std::unique_ptr<RankLink>> links;
     std::vector<std::vector<std::vector<float>>> logs;
     Rendezvous rv;
+    DeviceGather dg;
     int transport = FGOICP_TRANSPORT_RCCL;
     std::vector<double> seconds;   // wall-clock of every rank's last run
 };
@@ -441,6 +509,8 @@ int fgoicp_multi_create(const float* tgt_xyz, size_t nt, const float* src_xyz, s
     m->transport = transport;
     m->rv.world = ndev;
     m->logs.resize(ndev);
+    m->dg.ptr.assign(ndev, nullptr);
+    m->dg.device.assign(ndev, 0);
     m->seconds.assign(ndev, 0.0);
     fgoicp_solver_opts o{FGOICP_SCHEDULE_ROUND, 0, 0u, 0, 0.0f};
     if (opts) o = *opts;
@@ -487,7 +557,9 @@ int fgoicp_multi_create(const float* tgt_xyz, size_t nt, const float* src_xyz, s
         l->log = &m->logs[r];
         if (ndev > 1 && transport == FGOICP_TRANSPORT_RCCL) fgoicp_rccl_exchange(m->rccl[r], &l->inner);
         else l->rv = &m->rv;
-        fgoicp_exchange ex{r, ndev, link_allreduce_min, link_allgather, l.get()};
+        l->dg = &m->dg;
+        l->device = devices[r];
+        fgoicp_exchange ex{r, ndev, link_allreduce_min, link_allgather, l.get(), link_allgather_device};
         int rc = fgoicp_solver_set_exchange(m->solvers[r], ndev > 1 ? &ex : nullptr);
         if (rc) return fail(rc);
         m->links.push_back(std::move(l));
@@ -509,6 +581,7 @@ int fgoicp_multi_set_record(fgoicp_multi* m, int on) {
         m->links[r]->record = on != 0;
         m->links[r]->replay = false;
         if (on) m->logs[r].clear();
+        if (on) m->dg.log.clear();
     }
     return FGOICP_OK;
 }
@@ -520,7 +593,7 @@ int fgoicp_multi_run(fgoicp_multi* m, float* R_out9, float* t_out3) {
     std::vector<int> rcs(n, 0);
     std::vector<std::string> errs(n);
     std::vector<float> R(9 * (size_t)n), t(3 * (size_t)n);
-    for (auto& l : m->links) { l->replay = false; l->calls = 0; if (l->record) l->log->clear(); }
+    for (auto& l : m->links) { l->replay = false; l->calls = 0; if (l->record) { l->log->clear(); m->dg.log.clear(); } }
     m->rv.reset();
     std::atomic<int> first_failed{-1};
     std::vector<std::thread> th;
@@ -562,6 +635,7 @@ int fgoicp_multi_replay_rank(fgoicp_multi* m, int rank, double* seconds_out) {
     l->record = false;
     l->replay = true;
     l->replay_pos = 0;
+    l->dev_replay_pos = 0;
     float R[9], t[3];
     const auto t0 = std::chrono::steady_clock::now();
     const int rc = fgoicp_solver_run(m->solvers[rank], R, t);
@@ -569,6 +643,45 @@ int fgoicp_multi_replay_rank(fgoicp_multi* m, int rank, double* seconds_out) {
     l->replay = false;
     l->record = was_recording;
     return rc;
+}
+
+// ONE IterativeClosestPoint3D::run() executed by all ranks together (what a cooperative round does for every triggered refinement):
+// every rank thread scans its share of the source, the per-query results are all-gathered on device memory.  The result is rank 0's;
+// every rank must end with the same bits (checked).
+int fgoicp_multi_icp(fgoicp_multi* m, const float* R0, const float* t0, size_t max_iter, float convergence_threshold, float* sse_out, float* R_out9, float* t_out3,
+                     int* iterations_out) {
+    if (!m || !R0 || !t0 || !sse_out || !R_out9 || !t_out3) return FGOICP_ERR_INVALID_ARG;
+    const int n = (int)m->solvers.size();
+    std::vector<int> rcs(n, 0), its(n, 0);
+    std::vector<std::string> errs(n);
+    std::vector<float> sse(n), R(9 * (size_t)n), t(3 * (size_t)n);
+    for (auto& l : m->links) { l->replay = false; l->calls = 0; }
+    m->rv.reset();
+    std::vector<std::thread> th;
+    for (int r = 0; r < n; ++r)
+        th.emplace_back([&, r] {
+            RankLink* l = m->links[r].get();
+            rcs[r] = fgoicp::ctx_icp_coop(fgoicp_solver_ctx(m->solvers[r]), r, n, n > 1 ? link_allgather_device : nullptr, l, R0, t0, max_iter, convergence_threshold, &sse[r],
+                                          &R[9 * (size_t)r], &t[3 * (size_t)r], &its[r]);
+            if (rcs[r]) {
+                errs[r] = fgoicp_last_error();
+                m->rv.abort();
+                for (fgoicp_rccl* x : m->rccl) (void)fgoicp_rccl_abort(x);
+            }
+        });
+    for (auto& x : th) x.join();
+    for (int r = 0; r < n; ++r)
+        if (rcs[r]) { set_error("rank " + std::to_string(r) + ": " + errs[r]); return rcs[r]; }
+    for (int r = 1; r < n; ++r)
+        if (std::memcmp(&sse[0], &sse[r], 4) != 0 || std::memcmp(&R[0], &R[9 * (size_t)r], 36) != 0 || std::memcmp(&t[0], &t[3 * (size_t)r], 12) != 0 || its[r] != its[0]) {
+            set_error("fgoicp_multi_icp: ranks ended with different results");
+            return FGOICP_ERR_EXCHANGE;
+        }
+    *sse_out = sse[0];
+    std::memcpy(R_out9, R.data(), 36);
+    std::memcpy(t_out3, t.data(), 12);
+    if (iterations_out) *iterations_out = its[0];
+    return FGOICP_OK;
 }
 
 int fgoicp_multi_world(const fgoicp_multi* m) { return m ? (int)m->solvers.size() : 0; }

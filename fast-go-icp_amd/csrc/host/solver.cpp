@@ -30,6 +30,11 @@ struct HipOps {
     int icp(const float* R0, const float* t0, size_t max_iter, float thr, float* sse, float* R9, float* t3, int* iters) {
         return ctx_icp(ctx, R0, t0, max_iter, thr, sse, R9, t3, iters);
     }
+    // one ICP run executed by all ranks together (cooperative refinements of the sharded ROUND schedule)
+    int icp_coop(int rank, int world, int (*gather)(void*, size_t, void*), void* user, const float* R0, const float* t0, size_t max_iter, float thr, float* sse,
+                 float* R9, float* t3, int* iters) {
+        return ctx_icp_coop(ctx, rank, world, gather, user, R0, t0, max_iter, thr, sse, R9, t3, iters);
+    }
     // a refinement that runs next to the bounds work (late-joining ICP of the ROUND schedule): ICP lane 1, its own streams
     int icp_background(const float* R0, const float* t0, size_t max_iter, float thr, float* sse, float* R9, float* t3, int* iters) {
         return ctx_icp_lane(ctx, 1, R0, t0, max_iter, thr, sse, R9, t3, iters);
@@ -120,6 +125,7 @@ int fgoicp_solver_set_exchange(fgoicp_solver* s, const fgoicp_exchange* ex) {
         e.allreduce_min = ex->allreduce_min;
         e.allgather = ex->allgather;
         e.user = ex->user;
+        e.allgather_device = ex->allgather_device;
     } else {
         s->has_ex = false;
     }

@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .nodes import from_glm
+from .nodes import from_glm, to_glm
 from .registration import Registration, _cloud, _fp
 
 
@@ -93,6 +93,13 @@ class MultiGoICP:
         R = np.empty(9, np.float32); t = np.empty(3, np.float32)
         _lib.check(self._lib.fgoicp_multi_run(self._h, _fp(R), _fp(t)), "fgoicp_multi_run")
         return from_glm(R), t
+
+    def icp(self, R0, t0, max_iter=100, convergence_threshold=0.005):
+        """One ICP run executed by all ranks together (fgoicp_multi_icp) -> (sse, R, t, iterations); in the solver's scaled frame."""
+        sse = np.empty(1, np.float32); R = np.empty(9, np.float32); t = np.empty(3, np.float32); it = np.empty(1, np.int32)
+        _lib.check(self._lib.fgoicp_multi_icp(self._h, _fp(to_glm(np.asarray(R0, np.float32))), _fp(np.ascontiguousarray(np.asarray(t0, np.float32))), int(max_iter),
+                                              float(convergence_threshold), _fp(sse), _fp(R), _fp(t), it.ctypes.data_as(_lib.c_int_p)), "fgoicp_multi_icp")
+        return np.float32(sse[0]), from_glm(R), t, int(it[0])
 
     def test_fault(self, rank, call):
         """TEST HOOK: the call-th exchange of `rank` in the next run fails, once."""

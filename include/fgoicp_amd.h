@@ -207,6 +207,15 @@ typedef struct fgoicp_exchange {
     int (*allreduce_min)(float* buf, size_t n, void* user);
     int (*allgather)(const float* send, float* recv, size_t n_per_rank, void* user);
     void* user;
+    /* Optional (NULL = off).  In-place all-gather on DEVICE memory of the calling rank's context: on return
+     * device_buf[r * bytes_per_rank .. (r + 1) * bytes_per_rank) holds rank r's chunk, for every r (RCCL: ncclAllGather with
+     * sendbuff = recvbuff + rank * count).  With it a round's refinements become COOPERATIVE: the child bounds are exchanged first,
+     * every rank applies the trigger rule of fgoicp.cpp:74-88 to ALL children in the single-GPU order, and each triggered
+     * IterativeClosestPoint3D::run() is executed by all ranks together — every rank scans 1/world of the source for the two exact
+     * nearest-neighbour passes of an iteration, the per-query results (4 B each) are all-gathered through this hook, the sums and the
+     * SVD are replicated.  Results are the single-GPU bits on every rank.  Called twice per ICP iteration, from the thread that
+     * called fgoicp_solver_run; the context's streams are idle during the call. */
+    int (*allgather_device)(void* device_buf, size_t bytes_per_rank, void* user);
 } fgoicp_exchange;
 
 typedef struct fgoicp_solver_opts {
@@ -298,6 +307,12 @@ void fgoicp_multi_destroy(fgoicp_multi* m);
  * If a rank fails, the exchange is aborted for all of them (nobody waits for the failed rank) and the call returns that rank's
  * status and message; with the RCCL transport the object cannot run again afterwards. */
 int fgoicp_multi_run(fgoicp_multi* m, float* R_out9, float* t_out3);
+/* One IterativeClosestPoint3D::run() (icp3d.cu:80-108) executed by ALL ranks together: each scans 1/world of the source for the two
+ * exact nearest-neighbour passes of an iteration, the per-query results are all-gathered on device memory, sums and SVD are
+ * replicated.  Same (sse, R, t, iterations) as fgoicp_icp on one GPU, bit for bit, on every rank (checked).  This is what every
+ * refinement of a multi-rank run is (fgoicp_exchange.allgather_device). */
+int fgoicp_multi_icp(fgoicp_multi* m, const float* R0, const float* t0, size_t max_iter, float convergence_threshold, float* sse_out, float* R_out9, float* t_out3,
+                     int* iterations_out);
 int fgoicp_multi_world(const fgoicp_multi* m);
 fgoicp_solver* fgoicp_multi_solver(fgoicp_multi* m, int rank);     /* borrowed: stats, getters */
 int fgoicp_multi_seconds(const fgoicp_multi* m, int rank, double* seconds);   /* wall-clock of that rank's last run() */

@@ -31,7 +31,7 @@ def main():
         G = np.load(os.path.join(REPO, "tests", "golden", "goicp_golden.npz"))
         d = hh.HostDriver(G[case + "tgt"], G[case + "src"], float(G[case + "res"]), float(G[case + "mse"]), schedule=1, round_width=K)
     ex = TorchExchange()
-    d.set_exchange(rank, world, ex._allreduce_min, ex._allgather)
+    d.set_exchange(rank, world, ex._allreduce_min, ex._allgather, coop=os.environ.get("FGOICP_TEST_COOP", "0") == "1")
     r = d.run()
     np.savez(f"{out_prefix}.rank{rank}.npz", R=r["R"], t=r["t"], sse=r["best_sse"], exchange_calls=ex.calls,
              **{k: v for k, v in r["stats"].items()})

@@ -47,6 +47,7 @@ def lib():
         L.harness_seconds.restype = C.c_double
         L.harness_destroy.argtypes = [C.c_void_p]
         L.harness_set_exchange.argtypes = [C.c_void_p, C.c_int, C.c_int, AR, AG]
+        L.harness_set_exchange_coop.argtypes = [C.c_void_p, C.c_int, C.c_int, AR, AG, C.c_int]
         L.harness_preproc.argtypes = [C.c_void_p, _fp, _fp, _fp]
         L.harness_run.argtypes = [C.c_void_p, _fp, _fp, _fp, _fp, C.POINTER(C.c_ulonglong)]
         L.harness_rotation.argtypes = [C.c_float, C.c_float, C.c_float, _fp, _fp, C.POINTER(C.c_int)]
@@ -88,9 +89,10 @@ class HostDriver:
             lib().harness_destroy(self._h)
             self._h = None
 
-    def set_exchange(self, rank, world, allreduce_min, allgather):
+    def set_exchange(self, rank, world, allreduce_min, allgather, coop=False):
+        """coop: cooperative rounds (the driver flow a device all-gather switches on; the CPU backend runs every ICP replicated)"""
         self._cbs = (AR(allreduce_min), AG(allgather))
-        lib().harness_set_exchange(self._h, rank, world, *self._cbs)
+        lib().harness_set_exchange_coop(self._h, rank, world, *self._cbs, int(bool(coop)))
 
     def preproc(self):
         offs = np.empty(6, np.float32); scale = C.c_float(); b = np.empty(6, np.float32)

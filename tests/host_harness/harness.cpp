@@ -45,6 +45,11 @@ struct OracleOps {
         std::memcpy(ub, slot_ub[slot].data(), slot_ub[slot].size() * sizeof(float));
         return 0;
     }
+    // cooperative refinement: the CPU backend has nothing to split — every rank runs the whole (deterministic) loop: same result on every rank
+    int icp_coop(int, int, int (*)(void*, size_t, void*), void*, const float* R0, const float* t0, size_t max_iter, float thr, float* sse, float* R9, float* t3,
+                 int* iters) {
+        return icp(R0, t0, max_iter, thr, sse, R9, t3, iters);
+    }
     int icp_background(const float* R0, const float* t0, size_t max_iter, float thr, float* sse, float* R9, float* t3, int* iters) {
         return icp(R0, t0, max_iter, thr, sse, R9, t3, iters);  // the oracle's ICP object is local to the call: safe next to the bounds operator
     }
@@ -130,6 +135,14 @@ void* harness_create(const float* tgt, size_t nt, const float* src, size_t ns, f
 void harness_destroy(void* p) { delete static_cast<Harness*>(p); }
 void harness_set_exchange(void* p, int rank, int world, ar_fn ar, ag_fn ag) {
     Exchange e; e.rank = rank; e.world = world; e.allreduce_min = ar; e.allgather = ag; e.user = nullptr;
+    static_cast<Harness*>(p)->drv->set_exchange(e);
+}
+// coop != 0: the exchange also offers a device all-gather, which switches the driver to COOPERATIVE rounds (bounds exchanged first,
+// triggers in the single-GPU child order on every rank).  The CPU backend never calls the hook (OracleOps::icp_coop runs the whole loop).
+static int harness_no_device_gather(void*, size_t, void*) { return 1; }
+void harness_set_exchange_coop(void* p, int rank, int world, ar_fn ar, ag_fn ag, int coop) {
+    Exchange e; e.rank = rank; e.world = world; e.allreduce_min = ar; e.allgather = ag; e.user = nullptr;
+    e.allgather_device = coop ? harness_no_device_gather : nullptr;
     static_cast<Harness*>(p)->drv->set_exchange(e);
 }
 void harness_preproc(void* p, float* offs6, float* scale, float* bounds6) {

@@ -19,11 +19,12 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch(tmp_path, case, K, world, late="0"):
+def launch(tmp_path, case, K, world, late="0", coop="0", extra_env=None):
     from tests import host_harness
     host_harness.build()  # once, here: the ranks only load it
-    prefix = str(tmp_path / f"out_{case}{K}_{world}_{late}")
-    env = dict(os.environ, OMP_NUM_THREADS="1" if world > 3 else "2", FGOICP_HOST_THREADS="1" if world > 3 else "4", FGOICP_LATE_ICP=late)
+    prefix = str(tmp_path / f"out_{case}{K}_{world}_{late}_{coop}")
+    env = dict(os.environ, OMP_NUM_THREADS="1" if world > 3 else "2", FGOICP_HOST_THREADS="1" if world > 3 else "4", FGOICP_LATE_ICP=late, FGOICP_TEST_COOP=coop,
+               **(extra_env or {}))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(REPO, "tests", "dist_worker.py"), prefix, case, str(K)]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -65,6 +66,36 @@ def test_late_joining_refinement_keeps_the_ranks_identical_and_the_optimum(tmp_p
     assert abs(float(a["sse"]) - float(G[case + "sse"])) <= eps + 2e-3 * float(G[case + "sse"])
     ang = np.degrees(np.arccos(np.clip((np.trace(a["R"].astype(np.float64).T @ G[case + "R"].astype(np.float64)) - 1) / 2, -1, 1)))
     assert ang < 2.0, ang
+
+
+@pytest.mark.parametrize("case,K,world", [("runbun_", 0, 2), ("runsyn_", 1, 3), ("runbun_", 2, 3)])
+def test_cooperative_rounds_reproduce_the_single_process_run(tmp_path, case, K, world):
+    """Cooperative rounds (the flow an exchange with a device all-gather switches on): the child bounds are exchanged
+    first, then EVERY rank applies the trigger rule of fgoicp.cpp:74-88 to ALL children in the single-process child order, each
+    triggered ICP being one run all ranks execute together.  One exchange per round; the replicated state is identical on every
+    rank; and — with the tail-batch rule off, so that a task's batches do not depend on which tasks share its rank — the run IS the
+    single-process ROUND run: same sequence of incumbents, same (R, t, sse) bit for bit, same rounds and ICP runs."""
+    from tests import host_harness as hh
+    env = {"FGOICP_TAIL_BATCH": "0"}
+    ranks = launch(tmp_path, case, K, world, coop="1", extra_env=env)
+    for r in ranks[1:]:
+        assert np.array_equal(ranks[0]["R"], r["R"]) and np.array_equal(ranks[0]["t"], r["t"]) and ranks[0]["sse"] == r["sse"]
+        assert r["rounds"] == ranks[0]["rounds"] and r["icp_runs"] == ranks[0]["icp_runs"] and r["icp_iters"] == ranks[0]["icp_iters"]
+    a = ranks[0]
+    assert 0 < a["exchange_calls"] <= a["rounds"]  # one all-gather per round that evaluated children, nothing else on the CPU backend
+    assert sum(int(r["rot_cubes"]) for r in ranks) > int(a["rot_cubes"]) > 0
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        one = hh.HostDriver(G[case + "tgt"], G[case + "src"], float(G[case + "res"]), float(G[case + "mse"]), schedule=1, round_width=K).run()
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    if K:  # a fixed round width pops K cubes per round whatever the world size -> the very same rounds (adaptive starts at 32 per rank)
+        assert np.array_equal(a["R"], one["R"]) and np.array_equal(a["t"], one["t"]) and np.float32(a["sse"]) == np.float32(one["best_sse"])
+        assert int(a["rounds"]) == one["stats"]["rounds"] and int(a["icp_runs"]) == one["stats"]["icp_runs"] and int(a["icp_iters"]) == one["stats"]["icp_iters"]
+        assert sum(int(r["rot_cubes"]) for r in ranks) == one["stats"]["rot_cubes"]
+    assert float(a["sse"]) == pytest.approx(float(G[case + "sse"]), rel=1e-5) and np.allclose(a["R"], G[case + "R"], atol=1e-5)
 
 
 def test_world_size_3_uneven_sharding(tmp_path):

@@ -48,6 +48,61 @@ def test_ranks_on_one_gpu_reach_the_single_gpu_optimum(fg, gpu_required, monkeyp
     m.close()
 
 
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_cooperative_icp_returns_the_single_gpu_bits(fg, gpu_required, world):
+    """fgoicp_multi_icp: ONE ICP run executed by `world` ranks together (each scans 1/world of the source per pass, the per-query
+    results are all-gathered on device memory, sums and SVD replicated) == fgoicp_icp on one context, bit for bit: sse, R, t and the
+    iteration count — from a far start (many iterations), from the optimum (the loop ends at once) and with max_iter reached.  A
+    cloud whose size is not a multiple of the ranks' 256-query blocks, and more ranks than the smallest share needs."""
+    tgt, src, R_gt, t_gt = fg.synth.workload("small", angle_deg=25.0)
+    src = src[:len(src) - 37]
+    m = fg.MultiGoICP(tgt, src, 0.01, 1e-3, devices=[0] * world, transport=fg.TRANSPORT_IN_PROCESS)
+    reg = m.registration(0)
+    rng = np.random.default_rng(3)
+    starts = [(np.eye(3, dtype=np.float32), np.zeros(3, np.float32), 100), (fg.synth.random_rotation(rng, 12.0).astype(np.float32), rng.uniform(-0.05, 0.05, 3).astype(np.float32), 100),
+              (np.eye(3, dtype=np.float32), np.zeros(3, np.float32), 3)]
+    for R0, t0, mi in starts:
+        icp = fg.IterativeClosestPoint3D(reg, None, None, mi, 0.005, R0, t0)
+        e1, R1, t1 = icp.run()
+        e, R, t, it = m.icp(R0, t0, mi, 0.005)
+        assert np.float32(e).view(np.uint32) == np.float32(e1).view(np.uint32) and np.array_equal(R, R1) and np.array_equal(t, t1) and it == icp.iterations, (world, mi, e, e1)
+    m.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_cooperative_rounds_are_the_single_gpu_run(fg, gpu_required, monkeypatch, world):
+    """The multi-rank run with cooperative refinements (the default when the exchange can all-gather device memory) against ONE GPU:
+    bounds exchanged first, triggers on every rank in the single-GPU child order, each ICP run by all ranks together.  With a fixed
+    round width and the tail-batch rule off (a task's batches then do not depend on which tasks share its rank) the N-rank run IS
+    the one-GPU ROUND run: same (R, t, sse) bit for bit, same rounds, ICP runs and iterations, the rotation cubes split between
+    the ranks.  FGOICP_COOP_ICP=0 (round 2's flow: a rank refines its own children alone) reaches the same optimum to 1e-5."""
+    monkeypatch.setenv("FGOICP_TAIL_BATCH", "0")
+    tgt, src, R_gt, t_gt = fg.synth.workload("small", angle_deg=150.0, min_angle_deg=110.0)
+    mse = 2e-4
+    one = fg.FastGoICP(tgt, src, 0.01, mse, schedule=fg.SCHEDULE_ROUND, round_width=6)
+    R1, t1 = one.run()
+    e1, st1 = one.get_best_error(), one.stats()
+    one.close()
+    m = fg.MultiGoICP(tgt, src, 0.01, mse, devices=[0] * world, transport=fg.TRANSPORT_IN_PROCESS, round_width=6)
+    m.set_record(True)
+    R, t = m.run()
+    st = [m.stats(r) for r in range(world)]
+    assert np.array_equal(R, R1) and np.array_equal(t, t1) and np.float32(m.get_best_error()).view(np.uint32) == np.float32(e1).view(np.uint32)
+    for s in st:
+        assert (s["rounds"], s["icp_runs"], s["icp_iters"]) == (st1["rounds"], st1["icp_runs"], st1["icp_iters"])
+    assert sum(s["rot_cubes"] for s in st) == st1["rot_cubes"] and min(s["rot_cubes"] for s in st) > 0
+    assert sum(s["trans_cubes"] for s in st) == st1["trans_cubes"]
+    # one rank alone against the recording (bounds exchanges and device all-gathers): same share, same end state
+    secs = m.replay_rank(world - 1)
+    assert secs > 0 and m.stats(world - 1)["trans_cubes"] == st[world - 1]["trans_cubes"] and m.get_best_error(world - 1) == m.get_best_error(0)
+    m.close()
+    monkeypatch.setenv("FGOICP_COOP_ICP", "0")
+    m = fg.MultiGoICP(tgt, src, 0.01, mse, devices=[0] * world, transport=fg.TRANSPORT_IN_PROCESS, round_width=6)
+    R, t = m.run()
+    assert same((R, t, m.get_best_error()), (R1, t1, e1), 1e-5)
+    m.close()
+
+
 def test_a_failing_rank_ends_the_run_for_all_ranks(fg, gpu_required):
     """One rank's exchange fails mid-run (fgoicp_multi_test_fault, a test hook of the ABI): the others must not wait for it in
     their next collective; the call returns that rank's error and THE SAME OBJECT runs cleanly afterwards (the rendezvous is
