@@ -46,6 +46,7 @@ FLAG_NO_WEIGHT_QUANT = 1 << 0
 FLAG_NO_MORTON = 1 << 1
 FLAG_PROFILE = 1 << 2
 FLAG_BRUTE_FORCE_NN = 1 << 3
+FLAG_CURVE_ORDER = 1 << 4
 SCHEDULE_SERIAL = 0
 SCHEDULE_ROUND = 1
 
@@ -109,6 +110,7 @@ _SIGS = {
     "fgoicp_multi_solver": (C.c_void_p, [C.c_void_p, C.c_int]),
     "fgoicp_multi_seconds": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     "fgoicp_multi_set_record": (C.c_int, [C.c_void_p, C.c_int]),
+    "fgoicp_multi_recorded": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "fgoicp_multi_test_fault": (C.c_int, [C.c_void_p, C.c_int, C.c_long]),
     "fgoicp_multi_replay_rank": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
 }

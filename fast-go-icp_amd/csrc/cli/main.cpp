@@ -64,8 +64,9 @@ int main(int argc, char* argv[]) {
     float best_error = 0.f;
     std::chrono::duration<double> elapsed_seconds{};
     if (gpus > 1) {
-        // EXTENSION: one host thread + one solver per GPU, children of every expansion round dealt round-robin, one RCCL
-        // all-reduce(min) + one all-gather per round (include/fgoicp_amd.h, fgoicp_multi_*).  Always the ROUND schedule.
+        // EXTENSION: one host thread + one solver per GPU (include/fgoicp_amd.h, fgoicp_multi_*).  params.schedule = "serial" (the
+        // default) keeps the reference's exact trajectory and deals the inner BnBs of every speculative evaluation over the GPUs;
+        // "round" deals the children of every expansion round (one RCCL all-gather per round; fastest).
         std::vector<int> devices;
         for (int d = 0; d < gpus; ++d) devices.push_back(d);
         int transport = FGOICP_TRANSPORT_RCCL;
@@ -74,15 +75,18 @@ int main(int argc, char* argv[]) {
             for (const char* p = e; *p;) { devices.push_back(std::atoi(p)); while (*p && *p != ',') ++p; if (*p) ++p; }
             transport = FGOICP_TRANSPORT_IN_PROCESS;
         }
-        icp::Logger(icp::LogLevel::Info) << "Sharding the search over " << devices.size() << " GPUs (schedule: expansion rounds)";
-        fgoicp_solver_opts o{FGOICP_SCHEDULE_ROUND, schedule == FGOICP_SCHEDULE_ROUND ? config.params.round_width : 0, 0u, 0, config.params.trim_fraction};
+        icp::Logger(icp::LogLevel::Info) << "Sharding the search over " << devices.size() << " GPUs (schedule: "
+                                         << (schedule == FGOICP_SCHEDULE_ROUND ? "expansion rounds" : "the reference's order, evaluations sharded") << ")";
+        fgoicp_solver_opts o{schedule, schedule == FGOICP_SCHEDULE_ROUND ? config.params.round_width : 1, 0u, 0, config.params.trim_fraction};
         fgoicp_multi* m = nullptr;
         icp::check_status(fgoicp_multi_create(&pct.data()->x, pct.size(), &pcs.data()->x, pcs.size(), config.params.lut_resolution, config.params.mse_threshold, &o,
                                               devices.data(), (int)devices.size(), transport, &m), "fgoicp_multi_create");
         auto start = std::chrono::high_resolution_clock::now();
         icp::check_status(fgoicp_multi_run(m, R.data(), &t.x), "fgoicp_multi_run");
         elapsed_seconds = std::chrono::high_resolution_clock::now() - start;
-        for (int r = 0; r < (int)devices.size(); ++r) {  // counters summed over the ranks; rank 0's incumbent is every rank's
+        // ROUND: counters summed over the ranks; SERIAL: every rank holds the whole trajectory's counters (rank 0's are reported).
+        // Rank 0's incumbent is every rank's.
+        for (int r = 0; r < (schedule == FGOICP_SCHEDULE_ROUND ? (int)devices.size() : 1); ++r) {
             fgoicp_run_stats s1{};
             icp::check_status(fgoicp_solver_stats(fgoicp_multi_solver(m, r), &s1), "fgoicp_solver_stats");
             st.trans_cubes += s1.trans_cubes; st.rot_cubes += s1.rot_cubes; st.icp_runs += s1.icp_runs; st.icp_iters += s1.icp_iters;

@@ -8,7 +8,7 @@
 
 namespace fgoicp {
 
-BvhHost bvh_build_host(const float4* p, size_t n) {
+BvhHost bvh_build_host(const float4* p, size_t n, std::vector<uint32_t>* order) {
     BvhHost h;
     const size_t nleaf_needed = (n + kBvhLeaf - 1) / kBvhLeaf;
     int depth = 0;
@@ -17,7 +17,11 @@ BvhHost bvh_build_host(const float4* p, size_t n) {
     h.depth = depth;
     h.first_leaf = (int)(nleaf - 1);
     const size_t nnodes = 2 * nleaf - 1;
-    const std::vector<uint32_t> perm = morton_order(reinterpret_cast<const float*>(p), n, 4);
+    // leaves = the cells of a k-d tree (FGOICP_BVH_ORDER=1, default) or runs of the space-filling curve (0): morton.hpp
+    static const bool kd = [] { const char* e = std::getenv("FGOICP_BVH_ORDER"); return !e || std::atoi(e) != 0; }();  // tuning knob / A-B
+    std::vector<uint32_t> own;
+    std::vector<uint32_t>& perm = order ? *order : own;
+    if (perm.size() != n) perm = kd ? kd_order(reinterpret_cast<const float*>(p), n, 4, (size_t)kBvhLeaf) : morton_order(reinterpret_cast<const float*>(p), n, 4);
     h.pts.assign(nleaf * kBvhLeaf, make_float4(FLT_MAX, FLT_MAX, FLT_MAX, 0.f));
     for (size_t i = 0; i < nleaf * kBvhLeaf; ++i) {
         uint32_t idx = 0x7fffffffu;

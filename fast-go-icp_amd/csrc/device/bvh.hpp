@@ -36,7 +36,9 @@ struct BvhHost {
 };
 
 // Builds the tree over n points (xyz float4, w ignored); original indices are the positions in `p`.
-BvhHost bvh_build_host(const float4* p, size_t n);
+// `order`: empty = computed here (and returned through it); otherwise the order to use — a second tree over the same points up to a
+// common shift (the LUT build's) is as tight under the first one's order and skips the sort.
+BvhHost bvh_build_host(const float4* p, size_t n, std::vector<uint32_t>* order = nullptr);
 
 struct BvhDevice {
     float4* box = nullptr;

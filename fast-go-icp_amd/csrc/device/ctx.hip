@@ -762,7 +762,7 @@ int ctx_icp(fgoicp_ctx* c, const float* R0, const float* t0, size_t max_iter, fl
 // called; on return chunk r of buf holds rank r's results, for every r.
 int ctx_icp_coop(fgoicp_ctx* c, int rank, int world, int (*gather)(void* dev_buf, size_t bytes_per_rank, void* user), void* user, const float* R0,
                  const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3, int* iters_out) {
-    if (world <= 1 || !gather || c->inliers || c->brute_force_nn) return ctx_icp(c, R0, t0, max_iter, thr, sse_out, R_out9, t_out3, iters_out);
+    if (world <= 1 || !gather || c->inliers || c->brute_force_nn || c->ns < c->coop_split_min) return ctx_icp(c, R0, t0, max_iter, thr, sse_out, R_out9, t_out3, iters_out);
     if (rank < 0 || rank >= world) { set_error("ctx_icp_coop: rank out of range"); return FGOICP_ERR_INVALID_ARG; }
     HIPCHK(hipSetDevice(c->device));
     fgoicp_ctx::IcpLane& L = c->lanes[0];
@@ -1200,7 +1200,17 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
     // contraction order (registration.cu:39-41).  Target: caller order (index tie rule), w = 0.
     c->perm.resize(ns);
     if (flags & FGOICP_FLAG_NO_MORTON) std::iota(c->perm.begin(), c->perm.end(), 0u);
-    else c->perm = morton_order(src_xyz, ns, 3);
+    else {
+        // k-d order with runs of 64 points (a wave of the exact scan; any chunk of 64 << k consecutive points is one k-d cell,
+        // morton.hpp) unless the caller asks for the Hilbert curve (FGOICP_FLAG_CURVE_ORDER).  Measured against the curve (round 3,
+        // profiles/r03_ab_kd_order.txt): bounds kernel 1625 -> 1478 us per launch on the bunny shape (a chunk's LUT footprint is one
+        // compact cell instead of a run that straddles curve cells), 5540 -> 5324 us on the dragon shape, ICP iteration 222 -> 169 us
+        // at 437k points; with 20 % volume outliers (1M trimmed) the cells grow tails along the surface normal and the trimmed ICP is
+        // 13 % SLOWER — hence the flag.  FGOICP_POINT_CURVE overrides: 2 = k-d, 1 = Hilbert, 0 = Z-order.
+        static const int forced = [] { const char* e = std::getenv("FGOICP_POINT_CURVE"); return e ? std::atoi(e) : -1; }();  // tuning knob
+        const int mode = forced >= 0 ? forced : ((flags & FGOICP_FLAG_CURVE_ORDER) ? 1 : 2);
+        c->perm = point_order(src_xyz, ns, 3, 64, mode);
+    }
     {
         std::vector<float4> h(ns);
         for (size_t i = 0; i < ns; ++i) {
@@ -1234,9 +1244,10 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
             }
             (void)hipFree(d_tgt_shift);
         } else {
-            CHK(bvh_upload(bvh_build_host(h.data(), nt), &c->bvh_tgt));
+            std::vector<uint32_t> order;  // one sort for both trees
+            CHK(bvh_upload(bvh_build_host(h.data(), nt, &order), &c->bvh_tgt));
             BvhDevice shifted;  // the LUT is built from the SHIFTED targets (pc + offset in fp32), its own tree
-            e3 = bvh_upload(bvh_build_host(hs.data(), nt), &shifted);
+            e3 = bvh_upload(bvh_build_host(hs.data(), nt, &order), &shifted);
             float* scratch = nullptr;
             if (e3 == hipSuccess) e3 = hipMalloc(&scratch, total * sizeof(float));
             if (e3 == hipSuccess) {
@@ -1336,6 +1347,7 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
         c->max_groups = std::max(512, c->max_subcubes / 8);
         if (const char* e = std::getenv("FGOICP_FINALIZE_SIDE")) c->finalize_on_side = std::atoi(e) != 0;  // tuning knob
         if (const char* e = std::getenv("FGOICP_ICP_SEED")) c->icp_seeding = std::atoi(e) != 0;             // tuning knob
+        if (const char* e = std::getenv("FGOICP_COOP_SPLIT_MIN")) c->coop_split_min = (size_t)std::max(0L, std::atol(e));  // tuning knob
         if (const char* e = std::getenv("FGOICP_UNITS")) { const int v = std::atoi(e); c->unit_m = (v == 4 || v == 8) ? v : 0; }  // tuning knob: siblings per work item
         if (c->lut_layout == 4) c->unit_m = 0;  // the apron layout has no sibling-unit kernel
         if (const char* e = std::getenv("FGOICP_SMALL_TICK")) c->small_tick_items = std::max(0, std::atoi(e));  // tuning knob: items

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <numeric>
 #include <vector>
 
@@ -65,6 +66,95 @@ inline std::vector<uint32_t> morton_order(const float* xyz, size_t n, size_t str
     }
     std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return code[a] < code[b]; });
     return perm;
+}
+
+// K-D ORDER (round 3).  The same implicit complete binary tree as a sorted curve gives — node at level L owns a run of
+// leaf << (depth - L) consecutive points — but the runs are the cells of a k-d tree: a node's points are split at the position
+// the implicit layout prescribes (the left child takes as many whole leaves as it can hold) along the LONGEST axis of their
+// bounding box.  Every node's box is then as tight as a box over that many points gets, whereas a run of a space-filling curve
+// through a SURFACE straddles cell boundaries of the curve: its box is the union of two or three patches.  Measured on the
+// dragon-shape pair at the optimum (tools/kd_sim.py, the scan's own rules): leaf boxes 0.0079 -> 0.0052 across, leaves a
+// 64-query group has to scan 10.5 -> 7.0 (-> 5.5 when the queries are grouped the same way).  Ties are broken by index, so the
+// order is a function of the input alone.  Only locality depends on the order, results do not.
+struct KdItem { float c[3]; uint32_t idx; };  // the points themselves are moved (16 bytes each): every pass streams through memory
+inline void kd_order_rec(KdItem* it, size_t n, size_t cap_leaves, size_t leaf, int spawn_depth);
+inline int kd_longest_axis(const KdItem* it, size_t n) {
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) lo[a] = hi[a] = it[0].c[a];
+    for (size_t i = 1; i < n; ++i)
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], it[i].c[a]);
+            hi[a] = std::max(hi[a], it[i].c[a]);
+        }
+    int ax = 0;
+    if (hi[1] - lo[1] > hi[ax] - lo[ax]) ax = 1;
+    if (hi[2] - lo[2] > hi[ax] - lo[ax]) ax = 2;
+    return ax;
+}
+// compared through an order-preserving integer image of the float: a TOTAL order whatever the input holds (a NaN would make `<` on
+// floats an inconsistent comparator, which std::nth_element may answer with out-of-range accesses)
+inline void kd_split(KdItem* it, size_t n, size_t at, int ax) {
+    auto key = [ax](const KdItem& p) {
+        uint32_t u;
+        std::memcpy(&u, &p.c[ax], 4);
+        return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+    };
+    std::nth_element(it, it + at, it + n, [&](const KdItem& a, const KdItem& b) {
+        const uint32_t ka = key(a), kb = key(b);
+        return ka < kb || (ka == kb && a.idx < b.idx);
+    });
+}
+// inside a leaf: median splits down to single points, so that neighbouring positions (lanes) hold neighbouring points
+inline void kd_order_fine(KdItem* it, size_t n) {
+    while (n > 2) {
+        const size_t half = n / 2;
+        kd_split(it, n, half, kd_longest_axis(it, n));
+        kd_order_fine(it, half);
+        it += half;
+        n -= half;
+    }
+}
+inline std::vector<uint32_t> kd_order(const float* xyz, size_t n, size_t stride, size_t leaf, bool fine = false) {
+    std::vector<uint32_t> perm(n);
+    std::iota(perm.begin(), perm.end(), 0u);
+    if (n <= leaf) return perm;
+    size_t cap = 1;
+    while (cap * leaf < n) cap *= 2;
+    std::vector<KdItem> it(n);
+    for (size_t i = 0; i < n; ++i) it[i] = KdItem{{xyz[stride * i], xyz[stride * i + 1], xyz[stride * i + 2]}, (uint32_t)i};
+    kd_order_rec(it.data(), n, cap, leaf, n >= 100000 ? 3 : 0);
+    if (fine)
+        for (size_t l = 0; l * leaf < n; ++l) kd_order_fine(it.data() + l * leaf, std::min(leaf, n - l * leaf));
+    for (size_t i = 0; i < n; ++i) perm[i] = it[i].idx;
+    return perm;
+}
+
+}  // namespace fgoicp
+
+#include <future>
+
+namespace fgoicp {
+
+inline void kd_order_rec(KdItem* it, size_t n, size_t cap_leaves, size_t leaf, int spawn_depth) {
+    std::vector<std::future<void>> left;
+    while (cap_leaves > 1 && n > leaf) {
+        const size_t half = cap_leaves / 2 * leaf;  // what the left child holds when it is full
+        if (n <= half) { cap_leaves /= 2; continue; }  // everything goes left: the right subtree stays empty
+        kd_split(it, n, half, kd_longest_axis(it, n));
+        if (spawn_depth > 0) left.push_back(std::async(std::launch::async, kd_order_rec, it, half, cap_leaves / 2, leaf, spawn_depth - 1));
+        else kd_order_rec(it, half, cap_leaves / 2, leaf, 0);
+        it += half;
+        n -= half;
+        cap_leaves /= 2;
+        if (spawn_depth > 0) --spawn_depth;
+    }
+    for (auto& f : left) f.get();
+}
+
+// The order of a point set for device work: 1 (default) = Hilbert curve, 0 = Z-order, 2 = k-d order with runs of `leaf` points.
+inline std::vector<uint32_t> point_order(const float* xyz, size_t n, size_t stride, size_t leaf, int mode) {
+    static const bool fine = [] { const char* e = std::getenv("FGOICP_KD_FINE"); return e && std::atoi(e) != 0; }();  // tuning knob / A-B
+    return mode == 2 ? kd_order(xyz, n, stride, leaf, fine) : morton_order(xyz, n, stride);
 }
 
 }  // namespace fgoicp

@@ -348,7 +348,7 @@ template <class Ops>
 class GoIcpDriver {
 public:
     GoIcpDriver(Ops& ops, size_t ns, float mse_threshold, int schedule, int round_width)
-        : ops_(ops), sse_threshold_(ns * mse_threshold), schedule_(schedule), round_width_(round_width < 0 ? 0 : round_width) {
+        : ops_(ops), sse_threshold_(ns * mse_threshold), ns_(ns), schedule_(schedule), round_width_(round_width < 0 ? 0 : round_width) {
         int nthreads = 4;
         if (const char* e = std::getenv("FGOICP_HOST_THREADS")) nthreads = std::atoi(e);
         const int hw = (int)std::thread::hardware_concurrency();
@@ -432,8 +432,16 @@ private:
     }
     // Cooperative refinements (world > 1 and the exchange can all-gather device memory): EVERY ICP of a run — the initial one, a
     // round's triggers, the final refinement — is then one run that all ranks execute together (Ops::icp_coop), at the same points of
-    // the replicated control flow.  FGOICP_COOP_ICP=0: the round-2 flow (a rank refines its own children alone).
-    bool coop() const { return coop_icp_ && ex_.world > 1 && ex_.allgather_device != nullptr; }
+    // the replicated control flow.  FGOICP_COOP_ICP: 0 = the round-2 flow (a rank refines its own children alone, against its own
+    // running best), 1 = always cooperative, unset = by size: clouds of at least FGOICP_COOP_MIN_POINTS (131072) source points.
+    // Measured on the 8-rank replay (profiles/r03_scale_replay.jsonl): the cooperative flow runs the one-GPU run's refinements and no
+    // others (dragon shape: 41 ms of ICP in all, against 196 ms summed over the ranks of the private flow, whose slowest rank spends
+    // 56 ms) but runs them on every rank one after another; the private flow runs more of them, in parallel.  437k points: 6.0x ->
+    // 6.4x; 40k points (ICP iterations are latency chains of 50 us whatever the share): 5.6x -> 4.9x, hence the size rule.
+    bool coop() const {
+        if (ex_.world <= 1 || ex_.allgather_device == nullptr) return false;
+        return coop_icp_ < 0 ? ns_ >= coop_min_points_ : coop_icp_ != 0;
+    }
     void set_best_sse_only(float sse) { std::lock_guard<std::mutex> g(mu_); best_sse_ = sse; }
     void set_last(const Mat3f& R, const Vec3f& t) { std::lock_guard<std::mutex> g(mu_); last_R_ = R; last_t_ = t; }
 
@@ -505,7 +513,7 @@ private:
             }
             if (tasks.empty()) return kDriverOk;
             account_submissions_ = false;
-            const int rc = run_task_list(tasks, cubes);
+            const int rc = serial_sharded() ? run_task_list_sharded(tasks, cubes) : run_task_list(tasks, cubes);
             account_submissions_ = true;
             return rc;
         };
@@ -581,6 +589,68 @@ private:
                 rcand.push(child);
             }
             cache.erase(key);
+        }
+        return kDriverOk;
+    }
+
+    // SERIAL ON N RANKS (round 3).  Everything the reference's trajectory consists of — the queue, the incumbent, the cache, the
+    // commit order, the counters — is replicated and stays identical on every rank by construction; what is SHARDED is the only
+    // expensive part, the speculative evaluation: the tasks of one `evaluate` call are dealt over the ranks by child (a child's UB and
+    // LB task stay on one device: twins and the memo need both), every rank runs its share, and ONE all-gather returns each task's
+    // outcome — exactly the fields a commit reads (best_ub, best_t, count, batches; fgoicp.cpp:69-72, :90, :132).  A task's inner BnB
+    // does not depend on the company it keeps (SERIAL tasks pop the reference's 32 nodes whatever the list), so its outcome is the
+    // one-GPU run's bit for bit, and so are all pops, pushes, counters and the result.  The refinements (:74-88) are cooperative runs
+    // of all ranks (Ops::icp_coop) when the exchange can all-gather device memory, replicated runs otherwise: same bits either way.
+    // The integer counters travel as 16-bit pieces in floats (exact; no transport may touch them).  FGOICP_SERIAL_SHARD=0: every rank
+    // evaluates everything (replicated run).
+    bool serial_sharded() const { return serial_shard_ && ex_.world > 1 && ex_.allgather != nullptr; }
+    int run_task_list_sharded(std::vector<Task*>& tasks, const std::vector<const RotCube*>& cubes) {
+        const int rank = ex_.rank, world = ex_.world;
+        constexpr size_t F = 10;  // floats per task outcome
+        std::vector<int> owner(tasks.size());
+        std::vector<size_t> n_of((size_t)world, 0);
+        int child = -1;
+        const RotCube* prev = nullptr;
+        for (size_t i = 0; i < tasks.size(); ++i) {
+            if (cubes[i] != prev) { ++child; prev = cubes[i]; }
+            owner[i] = child % world;
+            n_of[(size_t)owner[i]]++;
+        }
+        const size_t cap = *std::max_element(n_of.begin(), n_of.end());
+        std::vector<Task*> mine_t;
+        std::vector<const RotCube*> mine_c;
+        for (size_t i = 0; i < tasks.size(); ++i)
+            if (owner[i] == rank) { mine_t.push_back(tasks[i]); mine_c.push_back(cubes[i]); }
+        if (!mine_t.empty()) {
+            const int rc = run_task_list(mine_t, mine_c);
+            if (rc) return rc;
+        }
+        std::vector<float> send(cap * F, 0.f), recv(cap * F * (size_t)world, 0.f);
+        for (size_t k = 0; k < mine_t.size(); ++k) {
+            const Task& t = *mine_t[k];
+            float* p = &send[F * k];
+            p[0] = t.best_ub; p[1] = t.best_t.x; p[2] = t.best_t.y; p[3] = t.best_t.z;
+            for (int j = 0; j < 3; ++j) {
+                p[4 + j] = (float)((t.count >> (16 * j)) & 0xffffu);
+                p[7 + j] = (float)((t.batches >> (16 * j)) & 0xffffu);
+            }
+        }
+        if (ex_.allgather(send.data(), recv.data(), cap * F, ex_.user)) return kDriverExchangeFailed;
+        std::vector<size_t> pos((size_t)world, 0);
+        for (size_t i = 0; i < tasks.size(); ++i) {
+            const int o = owner[i];
+            const float* p = &recv[(size_t)o * cap * F + F * pos[(size_t)o]++];
+            if (o == rank) continue;
+            Task& t = *tasks[i];
+            t.best_ub = p[0];
+            t.best_t = Vec3f{p[1], p[2], p[3]};
+            t.count = t.batches = 0;
+            for (int j = 0; j < 3; ++j) {
+                t.count |= (uint64_t)p[4 + j] << (16 * j);
+                t.batches |= (uint64_t)p[7 + j] << (16 * j);
+            }
+            t.cand = std::priority_queue<TransCube>();
+            t.done = true;
         }
         return kDriverOk;
     }
@@ -1092,7 +1162,9 @@ private:
     double t_pop_ = 0, t_ops_ = 0, t_push_ = 0;
     double t_prep_[3] = {0, 0, 0};  // FGOICP_TIMING: pops / pair matching / packing inside prepare_half
     const bool timing_ = std::getenv("FGOICP_TIMING") != nullptr;  // host-side timing lines on stderr
-    const bool coop_icp_ = [] { const char* e = std::getenv("FGOICP_COOP_ICP"); return !e || std::atoi(e) != 0; }();  // tuning knob / A-B: 0 = every rank refines its own children alone
+    const bool serial_shard_ = [] { const char* e = std::getenv("FGOICP_SERIAL_SHARD"); return !e || std::atoi(e) != 0; }();  // tuning knob / A-B: 0 = SERIAL on N ranks runs replicated
+    const int coop_icp_ = [] { const char* e = std::getenv("FGOICP_COOP_ICP"); return e ? (std::atoi(e) != 0 ? 1 : 0) : -1; }();  // tuning knob / A-B: 0 = every rank refines its own children alone, 1 = cooperative rounds, unset = by size
+    const size_t coop_min_points_ = [] { const char* e = std::getenv("FGOICP_COOP_MIN_POINTS"); return e ? (size_t)std::max(0L, std::atol(e)) : (size_t)131072; }();  // tuning knob
     const int late_icp_ = [] { const char* e = std::getenv("FGOICP_LATE_ICP"); return e ? std::atoi(e) : 0; }();  // tuning knob (ROUND): 0 = off (default: measured slower, see above), 1 = with an exchange (world > 1), 2 = always
     bool use_twins_ = [] { const char* e = std::getenv("FGOICP_TWINS"); return !e || std::atoi(e) != 0; }();  // tuning knob
     const size_t round_batch_ = [] { const char* e = std::getenv("FGOICP_ROUND_BATCH"); const int v = e ? std::atoi(e) : 48; return (size_t)(v >= 8 && v <= 64 ? v : 48); }();  // tuning knob (ROUND only; SERIAL keeps the reference's 32)
@@ -1104,6 +1176,7 @@ private:
     bool account_submissions_ = true;   // false while SERIAL speculates: work is accounted per committed task instead
     std::unique_ptr<WorkerPool> pool_;
     float sse_threshold_;
+    size_t ns_;
     int schedule_, round_width_;
     Exchange ex_;
     DriverStats stats_;

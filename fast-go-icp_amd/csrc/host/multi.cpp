@@ -371,7 +371,16 @@ struct Rendezvous {
 struct DeviceGather {    // in-process all-gather on device memory: where every rank's buffer lives (written before the first barrier)
     std::vector<void*> ptr;
     std::vector<int> device;
-    std::vector<std::vector<unsigned char>> log;  // recorded gathers (whole buffers, written by rank 0): what a replayed rank receives
+    // recorded gathers (whole buffers, kept in DEVICE memory by rank 0): what a replayed rank receives.  The replay leaves the
+    // transfer out, like the replay of the host-side exchanges: its copies are on-device (microseconds); tools/scale_replay.py
+    // charges the collective's measured software path and a modelled wire time per gather instead.
+    struct Rec { void* d = nullptr; size_t bytes = 0; int device = 0; };
+    std::vector<Rec> log;
+    void clear_log() {
+        for (Rec& r : log) { (void)hipSetDevice(r.device); (void)hipFree(r.d); }
+        log.clear();
+    }
+    ~DeviceGather() { clear_log(); }
 };
 
 struct RankLink {        // what one rank's exchange callbacks see
@@ -433,15 +442,21 @@ int link_allgather(const float* send, float* recv, size_t n, void* user) {
 // Cooperative ICP's all-gather.  In process: every rank publishes its buffer, waits for the others, copies their chunks into its
 // own buffer (peer copies between devices, plain copies when the ranks share one), and waits again before anybody overwrites its
 // chunk.  Recording keeps the gathered buffer (rank 0's copy; they are equal); a replayed rank, alone on the device, computes its own
-// chunk and takes the others from the recording — the upload stands in for the transfer of the collective.
+// chunk and takes the others from the recording (on-device copies: the transfer itself is left out of a replay and charged by the caller).
 int link_allgather_device(void* buf, size_t bytes, void* user) {
     RankLink* l = static_cast<RankLink*>(user);
     const size_t total = bytes * (size_t)l->world;
     if (l->replay) {
-        if (!l->dg || l->dev_replay_pos >= l->dg->log.size() || l->dg->log[l->dev_replay_pos].size() != total) return 1;
-        const std::vector<unsigned char>& rec = l->dg->log[l->dev_replay_pos++];
-        for (int p = 0; p < l->world; ++p)
-            if (p != l->rank && hipMemcpy(static_cast<char*>(buf) + bytes * p, rec.data() + bytes * p, bytes, hipMemcpyHostToDevice) != hipSuccess) return 1;
+        if (!l->dg || l->dev_replay_pos >= l->dg->log.size() || l->dg->log[l->dev_replay_pos].bytes != total) return 1;
+        const DeviceGather::Rec& rec = l->dg->log[l->dev_replay_pos++];
+        const size_t lo = bytes * (size_t)l->rank, hi = lo + bytes;  // everything but this rank's own chunk: two contiguous ranges
+        auto copy = [&](size_t from, size_t to) {
+            if (from >= to) return hipSuccess;
+            char* dst = static_cast<char*>(buf) + from;
+            const char* src = static_cast<const char*>(rec.d) + from;
+            return rec.device == l->device ? hipMemcpyAsync(dst, src, to - from, hipMemcpyDeviceToDevice, nullptr) : hipMemcpyPeerAsync(dst, l->device, src, rec.device, to - from, nullptr);
+        };
+        if (copy(0, lo) != hipSuccess || copy(hi, total) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return 1;
         return 0;
     }
     if (l->calls++ == l->fail_at) { l->fail_at = -1; set_error("injected exchange fault (fgoicp_multi_test_fault)"); return 1; }
@@ -466,9 +481,12 @@ int link_allgather_device(void* buf, size_t bytes, void* user) {
         rc = l->inner.allgather_device(buf, bytes, l->inner.user);
     }
     if (!rc && l->record && l->rank == 0 && l->dg) {
-        std::vector<unsigned char> rec(total);
-        if (hipMemcpy(rec.data(), buf, total, hipMemcpyDeviceToHost) != hipSuccess) return 1;
-        l->dg->log.push_back(std::move(rec));
+        DeviceGather::Rec rec;
+        rec.bytes = total;
+        rec.device = l->device;
+        if (hipMalloc(&rec.d, total) != hipSuccess) { set_error("recording a device all-gather: out of device memory"); return 1; }
+        if (hipMemcpyAsync(rec.d, buf, total, hipMemcpyDeviceToDevice, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { (void)hipFree(rec.d); return 1; }
+        l->dg->log.push_back(rec);
     }
     return rc;
 }
@@ -514,7 +532,8 @@ int fgoicp_multi_create(const float* tgt_xyz, size_t nt, const float* src_xyz, s
     m->seconds.assign(ndev, 0.0);
     fgoicp_solver_opts o{FGOICP_SCHEDULE_ROUND, 0, 0u, 0, 0.0f};
     if (opts) o = *opts;
-    o.schedule = FGOICP_SCHEDULE_ROUND;  // only expansion rounds shard (SERIAL is the single-GPU reference order)
+    // both schedules shard: ROUND deals a round's children over the ranks, SERIAL (the reference's exact order) deals the tasks of
+    // every speculative evaluation (driver.hpp: run_task_list_sharded); opts == NULL: ROUND, adaptive width
     auto fail = [&](int rc) { fgoicp_multi_destroy(m.release()); return rc; };
     for (int r = 0; r < ndev; ++r) {
         o.device = devices[r];
@@ -575,13 +594,21 @@ int fgoicp_multi_test_fault(fgoicp_multi* m, int rank, long call) {
     return FGOICP_OK;
 }
 
+// What the last recorded run exchanged: host-side collectives of `rank` (all-reduces and all-gathers) and device all-gathers.
+int fgoicp_multi_recorded(const fgoicp_multi* m, int rank, uint64_t* host_exchanges, uint64_t* device_allgathers) {
+    if (!m || rank < 0 || rank >= (int)m->logs.size()) return FGOICP_ERR_INVALID_ARG;
+    if (host_exchanges) *host_exchanges = m->logs[(size_t)rank].size();
+    if (device_allgathers) *device_allgathers = m->dg.log.size();
+    return FGOICP_OK;
+}
+
 int fgoicp_multi_set_record(fgoicp_multi* m, int on) {
     if (!m) return FGOICP_ERR_INVALID_ARG;
     for (size_t r = 0; r < m->links.size(); ++r) {
         m->links[r]->record = on != 0;
         m->links[r]->replay = false;
         if (on) m->logs[r].clear();
-        if (on) m->dg.log.clear();
+        if (on) m->dg.clear_log();
     }
     return FGOICP_OK;
 }
@@ -593,7 +620,7 @@ int fgoicp_multi_run(fgoicp_multi* m, float* R_out9, float* t_out3) {
     std::vector<int> rcs(n, 0);
     std::vector<std::string> errs(n);
     std::vector<float> R(9 * (size_t)n), t(3 * (size_t)n);
-    for (auto& l : m->links) { l->replay = false; l->calls = 0; if (l->record) { l->log->clear(); m->dg.log.clear(); } }
+    for (auto& l : m->links) { l->replay = false; l->calls = 0; if (l->record) { l->log->clear(); m->dg.clear_log(); } }
     m->rv.reset();
     std::atomic<int> first_failed{-1};
     std::vector<std::thread> th;

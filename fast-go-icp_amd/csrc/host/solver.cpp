@@ -85,7 +85,7 @@ int fgoicp_solver_create(const float* tgt_xyz, size_t nt, const float* src_xyz, 
     s->scaling_factor = scale_point_clouds(s->pct, s->pcs);
     point_cloud_ranges(s->pct, s->bounds6);
     int rc = fgoicp_ctx_create(reinterpret_cast<const float*>(s->pct.data()), nt, reinterpret_cast<const float*>(s->pcs.data()), ns,
-                               s->bounds6, lut_resolution, o.device, o.ctx_flags, &s->ctx);
+                               s->bounds6, lut_resolution, o.device, o.ctx_flags | (o.trim_fraction > 0.0f ? (unsigned)FGOICP_FLAG_CURVE_ORDER : 0u), &s->ctx);
     if (rc) return rc;
     s->ops.ctx = s->ctx;
     size_t n_thr = ns;  // sse_threshold = n * mse_threshold (fgoicp.hpp:23); over the inliers when trimming

@@ -68,10 +68,10 @@ class MultiGoICP:
     """icp::FastGoICP sharded over several GPUs of one node from ONE process (one host thread + one solver per device)."""
 
     def __init__(self, pct, pcs, lut_resolution=0.005, mse_threshold=1e-3, devices=(0,), transport=_lib.TRANSPORT_RCCL, round_width=0, flags=0,
-                 trim_fraction=0.0):
+                 trim_fraction=0.0, schedule=_lib.SCHEDULE_ROUND):
         self._lib = _lib.load()
         pct, pcs = _cloud(pct), _cloud(pcs)
-        opts = _lib.SolverOpts(_lib.SCHEDULE_ROUND, int(round_width), int(flags), 0, float(trim_fraction))
+        opts = _lib.SolverOpts(int(schedule), int(round_width), int(flags), 0, float(trim_fraction))  # SCHEDULE_SERIAL: the reference's trajectory, sharded
         dev = np.asarray(list(devices), np.int32)
         self._h = C.c_void_p()
         _lib.check(self._lib.fgoicp_multi_create(_fp(pct), len(pct), _fp(pcs), len(pcs), float(lut_resolution), float(mse_threshold), C.byref(opts),
@@ -107,6 +107,12 @@ class MultiGoICP:
 
     def set_record(self, on=True):
         _lib.check(self._lib.fgoicp_multi_set_record(self._h, int(bool(on))), "fgoicp_multi_set_record")
+
+    def recorded(self, rank=0):
+        """(host-side collectives of `rank`, device all-gathers) of the last recorded run"""
+        h, d = C.c_uint64(), C.c_uint64()
+        _lib.check(self._lib.fgoicp_multi_recorded(self._h, int(rank), C.byref(h), C.byref(d)), "fgoicp_multi_recorded")
+        return h.value, d.value
 
     def replay_rank(self, rank):
         """Wall-clock of `rank` running alone against the recorded exchange results."""

@@ -48,7 +48,10 @@ enum {
     FGOICP_FLAG_NO_WEIGHT_QUANT = 1u << 0, /* trilinear weights in full fp32 instead of CUDA's 1.8 fixed point */
     FGOICP_FLAG_NO_MORTON       = 1u << 1, /* keep the source cloud in caller order on the device             */
     FGOICP_FLAG_PROFILE         = 1u << 2, /* bracket every bounds kernel with HIP events (fgoicp_ctx_profile) */
-    FGOICP_FLAG_BRUTE_FORCE_NN  = 1u << 3  /* O(n*m) brute-force kernels for LUT build / SSE / ICP instead of the exact BVH */
+    FGOICP_FLAG_BRUTE_FORCE_NN  = 1u << 3, /* O(n*m) brute-force kernels for LUT build / SSE / ICP instead of the exact BVH */
+    FGOICP_FLAG_CURVE_ORDER     = 1u << 4  /* source cloud along the Hilbert curve instead of in k-d order on the device: for sources with outliers
+                                              spread through the volume (trimmed runs; fgoicp_solver_create sets it when trim_fraction > 0).  Locality only:
+                                              results do not depend on the order */
 };
 
 /*
@@ -297,7 +300,11 @@ void fgoicp_rccl_destroy(fgoicp_rccl* x);
 
 /* One process, one host thread + one solver per device — what `fast-go-icp --gpus N` runs.  devices[r] = HIP ordinal of rank r.
  * FGOICP_TRANSPORT_RCCL needs distinct devices; FGOICP_TRANSPORT_IN_PROCESS (a shared-memory rendezvous of the rank threads)
- * takes any list, e.g. {0, 0, 0, 0}: four ranks rehearsed on one GPU.  The schedule is always FGOICP_SCHEDULE_ROUND. */
+ * takes any list, e.g. {0, 0, 0, 0}: four ranks rehearsed on one GPU.  opts->schedule selects what is sharded (opts == NULL:
+ * ROUND, adaptive width): FGOICP_SCHEDULE_ROUND deals the children of an expansion round over the ranks (fastest; an epsilon-optimal
+ * result reached in another order than the reference's); FGOICP_SCHEDULE_SERIAL keeps the reference's exact trajectory
+ * (fgoicp.cpp:32-100: same pops, pushes, counters and result as the one-GPU SERIAL run, bit for bit, on every rank) and deals the
+ * inner BnBs of every speculative evaluation over the ranks — one all-gather per evaluation, cooperative refinements. */
 typedef struct fgoicp_multi fgoicp_multi;
 enum { FGOICP_TRANSPORT_RCCL = 0, FGOICP_TRANSPORT_IN_PROCESS = 1 };
 int fgoicp_multi_create(const float* tgt_xyz, size_t nt, const float* src_xyz, size_t ns, float lut_resolution, float mse_threshold,
@@ -319,6 +326,8 @@ int fgoicp_multi_seconds(const fgoicp_multi* m, int rank, double* seconds);   /*
 /* Scaling rehearsal on fewer GPUs than ranks: record what every exchange returned during a run, then run ONE rank alone
  * against the recording — the time that rank would need on a GPU of its own, without the collectives' latency. */
 int fgoicp_multi_set_record(fgoicp_multi* m, int on);
+/* What the last recorded run exchanged: the host-side collectives of `rank` and the device all-gathers of the cooperative ICP runs. */
+int fgoicp_multi_recorded(const fgoicp_multi* m, int rank, uint64_t* host_exchanges, uint64_t* device_allgathers);
 /* TEST HOOK, not part of the drop-in surface: the call-th exchange of `rank` in the next run fails, once. */
 int fgoicp_multi_test_fault(fgoicp_multi* m, int rank, long call);
 int fgoicp_multi_replay_rank(fgoicp_multi* m, int rank, double* seconds_out);

@@ -115,7 +115,7 @@ def test_invalid_arguments_are_refused_before_any_device_work(fg):
     dev = (C.c_int * 1)(0)
     assert lib.fgoicp_multi_create(fp, 4, fp, 4, 0.1, 1e-3, None, dev, 1, 7, C.byref(h)) == 1  # unknown transport
     assert lib.fgoicp_multi_run(None, None, None) == 1 and lib.fgoicp_multi_world(None) == 0 and not lib.fgoicp_multi_solver(None, 0)
-    assert lib.fgoicp_multi_set_record(None, 1) == 1 and lib.fgoicp_multi_replay_rank(None, 0, None) == 1 and lib.fgoicp_multi_seconds(None, 0, None) == 1
+    assert lib.fgoicp_multi_recorded(None, 0, None, None) == 1 and lib.fgoicp_multi_set_record(None, 1) == 1 and lib.fgoicp_multi_replay_rank(None, 0, None) == 1 and lib.fgoicp_multi_seconds(None, 0, None) == 1
     assert lib.fgoicp_rccl_comm_count(None, None) == 1 and lib.fgoicp_multi_test_fault(None, 0, 0) == 1 and lib.fgoicp_ctx_test_sort_fault(None, 0) == 1
     lib.fgoicp_multi_destroy(None); lib.fgoicp_rccl_destroy(None)  # no-ops
     assert b"invalid" in lib.fgoicp_last_error() or b"" == lib.fgoicp_last_error()[:0]

@@ -24,6 +24,7 @@ def launch(tmp_path, case, K, world, late="0", coop="0", extra_env=None):
     host_harness.build()  # once, here: the ranks only load it
     prefix = str(tmp_path / f"out_{case}{K}_{world}_{late}_{coop}")
     env = dict(os.environ, OMP_NUM_THREADS="1" if world > 3 else "2", FGOICP_HOST_THREADS="1" if world > 3 else "4", FGOICP_LATE_ICP=late, FGOICP_TEST_COOP=coop,
+               FGOICP_COOP_ICP=coop,  # the flow itself is chosen by cloud size (driver.hpp coop()); these clouds are small: forced here
                **(extra_env or {}))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(REPO, "tests", "dist_worker.py"), prefix, case, str(K)]
@@ -96,6 +97,29 @@ def test_cooperative_rounds_reproduce_the_single_process_run(tmp_path, case, K, 
         assert int(a["rounds"]) == one["stats"]["rounds"] and int(a["icp_runs"]) == one["stats"]["icp_runs"] and int(a["icp_iters"]) == one["stats"]["icp_iters"]
         assert sum(int(r["rot_cubes"]) for r in ranks) == one["stats"]["rot_cubes"]
     assert float(a["sse"]) == pytest.approx(float(G[case + "sse"]), rel=1e-5) and np.allclose(a["R"], G[case + "R"], atol=1e-5)
+
+
+@pytest.mark.parametrize("case,world,coop", [("runbun_", 2, "1"), ("runsyn_", 3, "0")])
+def test_sharded_serial_schedule_is_the_reference_trajectory(tmp_path, case, world, coop):
+    """SERIAL on N ranks (driver.hpp run_task_list_sharded): queue, incumbent, cache and commit order replicated, the inner BnBs of
+    every speculative evaluation dealt over the ranks, one all-gather of the task outcomes per evaluation.  EVERY rank must end with
+    the reference trajectory's counters — the golden SERIAL record, i.e. the oracle's literal driver: subcubes, operator calls,
+    rotation cubes, ICP runs and iterations, inner BnBs — and its result, bit for bit; and the evaluations must really have been
+    shared (FGOICP_TIMING-free check: the exchange was used, and a replicated control run needs none)."""
+    env = {"FGOICP_TEST_SCHEDULE": "0"}
+    ranks = launch(tmp_path, case, 0, world, coop=coop, extra_env=env)
+    keys = ("trans_cubes", "bounds_calls", "rot_cubes", "icp_runs", "icp_iters", "inner_bnb")
+    for r in ranks:
+        assert [int(r[k]) for k in keys] == list(G[case + "stats"])
+        assert np.array_equal(r["R"], ranks[0]["R"]) and np.array_equal(r["t"], ranks[0]["t"]) and r["sse"] == ranks[0]["sse"]
+        assert int(r["exchange_calls"]) == int(ranks[0]["exchange_calls"]) > 0
+    a = ranks[0]
+    assert np.float32(a["sse"]) == np.float32(G[case + "sse"]) and np.array_equal(a["R"], G[case + "R"]) and np.array_equal(a["t"], G[case + "t"])
+    # FGOICP_SERIAL_SHARD=0: every rank walks the trajectory alone (no exchange at all on the CPU backend) — same record
+    ranks = launch(tmp_path, case, 1, world, coop=coop, extra_env=dict(env, FGOICP_SERIAL_SHARD="0"))
+    for r in ranks:
+        assert [int(r[k]) for k in keys] == list(G[case + "stats"]) and int(r["exchange_calls"]) == 0
+        assert np.float32(r["sse"]) == np.float32(G[case + "sse"])
 
 
 def test_world_size_3_uneven_sharding(tmp_path):

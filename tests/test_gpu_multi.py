@@ -49,11 +49,14 @@ def test_ranks_on_one_gpu_reach_the_single_gpu_optimum(fg, gpu_required, monkeyp
 
 
 @pytest.mark.parametrize("world", [2, 3, 5])
-def test_cooperative_icp_returns_the_single_gpu_bits(fg, gpu_required, world):
+def test_cooperative_icp_returns_the_single_gpu_bits(fg, gpu_required, monkeypatch, world):
     """fgoicp_multi_icp: ONE ICP run executed by `world` ranks together (each scans 1/world of the source per pass, the per-query
     results are all-gathered on device memory, sums and SVD replicated) == fgoicp_icp on one context, bit for bit: sse, R, t and the
     iteration count — from a far start (many iterations), from the optimum (the loop ends at once) and with max_iter reached.  A
-    cloud whose size is not a multiple of the ranks' 256-query blocks, and more ranks than the smallest share needs."""
+    cloud whose size is not a multiple of the ranks' 256-query blocks, and more ranks than the smallest share needs.
+    FGOICP_COOP_SPLIT_MIN=0: by default the scans are not split (the loop runs replicated on every rank: measured no slower at 437k
+    points on 8 ranks) — the last case checks that default against the same bits."""
+    monkeypatch.setenv("FGOICP_COOP_SPLIT_MIN", "0")
     tgt, src, R_gt, t_gt = fg.synth.workload("small", angle_deg=25.0)
     src = src[:len(src) - 37]
     m = fg.MultiGoICP(tgt, src, 0.01, 1e-3, devices=[0] * world, transport=fg.TRANSPORT_IN_PROCESS)
@@ -67,16 +70,26 @@ def test_cooperative_icp_returns_the_single_gpu_bits(fg, gpu_required, world):
         e, R, t, it = m.icp(R0, t0, mi, 0.005)
         assert np.float32(e).view(np.uint32) == np.float32(e1).view(np.uint32) and np.array_equal(R, R1) and np.array_equal(t, t1) and it == icp.iterations, (world, mi, e, e1)
     m.close()
+    monkeypatch.delenv("FGOICP_COOP_SPLIT_MIN")
+    m = fg.MultiGoICP(tgt, src, 0.01, 1e-3, devices=[0] * world, transport=fg.TRANSPORT_IN_PROCESS)
+    e, R, t, it = m.icp(*starts[1][:2], 100, 0.005)
+    icp = fg.IterativeClosestPoint3D(m.registration(0), None, None, 100, 0.005, *starts[1][:2])
+    e1, R1, t1 = icp.run()
+    assert np.float32(e).view(np.uint32) == np.float32(e1).view(np.uint32) and np.array_equal(R, R1) and np.array_equal(t, t1) and it == icp.iterations
+    m.close()
 
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_cooperative_rounds_are_the_single_gpu_run(fg, gpu_required, monkeypatch, world):
-    """The multi-rank run with cooperative refinements (the default when the exchange can all-gather device memory) against ONE GPU:
+    """The multi-rank run with cooperative refinements (the default for clouds of at least 131072 source points when the exchange can
+    all-gather device memory; forced here) against ONE GPU:
     bounds exchanged first, triggers on every rank in the single-GPU child order, each ICP run by all ranks together.  With a fixed
     round width and the tail-batch rule off (a task's batches then do not depend on which tasks share its rank) the N-rank run IS
     the one-GPU ROUND run: same (R, t, sse) bit for bit, same rounds, ICP runs and iterations, the rotation cubes split between
     the ranks.  FGOICP_COOP_ICP=0 (round 2's flow: a rank refines its own children alone) reaches the same optimum to 1e-5."""
     monkeypatch.setenv("FGOICP_TAIL_BATCH", "0")
+    monkeypatch.setenv("FGOICP_COOP_ICP", "1")        # by default the flow is chosen by cloud size (cooperative from 131072 source points)
+    monkeypatch.setenv("FGOICP_COOP_SPLIT_MIN", "0")  # and split the scans of every ICP over the ranks (default: replicated runs)
     tgt, src, R_gt, t_gt = fg.synth.workload("small", angle_deg=150.0, min_angle_deg=110.0)
     mse = 2e-4
     one = fg.FastGoICP(tgt, src, 0.01, mse, schedule=fg.SCHEDULE_ROUND, round_width=6)
@@ -100,6 +113,36 @@ def test_cooperative_rounds_are_the_single_gpu_run(fg, gpu_required, monkeypatch
     m = fg.MultiGoICP(tgt, src, 0.01, mse, devices=[0] * world, transport=fg.TRANSPORT_IN_PROCESS, round_width=6)
     R, t = m.run()
     assert same((R, t, m.get_best_error()), (R1, t1, e1), 1e-5)
+    m.close()
+
+
+@pytest.mark.parametrize("world,split", [(2, "0"), (3, None), (5, "0")])
+def test_sharded_serial_schedule_is_the_single_gpu_serial_run(fg, gpu_required, monkeypatch, world, split):
+    """SERIAL — the reference's exact trajectory (fgoicp.cpp:32-100) — on N ranks: the inner BnBs of every speculative evaluation are
+    dealt over the ranks, everything else is replicated (driver.hpp run_task_list_sharded).  EVERY rank must end with the one-GPU
+    SERIAL run's counters (subcubes, operator calls, rotation cubes, inner BnBs, ICP runs and iterations, pops) and its (R, t, sse),
+    bit for bit — with the refinements split over the ranks (FGOICP_COOP_ICP=1, FGOICP_COOP_SPLIT_MIN=0) or replicated (the default).
+    Replaying one rank alone against the recording ends in the same state."""
+    if split is not None:
+        monkeypatch.setenv("FGOICP_COOP_ICP", "1")
+        monkeypatch.setenv("FGOICP_COOP_SPLIT_MIN", split)
+    tgt, src, R_gt, t_gt = fg.synth.workload("small", angle_deg=150.0, min_angle_deg=110.0)
+    mse = 2e-4
+    one = fg.FastGoICP(tgt, src, 0.01, mse, schedule=fg.SCHEDULE_SERIAL)
+    R1, t1 = one.run()
+    e1, st1 = one.get_best_error(), one.stats()
+    one.close()
+    keys = ("trans_cubes", "bounds_calls", "rot_cubes", "icp_runs", "icp_iters", "inner_bnb", "rounds")
+    m = fg.MultiGoICP(tgt, src, 0.01, mse, devices=[0] * world, transport=fg.TRANSPORT_IN_PROCESS, schedule=fg.SCHEDULE_SERIAL)
+    m.set_record(True)
+    R, t = m.run()
+    assert np.array_equal(R, R1) and np.array_equal(t, t1) and np.float32(m.get_best_error()).view(np.uint32) == np.float32(e1).view(np.uint32)
+    for r in range(world):
+        st = m.stats(r)
+        assert [st[k] for k in keys] == [st1[k] for k in keys], (r, st, st1)
+    secs = m.replay_rank(world - 1)
+    st = m.stats(world - 1)
+    assert secs > 0 and [st[k] for k in keys] == [st1[k] for k in keys] and m.get_best_error(world - 1) == m.get_best_error(0)
     m.close()
 
 
@@ -175,3 +218,16 @@ def test_cli_gpus_flag(fg, gpu_required, tmp_path):
         txt = (tmp_path / f"{name}_out.toml").read_text()
         out[name] = float(re.search(r"^sse = (.*)$", txt, re.M).group(1))
     assert out["two"] == pytest.approx(out["one"], rel=1e-5)
+    # the default schedule ("serial": the reference's order) with --gpus 2: the one-GPU record, counter for counter
+    rec = {}
+    for name, extra, env in (("s_one", [], {}), ("s_two", ["--gpus", "2"], {"FGOICP_MULTI_DEVICES": "0,0"})):
+        cfg = tmp_path / f"{name}.toml"
+        cfg.write_text(f'[io]\ntarget = "{tmp_path}/tgt.txt"\nsource = "{tmp_path}/src.txt"\noutput = "{tmp_path}/{name}_out.toml"\n'
+                       f'[params]\nsource_subsample = 1.0\nlut_resolution = {float(G["runsyn_res"])}\nmse_threshold = {float(G["runsyn_mse"])}\nseed = 3\n')
+        p = subprocess.run([exe, "-c", str(cfg), *extra], capture_output=True, text=True, timeout=300, env={**os.environ, **env})
+        assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+        if extra:
+            assert "the reference's order, evaluations sharded" in p.stdout
+        txt = (tmp_path / f"{name}_out.toml").read_text()
+        rec[name] = re.sub(r"^seconds = .*$", "", txt, flags=re.M)  # R, t, sse, mse, subcubes, rotation cubes, ICP runs and iterations, pops
+    assert rec["s_two"] == rec["s_one"]
