@@ -405,12 +405,16 @@ def main():
         line.update({k: s[k] for k in ("rot_cubes_rank0", "icp_runs_rank0", "rounds", "seconds_bnb_rank0", "seconds_icp_rank0", "setup_s_upload_plus_lut_build")})
         line["result"] = {"best_sse": head["best_sse"], "rotation_error_deg_vs_ground_truth": s["rotation_error_deg_vs_ground_truth"],
                           "translation_error_vs_ground_truth": s["translation_error_vs_ground_truth"]}
-        line["roofline"] = roofline(head, pmc_all.get("headline"), {
-            "limited_by": "L1-miss concurrency x L2 latency, not HBM bytes (round-3 counters of this kernel, profiles/bench_pmc_extra.json [headline]: L1 hit rate 41 %, the L1 "
-                          "in pending-stall 55 % of its cycles, 320 cycles per L1 miss, VALU issue 37 %); a build whose gathers all hit on chip runs 1.71x faster "
-                          "(profiles/r02_ablation_fixed_tick.txt); the plain LUT that fits the Infinity Cache moves 37 % fewer bytes and is 1.58x slower "
-                          "(profiles/r03_ab_lut_layout_final_ticks.txt)"})
+        line["roofline"] = roofline(head, pmc_all.get("headline"), {})
         utilisation(line["roofline"], pmc_extra.get("headline"))
+        u = line["roofline"].get("utilisation") or {}
+        if u.get("valu"):  # the counters of THIS kernel build (profiles/bench_pmc_extra.json [headline]), not a remembered figure
+            line["roofline"]["limited_by"] = (
+                f"L1-miss concurrency x L2 latency and VALU issue, not HBM bytes (counters of this kernel, profiles/bench_pmc_extra.json [headline]: L1 hit rate "
+                f"{100 * u.get('l1_hit_rate', 0):.0f} %, the L1 in pending-stall {100 * u.get('l1_pending_stall_frac', 0):.0f} % of its cycles, {u.get('l1_miss_latency_cycles', 0):.0f} cycles per L1 miss, "
+                f"VALU issue {100 * (u['valu'].get('frac_cycle_based') or u['valu']['frac']):.0f} %, measured HBM traffic {100 * (line['roofline'].get('hbm_actual_frac') or 0):.0f} % of the peak); round 2: a build whose "
+                "gathers all hit on chip ran 1.71x faster (profiles/r02_ablation_fixed_tick.txt), the plain LUT that fits the Infinity Cache moved 37 % fewer bytes and was 1.58x slower "
+                "(profiles/r03_ab_lut_layout_final_ticks.txt); round 3: the k-d order of the source cloud cut the traffic by a third and the launch by 9 % (profiles/r03_ab_kd_order.txt)")
 
     # BASELINE.md's parameters (mse_threshold 1e-3) on the same clouds
     dflt = None

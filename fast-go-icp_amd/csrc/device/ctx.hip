@@ -791,24 +791,33 @@ int ctx_icp_coop(fgoicp_ctx* c, int rank, int world, int (*gather)(void* dev_buf
     Mat3f last_R = Mat3f::identity();
     Vec3f last_t{0, 0, 0};
     int iters = 0;
-    while (iter++ < max_iter && (last_sse - sse) > thr * last_sse) {  // icp3d.cu:94
-        last_sse = sse;
-        last_R = R;
-        last_t = t;
-        // procrustes (icp3d.cu:140-172): correspondences of my share, gathered; sums over everything
-        if (nq > 0)
-            launch_nn_scan(L.d_work + qb, nq, c->bvh_tgt.view(), c->d_lut, c->geom, nullptr, nullptr, 0, 1, c->d_tgt, nt, iters > 0 && seeding ? idx + qb : nullptr, nullptr,
-                           nullptr, idx + qb, S);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(S));
-        if (gather(idx, sizeof(uint32_t) * per, user)) return FGOICP_ERR_EXCHANGE;
+    // The loop is lane_icp_dual's (one walk per iteration serves the exact SSE of iteration k and the correspondences of iteration k + 1),
+    // with the walk cut down to this rank's queries and two in-place all-gathers behind it: ONE scan, two gathers and two host syncs
+    // per iteration (a first version ran the two scans one after the other: two scans, two gathers, four syncs).
+    auto reduce_pass = [&]() {  // sums, centroids, covariance of the correspondences in idx[] (all ranks' shares), as ctx_procrustes_device
         launch_icp_sums(L.d_work, c->d_tgt, idx, ns, nt, nullptr, L.d_bp, nb, S);
         launch_icp_centroids(L.d_bp, nb, ns, L.d_cen, L.hd_cen, S);
         launch_icp_cov(L.d_work, c->d_tgt, idx, ns, nt, L.d_cen, nullptr, L.d_bp2, nb, S);
         launch_sum_partials(L.d_bp2, nb, 9, L.hd_sums, S);
+        L.cov_on_host = false;
+    };
+    bool pending = false;
+    if (max_iter > 0) {  // pass 1 (icp3d.cu:140-172): correspondences of my share, gathered; sums over everything
+        if (nq > 0)
+            launch_nn_scan(L.d_work + qb, nq, c->bvh_tgt.view(), c->d_lut, c->geom, nullptr, nullptr, 0, 1, c->d_tgt, nt, nullptr, nullptr, nullptr, idx + qb, S);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(S));
-        L.cov_on_host = false;
+        if (gather(idx, sizeof(uint32_t) * per, user)) return FGOICP_ERR_EXCHANGE;
+        reduce_pass();
+        pending = true;
+    }
+    while (iter++ < max_iter && (last_sse - sse) > thr * last_sse) {  // icp3d.cu:94
+        last_sse = sse;
+        last_R = R;
+        last_t = t;
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(S));  // first iteration: pass 1; later: a no-op (the SSE's sync below drained the stream)
+        pending = false;
         Mat3f Rn;
         Vec3f tn;
         procrustes_finish(L, &Rn, &tn, nullptr, nullptr);
@@ -816,13 +825,20 @@ int ctx_icp_coop(fgoicp_ctx* c, int rank, int world, int (*gather)(void* dev_buf
         R = Rn * R;                                              // :101
         t = Rn * t + tn;                                         // :102
         const float t3[3] = {t.x, t.y, t.z};
-        launch_transform_inplace(L.d_work, ns, Rn.m, tn3, S);    // :100
-        // compute_sse_error(R, t) (:103): minima of my share, gathered; one sum over everything
-        if (nq > 0)
-            launch_nn_scan(c->d_src + qb, nq, c->bvh_tgt.view(), c->d_lut, c->geom, R.m, t3, 1, 0, c->d_tgt, nt, seeding ? idx + qb : nullptr, nullptr, nullptr, mins + qb, S);
+        launch_transform_inplace(L.d_work, ns, Rn.m, tn3, S);    // :100 (the whole cloud: the reductions read all of it)
+        const bool next = iter < max_iter;
+        if (nq > 0) {
+            if (next)  // compute_sse_error(R, t) (:103) of this iteration and the correspondences of the next: one walk, my share
+                launch_nn_scan_dual(L.d_work + qb, nullptr, nullptr, 0, c->d_src + qb, R.m, t3, nq, c->bvh_tgt.view(), c->d_lut, c->geom, c->d_tgt, nt, seeding ? idx + qb : nullptr,
+                                    nullptr, nullptr, nullptr, nullptr, idx + qb, mins + qb, nullptr, nullptr, nullptr, S);
+            else       // the last iteration the loop can make: no pass rides along
+                launch_nn_scan(c->d_src + qb, nq, c->bvh_tgt.view(), c->d_lut, c->geom, R.m, t3, 1, 0, c->d_tgt, nt, seeding ? idx + qb : nullptr, nullptr, nullptr, mins + qb, S);
+        }
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(S));
+        if (next && gather(idx, sizeof(uint32_t) * per, user)) return FGOICP_ERR_EXCHANGE;
         if (gather(mins, sizeof(uint32_t) * per, user)) return FGOICP_ERR_EXCHANGE;
+        if (next) { reduce_pass(); pending = true; }  // speculative, as on one GPU (the loop may end on this iteration's SSE)
         launch_sum_f32_as_f64(mins, ns, L.d_bp3, nb, S);
         launch_sum_partials(L.d_bp3, nb, 1, L.hd_sums + 12, S);
         HIPCHK(hipGetLastError());
@@ -830,6 +846,7 @@ int ctx_icp_coop(fgoicp_ctx* c, int rank, int world, int (*gather)(void* dev_buf
         sse = (float)L.h_sums[12];
         ++iters;
     }
+    if (pending) HIPCHK(hipStreamSynchronize(S));  // the speculative pass: drained, not used
     const bool cur_best = sse < last_sse;  // :106-107
     *sse_out = cur_best ? sse : last_sse;
     const Mat3f& Ro = cur_best ? R : last_R;

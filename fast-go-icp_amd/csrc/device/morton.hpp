@@ -151,10 +151,72 @@ inline void kd_order_rec(KdItem* it, size_t n, size_t cap_leaves, size_t leaf, i
     for (auto& f : left) f.get();
 }
 
-// The order of a point set for device work: 1 (default) = Hilbert curve, 0 = Z-order, 2 = k-d order with runs of `leaf` points.
+// MIXED ORDER (mode 3): a cloud with outliers scattered through the volume (trimmed Go-ICP's input) is two populations — a surface
+// sample and a sparse volume sample — and a k-d cell over both is a surface patch plus the outliers above and below it (the tails that
+// make the k-d order lose there, ctx.hip).  Here the points are split by LOCAL DENSITY first: the grid level of the Hilbert code is
+// chosen so that the median point shares its cell with at least 8 others, a point alone in its cell is "scattered"; the dense
+// points come first in k-d order (pure surface patches), the scattered ones follow along the curve.  Fewer than 1 % scattered: plain
+// k-d order.  Locality only — results do not depend on the order.
+// MEASURED (profiles/r03_ab_kd_order.txt, third pass), 1M points with 20 % outliers, trimmed run: 1.40 s against 1.25 s with the plain
+// Hilbert order and 1.36 s with the plain k-d order (ICP 543 / 459 / 514 ms, bounds kernel 5 640 / 5 290 / 5 250 us per launch) — a
+// recorded negative: the trimmed kernels do better when a wave's queries mix both populations than when whole waves are outliers
+// (the row sample of the trimmed bounds, every 32nd point, also stops being a sample of the row).  Kept as FGOICP_POINT_CURVE=3.
+inline std::vector<uint32_t> mixed_order(const float* xyz, size_t n, size_t stride, size_t leaf, bool fine, size_t* n_dense_out = nullptr) {
+    if (n_dense_out) *n_dense_out = n;
+    if (n <= 4 * leaf) return kd_order(xyz, n, stride, leaf, fine);
+    float lo[3] = {xyz[0], xyz[1], xyz[2]}, hi[3] = {xyz[0], xyz[1], xyz[2]};
+    for (size_t i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], xyz[stride * i + a]);
+            hi[a] = std::max(hi[a], xyz[stride * i + a]);
+        }
+    const float ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
+    if (!(ext > 0)) return kd_order(xyz, n, stride, leaf, fine);
+    std::vector<uint64_t> keyed(n);  // (code, index): one flat sort
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t c[3];
+        for (int a = 0; a < 3; ++a) c[a] = (uint32_t)std::min(1023.0f, std::max(0.0f, (xyz[stride * i + a] - lo[a]) / ext * 1023.0f));
+        keyed[i] = ((uint64_t)hilbert30(c[0], c[1], c[2]) << 32) | (uint64_t)i;
+    }
+    std::sort(keyed.begin(), keyed.end());
+    std::vector<uint32_t> code(n), by_code(n);  // by position in curve order
+    for (size_t k = 0; k < n; ++k) { code[k] = (uint32_t)(keyed[k] >> 32); by_code[k] = (uint32_t)keyed[k]; }
+    std::vector<uint32_t> cnt(n);  // per position of by_code: the population of its cell at the level under test
+    int level = 0;
+    for (int L = 10; L >= 1; --L) {
+        const int sh = 3 * (10 - L);
+        for (size_t b = 0; b < n;) {
+            size_t e = b + 1;
+            while (e < n && (code[e] >> sh) == (code[b] >> sh)) ++e;
+            for (size_t k = b; k < e; ++k) cnt[k] = (uint32_t)(e - b);
+            b = e;
+        }
+        std::vector<uint32_t> tmp(cnt);
+        std::nth_element(tmp.begin(), tmp.begin() + n / 2, tmp.end());
+        if (tmp[n / 2] >= 9) { level = L; break; }
+    }
+    if (level == 0) return kd_order(xyz, n, stride, leaf, fine);
+    std::vector<uint32_t> dense, scattered;
+    for (size_t k = 0; k < n; ++k) (cnt[k] <= 1 ? scattered : dense).push_back(by_code[k]);  // both stay in curve order
+    if (scattered.size() * 100 < n) return kd_order(xyz, n, stride, leaf, fine);
+    std::vector<float> dp(3 * dense.size());
+    for (size_t i = 0; i < dense.size(); ++i)
+        for (int a = 0; a < 3; ++a) dp[3 * i + a] = xyz[stride * dense[i] + a];
+    const std::vector<uint32_t> kd = kd_order(dp.data(), dense.size(), 3, leaf, fine);
+    std::vector<uint32_t> perm;
+    perm.reserve(n);
+    for (uint32_t j : kd) perm.push_back(dense[j]);
+    for (uint32_t j : scattered) perm.push_back(j);
+    if (n_dense_out) *n_dense_out = dense.size();
+    return perm;
+}
+
+// The order of a point set for device work: 1 = Hilbert curve, 0 = Z-order, 2 = k-d order with runs of `leaf` points, 3 = mixed.
 inline std::vector<uint32_t> point_order(const float* xyz, size_t n, size_t stride, size_t leaf, int mode) {
-    static const bool fine = [] { const char* e = std::getenv("FGOICP_KD_FINE"); return e && std::atoi(e) != 0; }();  // tuning knob / A-B
-    return mode == 2 ? kd_order(xyz, n, stride, leaf, fine) : morton_order(xyz, n, stride);
+    // inside a 64-point run: median splits down to pairs, so that neighbouring lanes hold neighbouring points (their gathers share LUT
+    // lines): dragon-shape bounds kernel 5240 -> 5084 us per launch, bunny shape unchanged (profiles/r03_ab_kd_order.txt)
+    static const bool fine = [] { const char* e = std::getenv("FGOICP_KD_FINE"); return !e || std::atoi(e) != 0; }();  // tuning knob / A-B
+    return mode == 3 ? mixed_order(xyz, n, stride, leaf, fine) : mode == 2 ? kd_order(xyz, n, stride, leaf, fine) : morton_order(xyz, n, stride);
 }
 
 }  // namespace fgoicp

@@ -17,7 +17,7 @@ AG = C.CFUNCTYPE(C.c_int, _fp, _fp, C.c_size_t, C.c_void_p)
 def build():
     from oracle import pyoracle
     pyoracle.build()
-    deps = [os.path.join(_DIR, "harness.cpp"), os.path.join(_REPO, "fast-go-icp_amd/csrc/host/driver.hpp"),
+    deps = [os.path.join(_DIR, "harness.cpp"), os.path.join(_REPO, "fast-go-icp_amd/csrc/host/driver.hpp"), os.path.join(_REPO, "fast-go-icp_amd/csrc/device/morton.hpp"),
             os.path.join(_REPO, "fast-go-icp_amd/csrc/host/math3.hpp"), os.path.join(_REPO, "oracle/libgoicp_oracle.so")]
     if not os.path.exists(_SO) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps):
         tmp = f"{_SO}.{os.getpid()}.tmp"  # several ranks of a world-size-N test may get here together: build aside, rename atomically
@@ -107,6 +107,17 @@ class HostDriver:
             raise RuntimeError(f"driver failed with status {rc}")
         names = ["trans_cubes", "bounds_calls", "rot_cubes", "icp_runs", "icp_iters", "inner_bnb", "rounds"]
         return dict(R=R.reshape(3, 3).T.copy(), t=t, t_scaled=ts, best_sse=np.float32(sse.value), stats={n: int(st[i]) for i, n in enumerate(names)})
+
+
+def point_order(xyz, leaf=64, mode=2, fine=True):
+    """csrc/device/morton.hpp: the order a cloud is stored in on the device (1 = Hilbert curve, 2 = k-d cells, 3 = density split)"""
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    perm = np.empty(len(xyz), np.uint32)
+    L = lib()
+    L.harness_point_order.argtypes = [_fp, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
+    L.harness_point_order.restype = None
+    L.harness_point_order(_f(xyz), len(xyz), int(leaf), int(mode), int(bool(fine)), perm.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return perm
 
 
 def rotation(x, y, z):

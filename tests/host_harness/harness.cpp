@@ -6,6 +6,7 @@
 #include <memory>
 #include <vector>
 
+#include "../../fast-go-icp_amd/csrc/device/morton.hpp"
 #include "../../fast-go-icp_amd/csrc/host/driver.hpp"
 #include "../../oracle/goicp_oracle.hpp"
 
@@ -186,4 +187,10 @@ void harness_svd3(const double* A9, double* U9, double* S3, double* V9) {
     svd3_jacobi(A, U, S3, V);
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { U9[3 * i + j] = U[i][j]; V9[3 * i + j] = V[i][j]; }
 }
+// the point orders of csrc/device/morton.hpp (host code): mode 1 = curve, 2 = k-d cells of `leaf` points (+ in-leaf order), 3 = density split
+void harness_point_order(const float* xyz, size_t n, size_t leaf, int mode, int fine, uint32_t* perm_out) {
+    const std::vector<uint32_t> p = mode == 3 ? fgoicp::mixed_order(xyz, n, 3, leaf, fine != 0) : mode == 2 ? fgoicp::kd_order(xyz, n, 3, leaf, fine != 0) : fgoicp::morton_order(xyz, n, 3);
+    std::memcpy(perm_out, p.data(), sizeof(uint32_t) * n);
+}
+
 }  // extern "C"

@@ -155,3 +155,52 @@ def test_serial_speculation_modes_walk_the_same_trajectory(tmp_path):
         for mode, sched in combos[1:]:
             o = run(mode, sched, pre)
             assert o["stats"] == ref["stats"] and o["R"] == ref["R"] and o["t"] == ref["t"] and o["sse"] == ref["sse"], (pre, mode, sched)
+
+
+@pytest.mark.parametrize("n,leaf", [(1, 32), (31, 32), (33, 32), (64, 64), (1000, 32), (6000, 64), (40097, 64)])
+def test_kd_order_is_a_permutation_whose_runs_are_kd_cells(n, leaf):
+    """csrc/device/morton.hpp kd_order: the order the target tree and the source cloud are stored in.  It must be a permutation for
+    any size (ragged last leaf, fewer points than a leaf), and every node of the implicit complete binary tree — a run of
+    leaf << k points starting at a multiple of its size — must be split by an axis-aligned plane between its two children
+    (max of the left <= min of the right along one axis): that is what makes every run's box tight.  Ties, duplicates and
+    non-finite coordinates must not break it (the comparator is a total order on the bit patterns)."""
+    from tests import host_harness as hh
+    rng = np.random.default_rng(n)
+    p = rng.normal(size=(n, 3)).astype(np.float32)
+    p[rng.integers(0, n, max(1, n // 10))] = p[0]  # duplicates
+    perm = hh.point_order(p, leaf, 2, True)
+    assert sorted(perm.tolist()) == list(range(n))
+    q = p[perm]
+    cap = 1
+    while cap * leaf < n:
+        cap *= 2
+    size = cap * leaf
+    while size > leaf:
+        half = size // 2
+        for b in range(0, n, size):
+            if b + half >= n:
+                continue  # the right child is empty
+            left, right = q[b:b + half], q[b + half:min(n, b + size)]
+            assert (left.max(0) <= right.min(0)).any(), (size, b)
+        size = half
+    # the other orders are permutations too, and the density split falls back to the k-d order when nothing is scattered
+    for mode in (1, 3):
+        assert sorted(hh.point_order(p, leaf, mode, True).tolist()) == list(range(n))
+    if n >= 4:
+        bad = p.copy()
+        bad[1] = np.nan; bad[2] = np.inf; bad[3] = -np.inf
+        assert sorted(hh.point_order(bad, leaf, 2, True).tolist()) == list(range(n))
+
+
+def test_density_split_order_puts_scattered_points_last():
+    from tests import host_harness as hh
+    rng = np.random.default_rng(5)
+    v = rng.normal(size=(20000, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    out = rng.uniform(-1.5, 1.5, size=(5000, 3))
+    p = np.concatenate([v, out]).astype(np.float32)
+    p = p[rng.permutation(len(p))]
+    perm = hh.point_order(p, 64, 3, True)
+    assert sorted(perm.tolist()) == list(range(len(p)))
+    r = np.linalg.norm(p[perm], axis=1)
+    on_surface = np.abs(r - 1.0) < 1e-3
+    assert on_surface[:19000].mean() > 0.93 and on_surface[-4000:].mean() < 0.05  # an outlier that shares its grid cell counts as dense

@@ -12,6 +12,7 @@ from the recording (a pageable host-to-device copy of (W-1)/W of the buffer stan
 path of an in-place RCCL all-gather on device memory (one-rank communicator, same buffer size) is measured and charged twice per ICP
 iteration, and the xGMI payload time is MODELLED (not measurable on one GPU): (W-1)/W of the buffer at 50 GB/s, a third of one link.
 
+FGOICP_REPLAY_TRIM=0.2 (with the workload synthetic1m_outliers, mse 1e-3): the trimmed run of BASELINE configs[4].
 FGOICP_REPLAY_SCHEDULE=serial: the reference's exact order on both sides (one GPU: SERIAL; W ranks: SERIAL, evaluations sharded).
 
     python tools/scale_replay.py <world> [workload] [mse] [res] [repeats]     -> one JSON line
@@ -33,14 +34,15 @@ def main():
     tgt, src, _, _ = fg.synth.workload(workload, angle_deg=150.0, min_angle_deg=110.0)
     serial = os.environ.get("FGOICP_REPLAY_SCHEDULE", "round") == "serial"
     sched = fg.SCHEDULE_SERIAL if serial else fg.SCHEDULE_ROUND
-    one = fg.FastGoICP(tgt, src, res, mse, schedule=sched, round_width=1 if serial else 0, device=0)
+    trim = float(os.environ.get("FGOICP_REPLAY_TRIM", "0"))  # e.g. 0.2 with the workload synthetic1m_outliers (BASELINE configs[4])
+    one = fg.FastGoICP(tgt, src, res, mse, schedule=sched, round_width=1 if serial else 0, device=0, trim_fraction=trim)
     t1 = 1e30
     for _ in range(repeats + 1):
         t0 = time.perf_counter(); R1, _t = one.run(); t1 = min(t1, time.perf_counter() - t0)
     st1 = one.stats()
     e1 = float(one.get_best_error())
     one.close()
-    m = fg.MultiGoICP(tgt, src, res, mse, devices=[0] * world, transport=fg.TRANSPORT_IN_PROCESS, schedule=sched, round_width=1 if serial else 0)
+    m = fg.MultiGoICP(tgt, src, res, mse, devices=[0] * world, transport=fg.TRANSPORT_IN_PROCESS, schedule=sched, round_width=1 if serial else 0, trim_fraction=trim)
     m.set_record(True)
     t0 = time.perf_counter(); R, t = m.run(); together = time.perf_counter() - t0
     times, subs, icps, rounds, iters_rank = [], [], [], None, []
@@ -82,7 +84,7 @@ def main():
     t_wire = per_bytes * (world - 1) / 50e9
     t_host = max(t_ar, t_ag)  # every recorded host-side collective is charged the dearer of the two
     with_coll = [times[r] + host_ex[r] * t_host + dev_gathers * (t_dev + t_wire) for r in range(world)]
-    out = {"workload": workload, "schedule": "serial" if serial else "round", "world": world, "mse_threshold": mse, "late_icp": late, "coop_icp": coop, "T1_s": t1, "subcubes_1": int(st1["trans_cubes"]), "rounds_1": int(st1["rounds"]),
+    out = {"workload": workload, "trim_fraction": trim, "schedule": "serial" if serial else "round", "world": world, "mse_threshold": mse, "late_icp": late, "coop_icp": coop, "T1_s": t1, "subcubes_1": int(st1["trans_cubes"]), "rounds_1": int(st1["rounds"]),
            "T_rank_s": times, "subcubes_rank": subs, "seconds_icp_rank": icps, "rounds": rounds,
            "estimated_speedup": t1 / max(times), "estimated_efficiency": t1 / max(times) / world,
            "allreduce_us_rccl_world1": t_ar * 1e6, "allgather_us_rccl_world1": t_ag * 1e6, "host_exchanges_rank": host_ex,
