@@ -757,12 +757,13 @@ int ctx_icp(fgoicp_ctx* c, const float* R0, const float* t0, size_t max_iter, fl
 // reductions (sums, centroids, covariance, SSE) over the WHOLE cloud with the single-GPU kernels and the 3x3 SVD on its host.  A
 // query's nearest neighbour does not depend on which queries are scanned next to it and the reductions see the same arrays in the
 // same order on every rank, so (sse, R, t, iterations) are the single-GPU loop's bits on every rank — no result needs to be
-// exchanged, and an N-rank run refines exactly like a one-rank run.  Trimmed and brute-force contexts run the whole loop on every
-// rank instead (replicated: same bits, no speed-up).  `gather(buf, bytes_per_rank, user)`: the caller's stream is idle when it is
+// exchanged, and an N-rank run refines exactly like a one-rank run.  Brute-force contexts, and every context below
+// coop_split_min source points (the default: never split), run the whole loop on every rank instead (replicated: same bits).  `gather(buf, bytes_per_rank, user)`: the caller's stream is idle when it is
 // called; on return chunk r of buf holds rank r's results, for every r.
 int ctx_icp_coop(fgoicp_ctx* c, int rank, int world, int (*gather)(void* dev_buf, size_t bytes_per_rank, void* user), void* user, const float* R0,
                  const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3, int* iters_out) {
-    if (world <= 1 || !gather || c->inliers || c->brute_force_nn || c->ns < c->coop_split_min) return ctx_icp(c, R0, t0, max_iter, thr, sse_out, R_out9, t_out3, iters_out);
+    const size_t split_min = c->inliers ? std::min(c->coop_split_min, c->coop_split_trim_min) : c->coop_split_min;
+    if (world <= 1 || !gather || c->brute_force_nn || c->ns < split_min || !c->icp_overlap) return ctx_icp(c, R0, t0, max_iter, thr, sse_out, R_out9, t_out3, iters_out);
     if (rank < 0 || rank >= world) { set_error("ctx_icp_coop: rank out of range"); return FGOICP_ERR_INVALID_ARG; }
     HIPCHK(hipSetDevice(c->device));
     fgoicp_ctx::IcpLane& L = c->lanes[0];
@@ -793,22 +794,45 @@ int ctx_icp_coop(fgoicp_ctx* c, int rank, int world, int (*gather)(void* dev_buf
     int iters = 0;
     // The loop is lane_icp_dual's (one walk per iteration serves the exact SSE of iteration k and the correspondences of iteration k + 1),
     // with the walk cut down to this rank's queries and two in-place all-gathers behind it: ONE scan, two gathers and two host syncs
-    // per iteration (a first version ran the two scans one after the other: two scans, two gathers, four syncs).
-    auto reduce_pass = [&]() {  // sums, centroids, covariance of the correspondences in idx[] (all ranks' shares), as ctx_procrustes_device
+    // per iteration (a first version ran the two scans one after the other: two scans, two gathers, four syncs).  Trimmed contexts
+    // (c->inliers): the LUT brackets, the cuts and the inlier selection run over the whole cloud on every rank (cheap, replicated), the
+    // walk — 85 % of a trimmed iteration at 1M points — on the share; the reductions are the single-GPU loop's own enqueue functions.
+    const bool trimmed = c->inliers != 0, skip = trimmed && c->trim_skip;
+    struct MinBitsGuard {  // sse_enqueue's trimmed selection reads L.d_min_bits: it is pointed at the gathered buffer for the duration of the run
+        fgoicp_ctx::IcpLane& L; uint32_t* saved;
+        MinBitsGuard(fgoicp_ctx::IcpLane& l, uint32_t* m) : L(l), saved(l.d_min_bits) { L.d_min_bits = m; }
+        ~MinBitsGuard() { L.d_min_bits = saved; }
+    } guard(L, mins);
+    auto reduce_pass = [&]() -> int {  // inlier cut (trimmed), sums, centroids, covariance of the correspondences in idx[] (all ranks' shares)
+        if (trimmed) return procrustes_enqueue(c, L, nullptr, idx, L.d_sel_wide2, S, nullptr, nullptr, 2);
         launch_icp_sums(L.d_work, c->d_tgt, idx, ns, nt, nullptr, L.d_bp, nb, S);
         launch_icp_centroids(L.d_bp, nb, ns, L.d_cen, L.hd_cen, S);
         launch_icp_cov(L.d_work, c->d_tgt, idx, ns, nt, L.d_cen, nullptr, L.d_bp2, nb, S);
         launch_sum_partials(L.d_bp2, nb, 9, L.hd_sums, S);
         L.cov_on_host = false;
+        return FGOICP_OK;
+    };
+    auto sse_sum = [&]() -> int {  // compute_sse_error's sum over the gathered minima (trimmed: the k smallest)
+        if (trimmed) return sse_enqueue(c, L, nullptr, nullptr, nullptr, S, 2);
+        launch_sum_f32_as_f64(mins, ns, L.d_bp3, nb, S);
+        launch_sum_partials(L.d_bp3, nb, 1, L.hd_sums + 12, S);
+        L.sse_on_host = false;
+        return FGOICP_OK;
     };
     bool pending = false;
     if (max_iter > 0) {  // pass 1 (icp3d.cu:140-172): correspondences of my share, gathered; sums over everything
+        if (skip) {
+            launch_nn_prep(L.d_work, ns, c->d_lut, c->geom, nullptr, nullptr, 0, c->d_tgt, nt, nullptr, c->tgt_box6, L.d_nn_ub2, L.d_nn_lb2, S);
+            launch_trim_select(L.d_nn_ub2, ns, (int)c->inliers, nullptr, L.d_sel + 4, L.d_sel_wide2, S);
+        }
         if (nq > 0)
-            launch_nn_scan(L.d_work + qb, nq, c->bvh_tgt.view(), c->d_lut, c->geom, nullptr, nullptr, 0, 1, c->d_tgt, nt, nullptr, nullptr, nullptr, idx + qb, S);
+            launch_nn_scan(L.d_work + qb, nq, c->bvh_tgt.view(), c->d_lut, c->geom, nullptr, nullptr, 0, 1, c->d_tgt, nt, nullptr, skip ? L.d_nn_lb2 + qb : nullptr,
+                           skip ? L.d_sel + 4 : nullptr, idx + qb, S);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(S));
         if (gather(idx, sizeof(uint32_t) * per, user)) return FGOICP_ERR_EXCHANGE;
-        reduce_pass();
+        int rc = reduce_pass();
+        if (rc) return rc;
         pending = true;
     }
     while (iter++ < max_iter && (last_sse - sse) > thr * last_sse) {  // icp3d.cu:94
@@ -827,23 +851,38 @@ int ctx_icp_coop(fgoicp_ctx* c, int rank, int world, int (*gather)(void* dev_buf
         const float t3[3] = {t.x, t.y, t.z};
         launch_transform_inplace(L.d_work, ns, Rn.m, tn3, S);    // :100 (the whole cloud: the reductions read all of it)
         const bool next = iter < max_iter;
+        const uint32_t* seed = seeding ? idx : nullptr;          // the gathered correspondences of the pass the host has just consumed
+        const float *lbA = nullptr, *lbB = nullptr;
+        const uint32_t *uA = nullptr, *uB = nullptr;
+        if (skip) {  // trimmed: brackets and cuts of both query sets, whole cloud, as lane_icp_dual
+            if (next) {
+                launch_nn_prep(L.d_work, ns, c->d_lut, c->geom, nullptr, nullptr, 0, c->d_tgt, nt, seed, c->tgt_box6, L.d_nn_ub2, L.d_nn_lb2, S);
+                launch_trim_select(L.d_nn_ub2, ns, (int)c->inliers, nullptr, L.d_sel + 4, L.d_sel_wide2, S);
+                lbA = L.d_nn_lb2 + qb; uA = L.d_sel + 4;
+            }
+            launch_nn_prep(c->d_src, ns, c->d_lut, c->geom, R.m, t3, 1, c->d_tgt, nt, seed, c->tgt_box6, L.d_nn_ub, L.d_nn_lb, S);
+            launch_trim_select(L.d_nn_ub, ns, (int)c->inliers, nullptr, L.d_sel + 8, L.d_sel_wide, S);
+            lbB = L.d_nn_lb + qb; uB = L.d_sel + 8;
+        }
         if (nq > 0) {
             if (next)  // compute_sse_error(R, t) (:103) of this iteration and the correspondences of the next: one walk, my share
-                launch_nn_scan_dual(L.d_work + qb, nullptr, nullptr, 0, c->d_src + qb, R.m, t3, nq, c->bvh_tgt.view(), c->d_lut, c->geom, c->d_tgt, nt, seeding ? idx + qb : nullptr,
-                                    nullptr, nullptr, nullptr, nullptr, idx + qb, mins + qb, nullptr, nullptr, nullptr, S);
+                launch_nn_scan_dual(L.d_work + qb, nullptr, nullptr, 0, c->d_src + qb, R.m, t3, nq, c->bvh_tgt.view(), c->d_lut, c->geom, c->d_tgt, nt, seed ? seed + qb : nullptr,
+                                    lbA, uA, lbB, uB, idx + qb, mins + qb, nullptr, nullptr, nullptr, S);
             else       // the last iteration the loop can make: no pass rides along
-                launch_nn_scan(c->d_src + qb, nq, c->bvh_tgt.view(), c->d_lut, c->geom, R.m, t3, 1, 0, c->d_tgt, nt, seeding ? idx + qb : nullptr, nullptr, nullptr, mins + qb, S);
+                launch_nn_scan(c->d_src + qb, nq, c->bvh_tgt.view(), c->d_lut, c->geom, R.m, t3, 1, 0, c->d_tgt, nt, seed ? seed + qb : nullptr, lbB, uB, mins + qb, S);
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(S));
         if (next && gather(idx, sizeof(uint32_t) * per, user)) return FGOICP_ERR_EXCHANGE;
         if (gather(mins, sizeof(uint32_t) * per, user)) return FGOICP_ERR_EXCHANGE;
-        if (next) { reduce_pass(); pending = true; }  // speculative, as on one GPU (the loop may end on this iteration's SSE)
-        launch_sum_f32_as_f64(mins, ns, L.d_bp3, nb, S);
-        launch_sum_partials(L.d_bp3, nb, 1, L.hd_sums + 12, S);
+        int rc = FGOICP_OK;
+        if (next) { rc = reduce_pass(); pending = true; }  // speculative, as on one GPU (the loop may end on this iteration's SSE)
+        if (rc) return rc;
+        rc = sse_sum();
+        if (rc) return rc;
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(S));
-        sse = (float)L.h_sums[12];
+        sse = sse_result(c, L);
         ++iters;
     }
     if (pending) HIPCHK(hipStreamSynchronize(S));  // the speculative pass: drained, not used
@@ -1364,7 +1403,7 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
         c->max_groups = std::max(512, c->max_subcubes / 8);
         if (const char* e = std::getenv("FGOICP_FINALIZE_SIDE")) c->finalize_on_side = std::atoi(e) != 0;  // tuning knob
         if (const char* e = std::getenv("FGOICP_ICP_SEED")) c->icp_seeding = std::atoi(e) != 0;             // tuning knob
-        if (const char* e = std::getenv("FGOICP_COOP_SPLIT_MIN")) c->coop_split_min = (size_t)std::max(0L, std::atol(e));  // tuning knob
+        if (const char* e = std::getenv("FGOICP_COOP_SPLIT_MIN")) c->coop_split_min = c->coop_split_trim_min = (size_t)std::max(0L, std::atol(e));  // tuning knob (both thresholds)
         if (const char* e = std::getenv("FGOICP_UNITS")) { const int v = std::atoi(e); c->unit_m = (v == 4 || v == 8) ? v : 0; }  // tuning knob: siblings per work item
         if (c->lut_layout == 4) c->unit_m = 0;  // the apron layout has no sibling-unit kernel
         if (const char* e = std::getenv("FGOICP_SMALL_TICK")) c->small_tick_items = std::max(0, std::atoi(e));  // tuning knob: items

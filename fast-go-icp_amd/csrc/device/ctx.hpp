@@ -78,6 +78,7 @@ struct fgoicp_ctx {
     size_t coop_split_min = (size_t)-1;      // cooperative ICP: source clouds of at least this many points split the two scans of an iteration over the ranks (FGOICP_COOP_SPLIT_MIN); default: never —
                                              // the loop runs replicated on every rank (same bits).  Measured at 437k points on 8 ranks: a 55k-query share is a latency chain like the whole scan, 2 gathers and 4 syncs per
                                              // iteration on top: 25-44 ms of ICP per rank split against 41 ms replicated, 6.2x against 6.4x with the gathers charged
+    size_t coop_split_trim_min = 262144;     // ... trimmed contexts split from this size on: a trimmed iteration is long (1.5 ms at 1M points, 85 % of it the walk) and splitting pays — 8-rank replay of the 1M trimmed run 1.84x -> 2.69x (2.45x with the 632 gathers charged)
     bool icp_seeding = true;                 // ICP passes seed their exact NN search with the previous pass's correspondences
     float4* d_chunk_cen = nullptr;           // centroid of every chunk (source frame)
     TickSlot slots[2];

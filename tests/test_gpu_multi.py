@@ -79,6 +79,25 @@ def test_cooperative_icp_returns_the_single_gpu_bits(fg, gpu_required, monkeypat
     m.close()
 
 
+def test_cooperative_trimmed_icp_returns_the_single_gpu_bits(fg, gpu_required, monkeypatch):
+    """The trimmed loop split the same way (brackets, cuts and the inlier selection over the whole cloud on every rank, the dual walk
+    on the rank's share, skipped queries included): == the one-context trimmed ICP, bit for bit, with and without the skip lists."""
+    monkeypatch.setenv("FGOICP_COOP_SPLIT_MIN", "0")
+    tgt, src, R_gt, t_gt = fg.synth.workload("small", angle_deg=25.0, outlier_frac=0.2)
+    for skip in ("1", "0"):
+        monkeypatch.setenv("FGOICP_TRIM_SKIP", skip)
+        m = fg.MultiGoICP(tgt, src, 0.01, 1e-3, devices=[0] * 3, transport=fg.TRANSPORT_IN_PROCESS, trim_fraction=0.2)
+        reg = m.registration(0)
+        rng = np.random.default_rng(4)
+        for R0, t0, mi in ((np.eye(3, dtype=np.float32), np.zeros(3, np.float32), 100), (fg.synth.random_rotation(rng, 10.0).astype(np.float32), rng.uniform(-0.05, 0.05, 3).astype(np.float32), 100),
+                           (np.eye(3, dtype=np.float32), np.zeros(3, np.float32), 2)):
+            icp = fg.IterativeClosestPoint3D(reg, None, None, mi, 0.005, R0, t0)
+            e1, R1, t1 = icp.run()
+            e, R, t, it = m.icp(R0, t0, mi, 0.005)
+            assert np.float32(e).view(np.uint32) == np.float32(e1).view(np.uint32) and np.array_equal(R, R1) and np.array_equal(t, t1) and it == icp.iterations, (skip, mi, e, e1, it, icp.iterations)
+        m.close()
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_cooperative_rounds_are_the_single_gpu_run(fg, gpu_required, monkeypatch, world):
     """The multi-rank run with cooperative refinements (the default for clouds of at least 131072 source points when the exchange can
