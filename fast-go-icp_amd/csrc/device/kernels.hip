@@ -576,19 +576,36 @@ __global__ __launch_bounds__(64) void tick_scatter_kernel(const unsigned short* 
 // on one CU at the same time and share its L1 (the XCD remap alone spreads neighbours over the 32 CUs of an XCD: they share
 // the L2 only).  NT = 1: the source points are loaded non-temporally (they stream through once per item; kept out of the L1
 // they leave it to the LUT lines).
-// Trimmed mode: the per-point e of an output row, and — samp_shift > 0 — every 2^samp_shift-th point of the (Hilbert-ordered) cloud
+// Trimmed mode: the per-point e of an output row, and — samp_shift > 0 — one point of every run of 2^samp_shift points of the stored cloud
 // once more in a compact SAMPLE behind the row (offset: ns rounded up to 64 floats): a systematic sample of the row that the selection
 // reads first (125 KB instead of 4 MB at 1M points) to bracket the cut, so that it needs ONE pass over the row instead of two
 // (trim_rows_sampled_kernel).  The sample only steers; the selection verifies the bracket exactly and falls back if it is wrong.
 __host__ __device__ __forceinline__ size_t trim_sample_offset(int ns) { return ((size_t)ns + 63) & ~(size_t)63; }  // the sample starts on a 256-byte boundary of its row
+// Which point of run r (2^samp_shift consecutive points) is its sample: a hashed position, not the first one.  The stored order
+// is structured (k-d order: position 0 of every 64-point run is a corner of its cell), and a sample that always takes the same
+// position is a biased sample of the row — the bracket then misses and the selection falls back to two passes (13 % of the rows
+// of a surface cloud in k-d order against 1-2 % in Hilbert order; with the hashed position both orders are at 1-2 %).  One per
+// run either way (stratified); the last, partial run takes its first point.
+__device__ __forceinline__ bool trim_is_sample(int i, int samp_shift, int ns) {
+    const int mask = (1 << samp_shift) - 1, run = i >> samp_shift;
+    int pos = (int)(((unsigned)run * 0x9E3779B1u) >> 16) & mask;
+    if (((run << samp_shift) | pos) >= ns) pos = 0;
+    return (i & mask) == pos;
+}
 __device__ __forceinline__ void trim_store(float* __restrict__ evals, size_t row_base, int i, float e, int samp_shift, int ns) {
     evals[row_base + (size_t)i] = e;
-    if (samp_shift > 0 && (i & ((1 << samp_shift) - 1)) == 0) evals[row_base + trim_sample_offset(ns) + (size_t)(i >> samp_shift)] = e;
+    if (samp_shift > 0 && trim_is_sample(i, samp_shift, ns)) evals[row_base + trim_sample_offset(ns) + (size_t)(i >> samp_shift)] = e;
 }
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+// FGOICP_BOUNDS_WAVES (development builds, tools/ab_waves.sh): ask the register allocator for that many resident waves per SIMD
+#ifdef FGOICP_BOUNDS_WAVES
+#define FGOICP_BOUNDS_OCC __attribute__((amdgpu_waves_per_eu(FGOICP_BOUNDS_WAVES, FGOICP_BOUNDS_WAVES)))
+#else
+#define FGOICP_BOUNDS_OCC
+#endif
 template <int THREADS, int P, int ZPAIR, int TRIM, int WPG = 1, int NT = 0>
-__global__ __launch_bounds__(THREADS * WPG) void bounds_sorted_kernel(const float4* __restrict__ src, int ns, const float* __restrict__ lut,
+__global__ __launch_bounds__(THREADS * WPG) FGOICP_BOUNDS_OCC void bounds_sorted_kernel(const float4* __restrict__ src, int ns, const float* __restrict__ lut,
                                                                 const float2* __restrict__ zp, LutGeom g,
                                                                 const TickGroup* __restrict__ groups, const TickSub* __restrict__ subs,
                                                                 const unsigned* __restrict__ sorted, int nchunk, int chunk_pts,
@@ -713,18 +730,14 @@ __global__ __launch_bounds__(THREADS * WPG) void bounds_sorted_kernel(const floa
             acc[1] += valid ? (double)lbv : 0.0;
         }
         if (TRIM && samp_shift > 0) {
-            // the row's sample (see trim_store): every 2^samp_shift-th point once more behind the row.  i = first + k * THREADS and
-            // first - tix is a multiple of THREADS * P, so ONE test per pass finds the lanes that can hold a sample point for some k
-            const int mask = (1 << samp_shift) - 1;
-            if (((int)tix & mask & (THREADS - 1)) == 0) {
-                const size_t off = trim_sample_offset(ns);
+            // the row's sample (see trim_store / trim_is_sample): one point of every run of 2^samp_shift once more behind the row
+            const size_t off = trim_sample_offset(ns);
 #pragma unroll
-                for (int k = 0; k < P; ++k) {
-                    const int i = first + k * THREADS;
-                    if (i < ns && (i & mask) == 0) {
-                        evals[(size_t)sb.out0 * erow + off + (size_t)(i >> samp_shift)] = te0[k];
-                        if (dual) evals[(size_t)sb.out1 * erow + off + (size_t)(i >> samp_shift)] = te1[k];
-                    }
+            for (int k = 0; k < P; ++k) {
+                const int i = first + k * THREADS;
+                if (i < ns && trim_is_sample(i, samp_shift, ns)) {
+                    evals[(size_t)sb.out0 * erow + off + (size_t)(i >> samp_shift)] = te0[k];
+                    if (dual) evals[(size_t)sb.out1 * erow + off + (size_t)(i >> samp_shift)] = te1[k];
                 }
             }
         }
