@@ -935,7 +935,15 @@ private:
         // ROUND, tail of a round: a few long-running tasks are left and every tick is a latency-bound device round trip that fills a
         // fraction of the GPU.  Such a half takes bigger batches (the extra nodes are the next-best of the task's own queue: some
         // would have been pruned by the results of the batch before — paid with idle capacity — and the round ends in fewer ticks).
-        const size_t tail_cap = (tail_batch_ && h.members.size() <= tail_tasks_) ? tail_batch_ : 0;
+        // the fewer tasks a half holds, the more of a tick is round-trip latency and the bigger the batch may be: 128 nodes from 32 tasks
+        // down, 256 from 16, 512 from 8 (measured: default-threshold bunny step 17.3 -> 15.6 ms, the 16 tasks of its one round; certify runs
+        // unchanged; profiles/r03_ab_tail_batch.txt) — for clouds of up to 200 000 points: on the dragon shape every extra node is 437k
+        // point evaluations on a device that is full anyway (512: +2 % subcubes and time).  FGOICP_TAIL_BATCH fixes the size.
+        size_t tail_cap = 0;
+        if (tail_batch_ && h.members.size() <= tail_tasks_) {
+            tail_cap = tail_batch_;
+            if (!tail_batch_fixed_ && ns_ <= 200000) tail_cap = h.members.size() <= tail_tasks_ / 4 ? 512 : h.members.size() <= tail_tasks_ / 2 ? 256 : tail_batch_;
+        }
         const std::function<void(size_t)> pop_fn = [&](size_t k) {
             Task& tk = *tasks[h.members[k]];
             if (tk.batch_cap != 32) tk.batch_cap = tail_cap ? tail_cap : round_batch_;  // SERIAL tasks keep the reference's 32 (fgoicp.cpp:122)
@@ -978,19 +986,19 @@ private:
             Task &ub = *tasks[h.live[pairs[q]]], &lb = *tasks[h.live[pairs[q] + 1]];
             auto& tw = h.pair_twins[q];
             const size_t n0 = ub.batch.size(), n1 = lb.batch.size();
-            if (n0 > 128 || n1 > 128) return;  // batches hold <= 128 nodes (32 in the reference, fgoicp.cpp:122); the table below assumes it
-            int table[256];
+            if (n0 > 512 || n1 > 512) return;  // batches hold <= 512 nodes (32 in the reference, fgoicp.cpp:122); the table below assumes it
+            int table[1024];
             for (int& x : table) x = -1;
             for (size_t j = 0; j < n1; ++j) {
                 if (lb.brow[j] < 0) continue;
-                uint32_t sl = (uint32_t)NodeKeyHash()(node_key(lb.batch[j])) & 255u;
-                while (table[sl] >= 0) sl = (sl + 1) & 255u;
+                uint32_t sl = (uint32_t)NodeKeyHash()(node_key(lb.batch[j])) & 1023u;
+                while (table[sl] >= 0) sl = (sl + 1) & 1023u;
                 table[sl] = (int)j;
             }
             for (size_t i = 0; i < n0; ++i) {
                 const NodeKey ki = node_key(ub.batch[i]);
                 int hit = -1;
-                for (uint32_t sl = (uint32_t)NodeKeyHash()(ki) & 255u; table[sl] >= 0; sl = (sl + 1) & 255u)
+                for (uint32_t sl = (uint32_t)NodeKeyHash()(ki) & 1023u; table[sl] >= 0; sl = (sl + 1) & 1023u)
                     if (node_key(lb.batch[(size_t)table[sl]]) == ki) { hit = table[sl]; break; }
                 if (hit >= 0) tw.push_back({ub.brow[i], lb.brow[(size_t)hit]});
                 else if (memo_on && !lb.memo.find(ki)) {
@@ -1168,7 +1176,8 @@ private:
     const int late_icp_ = [] { const char* e = std::getenv("FGOICP_LATE_ICP"); return e ? std::atoi(e) : 0; }();  // tuning knob (ROUND): 0 = off (default: measured slower, see above), 1 = with an exchange (world > 1), 2 = always
     bool use_twins_ = [] { const char* e = std::getenv("FGOICP_TWINS"); return !e || std::atoi(e) != 0; }();  // tuning knob
     const size_t round_batch_ = [] { const char* e = std::getenv("FGOICP_ROUND_BATCH"); const int v = e ? std::atoi(e) : 48; return (size_t)(v >= 8 && v <= 64 ? v : 48); }();  // tuning knob (ROUND only; SERIAL keeps the reference's 32)
-    const size_t tail_batch_ = [] { const char* e = std::getenv("FGOICP_TAIL_BATCH"); const int v = e ? std::atoi(e) : 128; return (size_t)(v >= 8 && v <= 128 ? v : 0); }();  // tuning knob (ROUND): batch of a half with few tasks left (0 = off)
+    const bool tail_batch_fixed_ = std::getenv("FGOICP_TAIL_BATCH") != nullptr;
+    const size_t tail_batch_ = [] { const char* e = std::getenv("FGOICP_TAIL_BATCH"); const int v = e ? std::atoi(e) : 128; return (size_t)(v >= 8 && v <= 512 ? v : 0); }();  // tuning knob (ROUND): batch of a half with few tasks left (0 = off)
     const size_t tail_tasks_ = [] { const char* e = std::getenv("FGOICP_TAIL_TASKS"); const int v = e ? std::atoi(e) : 32; return (size_t)(v >= 0 ? v : 32); }();  // ... "few" = at most this many
     bool use_memo_ = [] { const char* e = std::getenv("FGOICP_MEMO"); return !e || std::atoi(e) != 0; }();    // tuning knob: memo of the twin task's evaluations
     const bool overlap_stats_ = std::getenv("FGOICP_OVERLAP_STATS") != nullptr;  // diagnostic: how many nodes both tasks of a rotation cube evaluate
