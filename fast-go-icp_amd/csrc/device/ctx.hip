@@ -1251,6 +1251,7 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
     g.scale = 1.0f / lut_resolution;
     g.off_x = -bounds6[0]; g.off_y = -bounds6[2]; g.off_z = -bounds6[4];
     g.quantize = (flags & FGOICP_FLAG_NO_WEIGHT_QUANT) ? 0 : 1;
+    g.idx = nullptr;  // set once the index LUT has been built (below)
 
     // clouds: float4 on the device.  Source: Morton order, w = x*x+y*y+z*z in the device
     // contraction order (registration.cu:39-41).  Target: caller order (index tie rule), w = 0.
@@ -1306,8 +1307,15 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
             e3 = bvh_upload(bvh_build_host(hs.data(), nt, &order), &shifted);
             float* scratch = nullptr;
             if (e3 == hipSuccess) e3 = hipMalloc(&scratch, total * sizeof(float));
+            // the index LUT (4 B per node; an allocation that fails just leaves the feature off).  Built in round 3, bit-identical (146 GPU
+            // tests with it on), measured — and it buys NOTHING (profiles/r03_ab_lut_index.txt: ICP iteration 44.7 -> 46.4 us at 40k points,
+            // 169 -> 170 us at 437k, trimmed 1M ICP 463 -> 465 ms): the triangle bound's slack is not what makes the scans of a far state
+            // expensive — the leaf BOXES a large ball cuts are (tools/kd_sim.py-style count: 5.4 -> 16 leaves per query group 20 degrees
+            // off the optimum even with exact bounds).  OFF by default; FGOICP_LUT_INDEX=1 builds and uses it.
+            static const bool want_idx = [] { const char* e = std::getenv("FGOICP_LUT_INDEX"); return e && std::atoi(e) != 0; }();  // tuning knob / A-B
+            if (e3 == hipSuccess && want_idx && hipMalloc(&c->d_lut_idx, total * sizeof(uint32_t)) != hipSuccess) { c->d_lut_idx = nullptr; (void)hipGetLastError(); }
             if (e3 == hipSuccess) {
-                launch_lut_build_scan(shifted.view(), g, scratch, c->d_lut, c->stream);
+                launch_lut_build_scan(shifted.view(), g, scratch, c->d_lut, c->stream, c->d_lut_idx);
                 e3 = hipGetLastError();
                 if (e3 == hipSuccess) e3 = hipStreamSynchronize(c->stream);
             }
@@ -1315,6 +1323,7 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
             bvh_free(&shifted);
         }
         if (e3 != hipSuccess) { set_error(std::string("LUT build failed: ") + hipGetErrorString(e3)); return fail(e3 == hipErrorOutOfMemory ? FGOICP_ERR_OOM : FGOICP_ERR_HIP); }
+        g.idx = c->d_lut_idx;  // from here on the exact scans seed their bounds with it (kernels.hip lut_upper_bound_d2)
         // Packed copy for the bounds kernel: 0 none, 1 z-pair (2x bytes, two rows per lookup), 2 yz-quad (4x bytes, one
         // line per lookup).  Measured: the quad wins on sparse clouds (every lane-gather its own line; +8 % at 40k
         // points), loses on dense ones (lanes share lines and the 4x footprint falls out of cache; -5 % at 437k), so it
@@ -1573,7 +1582,7 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
     for (auto& e : c->ev_stop) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_sel_start) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_sel_stop) if (e) (void)hipEventDestroy(e);
-    (void)hipFree(c->d_src); (void)hipFree(c->d_tgt); (void)hipFree(c->d_lut); (void)hipFree(c->d_lut_zp);
+    (void)hipFree(c->d_src); (void)hipFree(c->d_tgt); (void)hipFree(c->d_lut); (void)hipFree(c->d_lut_idx); (void)hipFree(c->d_lut_zp);
     (void)hipFree(c->d_partials);
     for (auto& L : c->lanes) {
         if (L.stream && L.stream != c->stream) { (void)hipStreamSynchronize(L.stream); (void)hipStreamDestroy(L.stream); }
@@ -1648,7 +1657,7 @@ int fgoicp_ctx_get_info(const fgoicp_ctx* c, fgoicp_ctx_info* out) {
         else if (c->lut_layout == 3) packed = (size_t)((c->geom.px + 3) / 4) * ((c->geom.py + 3) / 4) * ((c->geom.pz + 3) / 4) * 64 * sizeof(float4);
         else packed = padded * (c->lut_layout == 2 ? sizeof(float4) : sizeof(float2));
     }
-    out->lut_bytes = padded * sizeof(float) + packed;
+    out->lut_bytes = padded * sizeof(float) + packed + (c->d_lut_idx ? padded * sizeof(uint32_t) : 0);  // + the index LUT of the exact scans
     out->source_points_per_face_voxel = (double)c->ns / ((double)g.dx * g.dy + (double)g.dy * g.dz + (double)g.dx * g.dz);
     out->points_per_item = c->chunk_pts;
     out->items_per_evaluation = c->nchunk1;

@@ -2129,12 +2129,15 @@ __device__ __forceinline__ void box_scan(const BvhView t, float qx, float qy, fl
 // pruning bound; the result is the minimum over VISITED points, and the true nearest point is never
 // pruned while the bound stays >= its distance.  If fp32 rounding made a seed a hair too small and
 // some lane found nothing, the wave repeats the scan unseeded — the result is exact either way.
-__device__ __forceinline__ float scan_min_d2(const BvhView t, float qx, float qy, float qz, float ub, float init, bool active) {
+// `arg` (optional): receives the caller index (the leaf point's w) of a point that attains the minimum.
+__device__ __forceinline__ float scan_min_d2(const BvhView t, float qx, float qy, float qz, float ub, float init, bool active, uint32_t* arg = nullptr) {
     float best = ub < init ? ub : init;
     float found = init;
+    uint32_t who = 0x7fffffffu;
     box_scan(t, qx, qy, qz, active, 0, 1,
              [&](const float4 p, bool on) {
                  const float d = on ? dist_sq(qx, qy, qz, p.x, p.y, p.z) : kMasked;
+                 if (arg) who = d < found ? __float_as_uint(p.w) : who;
                  found = d < found ? d : found;
                  best = d < best ? d : best;
              },
@@ -2145,10 +2148,12 @@ __device__ __forceinline__ float scan_min_d2(const BvhView t, float qx, float qy
         box_scan(t, qx, qy, qz, redo, 0, 1,
                  [&](const float4 p, bool on) {
                      const float d = on ? dist_sq(qx, qy, qz, p.x, p.y, p.z) : kMasked;
+                     if (arg) who = d < found ? __float_as_uint(p.w) : who;
                      found = d < found ? d : found;
                  },
                  [&]() { return found; });
     }
+    if (arg) *arg = who;
     return found;
 }
 
@@ -2157,15 +2162,31 @@ __device__ __forceinline__ float scan_min_d2(const BvhView t, float qx, float qy
 // node nearest to q (clamped into the grid, so it also works outside the target's box) the slack is
 // at most half a voxel diagonal.  Inflated by 1e-4 relative + 1e-6 absolute: T was computed from
 // the shifted targets in fp32.
-__device__ __forceinline__ float lut_upper_bound_d2(const float* __restrict__ lut, const LutGeom& g, float qx, float qy, float qz) {
+// Round 3 (g.idx, the "index LUT"): the node also knows WHICH target point is nearest to it, and the distance from q to that very
+// point is a bound too — an exact one (it is one of the scan's candidates, same fp32 expression), and a much tighter one for a
+// query far from the surface: the triangle bound is loose by up to a voxel diagonal whatever the distance, so the ball it admits
+// cuts a cap of radius sqrt(2 d diag) out of the surface (43 leaves for d = 0.3 at resolution 0.005), while the nearest point of a
+// node half a voxel away is almost always the query's own nearest point or its neighbour.
+__device__ __forceinline__ float lut_upper_bound_d2(const float* __restrict__ lut, const LutGeom& g, float qx, float qy, float qz, const float4* __restrict__ tgt = nullptr,
+                                                    int nt = 0) {
     const float sx = qx + g.off_x, sy = qy + g.off_y, sz = qz + g.off_z;
     const float fx = fminf(fmaxf(rintf(sx * g.scale), 0.0f), (float)(g.dx - 1));
     const float fy = fminf(fmaxf(rintf(sy * g.scale), 0.0f), (float)(g.dy - 1));
     const float fz = fminf(fmaxf(rintf(sz * g.scale), 0.0f), (float)(g.dz - 1));
-    const float T = lut[((size_t)((int)fz + 1) * g.py + ((int)fy + 1)) * (size_t)g.px + ((int)fx + 1)];
+    const size_t node = ((size_t)((int)fz + 1) * g.py + ((int)fy + 1)) * (size_t)g.px + ((int)fx + 1);
+    const float T = lut[node];
     const float dx = sx - fx * g.resolution, dy = sy - fy * g.resolution, dz = sz - fz * g.resolution;
     const float u = sqrtf(T) + sqrtf(dx * dx + dy * dy + dz * dz);
-    return u * u * 1.0001f + 1e-6f;
+    float ub = u * u * 1.0001f + 1e-6f;
+    if (g.idx && tgt) {
+        const uint32_t j = g.idx[node];
+        if (j < (uint32_t)nt) {
+            const float4 c = tgt[j];
+            const float d = dist_sq(qx, qy, qz, c.x, c.y, c.z);
+            ub = d < ub ? d : ub;
+        }
+    }
+    return ub;
 }
 
 __device__ __forceinline__ float tie_threshold(float best) {  // see nn_tie_threshold_kernel
@@ -2198,7 +2219,7 @@ __global__ __launch_bounds__(kBlock) void nn_prep_kernel(const float4* __restric
         rotate(rt.R, p.x, p.y, p.z, qx, qy, qz);
         qx += rt.t[0]; qy += rt.t[1]; qz += rt.t[2];
     }
-    float ub = lut_upper_bound_d2(lut, g, qx, qy, qz);
+    float ub = lut_upper_bound_d2(lut, g, qx, qy, qz, tgt, nt);
     if (seed_idx) {
         const uint32_t j = seed_idx[i];
         if (j < (uint32_t)nt) {
@@ -2262,7 +2283,7 @@ __global__ __launch_bounds__(64 * kMaxParts) void nn_scan_kernel(const float4* p
         qx += rt.t[0]; qy += rt.t[1]; qz += rt.t[2];
     }
     // pass 1: minimum.  `found` = min over the points this wave visited, `best` additionally seeded.
-    float ub = lut_upper_bound_d2(lut, g, qx, qy, qz);
+    float ub = lut_upper_bound_d2(lut, g, qx, qy, qz, tgt, nt);
     if (seed_idx) {  // ICP: the previous pass's correspondence — the distance to ANY target point bounds the minimum, and
         const uint32_t j = seed_idx[i < n ? i : n - 1];  // one ICP step later it usually still IS the minimum (may alias `out`:
         if (j < (uint32_t)nt) {                          // every lane reads its own slot here and writes it at the very end)
@@ -2427,7 +2448,7 @@ __global__ __launch_bounds__(64 * kMaxParts) void nn_scan_dual_kernel(const floa
     }
     rotate(rtB.R, pB.x, pB.y, pB.z, bx, by, bz);
     bx += rtB.t[0]; by += rtB.t[1]; bz += rtB.t[2];
-    float ubA = lut_upper_bound_d2(lut, g, ax, ay, az), ubB = lut_upper_bound_d2(lut, g, bx, by, bz);
+    float ubA = lut_upper_bound_d2(lut, g, ax, ay, az, tgt, nt), ubB = lut_upper_bound_d2(lut, g, bx, by, bz, tgt, nt);
     if (seed_idx) {
         const uint32_t j = seed_idx[i < n ? i : n - 1];
         if (j < (uint32_t)nt) {
@@ -2586,7 +2607,7 @@ __global__ __launch_bounds__(kBlock) void lut_build_scan_coarse_kernel(BvhView t
     if (active) lut[((size_t)(iz + 1) * g.py + (iy + 1)) * (size_t)g.px + (ix + 1)] = v;
 }
 
-__global__ __launch_bounds__(kBlock) void lut_build_scan_kernel(BvhView t, LutGeom g, const float* __restrict__ coarse, float* __restrict__ lut) {
+__global__ __launch_bounds__(kBlock) void lut_build_scan_kernel(BvhView t, LutGeom g, const float* __restrict__ coarse, float* __restrict__ lut, uint32_t* __restrict__ lut_idx) {
     const int bx = (g.px + 3) / 4, by = (g.py + 3) / 4, bz = (g.pz + 3) / 4;
     const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
@@ -2600,8 +2621,13 @@ __global__ __launch_bounds__(kBlock) void lut_build_scan_kernel(BvhView t, LutGe
     const float T = coarse[((size_t)(kz + 1) * g.py + (ky + 1)) * (size_t)g.px + (kx + 1)];
     const float ddx = (float)(ix - kx) * g.resolution, ddy = (float)(iy - ky) * g.resolution, ddz = (float)(iz - kz) * g.resolution;
     const float u = sqrtf(T) + sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
-    const float v = scan_min_d2(t, cx, cy, cz, u * u * 1.0001f + 1e-6f, 3.402823466e+38f, active);  // FLT_MAX, :266
-    if (active) lut[((size_t)z * g.py + y) * (size_t)g.px + x] = v;
+    uint32_t who = 0x7fffffffu;
+    const float v = lut_idx ? scan_min_d2(t, cx, cy, cz, u * u * 1.0001f + 1e-6f, 3.402823466e+38f, active, &who)
+                            : scan_min_d2(t, cx, cy, cz, u * u * 1.0001f + 1e-6f, 3.402823466e+38f, active);  // FLT_MAX, :266
+    if (active) {
+        lut[((size_t)z * g.py + y) * (size_t)g.px + x] = v;
+        if (lut_idx) lut_idx[((size_t)z * g.py + y) * (size_t)g.px + x] = who;
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void fill_u32_kernel(uint32_t* p, uint32_t v, size_t n) {
@@ -3092,13 +3118,13 @@ void launch_nn_prep(const float4* pts, int n, const float* lut, const LutGeom& g
 }
 
 // `scratch` must hold as many floats as the padded LUT; it receives the coarse pass.
-void launch_lut_build_scan(const BvhView& t, const LutGeom& g, float* scratch, float* lut_padded, hipStream_t s) {
+void launch_lut_build_scan(const BvhView& t, const LutGeom& g, float* scratch, float* lut_padded, hipStream_t s, uint32_t* lut_idx) {
     auto cdiv = [](size_t a, size_t b) { return (a + b - 1) / b; };
     const size_t ncx = cdiv(g.dx, kLutCoarse), ncy = cdiv(g.dy, kLutCoarse), ncz = cdiv(g.dz, kLutCoarse);
     const size_t cwaves = cdiv(ncx, 4) * cdiv(ncy, 4) * cdiv(ncz, 4);
     hipLaunchKernelGGL(lut_build_scan_coarse_kernel, dim3((unsigned)cdiv(cwaves, kBlock / 64)), dim3(kBlock), 0, s, t, g, scratch);
     const size_t waves = cdiv(g.px, 4) * cdiv(g.py, 4) * cdiv(g.pz, 4);
-    hipLaunchKernelGGL(lut_build_scan_kernel, dim3((unsigned)cdiv(waves, kBlock / 64)), dim3(kBlock), 0, s, t, g, scratch, lut_padded);
+    hipLaunchKernelGGL(lut_build_scan_kernel, dim3((unsigned)cdiv(waves, kBlock / 64)), dim3(kBlock), 0, s, t, g, scratch, lut_padded, lut_idx);
 }
 
 #ifdef FGOICP_SCAN_STATS

@@ -26,6 +26,8 @@ struct LutGeom {
     int dx, dy, dz;              // reference dims (registration.cu:186-188)
     int px, py, pz;              // padded dims = d + 2
     int quantize;                // 1: interpolation weights in 1.8 fixed point (CUDA linear filtering)
+    const uint32_t* idx;         // optional (nullptr: none): per padded node the caller index of A nearest target point — the exact scans seed their
+                                 // pruning bound with the distance to it (round 3, kernels.hip lut_upper_bound_d2); not read by the bounds kernels
 };
 
 // One bounds launch = one rotation node + up to kMaxBatch translation nodes, passed by value in
@@ -133,7 +135,7 @@ void launch_nn_scan_dual(const float4* ptsA, const float* RA9, const float* tA3,
 // box6 = the target's bounding box {minx,maxx,miny,maxy,minz,maxz}
 void launch_nn_prep(const float4* pts, int n, const float* lut, const LutGeom& g, const float* R9, const float* t3, int apply, const float4* tgt, int nt,
                     const uint32_t* seed_idx, const float* box6, float* ub_out, float* lb_out, hipStream_t s);
-void launch_lut_build_scan(const BvhView& shifted_targets, const LutGeom& g, float* scratch_padded, float* lut_padded, hipStream_t s);
+void launch_lut_build_scan(const BvhView& shifted_targets, const LutGeom& g, float* scratch_padded, float* lut_padded, hipStream_t s, uint32_t* lut_idx_padded = nullptr);  // lut_idx: optional, per node the caller index of a nearest target
 
 // deterministic double sums: out[k] = sum_i vals[i*stride + k]  (k < width <= 16)
 void launch_sum_f32_as_f64(const uint32_t* bits, int n, double* block_partials, int nblocks, hipStream_t s, const int* done = nullptr);
