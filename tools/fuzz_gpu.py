@@ -161,6 +161,18 @@ def run_case(rng, idx):
         assert got == o["stats"], f"SERIAL counters {got} vs {o['stats']}"
         assert abs(e - float(o["best_sse"])) <= 1e-5 * max(float(o["best_sse"]), 1e-9), f"SERIAL sse {e} vs {o['best_sse']}"
         assert np.allclose(R, o["R"], atol=1e-5), "SERIAL R"
+        # the same trajectory with its evaluations dealt over W ranks (round 3: SERIAL on N ranks, driver.hpp run_task_list_sharded; W ranks on
+        # device 0 over the in-process transport): every rank must end with the one-GPU record, counter for counter and bit for bit
+        W = int(rng.choice([2, 3, 4]))
+        m = fg.MultiGoICP(tgt, src, res, mse, devices=[0] * W, transport=fg.TRANSPORT_IN_PROCESS, schedule=fg.SCHEDULE_SERIAL, trim_fraction=trim)
+        Rm, tm = m.run()
+        for rk in range(W):
+            stm = m.stats(rk)
+            gm = {k: int(stm[k]) for k in o["stats"]}
+            assert gm == got, f"SERIAL on {W} ranks, rank {rk}: counters {gm} vs {got}"
+            assert float(m.get_best_error(rk)) == e, f"SERIAL on {W} ranks, rank {rk}: sse {m.get_best_error(rk)} vs {e}"
+        assert np.array_equal(Rm, R) and np.array_equal(tm, t), f"SERIAL on {W} ranks: transform differs from the one-GPU run's"
+        m.close()
         r = fg.FastGoICP(tgt, src, res, mse, schedule=fg.SCHEDULE_ROUND, round_width=int(rng.choice([0, 1, 3])), trim_fraction=trim)
         r.run()
         er = float(r.get_best_error())
