@@ -431,10 +431,13 @@ def main():
         line["icp_latency"] = icp_latency(dflt)
 
     # the reference's own exploration order (the drop-in classes' default schedule)
-    if want("serial") and not a.no_serial and world == 1:
+    if want("serial") and not a.no_serial:
         ser = run_leg(env, fg, tgt, src, a.lut_resolution, a.mse_threshold, fg.SCHEDULE_SERIAL, 1, 1, 1)
+        if world > 1:  # SERIAL on N ranks: the trajectory is replicated, every rank's counters are the whole run's — not to be summed
+            ser["subcubes"] = ser["subcubes"] / world
         s = leg_summary(ser, R_gt, t_gt, f"{a.workload}-shape pair, mse_threshold={a.mse_threshold}, SERIAL schedule (the reference's pops, pushes and counters — "
-                                          "checked against the oracle's literal driver in tests), one step after 1 warm-up")
+                                          "checked against the oracle's literal driver in tests), one step after 1 warm-up"
+                                          + (f"; the inner BnBs of every speculative evaluation dealt over {world} ranks, one all-gather per evaluation" if world > 1 else ""))
         if head is not None:
             s["same_optimum_as_headline"] = bool(np.allclose(ser["R"], head["R"], atol=1e-5) and abs(ser["best_sse"] - head["best_sse"]) <= 1e-5 * head["best_sse"])
         s["roofline"] = roofline(ser, None)

@@ -156,6 +156,9 @@ def test_bench_two_rank_path_rehearsal(gpu_required):
     assert d["result"]["rotation_error_deg_vs_ground_truth"] < 0.5 and d["reference_default_threshold"]["same_optimum_as_headline"]
     assert 0 < d["rot_cubes_rank0"] < 2236 and "cpu_baseline" not in d  # sharded; the CPU leg is an N = 1 thing
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    # the reference's own trajectory, sharded over the two ranks: the one-GPU SERIAL record of this pair (1 625 992 subcubes, 2 236 rotation cubes)
+    ser = d["serial_reference_order"]
+    assert ser["subcubes_per_step"] == 1625992 and ser["rot_cubes_rank0"] == 2236 and ser["same_optimum_as_headline"]
 
 
 def test_cpp_facades_give_the_results_of_the_python_binding(fg, gpu_required, tmp_path):
