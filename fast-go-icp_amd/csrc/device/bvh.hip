@@ -8,6 +8,11 @@
 
 namespace fgoicp {
 
+bool bvh_kd_order() {
+    static const bool kd = [] { const char* e = std::getenv("FGOICP_BVH_ORDER"); return !e || std::atoi(e) != 0; }();  // tuning knob / A-B
+    return kd;
+}
+
 BvhHost bvh_build_host(const float4* p, size_t n, std::vector<uint32_t>* order) {
     BvhHost h;
     const size_t nleaf_needed = (n + kBvhLeaf - 1) / kBvhLeaf;
@@ -18,7 +23,7 @@ BvhHost bvh_build_host(const float4* p, size_t n, std::vector<uint32_t>* order) 
     h.first_leaf = (int)(nleaf - 1);
     const size_t nnodes = 2 * nleaf - 1;
     // leaves = the cells of a k-d tree (FGOICP_BVH_ORDER=1, default) or runs of the space-filling curve (0): morton.hpp
-    static const bool kd = [] { const char* e = std::getenv("FGOICP_BVH_ORDER"); return !e || std::atoi(e) != 0; }();  // tuning knob / A-B
+    const bool kd = bvh_kd_order();
     std::vector<uint32_t> own;
     std::vector<uint32_t>& perm = order ? *order : own;
     if (perm.size() != n) perm = kd ? kd_order(reinterpret_cast<const float*>(p), n, 4, (size_t)kBvhLeaf) : morton_order(reinterpret_cast<const float*>(p), n, 4);

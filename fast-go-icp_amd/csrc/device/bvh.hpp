@@ -39,6 +39,7 @@ struct BvhHost {
 // `order`: empty = computed here (and returned through it); otherwise the order to use — a second tree over the same points up to a
 // common shift (the LUT build's) is as tight under the first one's order and skips the sort.
 BvhHost bvh_build_host(const float4* p, size_t n, std::vector<uint32_t>* order = nullptr);
+bool bvh_kd_order();  // leaves = k-d cells (default) or runs of the space-filling curve (FGOICP_BVH_ORDER=0)
 
 struct BvhDevice {
     float4* box = nullptr;

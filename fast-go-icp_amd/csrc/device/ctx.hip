@@ -1267,6 +1267,7 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
         static const int forced = [] { const char* e = std::getenv("FGOICP_POINT_CURVE"); return e ? std::atoi(e) : -1; }();  // tuning knob
         const int mode = forced >= 0 ? forced : ((flags & FGOICP_FLAG_CURVE_ORDER) ? 1 : 2);
         c->perm = point_order(src_xyz, ns, 3, 64, mode);
+        c->source_order = mode;
     }
     {
         std::vector<float4> h(ns);
@@ -1302,6 +1303,7 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
             (void)hipFree(d_tgt_shift);
         } else {
             std::vector<uint32_t> order;  // one sort for both trees
+            c->tree_order = bvh_kd_order() ? 1 : 0;
             CHK(bvh_upload(bvh_build_host(h.data(), nt, &order), &c->bvh_tgt));
             BvhDevice shifted;  // the LUT is built from the SHIFTED targets (pc + offset in fp32), its own tree
             e3 = bvh_upload(bvh_build_host(hs.data(), nt, &order), &shifted);
@@ -1662,6 +1664,8 @@ int fgoicp_ctx_get_info(const fgoicp_ctx* c, fgoicp_ctx_info* out) {
     out->points_per_item = c->chunk_pts;
     out->items_per_evaluation = c->nchunk1;
     out->max_subcubes_per_window = c->max_subcubes;
+    out->source_order = c->source_order;
+    out->tree_order = c->tree_order;
     return FGOICP_OK;
 }
 

@@ -22,6 +22,7 @@ struct fgoicp_ctx {
     float4* d_tgt = nullptr;     // nt  x {x,y,z,0}, caller order (registration.hpp:61)
     float* d_lut = nullptr;      // (dx+2)(dy+2)(dz+2) floats, x fastest, replicated border
     int lut_layout = 1;          // 1: d_lut_zp is the z-paired copy (float2), 2: it is the yz-quad copy (float4)
+    int source_order = 0, tree_order = 0;  // what ctx_create chose (fgoicp_ctx_get_info)
     uint32_t* d_lut_idx = nullptr;  // index LUT (geom.idx): per padded node the caller index of a nearest target point; seeds of the exact scans (FGOICP_LUT_INDEX=0: none)
     float2* d_lut_zp = nullptr;  // z-paired copy {T[o], T[o + z-slice]} for the bounds kernel (2x the bytes, half the gathers)
     fgoicp::LutGeom geom{};

@@ -82,6 +82,8 @@ typedef struct fgoicp_ctx_info {
     int points_per_item;         /* 256 .. 2048 */
     int items_per_evaluation;    /* ceil(ns / points_per_item) */
     int max_subcubes_per_window;
+    int source_order;            /* order of the source cloud on the device: 0 = caller / Z-order, 1 = Hilbert curve, 2 = k-d cells of 64 points, 3 = density split */
+    int tree_order;              /* leaves of the target tree: 1 = k-d cells of 32 points, 0 = runs of the space-filling curve */
 } fgoicp_ctx_info;
 int fgoicp_ctx_get_info(const fgoicp_ctx* ctx, fgoicp_ctx_info* out);
 /* n single nodes of the LUT: out[i] = node (x, y, z) = xyz[3i..3i+2] (the value buildLUTKernel, registration.cu:258-278, stores at

@@ -570,6 +570,7 @@ def test_context_reports_what_it_derived_from_the_cloud_statistics(fg, gpu_requi
     for i, reg in ((a, sparse), (b, dense)):
         assert i["lut_dims"] == reg.lut_dims() and i["lut_nodes"] == int(np.prod(i["lut_dims"]))
         assert i["items_per_evaluation"] == -(-reg.ns // i["points_per_item"]) and i["max_subcubes_per_window"] >= 32
+        assert i["source_order"] == 2 and i["tree_order"] == 1  # k-d cells (round 3 defaults; FGOICP_FLAG_CURVE_ORDER / FGOICP_POINT_CURVE / FGOICP_BVH_ORDER change them)
         assert i["lut_bytes"] >= i["lut_nodes"] * 4 * (1 + (4 if i["lut_layout"] in (2, 4) else 2))
     assert a["source_points_per_face_voxel"] == pytest.approx(3000 / 3e4, rel=0.05) and a["lut_layout"] == 4 and a["points_per_item"] == 256
     assert b["source_points_per_face_voxel"] == pytest.approx(2.0, rel=0.05) and b["lut_layout"] == 1 and b["points_per_item"] == 2048

@@ -98,5 +98,6 @@ def simulate(name, ngroups=300, balanced=False):
                 scanned += (D <= B[:, None]).any(0).sum()
             print(f"{name}: queries {qn:8s} target {tn:8s}: per 64-query group leaves tested {tested/len(gs):6.1f} scanned {scanned/len(gs):6.1f}; mean leaf box diag {np.linalg.norm(hi-lo,axis=1).mean():.5f}")
 
-for name in sys.argv[1:]:
-    simulate(name)
+if __name__ == "__main__":
+    for name in sys.argv[1:]:
+        simulate(name)
