@@ -488,7 +488,9 @@ private:
 
     int bnb_so3_serial() {
         static const int mode = [] { const char* e = std::getenv("FGOICP_SERIAL_SPECULATE"); return e ? std::atoi(e) : 2; }();
-        static const int spec_cap = [] { const char* e = std::getenv("FGOICP_SERIAL_WIDTH"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();  // tuning knob
+        // width cap: 256 nodes per rank (the evaluations of a speculation are dealt over the ranks: the same tick sizes per rank at any world size)
+        static const int spec_cap_env = [] { const char* e = std::getenv("FGOICP_SERIAL_WIDTH"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 0; }();  // tuning knob
+        const int spec_cap = spec_cap_env > 0 ? spec_cap_env : 256 * (serial_sharded() ? ex_.world : 1);
         std::priority_queue<RotCube> rcand;
         rcand.push(RotCube(0.f, 0.f, 0.f, 1.0f, 0.f, best_sse()));
         std::map<SpecKey, SpecNode> cache;
