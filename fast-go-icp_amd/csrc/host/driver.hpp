@@ -491,6 +491,9 @@ private:
         // width cap: 256 nodes per rank (the evaluations of a speculation are dealt over the ranks: the same tick sizes per rank at any world size)
         static const int spec_cap_env = [] { const char* e = std::getenv("FGOICP_SERIAL_WIDTH"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 0; }();  // tuning knob
         const int spec_cap = spec_cap_env > 0 ? spec_cap_env : 256 * (serial_sharded() ? ex_.world : 1);
+        // how the width grows while the incumbent stands and where it restarts when it improves (tuning knobs; the trajectory does not depend on them)
+        static const int spec_grow = [] { const char* e = std::getenv("FGOICP_SERIAL_GROW"); const int v = e ? std::atoi(e) : 0; return v >= 2 && v <= 16 ? v : 2; }();
+        static const int spec_start = [] { const char* e = std::getenv("FGOICP_SERIAL_START"); const int v = e ? std::atoi(e) : 0; return v >= 1 && v <= 256 ? v : 1; }();
         std::priority_queue<RotCube> rcand;
         rcand.push(RotCube(0.f, 0.f, 0.f, 1.0f, 0.f, best_sse()));
         std::map<SpecKey, SpecNode> cache;
@@ -529,7 +532,7 @@ private:
             {
                 auto it = cache.find(key);
                 if (it == cache.end() || it->second.epoch != epoch) {  // not evaluated yet, or evaluated against a stale best_sse
-                    if (mode >= 2) width = epoch_of_last_speculation == epoch ? std::min(width * 2, spec_cap) : 1;
+                    if (mode >= 2) width = epoch_of_last_speculation == epoch ? std::min(width * spec_grow, spec_cap) : spec_start;
                     epoch_of_last_speculation = epoch;
                     std::vector<SpecNode*> batch;
                     SpecNode& mine = cache[key];
@@ -970,6 +973,32 @@ private:
                 tk.consume(tk.blb.data(), tk.bub.data());  // the whole batch came from the memo
             }
             tk.has_batch = true;
+            // SERIAL, tail of an evaluation (round 3): a SERIAL task pops the reference's 32 nodes per operator call (fgoicp.cpp:122) — that is part
+            // of the trajectory — so the tail of an evaluation is a long chain of round trips with a few tasks x 32 nodes each (tick log:
+            // 36 % of the kernel time of a SERIAL certify run sits in ticks of 256-1024 evaluations at 350 instead of 217 ns each).
+            // LOOK-AHEAD: the nodes the task pops NEXT if nothing changes — the tops of a COPY of its queue (the real heap is not touched:
+            // re-seating equal keys would change the pop order) — ride along as phantom rows of its own group; their bounds go into the
+            // task's memo, and a later batch that the memo serves entirely is consumed without a device round trip (the mechanism the LB
+            // tasks use for their twins' nodes).  The task's pops, pushes, counters and bounds are what they were: a node's sums do not
+            // depend on the tick it is evaluated in; look-ahead nodes that are never popped are wasted work, not counted.
+            // Measured (profiles/r03_ab_serial_ahead.txt): bunny-shape certify run 450 -> 377 ms (launches 1298 -> 410, evaluations + 5 %), the same run
+            // on 8 ranks 3.5x -> 4.6x; look-ahead up to 512 live tasks per half (480 / 224 / 96 nodes from a quarter / half / all of that down) —
+            // beyond that the wasted evaluations cost more than the round trips saved (2048 tasks: 414 ms), and on the dragon shape, where a node
+            // is 437k point evaluations on a device that is full anyway, 32 tasks is the limit (1.63 -> 1.59 s; 512: 1.78 s).
+            const size_t ahead_tasks = serial_ahead_tasks_ ? serial_ahead_tasks_ : (ns_ <= 200000 ? 512 : 32);
+            if (serial_ahead_ > 0 && tk.batch_cap == 32 && h.members.size() <= ahead_tasks && !tk.cand.empty()) {
+                const size_t want = h.members.size() <= ahead_tasks / 4 ? 15 * 32 : h.members.size() <= ahead_tasks / 2 ? 7 * 32 : 3 * 32;
+                std::priority_queue<TransCube> peek = tk.cand;
+                for (size_t got = 0; got < std::min(want, (size_t)serial_ahead_) && !peek.empty();) {
+                    const TransCube tn = peek.top();
+                    peek.pop();
+                    if (tk.best_error - tn.lb < sse_threshold_) break;  // the task would stop here (:120)
+                    if (!(tn.lb < tk.best_error)) continue;             // popped and dropped (:126)
+                    if (tk.memo.find(node_key(tn))) continue;
+                    tk.phantom.push_back(tn);
+                    ++got;
+                }
+            }
         };
         if (par) pool_->parallel_for(h.members.size(), pop_fn);
         else for (size_t k = 0; k < h.members.size(); ++k) pop_fn(k);
@@ -998,6 +1027,7 @@ private:
                 table[sl] = (int)j;
             }
             for (size_t i = 0; i < n0; ++i) {
+                if (ub.brow[i] < 0) continue;  // served from the UB task's own memo (look-ahead): no row of this submission to pair with
                 const NodeKey ki = node_key(ub.batch[i]);
                 int hit = -1;
                 for (uint32_t sl = (uint32_t)NodeKeyHash()(ki) & 1023u; table[sl] >= 0; sl = (sl + 1) & 1023u)
@@ -1178,6 +1208,8 @@ private:
     const int late_icp_ = [] { const char* e = std::getenv("FGOICP_LATE_ICP"); return e ? std::atoi(e) : 0; }();  // tuning knob (ROUND): 0 = off (default: measured slower, see above), 1 = with an exchange (world > 1), 2 = always
     bool use_twins_ = [] { const char* e = std::getenv("FGOICP_TWINS"); return !e || std::atoi(e) != 0; }();  // tuning knob
     const size_t round_batch_ = [] { const char* e = std::getenv("FGOICP_ROUND_BATCH"); const int v = e ? std::atoi(e) : 48; return (size_t)(v >= 8 && v <= 64 ? v : 48); }();  // tuning knob (ROUND only; SERIAL keeps the reference's 32)
+    const int serial_ahead_ = [] { const char* e = std::getenv("FGOICP_SERIAL_AHEAD"); return e ? std::max(0, std::atoi(e)) : 480; }();  // tuning knob: look-ahead nodes of a SERIAL task in the tail of an evaluation (0 = off)
+    const size_t serial_ahead_tasks_ = [] { const char* e = std::getenv("FGOICP_SERIAL_AHEAD_TASKS"); const int v = e ? std::atoi(e) : 0; return (size_t)(v > 0 ? v : 0); }();  // ... while its half holds at most this many tasks (0 = by cloud size: 512 / 32)
     const bool tail_batch_fixed_ = std::getenv("FGOICP_TAIL_BATCH") != nullptr;
     const size_t tail_batch_ = [] { const char* e = std::getenv("FGOICP_TAIL_BATCH"); const int v = e ? std::atoi(e) : 128; return (size_t)(v >= 8 && v <= 512 ? v : 0); }();  // tuning knob (ROUND): batch of a half with few tasks left (0 = off)
     const size_t tail_tasks_ = [] { const char* e = std::getenv("FGOICP_TAIL_TASKS"); const int v = e ? std::atoi(e) : 32; return (size_t)(v >= 0 ? v : 32); }();  // ... "few" = at most this many
