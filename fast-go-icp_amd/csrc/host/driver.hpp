@@ -949,6 +949,13 @@ private:
             tail_cap = tail_batch_;
             if (!tail_batch_fixed_ && ns_ <= 200000) tail_cap = h.members.size() <= tail_tasks_ / 4 ? 512 : h.members.size() <= tail_tasks_ / 2 ? 256 : tail_batch_;
         }
+        // the same rule made continuous (FGOICP_TICK_ROWS = R > 0): a half's batches are sized so that a tick carries about R rows — batch =
+        // R / live tasks, between ROUND's 48 and 512 — which also reaches the middle of a round on a rank of many (a few hundred tasks per
+        // half: ticks of 4 000 rows at 275 ns per evaluation where the one-GPU run's big ticks cost 207)
+        if (tick_rows_ > 0 && tail_batch_ && !tail_batch_fixed_ && ns_ <= 200000 && !h.members.empty()) {
+            const size_t b = std::min<size_t>(512, tick_rows_ / h.members.size());
+            tail_cap = b > round_batch_ ? b : 0;
+        }
         const std::function<void(size_t)> pop_fn = [&](size_t k) {
             Task& tk = *tasks[h.members[k]];
             if (tk.batch_cap != 32) tk.batch_cap = tail_cap ? tail_cap : round_batch_;  // SERIAL tasks keep the reference's 32 (fgoicp.cpp:122)
@@ -1210,6 +1217,7 @@ private:
     const size_t round_batch_ = [] { const char* e = std::getenv("FGOICP_ROUND_BATCH"); const int v = e ? std::atoi(e) : 48; return (size_t)(v >= 8 && v <= 64 ? v : 48); }();  // tuning knob (ROUND only; SERIAL keeps the reference's 32)
     const int serial_ahead_ = [] { const char* e = std::getenv("FGOICP_SERIAL_AHEAD"); return e ? std::max(0, std::atoi(e)) : 480; }();  // tuning knob: look-ahead nodes of a SERIAL task in the tail of an evaluation (0 = off)
     const size_t serial_ahead_tasks_ = [] { const char* e = std::getenv("FGOICP_SERIAL_AHEAD_TASKS"); const int v = e ? std::atoi(e) : 0; return (size_t)(v > 0 ? v : 0); }();  // ... while its half holds at most this many tasks (0 = by cloud size: 512 / 32)
+    const size_t tick_rows_ = [] { const char* e = std::getenv("FGOICP_TICK_ROWS"); const int v = e ? std::atoi(e) : 0; return (size_t)(v > 0 ? v : 0); }();  // tuning knob (ROUND): rows a tick should carry (0 = the stepwise tail rule)
     const bool tail_batch_fixed_ = std::getenv("FGOICP_TAIL_BATCH") != nullptr;
     const size_t tail_batch_ = [] { const char* e = std::getenv("FGOICP_TAIL_BATCH"); const int v = e ? std::atoi(e) : 128; return (size_t)(v >= 8 && v <= 512 ? v : 0); }();  // tuning knob (ROUND): batch of a half with few tasks left (0 = off)
     const size_t tail_tasks_ = [] { const char* e = std::getenv("FGOICP_TAIL_TASKS"); const int v = e ? std::atoi(e) : 32; return (size_t)(v >= 0 ? v : 32); }();  // ... "few" = at most this many
