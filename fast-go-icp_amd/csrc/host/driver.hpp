@@ -725,12 +725,19 @@ private:
             if (popped == 0) break;
             stats_.rounds++;
             const size_t nchild = children.size();
-            const size_t slots = (nchild + world - 1) / world;  // per-rank child slots
+            // Children are dealt in BLOCKS of deal_block_ consecutive children (siblings: `children` holds a parent's children next to each other):
+            // block b goes to rank b % world.  Block 1 = plain round-robin.  Siblings turn the cloud by nearly the same rotation, so their items
+            // land in the same LUT cells of a tick's locality sort — what the one-GPU run gets for free from having every child in one tick.
+            const size_t B = deal_block_, nblocks = (nchild + B - 1) / B;
+            const size_t slots = ((nblocks + world - 1) / world) * B;  // per-rank child slots
+            auto owner_of = [&](size_t i) { return (int)((i / B) % (size_t)world); };
+            auto slot_of = [&](size_t i) { return (i / (B * (size_t)world)) * B + i % B; };
             const float snapshot = best_sse();
 
-            // my children: global index i with i % world == rank → slot i / world
+            // my children, in child order (slot_of is increasing along it)
             std::vector<size_t> mine;
-            for (size_t i = rank; i < nchild; i += world) mine.push_back(i);
+            for (size_t i = 0; i < nchild; ++i)
+                if (owner_of(i) == rank) mine.push_back(i);
             std::vector<Task> boxes(2 * mine.size());
             std::vector<Task*> tasks;
             std::vector<const RotCube*> cubes;
@@ -767,7 +774,7 @@ private:
                 const size_t per = 5 * slots;
                 std::vector<float> send(per, 0.f), recv(per * world, 0.f);
                 for (size_t k = 0; k < mine.size(); ++k) {
-                    float* p = &send[5 * k];
+                    float* p = &send[5 * slot_of(mine[k])];
                     p[0] = boxes[2 * k + 1].best_ub;  // LB pass: its best_ub is the cube's lower bound (:90)
                     p[1] = boxes[2 * k].best_ub;      // UB pass
                     p[2] = boxes[2 * k].best_t.x; p[3] = boxes[2 * k].best_t.y; p[4] = boxes[2 * k].best_t.z;
@@ -775,7 +782,7 @@ private:
                 if (!ex_.allgather) return kDriverExchangeFailed;
                 if (nchild > 0 && ex_.allgather(send.data(), recv.data(), per, ex_.user)) return kDriverExchangeFailed;  // (a round may consist of cubes pushed unevaluated)
                 for (size_t i = 0; i < nchild; ++i) {
-                    const float* p = &recv[per * (i % world)] + 5 * (i / world);
+                    const float* p = &recv[per * (size_t)owner_of(i)] + 5 * slot_of(i);
                     lbs[i] = p[0];
                     ubs[i] = p[1];
                     const Vec3f bt{p[2], p[3], p[4]};
@@ -836,8 +843,8 @@ private:
                 std::memcpy(&send[1], loc_R.m, sizeof(float) * 9);
                 send[10] = loc_t.x; send[11] = loc_t.y; send[12] = loc_t.z;
                 for (size_t k = 0; k < mine.size(); ++k) {
-                    send[13 + 2 * k] = boxes[2 * k + 1].best_ub;  // LB pass: its best_ub is the cube's lower bound (:90)
-                    send[13 + 2 * k + 1] = boxes[2 * k].best_ub;  // UB pass
+                    send[13 + 2 * slot_of(mine[k])] = boxes[2 * k + 1].best_ub;  // LB pass: its best_ub is the cube's lower bound (:90)
+                    send[13 + 2 * slot_of(mine[k]) + 1] = boxes[2 * k].best_ub;  // UB pass
                 }
                 if (ex_.allgather(send.data(), recv.data(), per, ex_.user)) return kDriverExchangeFailed;
                 for (int r = 0; r < world; ++r) {  // lowest rank holding the global minimum wins
@@ -851,7 +858,7 @@ private:
                     }
                 }
                 for (size_t i = 0; i < nchild; ++i) {
-                    const float* p = &recv[per * (i % world)] + 13 + 2 * (i / world);
+                    const float* p = &recv[per * (size_t)owner_of(i)] + 13 + 2 * slot_of(i);
                     lbs[i] = p[0];
                     ubs[i] = p[1];
                 }
@@ -1218,6 +1225,7 @@ private:
     const int serial_ahead_ = [] { const char* e = std::getenv("FGOICP_SERIAL_AHEAD"); return e ? std::max(0, std::atoi(e)) : 480; }();  // tuning knob: look-ahead nodes of a SERIAL task in the tail of an evaluation (0 = off)
     const size_t serial_ahead_tasks_ = [] { const char* e = std::getenv("FGOICP_SERIAL_AHEAD_TASKS"); const int v = e ? std::atoi(e) : 0; return (size_t)(v > 0 ? v : 0); }();  // ... while its half holds at most this many tasks (0 = by cloud size: 512 / 32)
     const size_t tick_rows_ = [] { const char* e = std::getenv("FGOICP_TICK_ROWS"); const int v = e ? std::atoi(e) : 0; return (size_t)(v > 0 ? v : 0); }();  // tuning knob (ROUND): rows a tick should carry (0 = the stepwise tail rule)
+    const size_t deal_block_ = [] { const char* e = std::getenv("FGOICP_DEAL_BLOCK"); const int v = e ? std::atoi(e) : 0; return (size_t)(v >= 1 && v <= 64 ? v : 1); }();  // tuning knob (ROUND on N ranks): consecutive children dealt to one rank
     const bool tail_batch_fixed_ = std::getenv("FGOICP_TAIL_BATCH") != nullptr;
     const size_t tail_batch_ = [] { const char* e = std::getenv("FGOICP_TAIL_BATCH"); const int v = e ? std::atoi(e) : 128; return (size_t)(v >= 8 && v <= 512 ? v : 0); }();  // tuning knob (ROUND): batch of a half with few tasks left (0 = off)
     const size_t tail_tasks_ = [] { const char* e = std::getenv("FGOICP_TAIL_TASKS"); const int v = e ? std::atoi(e) : 32; return (size_t)(v >= 0 ? v : 32); }();  // ... "few" = at most this many
