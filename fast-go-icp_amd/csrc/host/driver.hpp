@@ -999,7 +999,9 @@ private:
             // on 8 ranks 3.5x -> 4.6x; look-ahead up to 512 live tasks per half (480 / 224 / 96 nodes from a quarter / half / all of that down) —
             // beyond that the wasted evaluations cost more than the round trips saved (2048 tasks: 414 ms), and on the dragon shape, where a node
             // is 437k point evaluations on a device that is full anyway, 32 tasks is the limit (1.63 -> 1.59 s; 512: 1.78 s).
-            const size_t ahead_tasks = serial_ahead_tasks_ ? serial_ahead_tasks_ : (ns_ <= 200000 ? 512 : 32);
+            // (clouds below 16 384 points: off — such runs are bound by the host's queue work, not by device round trips: on the shape of
+            // test/bunny.toml, 3 037 source points, the queue copies and memo look-ups add 15 ms of pops to a 100-ms run and save nothing)
+            const size_t ahead_tasks = serial_ahead_tasks_ ? serial_ahead_tasks_ : (ns_ < 16384 ? 0 : ns_ <= 200000 ? 512 : 32);
             if (serial_ahead_ > 0 && tk.batch_cap == 32 && h.members.size() <= ahead_tasks && !tk.cand.empty()) {
                 const size_t want = h.members.size() <= ahead_tasks / 4 ? 15 * 32 : h.members.size() <= ahead_tasks / 2 ? 7 * 32 : 3 * 32;
                 std::priority_queue<TransCube> peek = tk.cand;
