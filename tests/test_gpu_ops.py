@@ -677,3 +677,20 @@ def test_sibling_units_whole_run(fg, gpu_required, monkeypatch):
         for trim in (0.0, 0.2):
             a, b = res[("0", trim)], res[(units, trim)]
             assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3:] == b[3:], (units, trim, a, b)
+
+
+@pytest.mark.gpu
+def test_serial_look_ahead_changes_no_counter_on_the_device(fg, gpu_required, monkeypatch):
+    """SERIAL with and without its look-ahead (driver.hpp: a task's next nodes ride along as phantom rows into its memo) on a cloud big
+    enough for the default to switch it on: same pops, pushes, subcubes, operator calls, ICP runs and result bits — and fewer ticks."""
+    tgt, src, _, _ = fg.synth.make_pair(20000, 18000, (0.156, 0.152, 0.118), seed=31, angle_deg=150.0, min_angle_deg=110.0)
+    out = {}
+    for ahead in ("0", "480"):
+        monkeypatch.setenv("FGOICP_SERIAL_AHEAD", ahead)
+        s = fg.FastGoICP(tgt, src, 0.01, 1e-4, schedule=fg.SCHEDULE_SERIAL)
+        R, t = s.run()
+        st = s.stats()
+        out[ahead] = ([st[k] for k in ("trans_cubes", "bounds_calls", "rot_cubes", "icp_runs", "icp_iters", "inner_bnb", "rounds")], R.copy(), t.copy(), np.float32(s.get_best_error()))
+        s.close()
+    a, b = out["0"], out["480"]
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3].view(np.uint32) == b[3].view(np.uint32)

@@ -84,6 +84,20 @@ def test_serial_schedule_reproduces_reference_trajectory(pre):
     assert np.array_equal(r["t_scaled"], G[pre + "t_scaled"])
 
 
+@pytest.mark.parametrize("tasks,ahead", [("64", "480"), ("4", "96")])
+def test_serial_look_ahead_leaves_the_trajectory_alone(monkeypatch, tasks, ahead):
+    """SERIAL look-ahead (driver.hpp prepare_half: the nodes a task pops next ride along as phantom rows into its memo; a batch the
+    memo serves entirely is consumed without an operator call).  By default it is off for clouds this small (host-bound runs), so it
+    is switched on explicitly: every counter and the result must still be the golden record of the oracle's literal driver."""
+    monkeypatch.setenv("FGOICP_SERIAL_AHEAD_TASKS", tasks)
+    monkeypatch.setenv("FGOICP_SERIAL_AHEAD", ahead)
+    pre = "runsyn_"
+    for sched in (0, 5):  # 5 = SERIAL over the two-slot pipelined task loop with the twin-task memo logic on (as on the GPU)
+        r = hh.HostDriver(G[pre + "tgt"], G[pre + "src"], float(G[pre + "res"]), float(G[pre + "mse"]), schedule=sched).run()
+        assert [r["stats"][k] for k in KEYS] == list(G[pre + "stats"]), sched
+        assert np.array_equal(r["R"], G[pre + "R"]) and np.array_equal(r["t"], G[pre + "t"]) and r["best_sse"] == G[pre + "sse"]
+
+
 @pytest.mark.parametrize("pre,K,sched", [("runsyn_", 1, 1), ("runsyn_", 3, 1), ("runbun_", 2, 1), ("runsyn_", 2, 2), ("runbun_", 4, 2), ("runbun_", 0, 1), ("runsyn_", 0, 2)])
 def test_round_schedule_reaches_the_same_optimum(pre, K, sched):
     """sched 1 = ROUND, synchronous task loop; sched 2 = ROUND with the two-slot pipelined task loop; K = 0: adaptive width."""
