@@ -105,6 +105,11 @@ class Env:
         self.transport = None
         self.comm_ranks = None
         if self.world > 1:
+            # The trimmed leg's cooperative refinements would split their scans over the ranks through an in-place RCCL all-gather on device
+            # memory (fgoicp_exchange.allgather_device) — a collective no multi-GPU node has executed yet (tests: in-process ranks on one
+            # device, gloo).  The scaling run's headline must not depend on it: refinements run replicated here unless the caller opts in
+            # (FGOICP_COOP_SPLIT_MIN set in the environment, e.g. 262144 = the library's default for trimmed contexts).
+            os.environ.setdefault("FGOICP_COOP_SPLIT_MIN", str(1 << 62))
             import torch.distributed as dist
             self.dist = dist
             if a.rehearse_on_one_gpu:
