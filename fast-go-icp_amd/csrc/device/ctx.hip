@@ -1193,10 +1193,19 @@ extern "C" {
 const char* fgoicp_last_error(void) { return g_last_error.c_str(); }
 const char* fgoicp_version(void) { return "fgoicp_amd 0.1 (gfx950)"; }
 
+static int ctx_create_impl(const float* tgt_xyz, size_t nt, const float* src_xyz, size_t ns, const float* bounds6, float lut_resolution, int device, unsigned flags,
+                           fgoicp_ctx** out, fgoicp_ctx** partial);
 int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, size_t ns, const float* bounds6, float lut_resolution,
                       int device, unsigned flags, fgoicp_ctx** out) {
     if (!out) return FGOICP_ERR_INVALID_ARG;
     *out = nullptr;
+    fgoicp_ctx* partial = nullptr;  // what an exception (std::bad_alloc in a host-side table, a thread that cannot start) leaves half-built
+    const int rc = fgoicp::abi_guard("fgoicp_ctx_create", [&] { return ctx_create_impl(tgt_xyz, nt, src_xyz, ns, bounds6, lut_resolution, device, flags, out, &partial); });
+    if (rc != FGOICP_OK && partial && !*out) fgoicp_ctx_destroy(partial);
+    return rc;
+}
+static int ctx_create_impl(const float* tgt_xyz, size_t nt, const float* src_xyz, size_t ns, const float* bounds6, float lut_resolution, int device, unsigned flags,
+                           fgoicp_ctx** out, fgoicp_ctx** partial) {
     if (!tgt_xyz || !src_xyz || !bounds6 || nt == 0 || ns == 0 || !(lut_resolution > 0) || nt > 0x7ffffffeull || ns > 0x7ffffffeull) {
         set_error("fgoicp_ctx_create: invalid argument");
         return FGOICP_ERR_INVALID_ARG;
@@ -1214,6 +1223,7 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
     }
     HIPCHK(hipSetDevice(device));
     fgoicp_ctx* c = new fgoicp_ctx();
+    *partial = c;
     c->device = device;
     c->ns = ns;
     c->nt = nt;
@@ -1233,7 +1243,7 @@ int fgoicp_ctx_create(const float* tgt_xyz, size_t nt, const float* src_xyz, siz
     if (const char* e = std::getenv("FGOICP_TRIM_SKIP")) c->trim_skip = std::atoi(e) != 0;        // tuning knob
     if (const char* e = std::getenv("FGOICP_SORT_XCD")) c->sort_xcd = std::atoi(e) != 0;          // tuning knob
     if (const char* e = std::getenv("FGOICP_SORT_CHECK")) c->sort_check = std::atoi(e) != 0;      // tuning knob: 0 = no permutation check of the tick sort
-    auto fail = [&](int rc) { fgoicp_ctx_destroy(c); return rc; };
+    auto fail = [&](int rc) { fgoicp_ctx_destroy(c); *partial = nullptr; return rc; };
 #define CHK(expr) do { hipError_t e2_ = (expr); if (e2_ != hipSuccess) { set_error(std::string(#expr) + " failed: " + hipGetErrorString(e2_)); return fail(e2_ == hipErrorOutOfMemory ? FGOICP_ERR_OOM : FGOICP_ERR_HIP); } } while (0)
     CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 

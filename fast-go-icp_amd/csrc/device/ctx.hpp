@@ -1,6 +1,9 @@
 // Internal layout of the opaque fgoicp_ctx (include/fgoicp_amd.h).  Shared by the operator ABI
 // (ctx.hip) and the driver ABI (solver.cpp); not installed.
 #pragma once
+#include <exception>
+#include <new>
+#include <string>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -8,6 +11,7 @@
 #include <vector>
 
 #include "../host/math3.hpp"
+#include "../host/abi_guard.hpp"
 #include "bvh.hpp"
 #include "kernels.hpp"
 
@@ -159,6 +163,7 @@ struct fgoicp_ctx {
 
 namespace fgoicp {
 void set_error(const std::string& s);
+
 int ctx_bounds_multi(fgoicp_ctx* c, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets,
                      const float* tn4, float* lb_out, float* ub_out);
 int ctx_bounds_submit(fgoicp_ctx* c, int slot, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets, const float* tn4,

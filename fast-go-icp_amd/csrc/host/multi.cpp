@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "../../../include/fgoicp_amd.h"
+#include "abi_guard.hpp"
 
 namespace fgoicp {
 void set_error(const std::string& s);
@@ -494,6 +495,7 @@ int link_allgather_device(void* buf, size_t bytes, void* user) {
 }  // namespace
 
 struct fgoicp_multi {
+    ~fgoicp_multi();  // solvers and communicators go with the object (fgoicp_multi_destroy, a failed or throwing create)
     std::vector<int> devices;
     std::vector<fgoicp_solver*> solvers;
     std::vector<fgoicp_rccl*> rccl;
@@ -504,20 +506,26 @@ struct fgoicp_multi {
     int transport = FGOICP_TRANSPORT_RCCL;
     std::vector<double> seconds;   // wall-clock of every rank's last run
 };
+fgoicp_multi::~fgoicp_multi() {
+    for (fgoicp_solver* s : solvers) fgoicp_solver_destroy(s);
+    for (fgoicp_rccl* x : rccl) fgoicp_rccl_destroy(x);
+}
 
 extern "C" {
 
-void fgoicp_multi_destroy(fgoicp_multi* m) {
-    if (!m) return;
-    for (fgoicp_solver* s : m->solvers) fgoicp_solver_destroy(s);
-    for (fgoicp_rccl* x : m->rccl) fgoicp_rccl_destroy(x);
-    delete m;
-}
+void fgoicp_multi_destroy(fgoicp_multi* m) { delete m; }
 
+static int multi_create_impl(const float* tgt_xyz, size_t nt, const float* src_xyz, size_t ns, float lut_resolution, float mse_threshold, const fgoicp_solver_opts* opts,
+                             const int* devices, int ndev, int transport, fgoicp_multi** out);
 int fgoicp_multi_create(const float* tgt_xyz, size_t nt, const float* src_xyz, size_t ns, float lut_resolution, float mse_threshold,
                         const fgoicp_solver_opts* opts, const int* devices, int ndev, int transport, fgoicp_multi** out) {
     if (!out) return FGOICP_ERR_INVALID_ARG;
     *out = nullptr;
+    // (the object under construction is held by a unique_ptr inside; fgoicp_multi's destructor frees what it owns)
+    return fgoicp::abi_guard("fgoicp_multi_create", [&] { return multi_create_impl(tgt_xyz, nt, src_xyz, ns, lut_resolution, mse_threshold, opts, devices, ndev, transport, out); });
+}
+static int multi_create_impl(const float* tgt_xyz, size_t nt, const float* src_xyz, size_t ns, float lut_resolution, float mse_threshold, const fgoicp_solver_opts* opts,
+                             const int* devices, int ndev, int transport, fgoicp_multi** out) {
     if (!devices || ndev < 1 || (transport != FGOICP_TRANSPORT_RCCL && transport != FGOICP_TRANSPORT_IN_PROCESS)) {
         set_error("fgoicp_multi_create: invalid argument");
         return FGOICP_ERR_INVALID_ARG;
@@ -614,8 +622,12 @@ int fgoicp_multi_set_record(fgoicp_multi* m, int on) {
 }
 
 // Every rank's run() on its own host thread; the result is rank 0's (all ranks hold the same incumbent after the last exchange).
+static int multi_run_impl(fgoicp_multi* m, float* R_out9, float* t_out3);
 int fgoicp_multi_run(fgoicp_multi* m, float* R_out9, float* t_out3) {
     if (!m || !R_out9 || !t_out3) return FGOICP_ERR_INVALID_ARG;
+    return fgoicp::abi_guard("fgoicp_multi_run", [&] { return multi_run_impl(m, R_out9, t_out3); });
+}
+static int multi_run_impl(fgoicp_multi* m, float* R_out9, float* t_out3) {
     const int n = (int)m->solvers.size();
     std::vector<int> rcs(n, 0);
     std::vector<std::string> errs(n);

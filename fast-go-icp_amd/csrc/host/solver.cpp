@@ -58,14 +58,25 @@ struct fgoicp_solver {
     std::unique_ptr<GoIcpDriver<HipOps>> driver;
     fgoicp_exchange ex{};
     bool has_ex = false;
+    ~fgoicp_solver() {  // the context goes with the solver however the solver goes (fgoicp_solver_destroy, a failed or throwing create)
+        driver.reset();
+        fgoicp_ctx_destroy(ctx);
+    }
 };
 
 extern "C" {
 
+static int solver_create_impl(const float* tgt_xyz, size_t nt, const float* src_xyz, size_t ns, float lut_resolution, float mse_threshold, const fgoicp_solver_opts* opts,
+                              fgoicp_solver** out);
 int fgoicp_solver_create(const float* tgt_xyz, size_t nt, const float* src_xyz, size_t ns, float lut_resolution, float mse_threshold,
                          const fgoicp_solver_opts* opts, fgoicp_solver** out) {
     if (!out) return FGOICP_ERR_INVALID_ARG;
     *out = nullptr;
+    // (the solver under construction is held by a unique_ptr inside: an exception unwinds it, and its destructor frees the context)
+    return fgoicp::abi_guard("fgoicp_solver_create", [&] { return solver_create_impl(tgt_xyz, nt, src_xyz, ns, lut_resolution, mse_threshold, opts, out); });
+}
+static int solver_create_impl(const float* tgt_xyz, size_t nt, const float* src_xyz, size_t ns, float lut_resolution, float mse_threshold, const fgoicp_solver_opts* opts,
+                              fgoicp_solver** out) {
     if (!tgt_xyz || !src_xyz || nt == 0 || ns == 0 || !(lut_resolution > 0) || !(mse_threshold >= 0)) {
         set_error("fgoicp_solver_create: invalid argument");
         return FGOICP_ERR_INVALID_ARG;
@@ -94,7 +105,7 @@ int fgoicp_solver_create(const float* tgt_xyz, size_t nt, const float* src_xyz, 
         if (k < 1) k = 1;
         if (k < ns) {
             rc = ctx_set_inliers(s->ctx, k);
-            if (rc) { fgoicp_ctx_destroy(s->ctx); return rc; }
+            if (rc) return rc;
             n_thr = k;
         }
     }
@@ -105,8 +116,6 @@ int fgoicp_solver_create(const float* tgt_xyz, size_t nt, const float* src_xyz, 
 
 void fgoicp_solver_destroy(fgoicp_solver* s) {
     if (!s) return;
-    s->driver.reset();
-    fgoicp_ctx_destroy(s->ctx);
     delete s;
 }
 
@@ -133,8 +142,12 @@ int fgoicp_solver_set_exchange(fgoicp_solver* s, const fgoicp_exchange* ex) {
     return FGOICP_OK;
 }
 
+static int solver_run_impl(fgoicp_solver* s, float* R_out9, float* t_out3);
 int fgoicp_solver_run(fgoicp_solver* s, float* R_out9, float* t_out3) {
     if (!s || !R_out9 || !t_out3) return FGOICP_ERR_INVALID_ARG;
+    return fgoicp::abi_guard("fgoicp_solver_run", [&] { return solver_run_impl(s, R_out9, t_out3); });  // the host driver allocates (queues, tick buffers)
+}
+static int solver_run_impl(fgoicp_solver* s, float* R_out9, float* t_out3) {
     int rc = s->driver->run();
     if (rc == kDriverExchangeFailed) set_error("fgoicp_solver_run: exchange callback failed");
     if (rc) return rc;
