@@ -1210,6 +1210,16 @@ static int ctx_create_impl(const float* tgt_xyz, size_t nt, const float* src_xyz
         set_error("fgoicp_ctx_create: invalid argument");
         return FGOICP_ERR_INVALID_ARG;
     }
+    // non-finite coordinates: the reference would carry them into every sum (NaN bounds, a search that never prunes); refused here
+    auto finite_cloud = [](const float* p, size_t n) {
+        float acc = 0.0f;
+        for (size_t i = 0; i < 3 * n; ++i) acc += p[i] * 0.0f;  // stays 0 unless some coordinate is NaN or infinite
+        return acc == 0.0f;
+    };
+    if (!finite_cloud(tgt_xyz, nt) || !finite_cloud(src_xyz, ns) || !finite_cloud(bounds6, 2)) {
+        set_error("fgoicp_ctx_create: a cloud (or the target bounds) holds a non-finite coordinate");
+        return FGOICP_ERR_INVALID_ARG;
+    }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) {

@@ -160,3 +160,20 @@ def test_getters_can_be_polled_while_the_search_runs(fg, gpu_required):
     assert np.array_equal(R0, R1) and np.array_equal(t0, t1) and float(s.get_best_error()) == e0
     assert s.stats()["trans_cubes"] == st0["trans_cubes"]
     s.close()
+
+
+@pytest.mark.gpu
+def test_non_finite_coordinates_are_refused(fg, gpu_required):
+    """A NaN or an infinite coordinate in either cloud (the reference would carry it into every sum: NaN bounds, a search that never
+    prunes) is an FGOICP_ERR_INVALID_ARG at construction, for the operator context and for the solver."""
+    tgt, src, _, _ = fg.synth.workload("tiny", angle_deg=20.0)
+    for bad_val in (np.nan, np.inf, -np.inf):
+        for which in ("tgt", "src"):
+            t, s = tgt.copy(), src.copy()
+            (t if which == "tgt" else s)[7, 1] = bad_val
+            with pytest.raises(fg.FgoicpError, match="non-finite"):
+                fg.FastGoICP(t, s, 0.02, 1e-3)
+    pct, pcs, *_, bounds = fg.synth.preprocess(tgt, src)
+    pcs = pcs.copy(); pcs[3, 0] = np.nan
+    with pytest.raises(fg.FgoicpError, match="non-finite"):
+        fg.Registration(pct, pcs, bounds, 0.02)
