@@ -2,8 +2,10 @@
 #include "bvh.hpp"
 
 #include <cfloat>
+#include <cmath>
 #include <cstring>
 
+#include "../host/math3.hpp"
 #include "morton.hpp"
 
 namespace fgoicp {
@@ -53,6 +55,46 @@ BvhHost bvh_build_host(const float4* p, size_t n, std::vector<uint32_t>* order) 
             hi.x = std::max(hi.x, h.pts[i].x); hi.y = std::max(hi.y, h.pts[i].y); hi.z = std::max(hi.z, h.pts[i].z);
         }
     }
+    // LEAF SLABS (round 3): a leaf of a surface is flat, its axis-aligned box is not — a large ball around a far query cuts the box
+    // of every leaf inside a cap of radius sqrt(2 d s) (s = the box's size), while the leaf's points lie between two parallel planes a few
+    // noise amplitudes apart.  Per leaf: n = the direction of least variance of its points (|n| <= 1 after rounding), [a, b] = the range of
+    // n.p over them, widened by the rounding of both sides.  max(box distance, slab distance) is still a lower bound of the distance to
+    // every point of the leaf (kernels.hip box_walk refines its per-query test with it).
+    static const bool want_slab = [] { const char* e = std::getenv("FGOICP_BVH_SLAB"); return !e || std::atoi(e) != 0; }();  // tuning knob / A-B
+    if (want_slab) {
+        h.slab.assign(2 * nleaf, make_float4(0.f, 0.f, 0.f, 0.f));
+        for (size_t l = 0; l < nleaf; ++l) {
+            const size_t b0 = l * kBvhLeaf, b1 = std::min(n, b0 + kBvhLeaf);
+            if (b1 <= b0 + 2) continue;  // (0, 0, 0 | 0, 0): a slab that never rejects
+            double c[3] = {0, 0, 0};
+            for (size_t i = b0; i < b1; ++i) { c[0] += h.pts[i].x; c[1] += h.pts[i].y; c[2] += h.pts[i].z; }
+            for (double& v : c) v /= (double)(b1 - b0);
+            double C[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+            for (size_t i = b0; i < b1; ++i) {
+                const double d[3] = {h.pts[i].x - c[0], h.pts[i].y - c[1], h.pts[i].z - c[2]};
+                for (int r = 0; r < 3; ++r)
+                    for (int q = 0; q < 3; ++q) C[r][q] += d[r] * d[q];
+            }
+            double U[3][3], S[3], V[3][3];
+            svd3_jacobi(C, U, S, V);  // symmetric positive semi-definite: singular values descending, the last column = least variance
+            double nn[3] = {U[0][2], U[1][2], U[2][2]};
+            const double len = std::sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+            if (!(len > 0.5) || !std::isfinite(len)) continue;
+            const float nf[3] = {(float)(nn[0] / len * (1.0 - 1e-6)), (float)(nn[1] / len * (1.0 - 1e-6)), (float)(nn[2] / len * (1.0 - 1e-6))};
+            double lo = 1e300, hi = -1e300;
+            for (size_t i = b0; i < b1; ++i) {
+                const double pr = (double)nf[0] * h.pts[i].x + (double)nf[1] * h.pts[i].y + (double)nf[2] * h.pts[i].z;
+                lo = std::min(lo, pr);
+                hi = std::max(hi, pr);
+            }
+            const double m = 4e-7 * std::max(std::fabs(lo), std::fabs(hi)) + 1e-30;
+            h.slab[2 * l] = make_float4(nf[0], nf[1], nf[2], (float)(lo - m));
+            h.slab[2 * l + 1] = make_float4((float)(hi + m), 0.f, 0.f, 0.f);
+            // float conversion may round inwards: step outwards once more
+            h.slab[2 * l].w = std::nextafter(h.slab[2 * l].w, -FLT_MAX);
+            h.slab[2 * l + 1].x = std::nextafter(h.slab[2 * l + 1].x, FLT_MAX);
+        }
+    }
     for (long node = (long)h.first_leaf - 1; node >= 0; --node) {
         const size_t l = 2 * (size_t)node + 1, r = l + 1;
         float4& lo = h.box[2 * node];
@@ -73,14 +115,22 @@ hipError_t bvh_upload(const BvhHost& h, BvhDevice* d) {
     if (e != hipSuccess) return e;
     e = hipMemcpy(d->box, h.box.data(), h.box.size() * sizeof(float4), hipMemcpyHostToDevice);
     if (e != hipSuccess) return e;
+    if (!h.slab.empty()) {
+        e = hipMalloc(&d->slab, h.slab.size() * sizeof(float4));
+        if (e != hipSuccess) return e;
+        e = hipMemcpy(d->slab, h.slab.data(), h.slab.size() * sizeof(float4), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return e;
+    }
     return hipMemcpy(d->pts, h.pts.data(), h.pts.size() * sizeof(float4), hipMemcpyHostToDevice);
 }
 
 void bvh_free(BvhDevice* d) {
     if (d->box) (void)hipFree(d->box);
     if (d->pts) (void)hipFree(d->pts);
+    if (d->slab) (void)hipFree(d->slab);
     d->box = nullptr;
     d->pts = nullptr;
+    d->slab = nullptr;
 }
 
 }  // namespace fgoicp

@@ -24,6 +24,7 @@ constexpr int kBvhLeaf = 32;  // big leaves: leaf points are throughput work, tr
 struct BvhView {
     const float4* box;
     const float4* pts;
+    const float4* slab;  // optional (nullptr: none), 2 per leaf: {n.x, n.y, n.z, a}, {b, 0, 0, 0} — every point p of the leaf has a <= n.p <= b, |n| <= 1
     int depth;       // leaves live at this depth (root = 0)
     int first_leaf;  // (1 << depth) - 1
 };
@@ -31,6 +32,7 @@ struct BvhView {
 struct BvhHost {
     std::vector<float4> box;
     std::vector<float4> pts;
+    std::vector<float4> slab;  // 2 per leaf (see BvhView); empty = none
     int depth = 0;
     int first_leaf = 0;
 };
@@ -44,8 +46,9 @@ bool bvh_kd_order();  // leaves = k-d cells (default) or runs of the space-filli
 struct BvhDevice {
     float4* box = nullptr;
     float4* pts = nullptr;
+    float4* slab = nullptr;
     int depth = 0, first_leaf = 0;
-    BvhView view() const { return BvhView{box, pts, depth, first_leaf}; }
+    BvhView view() const { return BvhView{box, pts, slab, depth, first_leaf}; }
 };
 hipError_t bvh_upload(const BvhHost& h, BvhDevice* d);
 void bvh_free(BvhDevice* d);

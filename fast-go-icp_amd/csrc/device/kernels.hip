@@ -1976,8 +1976,16 @@ __device__ unsigned long long g_scan_times[4096 * 4];  // per block of the last 
 // The walk itself, independent of what a lane asks of a leaf: `wl` / `wh` = the wave's query region, radius() = the wave-uniform squared
 // pruning radius (re-evaluated after every leaf when one wave holds the queries alone), test(lo, hi) = the lane's flags for a leaf box
 // (0: the leaf cannot matter to this lane), leaf(point, flags) = what to do with each of the leaf's points.
-template <class RadiusFn, class TestFn, class LeafFn>
-__device__ __forceinline__ void box_walk(const BvhView t, const float (&wl)[3], const float (&wh)[3], int part, int nparts, RadiusFn radius, TestFn test, LeafFn leaf,
+// refine(flags, n.x, n.y, n.z, a, b) = the lane's flags again after the leaf's SLAB test (bvh.hpp: a <= n.p <= b for every point p of the leaf) —
+// only called for a leaf whose box some lane could not rule out, with the slab read through the scalar unit next to the leaf's points.
+__device__ __forceinline__ float slab_d2(float nx, float ny, float nz, float a, float b, float qx, float qy, float qz) {
+    const float nq = fma_(nz, qz, fma_(ny, qy, nx * qx));
+    float s = fmaxf(nq - b, a - nq);                                         // distance of q from the slab along n (|n| <= 1: never more than the true one)
+    s -= 2e-6f * fmaxf(fabsf(nq), fmaxf(fabsf(a), fabsf(b)));                // the rounding of n.q, relative to the magnitudes involved
+    return s > 0.0f ? s * s : 0.0f;
+}
+template <class RadiusFn, class TestFn, class LeafFn, class RefineFn>
+__device__ __forceinline__ void box_walk(const BvhView t, const float (&wl)[3], const float (&wh)[3], int part, int nparts, RadiusFn radius, TestFn test, LeafFn leaf, RefineFn refine,
                                          int* claim_ctr /* LDS word, zero on entry, when nparts > 1 (nullptr: round-robin) */,
                                          unsigned long long* flat_mask = nullptr /* LDS, 32 words: every wave of the block holds the SAME queries (nn_scan kernels) */) {
     const int lane = threadIdx.x & 63;
@@ -2007,12 +2015,17 @@ __device__ __forceinline__ void box_walk(const BvhView t, const float (&wl)[3], 
             ++cand;
             if (!mine) return;
         }
-        const int pl = test(lo, hi);
+        int pl = test(lo, hi);
         SCAN_STAT(3, 1);
+        typedef float v4f_c __attribute__((ext_vector_type(4)));
+        if (t.slab && __any(pl != 0)) {  // the box could not rule the leaf out for some lane: its slab may (a far query's ball cuts many boxes, few slabs)
+            const __attribute__((address_space(4))) v4f_c* sp = (const __attribute__((address_space(4))) v4f_c*)(t.slab + 2 * (size_t)__builtin_amdgcn_readfirstlane(leaf_id));
+            const v4f_c s0 = sp[0], s1 = sp[1];
+            pl = refine(pl, s0.x, s0.y, s0.z, s0.w, s1.x);
+        }
         if (__any(pl != 0)) {
             SCAN_STAT(4, 1);
             SCAN_STAT_LOCAL(stat_scanned);
-            typedef float v4f_c __attribute__((ext_vector_type(4)));
             const __attribute__((address_space(4))) v4f_c* lp = (const __attribute__((address_space(4))) v4f_c*)(t.pts + (size_t)__builtin_amdgcn_readfirstlane(leaf_id) * kBvhLeaf);
 #pragma unroll 4   // 4 points in flight keep the index-mode kernel at 61 VGPRs = 8 waves per SIMD (16: 91 VGPRs, 5 waves — the scan
             // lives on resident waves hiding each other's dependent loads; measured slower)
@@ -2122,7 +2135,8 @@ __device__ __forceinline__ void box_scan(const BvhView t, float qx, float qy, fl
     const float wh[3] = {wave_max_f(active ? qx : -big), wave_max_f(active ? qy : -big), wave_max_f(active ? qz : -big)};
     box_walk(t, wl, wh, part, nparts, [&]() { return wave_max_f(active ? bound() : 0.0f); },
              [&](const float4 lo, const float4 hi) { return (int)(active && !(box_d2(lo, hi, qx, qy, qz) * kBoxShrink > bound())); },
-             [&](const float4 c, int pl) { leaf(c, pl != 0); }, claim_ctr, flat_mask);
+             [&](const float4 c, int pl) { leaf(c, pl != 0); },
+             [&](int pl, float nx, float ny, float nz, float a, float b) { return (pl && slab_d2(nx, ny, nz, a, b, qx, qy, qz) * kBoxShrink > bound()) ? 0 : pl; }, claim_ctr, flat_mask);
 }
 
 // Minimum squared distance.  `ub` is any value >= the true minimum (or +huge): it only seeds the
@@ -2490,6 +2504,11 @@ __global__ __launch_bounds__(64 * kMaxParts) void nn_scan_dual_kernel(const floa
                  foundB = fminf(foundB, dB);
                  bestB = fminf(bestB, dB);
              },
+             [&](int fl, float nx, float ny, float nz, float a, float b) {
+                 if ((fl & 1) && slab_d2(nx, ny, nz, a, b, ax, ay, az) * kBoxShrink > bestA * 1.0000015f) fl &= ~1;
+                 if ((fl & 2) && slab_d2(nx, ny, nz, a, b, bx, by, bz) * kBoxShrink > bestB) fl &= ~2;
+                 return fl;
+             },
              dynamic_claim ? &claim_ctr[0] : nullptr);
     (void)any_act;
     if (nparts > 1) {
@@ -2527,6 +2546,11 @@ __global__ __launch_bounds__(64 * kMaxParts) void nn_scan_dual_kernel(const floa
                      const float dB = (fl & 2) ? dist_sq(bx, by, bz, c.x, c.y, c.z) : kMasked;
                      fA = fminf(fA, dA);
                      fB = fminf(fB, dB);
+                 },
+                 [&](int fl, float nx, float ny, float nz, float a, float b) {
+                     if ((fl & 1) && slab_d2(nx, ny, nz, a, b, ax, ay, az) * kBoxShrink > fA) fl &= ~1;
+                     if ((fl & 2) && slab_d2(nx, ny, nz, a, b, bx, by, bz) * kBoxShrink > fB) fl &= ~2;
+                     return fl;
                  },
                  dynamic_claim ? &claim_ctr[1] : nullptr);
         if (nparts > 1) {
