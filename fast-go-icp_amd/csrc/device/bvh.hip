@@ -4,6 +4,8 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 #include "../host/math3.hpp"
 #include "morton.hpp"
@@ -63,7 +65,9 @@ BvhHost bvh_build_host(const float4* p, size_t n, std::vector<uint32_t>* order) 
     static const bool want_slab = [] { const char* e = std::getenv("FGOICP_BVH_SLAB"); return !e || std::atoi(e) != 0; }();  // tuning knob / A-B
     if (want_slab) {
         h.slab.assign(2 * nleaf, make_float4(0.f, 0.f, 0.f, 0.f));
-        for (size_t l = 0; l < nleaf; ++l) {
+        const size_t nreal = (n + kBvhLeaf - 1) / kBvhLeaf;
+        auto slab_range = [&](size_t l0, size_t l1) {
+        for (size_t l = l0; l < l1; ++l) {
             const size_t b0 = l * kBvhLeaf, b1 = std::min(n, b0 + kBvhLeaf);
             if (b1 <= b0 + 2) continue;  // (0, 0, 0 | 0, 0): a slab that never rejects
             double c[3] = {0, 0, 0};
@@ -93,6 +97,24 @@ BvhHost bvh_build_host(const float4* p, size_t n, std::vector<uint32_t>* order) 
             // float conversion may round inwards: step outwards once more
             h.slab[2 * l].w = std::nextafter(h.slab[2 * l].w, -FLT_MAX);
             h.slab[2 * l + 1].x = std::nextafter(h.slab[2 * l + 1].x, FLT_MAX);
+        }
+        };
+        // one 3 x 3 eigen-decomposition per leaf: a few threads for big clouds (31 250 leaves at 1M points)
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t nth = nreal >= 4096 ? std::min<size_t>(8, hw > 1 ? hw : 1) : 1;
+        if (nth <= 1) {
+            slab_range(0, nreal);
+        } else {
+            std::vector<std::thread> th;
+            try {
+                for (size_t k = 0; k < nth; ++k) th.emplace_back(slab_range, nreal * k / nth, nreal * (k + 1) / nth);
+            } catch (...) {  // a thread that cannot start: the rest is done here
+                const size_t done = th.size();
+                for (auto& x : th) x.join();
+                th.clear();
+                slab_range(nreal * done / nth, nreal);
+            }
+            for (auto& x : th) x.join();
         }
     }
     for (long node = (long)h.first_leaf - 1; node >= 0; --node) {

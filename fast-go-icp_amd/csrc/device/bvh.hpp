@@ -16,7 +16,10 @@
 
 namespace fgoicp {
 
-constexpr int kBvhLeaf = 32;  // big leaves: leaf points are throughput work, tree levels are latency
+#ifndef FGOICP_BVH_LEAF   // development builds (tools/ab_bvh_leaf.sh): points per leaf
+#define FGOICP_BVH_LEAF 32
+#endif
+constexpr int kBvhLeaf = FGOICP_BVH_LEAF;  // big leaves: leaf points are throughput work, tree levels are latency
 
 // Device view.  Node i (heap order: children 2i+1, 2i+2) has box[2i] = {lo.xyz, -}, box[2i+1] = {hi.xyz, -}.
 // Leaves are the last level: leaf l = node first_leaf + l holds pts[kBvhLeaf*l .. kBvhLeaf*(l+1)) = {x, y, z, bits(original index)};
