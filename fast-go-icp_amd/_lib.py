@@ -96,6 +96,8 @@ _SIGS = {
     "fgoicp_solver_ctx": (C.c_void_p, [C.c_void_p]),
     "fgoicp_rccl_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "fgoicp_rccl_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.POINTER(C.c_void_p)]),
+    "fgoicp_rccl_create_ex": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "fgoicp_rccl_test_inprogress": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]),
     "fgoicp_rccl_exchange": (C.c_int, [C.c_void_p, C.POINTER(Exchange)]),
     "fgoicp_rccl_calls": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "fgoicp_rccl_abort": (C.c_int, [C.c_void_p]),

@@ -29,9 +29,9 @@
 
 #include "../../../include/fgoicp_amd.h"
 #include "abi_guard.hpp"
+#include "multi_link.hpp"
 
 namespace fgoicp {
-void set_error(const std::string& s);
 int ctx_icp_coop(fgoicp_ctx* c, int rank, int world, int (*gather)(void* dev_buf, size_t bytes_per_rank, void* user), void* user, const float* R0,
                  const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3, int* iters_out);  // csrc/device/ctx.hip
 }
@@ -54,6 +54,8 @@ struct fgoicp_rccl {
     // communicator, and the owner could be between its check and its ncclAllReduce — a use after free.)
     std::atomic<bool> dead{false};
     bool released = false;                        // owner only: the communicator has been aborted / destroyed
+    int test_inprogress = 0;                      // test hook (fgoicp_rccl_test_inprogress): that many collectives report ncclInProgress once
+    uint64_t settled = 0;                         // polls of ncclCommGetAsyncError that rccl_settle has made
 };
 
 namespace {
@@ -100,11 +102,7 @@ const RcclApi& rccl_api() {
         hipError_t e_ = (expr);                                                                            \
         if (e_ != hipSuccess) { set_error(std::string(#expr) + " failed: " + hipGetErrorString(e_)); return 1; } \
     } while (0)
-#define RCCL_NCCL(expr)                                                                                    \
-    do {                                                                                                   \
-        ncclResult_t r_ = (expr);                                                                          \
-        if (r_ != ncclSuccess) { set_error(std::string(#expr) + " failed: " + rccl_api().GetErrorString(r_)); return 1; } \
-    } while (0)
+// (RCCL_NCCL: see rccl_settle below — a collective on a non-blocking communicator may return ncclInProgress)
 
 int rccl_reserve(fgoicp_rccl* x, size_t n) {
     if (n <= x->cap) return 0;
@@ -153,6 +151,29 @@ int rccl_wait(fgoicp_rccl* x) {
     }
 }
 
+// fgoicp_multi_create forms its communicators NON-blocking (a rank must be able to abandon the set-up when a peer fails), and a
+// communicator stays what it was created as: every later call on it — the collectives included — may return ncclInProgress, which
+// means "not yet on the stream".  Nothing more may be enqueued on x->stream, and the buffers may not be touched, until
+// ncclCommGetAsyncError reports ncclSuccess (round 3 treated ncclInProgress as a failure and enqueued the copy back at
+// once).  On a blocking communicator (fgoicp_rccl_create, one process per GPU) the first status is final.
+int rccl_settle(fgoicp_rccl* x, ncclResult_t r, const char* what) {
+    if (x->test_inprogress > 0 && r == ncclSuccess) { --x->test_inprogress; r = ncclInProgress; }  // test hook: walk the polling path
+    for (unsigned spins = 0; r == ncclInProgress; ++spins) {
+        if (x->dead.load(std::memory_order_acquire)) return rccl_dead(x);
+        ncclResult_t st = ncclSuccess;
+        if (rccl_api().CommGetAsyncError(x->comm, &st) != ncclSuccess) { r = ncclInternalError; break; }
+        r = st;
+        if (r == ncclInProgress) { if ((spins & 63u) == 63u) std::this_thread::sleep_for(std::chrono::microseconds(20)); else std::this_thread::yield(); }
+        x->settled++;
+    }
+    if (r != ncclSuccess) {
+        set_error(std::string(what) + " failed: " + rccl_api().GetErrorString(r));
+        rccl_release(x);
+        return 1;
+    }
+    return 0;
+}
+
 int rccl_allreduce_min(float* buf, size_t n, void* user) {
     fgoicp_rccl* x = static_cast<fgoicp_rccl*>(user);
     if (x->released || x->dead.load(std::memory_order_acquire)) return rccl_dead(x);
@@ -160,7 +181,7 @@ int rccl_allreduce_min(float* buf, size_t n, void* user) {
     if (rccl_reserve(x, n)) return 1;
     std::memcpy(x->h_pin, buf, sizeof(float) * n);
     RCCL_HIP(hipMemcpyAsync(x->d_send, x->h_pin, sizeof(float) * n, hipMemcpyHostToDevice, x->stream));
-    RCCL_NCCL(rccl_api().AllReduce(x->d_send, x->d_recv, n, ncclFloat, ncclMin, x->comm, x->stream));
+    if (rccl_settle(x, rccl_api().AllReduce(x->d_send, x->d_recv, n, ncclFloat, ncclMin, x->comm, x->stream), "ncclAllReduce")) return 1;
     RCCL_HIP(hipMemcpyAsync(x->h_pin, x->d_recv, sizeof(float) * n, hipMemcpyDeviceToHost, x->stream));
     if (rccl_wait(x)) return 1;
     std::memcpy(buf, x->h_pin, sizeof(float) * n);
@@ -175,7 +196,7 @@ int rccl_allgather(const float* send, float* recv, size_t n, void* user) {
     if (rccl_reserve(x, n)) return 1;
     std::memcpy(x->h_pin, send, sizeof(float) * n);
     RCCL_HIP(hipMemcpyAsync(x->d_send, x->h_pin, sizeof(float) * n, hipMemcpyHostToDevice, x->stream));
-    RCCL_NCCL(rccl_api().AllGather(x->d_send, x->d_recv, n, ncclFloat, x->comm, x->stream));
+    if (rccl_settle(x, rccl_api().AllGather(x->d_send, x->d_recv, n, ncclFloat, x->comm, x->stream), "ncclAllGather")) return 1;
     RCCL_HIP(hipMemcpyAsync(x->h_pin + x->cap, x->d_recv, sizeof(float) * n * x->world, hipMemcpyDeviceToHost, x->stream));
     if (rccl_wait(x)) return 1;
     std::memcpy(recv, x->h_pin + x->cap, sizeof(float) * n * x->world);
@@ -189,7 +210,7 @@ int rccl_allgather_device(void* buf, size_t bytes, void* user) {
     fgoicp_rccl* x = static_cast<fgoicp_rccl*>(user);
     if (x->released || x->dead.load(std::memory_order_acquire)) return rccl_dead(x);
     RCCL_HIP(hipSetDevice(x->device));
-    RCCL_NCCL(rccl_api().AllGather(static_cast<char*>(buf) + bytes * (size_t)x->rank, buf, bytes, ncclInt8, x->comm, x->stream));
+    if (rccl_settle(x, rccl_api().AllGather(static_cast<char*>(buf) + bytes * (size_t)x->rank, buf, bytes, ncclInt8, x->comm, x->stream), "ncclAllGather (device)")) return 1;
     if (rccl_wait(x)) return 1;
     x->calls++;
     return 0;
@@ -273,16 +294,32 @@ static int rccl_join(fgoicp_rccl* x, const unsigned char* id128, const std::atom
     return FGOICP_OK;
 }
 
-int fgoicp_rccl_create(int rank, int world, const unsigned char* id128, int device, fgoicp_rccl** out) {
+// nonblocking != 0: the communicator is created with ncclConfig_t.blocking = 0, as fgoicp_multi_create does for its rank threads —
+// every collective then goes through rccl_settle's polling (tests/test_gpu_multi.py runs this on a one-rank communicator).
+int fgoicp_rccl_create_ex(int rank, int world, const unsigned char* id128, int device, int nonblocking, fgoicp_rccl** out) {
     if (!out) return FGOICP_ERR_INVALID_ARG;
     *out = nullptr;
     if (!id128) { set_error("fgoicp_rccl_create: invalid argument"); return FGOICP_ERR_INVALID_ARG; }
     fgoicp_rccl* x = nullptr;
     int rc = rccl_prepare(rank, world, device, &x);  // one process per GPU: a rank that fails here is its launcher's to report
     if (rc) return rc;
-    rc = rccl_join(x, id128, nullptr);
+    static const std::atomic<bool> never{false};
+    rc = rccl_join(x, id128, nonblocking ? &never : nullptr);
     if (rc) { fgoicp_rccl_destroy(x); return rc; }
     *out = x;
+    return FGOICP_OK;
+}
+int fgoicp_rccl_create(int rank, int world, const unsigned char* id128, int device, fgoicp_rccl** out) {
+    return fgoicp_rccl_create_ex(rank, world, id128, device, 0, out);
+}
+
+// TEST HOOK, not part of the drop-in surface: the next n collectives of x report ncclInProgress once before their real status, so
+// that the polling path of a non-blocking communicator runs on a box where RCCL itself answers at once.  settled_out (optional):
+// polls of ncclCommGetAsyncError made so far.
+int fgoicp_rccl_test_inprogress(fgoicp_rccl* x, int n, uint64_t* settled_out) {
+    if (!x || n < 0) return FGOICP_ERR_INVALID_ARG;
+    x->test_inprogress = n;
+    if (settled_out) *settled_out = x->settled;
     return FGOICP_OK;
 }
 
@@ -324,192 +361,60 @@ int fgoicp_rccl_calls(const fgoicp_rccl* x, uint64_t* calls) {
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------------------------------
-// One process, one host thread and one solver per device
+// One process, one host thread and one solver per device.  The transport-independent core — rendezvous, exchange callbacks with
+// recording / replay / fault injection, the per-rank threads — is multi_link.hpp (also instantiated, with host memory and the CPU
+// oracle's operators, by tests/host_harness/multi_asan.cpp under AddressSanitizer); here: the HIP runtime and RCCL underneath it.
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
 
-// In-process rendezvous of `world` threads: min-all-reduce and all-gather through shared memory (two generations of buffers,
-// so a fast rank may enter the next collective while a slow one still reads the last result).
-struct Rendezvous {
-    std::mutex m;
-    std::condition_variable cv;
-    int world = 1, arrived = 0;
-    uint64_t gen = 0;
-    bool aborted = false;  // a rank failed: nobody waits for it (reset by fgoicp_multi_run)
-    std::vector<float> acc[2];
-    void abort() {
-        std::lock_guard<std::mutex> lk(m);
-        aborted = true;
-        cv.notify_all();
-    }
-    void reset() {
-        std::lock_guard<std::mutex> lk(m);
-        aborted = false;
-        arrived = 0;
-    }
-    // false: aborted
-    bool run(size_t total, const std::function<void(std::vector<float>&, bool first)>& contribute, const std::function<void(const std::vector<float>&)>& collect) {
-        std::unique_lock<std::mutex> lk(m);
-        if (aborted) return false;
-        const uint64_t g = gen;
-        std::vector<float>& a = acc[g & 1];
-        const bool first = arrived == 0;
-        if (first) a.assign(total, 0.f);
-        contribute(a, first);
-        if (++arrived == world) {
-            arrived = 0;
-            ++gen;
-            cv.notify_all();
-        } else {
-            cv.wait(lk, [&] { return gen != g || aborted; });
-            if (gen == g) return false;
-        }
-        collect(a);
-        return true;
-    }
-};
-
-struct DeviceGather {    // in-process all-gather on device memory: where every rank's buffer lives (written before the first barrier)
-    std::vector<void*> ptr;
-    std::vector<int> device;
-    // recorded gathers (whole buffers, kept in DEVICE memory by rank 0): what a replayed rank receives.  The replay leaves the
-    // transfer out, like the replay of the host-side exchanges: its copies are on-device (microseconds); tools/scale_replay.py
-    // charges the collective's measured software path and a modelled wire time per gather instead.
-    struct Rec { void* d = nullptr; size_t bytes = 0; int device = 0; };
-    std::vector<Rec> log;
-    void clear_log() {
-        for (Rec& r : log) { (void)hipSetDevice(r.device); (void)hipFree(r.d); }
-        log.clear();
-    }
-    ~DeviceGather() { clear_log(); }
-};
-
-struct RankLink {        // what one rank's exchange callbacks see
-    int rank = 0, world = 1;
-    Rendezvous* rv = nullptr;
-    DeviceGather* dg = nullptr;
-    int device = 0;
-    size_t dev_replay_pos = 0;
-    fgoicp_exchange inner{};                      // transport underneath (RCCL) when rv == nullptr
-    bool record = false;
-    std::vector<std::vector<float>>* log = nullptr;   // results of every exchange, in order
-    size_t replay_pos = 0;
-    bool replay = false;
-    long fail_at = -1, calls = 0;                 // test hook (fgoicp_multi_test_fault): that exchange of that rank fails, once
-};
-
-int link_allreduce_min(float* buf, size_t n, void* user) {
-    RankLink* l = static_cast<RankLink*>(user);
-    if (l->replay) {
-        if (l->replay_pos >= l->log->size() || (*l->log)[l->replay_pos].size() != n) return 1;
-        std::memcpy(buf, (*l->log)[l->replay_pos++].data(), sizeof(float) * n);
-        return 0;
-    }
-    if (l->calls++ == l->fail_at) { l->fail_at = -1; set_error("injected exchange fault (fgoicp_multi_test_fault)"); return 1; }
-    int rc = 0;
-    if (l->rv) {
-        rc = l->rv->run(n,
-                        [&](std::vector<float>& a, bool first) { for (size_t i = 0; i < n; ++i) a[i] = first ? buf[i] : (buf[i] < a[i] ? buf[i] : a[i]); },
-                        [&](const std::vector<float>& a) { std::memcpy(buf, a.data(), sizeof(float) * n); }) ? 0 : 1;
-        if (rc) set_error("exchange aborted: another rank failed");
-    } else {
-        rc = l->inner.allreduce_min(buf, n, l->inner.user);
-    }
-    if (!rc && l->record) l->log->emplace_back(buf, buf + n);
-    return rc;
+int hip_mem_alloc(int device, size_t bytes, void** out) {
+    if (hipSetDevice(device) != hipSuccess || hipMalloc(out, bytes) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; set_error("device all-gather: hipMalloc failed"); return 1; }
+    return 0;
 }
-
-int link_allgather(const float* send, float* recv, size_t n, void* user) {
-    RankLink* l = static_cast<RankLink*>(user);
-    if (l->replay) {
-        if (l->replay_pos >= l->log->size() || (*l->log)[l->replay_pos].size() != n * (size_t)l->world) return 1;
-        std::memcpy(recv, (*l->log)[l->replay_pos++].data(), sizeof(float) * n * l->world);
-        return 0;
-    }
-    if (l->calls++ == l->fail_at) { l->fail_at = -1; set_error("injected exchange fault (fgoicp_multi_test_fault)"); return 1; }
-    int rc = 0;
-    if (l->rv) {
-        rc = l->rv->run(n * (size_t)l->world,
-                        [&](std::vector<float>& a, bool) { std::memcpy(a.data() + n * (size_t)l->rank, send, sizeof(float) * n); },
-                        [&](const std::vector<float>& a) { std::memcpy(recv, a.data(), sizeof(float) * n * l->world); }) ? 0 : 1;
-        if (rc) set_error("exchange aborted: another rank failed");
-    } else {
-        rc = l->inner.allgather(send, recv, n, l->inner.user);
-    }
-    if (!rc && l->record) l->log->emplace_back(recv, recv + n * (size_t)l->world);
-    return rc;
+void hip_mem_release(int device, void* p) {
+    if (!p) return;
+    (void)hipSetDevice(device);
+    (void)hipFree(p);
 }
-
-// Cooperative ICP's all-gather.  In process: every rank publishes its buffer, waits for the others, copies their chunks into its
-// own buffer (peer copies between devices, plain copies when the ranks share one), and waits again before anybody overwrites its
-// chunk.  Recording keeps the gathered buffer (rank 0's copy; they are equal); a replayed rank, alone on the device, computes its own
-// chunk and takes the others from the recording (on-device copies: the transfer itself is left out of a replay and charged by the caller).
-int link_allgather_device(void* buf, size_t bytes, void* user) {
-    RankLink* l = static_cast<RankLink*>(user);
-    const size_t total = bytes * (size_t)l->world;
-    if (l->replay) {
-        if (!l->dg || l->dev_replay_pos >= l->dg->log.size() || l->dg->log[l->dev_replay_pos].bytes != total) return 1;
-        const DeviceGather::Rec& rec = l->dg->log[l->dev_replay_pos++];
-        const size_t lo = bytes * (size_t)l->rank, hi = lo + bytes;  // everything but this rank's own chunk: two contiguous ranges
-        auto copy = [&](size_t from, size_t to) {
-            if (from >= to) return hipSuccess;
-            char* dst = static_cast<char*>(buf) + from;
-            const char* src = static_cast<const char*>(rec.d) + from;
-            return rec.device == l->device ? hipMemcpyAsync(dst, src, to - from, hipMemcpyDeviceToDevice, nullptr) : hipMemcpyPeerAsync(dst, l->device, src, rec.device, to - from, nullptr);
-        };
-        if (copy(0, lo) != hipSuccess || copy(hi, total) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return 1;
-        return 0;
-    }
-    if (l->calls++ == l->fail_at) { l->fail_at = -1; set_error("injected exchange fault (fgoicp_multi_test_fault)"); return 1; }
-    int rc = 0;
-    if (l->rv) {
-        auto barrier = [&] { return l->rv->run(0, [](std::vector<float>&, bool) {}, [](const std::vector<float>&) {}); };
-        l->dg->ptr[l->rank] = buf;
-        l->dg->device[l->rank] = l->device;
-        if (!barrier()) { set_error("exchange aborted: another rank failed"); return 1; }
-        for (int p = 0; p < l->world && !rc; ++p) {
-            if (p == l->rank) continue;
-            char* dst = static_cast<char*>(buf) + bytes * p;
-            const char* src = static_cast<const char*>(l->dg->ptr[p]) + bytes * p;
-            const hipError_t e = l->dg->device[p] == l->device ? hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice) : hipMemcpyPeer(dst, l->device, src, l->dg->device[p], bytes);
-            if (e != hipSuccess) { set_error(std::string("in-process device all-gather: ") + hipGetErrorString(e)); rc = 1; }
-        }
-        // device-to-device copies may return before they have landed, and the contexts' streams do not wait for the null stream
-        if (!rc && hipStreamSynchronize(nullptr) != hipSuccess) { set_error("in-process device all-gather: hipStreamSynchronize failed"); rc = 1; }
-        if (!barrier() && !rc) { set_error("exchange aborted: another rank failed"); rc = 1; }
-    } else {
-        if (!l->inner.allgather_device) { set_error("the transport has no device all-gather"); return 1; }
-        rc = l->inner.allgather_device(buf, bytes, l->inner.user);
-    }
-    if (!rc && l->record && l->rank == 0 && l->dg) {
-        DeviceGather::Rec rec;
-        rec.bytes = total;
-        rec.device = l->device;
-        if (hipMalloc(&rec.d, total) != hipSuccess) { set_error("recording a device all-gather: out of device memory"); return 1; }
-        if (hipMemcpyAsync(rec.d, buf, total, hipMemcpyDeviceToDevice, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { (void)hipFree(rec.d); return 1; }
-        l->dg->log.push_back(rec);
-    }
-    return rc;
+int hip_mem_copy(void* dst, int dst_device, const void* src, int src_device, size_t bytes) {
+    const hipError_t e = dst_device == src_device ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, nullptr) : hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, nullptr);
+    if (e != hipSuccess) { set_error(std::string("device all-gather: copy failed: ") + hipGetErrorString(e)); return 1; }
+    return 0;
 }
+int hip_mem_sync(int /*device*/) {
+    if (hipStreamSynchronize(nullptr) != hipSuccess) { set_error("device all-gather: hipStreamSynchronize failed"); return 1; }
+    return 0;
+}
+const fgoicp::DeviceMemApi kHipMem{hip_mem_alloc, hip_mem_release, hip_mem_copy, hip_mem_sync};
+
+struct HipBackend {
+    using Solver = fgoicp_solver;
+    static int run(Solver* s, float* R9, float* t3) { return fgoicp_solver_run(s, R9, t3); }
+    static int set_exchange(Solver* s, const fgoicp_exchange* ex) { return fgoicp_solver_set_exchange(s, ex); }
+    static void destroy(Solver* s) { fgoicp_solver_destroy(s); }
+    static int icp_coop(Solver* s, int rank, int world, int (*gather)(void*, size_t, void*), void* user, const float* R0, const float* t0, size_t max_iter, float thr, float* sse,
+                        float* R9, float* t3, int* iters) {
+        return fgoicp::ctx_icp_coop(fgoicp_solver_ctx(s), rank, world, gather, user, R0, t0, max_iter, thr, sse, R9, t3, iters);
+    }
+    static const char* last_error() { return fgoicp_last_error(); }
+    static const fgoicp::DeviceMemApi* mem() { return &kHipMem; }
+};
 
 }  // namespace
 
-struct fgoicp_multi {
-    ~fgoicp_multi();  // solvers and communicators go with the object (fgoicp_multi_destroy, a failed or throwing create)
-    std::vector<int> devices;
-    std::vector<fgoicp_solver*> solvers;
+struct fgoicp_multi : fgoicp::MultiCore<HipBackend> {
     std::vector<fgoicp_rccl*> rccl;
-    std::vector<std::unique_ptr<RankLink>> links;
-    std::vector<std::vector<std::vector<float>>> logs;
-    Rendezvous rv;
-    DeviceGather dg;
     int transport = FGOICP_TRANSPORT_RCCL;
-    std::vector<double> seconds;   // wall-clock of every rank's last run
+    // solvers, then the recordings (device memory), then the communicators the links point into — each exactly once, whatever
+    // path ends the object (fgoicp_multi_destroy, a failed or throwing create)
+    ~fgoicp_multi() override {
+        destroy_solvers();
+        dg.clear_log();
+        links.clear();
+        for (fgoicp_rccl* x : rccl) fgoicp_rccl_destroy(x);
+        rccl.clear();
+    }
 };
-fgoicp_multi::~fgoicp_multi() {
-    for (fgoicp_solver* s : solvers) fgoicp_solver_destroy(s);
-    for (fgoicp_rccl* x : rccl) fgoicp_rccl_destroy(x);
-}
 
 extern "C" {
 
@@ -531,203 +436,95 @@ static int multi_create_impl(const float* tgt_xyz, size_t nt, const float* src_x
         return FGOICP_ERR_INVALID_ARG;
     }
     auto m = std::make_unique<fgoicp_multi>();
-    m->devices.assign(devices, devices + ndev);
+    m->init(devices, ndev);
     m->transport = transport;
-    m->rv.world = ndev;
-    m->logs.resize(ndev);
-    m->dg.ptr.assign(ndev, nullptr);
-    m->dg.device.assign(ndev, 0);
-    m->seconds.assign(ndev, 0.0);
     fgoicp_solver_opts o{FGOICP_SCHEDULE_ROUND, 0, 0u, 0, 0.0f};
     if (opts) o = *opts;
     // both schedules shard: ROUND deals a round's children over the ranks, SERIAL (the reference's exact order) deals the tasks of
     // every speculative evaluation (driver.hpp: run_task_list_sharded); opts == NULL: ROUND, adaptive width
-    auto fail = [&](int rc) { fgoicp_multi_destroy(m.release()); return rc; };
     for (int r = 0; r < ndev; ++r) {
         o.device = devices[r];
         fgoicp_solver* s = nullptr;
         int rc = fgoicp_solver_create(tgt_xyz, nt, src_xyz, ns, lut_resolution, mse_threshold, &o, &s);
-        if (rc) return fail(rc);
+        if (rc) return rc;  // (m's destructor frees what has been built)
         m->solvers.push_back(s);
     }
-    if (ndev > 1 && transport == FGOICP_TRANSPORT_RCCL) {
+    const bool use_rccl = ndev > 1 && transport == FGOICP_TRANSPORT_RCCL;
+    if (use_rccl) {
         for (int a = 0; a < ndev; ++a)
             for (int b = a + 1; b < ndev; ++b)
-                if (devices[a] == devices[b]) { set_error("fgoicp_multi_create: the RCCL transport needs distinct devices (use FGOICP_TRANSPORT_IN_PROCESS to rehearse)"); return fail(FGOICP_ERR_INVALID_ARG); }
+                if (devices[a] == devices[b]) { set_error("fgoicp_multi_create: the RCCL transport needs distinct devices (use FGOICP_TRANSPORT_IN_PROCESS to rehearse)"); return FGOICP_ERR_INVALID_ARG; }
         unsigned char id[128];
         int rc = fgoicp_rccl_unique_id(id);
-        if (rc) return fail(rc);
-        m->rccl.assign(ndev, nullptr);
+        if (rc) return rc;
+        m->rccl.assign((size_t)ndev, nullptr);
         for (int r = 0; r < ndev; ++r) {  // phase 1, on this thread: what a rank can fail at on its own
-            rc = rccl_prepare(r, ndev, devices[r], &m->rccl[r]);
-            if (rc) { set_error("rank " + std::to_string(r) + ": " + fgoicp_last_error()); return fail(rc); }
+            rc = rccl_prepare(r, ndev, devices[r], &m->rccl[(size_t)r]);
+            if (rc) { set_error("rank " + std::to_string(r) + ": " + fgoicp_last_error()); return rc; }
         }
-        std::vector<int> rcs(ndev, 0);
-        std::vector<std::string> errs(ndev);
+        std::vector<int> rcs((size_t)ndev, 0);
+        std::vector<std::string> errs((size_t)ndev);
         std::atomic<bool> give_up{false};
         std::vector<std::thread> th;  // phase 2: the communicator forms when every rank has joined — one thread per rank, non-blocking init
+        fgoicp_multi* mp = m.get();
         for (int r = 0; r < ndev; ++r)
-            th.emplace_back([&, r] {
-                rcs[r] = rccl_join(m->rccl[r], id, &give_up);
-                if (rcs[r]) { errs[r] = fgoicp_last_error(); give_up.store(true, std::memory_order_release); }
+            th.emplace_back([&, mp, r] {
+                rcs[(size_t)r] = rccl_join(mp->rccl[(size_t)r], id, &give_up);
+                if (rcs[(size_t)r]) { errs[(size_t)r] = fgoicp_last_error(); give_up.store(true, std::memory_order_release); }
             });
         for (auto& t : th) t.join();
         for (int r = 0; r < ndev; ++r)
-            if (rcs[r] && errs[r].find("abandoned") == std::string::npos) { set_error("rank " + std::to_string(r) + ": " + errs[r]); return fail(rcs[r]); }
+            if (rcs[(size_t)r] && errs[(size_t)r].find("abandoned") == std::string::npos) { set_error("rank " + std::to_string(r) + ": " + errs[(size_t)r]); return rcs[(size_t)r]; }
         for (int r = 0; r < ndev; ++r)
-            if (rcs[r]) { set_error("rank " + std::to_string(r) + ": " + errs[r]); return fail(rcs[r]); }
+            if (rcs[(size_t)r]) { set_error("rank " + std::to_string(r) + ": " + errs[(size_t)r]); return rcs[(size_t)r]; }
+        fgoicp_multi* mraw = m.get();
+        m->abort_transport = [mraw] { for (fgoicp_rccl* x : mraw->rccl) (void)fgoicp_rccl_abort(x); };
     }
     for (int r = 0; r < ndev; ++r) {
-        auto l = std::make_unique<RankLink>();
-        l->rank = r;
-        l->world = ndev;
-        l->log = &m->logs[r];
-        if (ndev > 1 && transport == FGOICP_TRANSPORT_RCCL) fgoicp_rccl_exchange(m->rccl[r], &l->inner);
-        else l->rv = &m->rv;
-        l->dg = &m->dg;
-        l->device = devices[r];
-        fgoicp_exchange ex{r, ndev, link_allreduce_min, link_allgather, l.get(), link_allgather_device};
-        int rc = fgoicp_solver_set_exchange(m->solvers[r], ndev > 1 ? &ex : nullptr);
-        if (rc) return fail(rc);
-        m->links.push_back(std::move(l));
+        fgoicp_exchange inner{};
+        if (use_rccl) fgoicp_rccl_exchange(m->rccl[(size_t)r], &inner);
+        int rc = m->connect(r, use_rccl ? &inner : nullptr);
+        if (rc) return rc;
     }
     *out = m.release();
     return FGOICP_OK;
 }
 
 // TEST HOOK (tests/test_gpu_multi.py): the `call`-th exchange of `rank` in the next run fails, once.  Nothing in the product calls it.
-int fgoicp_multi_test_fault(fgoicp_multi* m, int rank, long call) {
-    if (!m || rank < 0 || rank >= (int)m->links.size()) return FGOICP_ERR_INVALID_ARG;
-    m->links[(size_t)rank]->fail_at = call;
-    return FGOICP_OK;
-}
+int fgoicp_multi_test_fault(fgoicp_multi* m, int rank, long call) { return m ? m->test_fault(rank, call) : FGOICP_ERR_INVALID_ARG; }
 
 // What the last recorded run exchanged: host-side collectives of `rank` (all-reduces and all-gathers) and device all-gathers.
 int fgoicp_multi_recorded(const fgoicp_multi* m, int rank, uint64_t* host_exchanges, uint64_t* device_allgathers) {
-    if (!m || rank < 0 || rank >= (int)m->logs.size()) return FGOICP_ERR_INVALID_ARG;
-    if (host_exchanges) *host_exchanges = m->logs[(size_t)rank].size();
-    if (device_allgathers) *device_allgathers = m->dg.log.size();
-    return FGOICP_OK;
+    return m ? m->recorded(rank, host_exchanges, device_allgathers) : FGOICP_ERR_INVALID_ARG;
 }
 
-int fgoicp_multi_set_record(fgoicp_multi* m, int on) {
-    if (!m) return FGOICP_ERR_INVALID_ARG;
-    for (size_t r = 0; r < m->links.size(); ++r) {
-        m->links[r]->record = on != 0;
-        m->links[r]->replay = false;
-        if (on) m->logs[r].clear();
-        if (on) m->dg.clear_log();
-    }
-    return FGOICP_OK;
-}
+int fgoicp_multi_set_record(fgoicp_multi* m, int on) { return m ? m->set_record(on) : FGOICP_ERR_INVALID_ARG; }
 
 // Every rank's run() on its own host thread; the result is rank 0's (all ranks hold the same incumbent after the last exchange).
-static int multi_run_impl(fgoicp_multi* m, float* R_out9, float* t_out3);
 int fgoicp_multi_run(fgoicp_multi* m, float* R_out9, float* t_out3) {
     if (!m || !R_out9 || !t_out3) return FGOICP_ERR_INVALID_ARG;
-    return fgoicp::abi_guard("fgoicp_multi_run", [&] { return multi_run_impl(m, R_out9, t_out3); });
-}
-static int multi_run_impl(fgoicp_multi* m, float* R_out9, float* t_out3) {
-    const int n = (int)m->solvers.size();
-    std::vector<int> rcs(n, 0);
-    std::vector<std::string> errs(n);
-    std::vector<float> R(9 * (size_t)n), t(3 * (size_t)n);
-    for (auto& l : m->links) { l->replay = false; l->calls = 0; if (l->record) { l->log->clear(); m->dg.clear_log(); } }
-    m->rv.reset();
-    std::atomic<int> first_failed{-1};
-    std::vector<std::thread> th;
-    for (int r = 0; r < n; ++r)
-        th.emplace_back([&, r] {
-            const auto t0 = std::chrono::steady_clock::now();
-            rcs[r] = fgoicp_solver_run(m->solvers[r], &R[9 * (size_t)r], &t[3 * (size_t)r]);
-            if (rcs[r]) {  // the others would wait for this rank in their next collective for ever: end the exchange for all
-                errs[r] = fgoicp_last_error();
-                int none = -1;
-                first_failed.compare_exchange_strong(none, r);
-                m->rv.abort();
-                for (fgoicp_rccl* x : m->rccl) (void)fgoicp_rccl_abort(x);
-            }
-            m->seconds[r] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        });
-    for (auto& x : th) x.join();
-    if (const int r = first_failed.load(); r >= 0) {  // the rank that failed on its own, not the ones it took down
-        set_error("rank " + std::to_string(r) + ": " + errs[r]);
-        return rcs[r];
-    }
-    for (int r = 1; r < n; ++r)
-        if (std::memcmp(&R[0], &R[9 * (size_t)r], 36) != 0 || std::memcmp(&t[0], &t[3 * (size_t)r], 12) != 0) {
-            set_error("fgoicp_multi_run: ranks ended with different incumbents");
-            return FGOICP_ERR_EXCHANGE;
-        }
-    std::memcpy(R_out9, R.data(), 36);
-    std::memcpy(t_out3, t.data(), 12);
-    return FGOICP_OK;
+    return fgoicp::abi_guard("fgoicp_multi_run", [&] { return m->run(R_out9, t_out3); });
 }
 
 // ONE rank alone against the recording of the last recorded run: what that rank would do on a GPU of its own (everything but
 // the latency of the collectives).  seconds_out = wall-clock of its run().
 int fgoicp_multi_replay_rank(fgoicp_multi* m, int rank, double* seconds_out) {
-    if (!m || rank < 0 || rank >= (int)m->solvers.size()) return FGOICP_ERR_INVALID_ARG;
-    RankLink* l = m->links[rank].get();
-    if (m->solvers.size() > 1 && l->log->empty()) { set_error("fgoicp_multi_replay_rank: nothing recorded (fgoicp_multi_set_record, then fgoicp_multi_run)"); return FGOICP_ERR_INVALID_ARG; }
-    const bool was_recording = l->record;
-    l->record = false;
-    l->replay = true;
-    l->replay_pos = 0;
-    l->dev_replay_pos = 0;
-    float R[9], t[3];
-    const auto t0 = std::chrono::steady_clock::now();
-    const int rc = fgoicp_solver_run(m->solvers[rank], R, t);
-    if (seconds_out) *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    l->replay = false;
-    l->record = was_recording;
-    return rc;
+    if (!m) return FGOICP_ERR_INVALID_ARG;
+    return fgoicp::abi_guard("fgoicp_multi_replay_rank", [&] { return m->replay_rank(rank, seconds_out); });
 }
 
-// ONE IterativeClosestPoint3D::run() executed by all ranks together (what a cooperative round does for every triggered refinement):
-// every rank thread scans its share of the source, the per-query results are all-gathered on device memory.  The result is rank 0's;
-// every rank must end with the same bits (checked).
+// ONE IterativeClosestPoint3D::run() executed by all ranks together (what a cooperative round does for every triggered refinement).
 int fgoicp_multi_icp(fgoicp_multi* m, const float* R0, const float* t0, size_t max_iter, float convergence_threshold, float* sse_out, float* R_out9, float* t_out3,
                      int* iterations_out) {
     if (!m || !R0 || !t0 || !sse_out || !R_out9 || !t_out3) return FGOICP_ERR_INVALID_ARG;
-    const int n = (int)m->solvers.size();
-    std::vector<int> rcs(n, 0), its(n, 0);
-    std::vector<std::string> errs(n);
-    std::vector<float> sse(n), R(9 * (size_t)n), t(3 * (size_t)n);
-    for (auto& l : m->links) { l->replay = false; l->calls = 0; }
-    m->rv.reset();
-    std::vector<std::thread> th;
-    for (int r = 0; r < n; ++r)
-        th.emplace_back([&, r] {
-            RankLink* l = m->links[r].get();
-            rcs[r] = fgoicp::ctx_icp_coop(fgoicp_solver_ctx(m->solvers[r]), r, n, n > 1 ? link_allgather_device : nullptr, l, R0, t0, max_iter, convergence_threshold, &sse[r],
-                                          &R[9 * (size_t)r], &t[3 * (size_t)r], &its[r]);
-            if (rcs[r]) {
-                errs[r] = fgoicp_last_error();
-                m->rv.abort();
-                for (fgoicp_rccl* x : m->rccl) (void)fgoicp_rccl_abort(x);
-            }
-        });
-    for (auto& x : th) x.join();
-    for (int r = 0; r < n; ++r)
-        if (rcs[r]) { set_error("rank " + std::to_string(r) + ": " + errs[r]); return rcs[r]; }
-    for (int r = 1; r < n; ++r)
-        if (std::memcmp(&sse[0], &sse[r], 4) != 0 || std::memcmp(&R[0], &R[9 * (size_t)r], 36) != 0 || std::memcmp(&t[0], &t[3 * (size_t)r], 12) != 0 || its[r] != its[0]) {
-            set_error("fgoicp_multi_icp: ranks ended with different results");
-            return FGOICP_ERR_EXCHANGE;
-        }
-    *sse_out = sse[0];
-    std::memcpy(R_out9, R.data(), 36);
-    std::memcpy(t_out3, t.data(), 12);
-    if (iterations_out) *iterations_out = its[0];
-    return FGOICP_OK;
+    return fgoicp::abi_guard("fgoicp_multi_icp", [&] { return m->icp(R0, t0, max_iter, convergence_threshold, sse_out, R_out9, t_out3, iterations_out); });
 }
 
 int fgoicp_multi_world(const fgoicp_multi* m) { return m ? (int)m->solvers.size() : 0; }
-fgoicp_solver* fgoicp_multi_solver(fgoicp_multi* m, int rank) { return m && rank >= 0 && rank < (int)m->solvers.size() ? m->solvers[rank] : nullptr; }
+fgoicp_solver* fgoicp_multi_solver(fgoicp_multi* m, int rank) { return m && rank >= 0 && rank < (int)m->solvers.size() ? m->solvers[(size_t)rank] : nullptr; }
 int fgoicp_multi_seconds(const fgoicp_multi* m, int rank, double* seconds) {
     if (!m || !seconds || rank < 0 || rank >= (int)m->seconds.size()) return FGOICP_ERR_INVALID_ARG;
-    *seconds = m->seconds[rank];
+    *seconds = m->seconds[(size_t)rank];
     return FGOICP_OK;
 }
 

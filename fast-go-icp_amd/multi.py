@@ -20,12 +20,12 @@ class RcclExchange:
     """One rank's RCCL communicator as an fgoicp_exchange (ncclCommInitRank blocks until every rank has called it).
     Drop-in for fgoicp_amd.dist.TorchExchange in FastGoICP.set_exchange: no Python in the per-round collectives."""
 
-    def __init__(self, rank, world, unique_id, device):
+    def __init__(self, rank, world, unique_id, device, nonblocking=False):
         self._lib = _lib.load()
         self.rank, self.world = int(rank), int(world)
         ident = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
         self._h = C.c_void_p()
-        _lib.check(self._lib.fgoicp_rccl_create(self.rank, self.world, ident, int(device), C.byref(self._h)), "fgoicp_rccl_create")
+        _lib.check(self._lib.fgoicp_rccl_create_ex(self.rank, self.world, ident, int(device), int(bool(nonblocking)), C.byref(self._h)), "fgoicp_rccl_create_ex")
         self.struct = _lib.Exchange()
         _lib.check(self._lib.fgoicp_rccl_exchange(self._h, C.byref(self.struct)), "fgoicp_rccl_exchange")
 
@@ -41,6 +41,12 @@ class RcclExchange:
         n = C.c_int()
         _lib.check(self._lib.fgoicp_rccl_comm_count(self._h, C.byref(n)), "fgoicp_rccl_comm_count")
         return n.value
+
+    def test_inprogress(self, n):
+        """TEST HOOK: the next n collectives report ncclInProgress once; returns the polls of ncclCommGetAsyncError made so far."""
+        polls = C.c_uint64()
+        _lib.check(self._lib.fgoicp_rccl_test_inprogress(self._h, int(n), C.byref(polls)), "fgoicp_rccl_test_inprogress")
+        return polls.value
 
     def abort(self):
         """A peer rank failed: the collective in flight here and every later one must end (fgoicp_rccl_abort raises the flag; the

@@ -289,6 +289,13 @@ typedef struct fgoicp_rccl fgoicp_rccl;
  * fgoicp_solver_set_exchange.  The collectives run on device buffers over xGMI, on a stream of their own. */
 int fgoicp_rccl_unique_id(unsigned char* id128);
 int fgoicp_rccl_create(int rank, int world_size, const unsigned char* id128, int device, fgoicp_rccl** out);
+/* The same with the kind of communicator chosen: nonblocking != 0 creates it with ncclConfig_t.blocking = 0 (what fgoicp_multi_create
+ * does for its rank threads, so that a rank can abandon the set-up when a peer fails); every collective on such a communicator may
+ * return ncclInProgress and is polled (ncclCommGetAsyncError) until it is on the stream before anything else is enqueued. */
+int fgoicp_rccl_create_ex(int rank, int world_size, const unsigned char* id128, int device, int nonblocking, fgoicp_rccl** out);
+/* TEST HOOK, not part of the drop-in surface: the next n collectives of x report ncclInProgress once before their real status (the
+ * polling path on a box where RCCL answers at once); settled_out (optional) = polls of ncclCommGetAsyncError made so far. */
+int fgoicp_rccl_test_inprogress(fgoicp_rccl* x, int n, uint64_t* settled_out);
 int fgoicp_rccl_exchange(fgoicp_rccl* x, fgoicp_exchange* out);   /* `out` borrows x: keep x alive while a solver uses it */
 int fgoicp_rccl_calls(const fgoicp_rccl* x, uint64_t* collectives);
 /* Ranks the communicator itself reports (ncclCommCount) — printed by bench.py so that a scaling run shows RCCL joined N ranks. */

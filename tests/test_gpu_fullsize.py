@@ -75,6 +75,49 @@ def test_dragon_full_run_is_schedule_independent_and_finds_the_ground_truth(fg, 
     assert ang_deg(R, dragon["R_gt"]) < 0.1 and np.linalg.norm(t - dragon["t_gt"]) < 1e-3 * 0.22
 
 
+def test_dragon_sharded_over_two_ranks(fg, dragon):
+    """BASELINE configs[3] (the dragon pair, the outer BnB sharded over ranks) on the one GPU of a test box: two in-process ranks on device 0
+    through fgoicp_multi, certify regime (ns * mse below the residual).
+    SERIAL — the reference's trajectory (fgoicp.cpp:32-100), the inner BnBs of every speculative evaluation dealt over the ranks: EVERY
+    rank must end with the one-GPU SERIAL run's counters and its (R, t, sse) bit for bit; one rank replayed alone against the recording
+    ends in the same state; the recorded object is destroyed afterwards (the sequence whose teardown once aborted).
+    ROUND — north_star's partitioning (a round's children dealt over the ranks; at this size the cooperative flow: bounds exchanged
+    first, triggers in the one-GPU child order, every ICP run by all ranks): the one-GPU optimum to 1e-5, identical incumbents on both ranks,
+    the rotation cubes split between them."""
+    mse = 5e-6
+    keys = ("trans_cubes", "bounds_calls", "rot_cubes", "icp_runs", "icp_iters", "inner_bnb", "rounds")
+    one = fg.FastGoICP(dragon["tgt"], dragon["src"], 0.005, mse, schedule=fg.SCHEDULE_SERIAL)
+    R1, t1 = one.run()
+    e1, st1 = one.get_best_error(), one.stats()
+    one.close()
+    m = fg.MultiGoICP(dragon["tgt"], dragon["src"], 0.005, mse, devices=[0, 0], transport=fg.TRANSPORT_IN_PROCESS, schedule=fg.SCHEDULE_SERIAL)
+    m.set_record(True)
+    R, t = m.run()
+    assert np.array_equal(R, R1) and np.array_equal(t, t1) and f32(m.get_best_error()).view(np.uint32) == f32(e1).view(np.uint32)
+    for r in range(2):
+        st = m.stats(r)
+        assert [st[k] for k in keys] == [st1[k] for k in keys], (r, st, st1)
+        assert m.registration(r).sort_fallbacks()[1] == 0
+    assert m.recorded(0)[0] > 0
+    assert m.replay_rank(1) > 0
+    st = m.stats(1)
+    assert [st[k] for k in keys] == [st1[k] for k in keys] and m.get_best_error(1) == m.get_best_error(0)
+    m.close()
+    one = fg.FastGoICP(dragon["tgt"], dragon["src"], 0.005, mse, schedule=fg.SCHEDULE_ROUND, round_width=0)
+    Rr, tr = one.run()
+    er, str1 = one.get_best_error(), one.stats()
+    one.close()
+    assert same_result((Rr, tr, er), (R1, t1, e1))
+    m = fg.MultiGoICP(dragon["tgt"], dragon["src"], 0.005, mse, devices=[0, 0], transport=fg.TRANSPORT_IN_PROCESS, schedule=fg.SCHEDULE_ROUND, round_width=0)
+    R, t = m.run()
+    assert same_result((R, t, m.get_best_error()), (Rr, tr, er))
+    sts = [m.stats(r) for r in range(2)]
+    assert m.get_best_error(1) == m.get_best_error(0)
+    assert min(s["rot_cubes"] for s in sts) > 0.3 * str1["rot_cubes"] and 0.7 * str1["trans_cubes"] < sum(s["trans_cubes"] for s in sts) < 1.5 * str1["trans_cubes"]
+    assert sts[0]["icp_runs"] == sts[1]["icp_runs"]  # cooperative flow: every refinement is run by both ranks, at the same points of the replicated control flow
+    m.close()
+
+
 def test_dragon_bounds_match_the_oracle_and_add_over_a_source_split(fg, oracle, dragon):
     """kernComputeBounds + the two reductions (registration.cu:27-60, :126-140) on all 437 645 points: against the oracle
     (its LUT filled from the device LUT, which is pinned by brute-force node values first), and additive over a split of
@@ -200,6 +243,28 @@ def test_trimmed_1m_full_run_recovers_the_ground_truth(fg, million):
     assert ang_deg(R, m["R_gt"]) < 0.15 and np.linalg.norm(t - m["t_gt"]) < 2e-3 * 0.2
     assert st["trans_cubes"] > 10000 and s.registration.sort_fallbacks()[1] == 0
     s.close()
+
+
+def test_trimmed_1m_on_two_ranks_with_split_scans(fg, million):
+    """BASELINE configs[4] sharded: the 1 M-point trimmed pair on two in-process ranks.  Trimmed contexts of this size split the exact
+    scans of every refinement over the ranks (device all-gathers of the per-query results): the run must recover the ground
+    truth, both ranks must hold the same incumbent bit for bit, device all-gathers must have happened, and the optimum must be the
+    one-GPU trimmed run's to 1e-5."""
+    m = million
+    one = fg.FastGoICP(m["tgt"], m["src"], 0.005, 1e-3, schedule=fg.SCHEDULE_ROUND, round_width=0, trim_fraction=0.2)
+    R1, t1 = one.run()
+    e1 = one.get_best_error()
+    one.close()
+    mm = fg.MultiGoICP(m["tgt"], m["src"], 0.005, 1e-3, devices=[0, 0], transport=fg.TRANSPORT_IN_PROCESS, schedule=fg.SCHEDULE_ROUND, round_width=0, trim_fraction=0.2)
+    mm.set_record(True)
+    R, t = mm.run()
+    assert ang_deg(R, m["R_gt"]) < 0.15 and np.linalg.norm(t - m["t_gt"]) < 2e-3 * 0.2
+    assert same_result((R, t, mm.get_best_error()), (R1, t1, e1))
+    assert mm.get_best_error(1) == mm.get_best_error(0)
+    host_ex, dev_gathers = mm.recorded(0)
+    assert host_ex > 0 and dev_gathers > 0
+    assert mm.replay_rank(0) > 0 and mm.get_best_error(0) == mm.get_best_error(1)
+    mm.close()
 
 
 # ------------------------------------------------------------------------------------------------

@@ -165,6 +165,33 @@ def test_sharded_serial_schedule_is_the_single_gpu_serial_run(fg, gpu_required, 
     m.close()
 
 
+def test_recorded_eight_rank_serial_run_replays_and_tears_down(fg, gpu_required):
+    """The sequence of tools/scale_replay.py whose teardown aborted once in round 3 (`double free or corruption` after the
+    8-rank SERIAL replay), as a test: create an 8-rank in-process fgoicp_multi, record a SERIAL run, replay EVERY rank alone against the
+    recording (twice for rank 0), form and destroy a one-rank RCCL communicator next to it as the script does, destroy the object —
+    and once more from the start (a teardown that corrupted the heap would take the second round or the process down).  The same
+    sequence runs under AddressSanitizer on the CPU (tests/test_multi_asan.py)."""
+    tgt, src, _, _ = fg.synth.workload("small", angle_deg=150.0, min_angle_deg=110.0)
+    keys = ("trans_cubes", "bounds_calls", "rot_cubes", "icp_runs", "icp_iters", "inner_bnb", "rounds")
+    one = fg.FastGoICP(tgt, src, 0.01, 2e-4, schedule=fg.SCHEDULE_SERIAL)
+    one.run()
+    e1, st1 = one.get_best_error(), one.stats()
+    one.close()
+    for _ in range(2):
+        m = fg.MultiGoICP(tgt, src, 0.01, 2e-4, devices=[0] * 8, transport=fg.TRANSPORT_IN_PROCESS, schedule=fg.SCHEDULE_SERIAL)
+        m.set_record(True)
+        m.run()
+        assert np.float32(m.get_best_error()).view(np.uint32) == np.float32(e1).view(np.uint32)
+        for r in list(range(8)) + [0]:
+            assert m.replay_rank(r) > 0
+            st = m.stats(r)
+            assert [st[k] for k in keys] == [st1[k] for k in keys] and m.get_best_error(r) == m.get_best_error(0)
+        ex = fg.RcclExchange(0, 1, fg.rccl_unique_id(), 0)
+        assert ex.warmup()
+        ex.close()
+        m.close()
+
+
 def test_a_failing_rank_ends_the_run_for_all_ranks(fg, gpu_required):
     """One rank's exchange fails mid-run (fgoicp_multi_test_fault, a test hook of the ABI): the others must not wait for it in
     their next collective; the call returns that rank's error and THE SAME OBJECT runs cleanly afterwards (the rendezvous is
@@ -192,6 +219,37 @@ def test_rccl_abort_fails_later_collectives(fg, gpu_required):
     buf = (C.c_float * 1)(1.0)
     assert ex.struct.allreduce_min(buf, 1, ex.struct.user) != 0
     assert b"aborted" in fg._lib.load().fgoicp_last_error()
+    ex.close()
+
+
+def test_rccl_nonblocking_communicator_settles_every_collective(fg, gpu_required):
+    """fgoicp_multi_create forms its communicators with ncclConfig_t.blocking = 0, and on such a communicator every collective may
+    return ncclInProgress (round 3 treated that as a failure).  The same kind of communicator with the one rank a test box
+    can form: the three collectives of the exchange return the right data, also when they are made to report ncclInProgress first
+    (fgoicp_rccl_test_inprogress, a test hook of the ABI) — the transport then polls ncclCommGetAsyncError before it enqueues the copy
+    back — and a whole run goes through it."""
+    import torch
+    ex = fg.RcclExchange(0, 1, fg.rccl_unique_id(), 0, nonblocking=True)
+    assert ex.comm_count == 1
+    for forced in (0, 3):
+        before = ex.test_inprogress(forced)
+        buf = (C.c_float * 3)(3.0, -1.0, 2.5)
+        assert ex.struct.allreduce_min(buf, 3, ex.struct.user) == 0 and list(buf) == [3.0, -1.0, 2.5]
+        send = (C.c_float * 70)(*range(70))
+        recv = (C.c_float * 70)()
+        assert ex.struct.allgather(send, recv, 70, ex.struct.user) == 0 and list(recv) == list(map(float, range(70)))
+        dev = torch.arange(4096, dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        assert ex.struct.allgather_device(dev.data_ptr(), 4096, ex.struct.user) == 0
+        assert torch.equal(dev.cpu(), torch.arange(4096, dtype=torch.uint8))
+        if forced:
+            assert ex.test_inprogress(0) >= before + forced  # the polling path ran once per forced collective
+    s = fg.FastGoICP(G["runsyn_tgt"], G["runsyn_src"], float(G["runsyn_res"]), float(G["runsyn_mse"]), schedule=fg.SCHEDULE_ROUND, round_width=2)
+    s.set_exchange(ex)
+    ex.test_inprogress(1000)
+    R, t = s.run()
+    assert np.allclose(R, G["runsyn_R"], atol=1e-5)
+    s.close()
     ex.close()
 
 
