@@ -7,7 +7,7 @@ There is no CPU implementation in this package: every operator raises if the HIP
 missing or no MI355X is visible."""
 from . import _lib, build, nodes, synth  # noqa: F401
 from ._lib import (FLAG_BRUTE_FORCE_NN, FLAG_CURVE_ORDER, FLAG_NO_MORTON, FLAG_NO_WEIGHT_QUANT, FLAG_PROFILE, SCHEDULE_ROUND, SCHEDULE_SERIAL, TRANSPORT_IN_PROCESS,  # noqa: F401
-                   TRANSPORT_RCCL, FgoicpError)
+                   TRANSPORT_RCCL, FgoicpError, dev_knobs)
 from .registration import IterativeClosestPoint3D, Registration, StreamPool, cloud_stats, icp_batch  # noqa: F401
 from .nodes import Rotation, RotNode, TransNode, from_glm, to_glm  # noqa: F401
 

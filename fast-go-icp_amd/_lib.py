@@ -53,6 +53,7 @@ SCHEDULE_ROUND = 1
 _SIGS = {
     "fgoicp_last_error": (C.c_char_p, []),
     "fgoicp_version": (C.c_char_p, []),
+    "fgoicp_dev_knobs": (C.c_int, []),
     "fgoicp_ctx_create": (C.c_int, [c_float_p, C.c_size_t, c_float_p, C.c_size_t, c_float_p, C.c_float, C.c_int, C.c_uint,
                                     C.POINTER(C.c_void_p)]),
     "fgoicp_ctx_destroy": (None, [C.c_void_p]),
@@ -87,6 +88,7 @@ _SIGS = {
                                        C.POINTER(SolverOpts), C.POINTER(C.c_void_p)]),
     "fgoicp_solver_destroy": (None, [C.c_void_p]),
     "fgoicp_solver_set_exchange": (C.c_int, [C.c_void_p, C.POINTER(Exchange)]),
+    "fgoicp_solver_set_log": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "fgoicp_solver_run": (C.c_int, [C.c_void_p, c_float_p, c_float_p]),
     "fgoicp_solver_best_error": (C.c_int, [C.c_void_p, c_float_p]),
     "fgoicp_solver_best_transform": (C.c_int, [C.c_void_p, c_float_p, c_float_p]),
@@ -143,6 +145,11 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def dev_knobs():
+    """True if the loaded library is the development build (reads the FGOICP_* A/B knobs; csrc/host/knobs.hpp)."""
+    return bool(load().fgoicp_dev_knobs())
 
 
 def exported_symbols():

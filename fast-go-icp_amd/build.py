@@ -12,7 +12,9 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
-LIB_PATH = os.environ.get("FGOICP_LIB") or os.path.join(LIB_DIR, "libfgoicp_amd.so")  # FGOICP_LIB: a development build elsewhere (tools/ablate.sh)
+DEFAULT_LIB = os.path.join(LIB_DIR, "libfgoicp_amd.so")
+DEV_LIB = os.path.join(LIB_DIR, "libfgoicp_amd_dev.so")  # the same sources with -DFGOICP_DEV_KNOBS (csrc/host/knobs.hpp): reads the A/B environment knobs, instantiates the rejected kernel variants
+LIB_PATH = os.environ.get("FGOICP_LIB") or DEFAULT_LIB  # FGOICP_LIB: another build to load (the development build, tools/ablate.sh)
 CLI_PATH = os.path.join(LIB_DIR, "fast-go-icp")
 
 SOURCES = [
@@ -49,17 +51,25 @@ def _newer(target, deps):
     return True
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, dev=True):
+    """Builds the shipped library (and the CLI) and, dev=True, the development build next to it.  Returns the path of the library the
+    package loads (FGOICP_LIB or the shipped one)."""
     os.makedirs(LIB_DIR, exist_ok=True)
     deps = [CSRC, os.path.join(REPO, "include")]
     srcs = [s for s in SOURCES if os.path.exists(s)]
     rebuilt = False
-    if force or not _newer(LIB_PATH, deps):
-        rebuilt = True
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-x", "hip", *COMMON_FLAGS, "-shared", "-o", LIB_PATH, *srcs, "-ldl"]  # RCCL is dlopen'ed on first use (csrc/host/multi.cpp)
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.run(cmd, check=True)
+    targets = [(DEFAULT_LIB, [])] + ([(DEV_LIB, ["-DFGOICP_DEV_KNOBS"])] if dev else [])
+    procs = []
+    for path, extra in targets:  # the two builds side by side (kernels.hip dominates either)
+        if force or not _newer(path, deps):
+            rebuilt = rebuilt or path == DEFAULT_LIB
+            cmd = [_hipcc(), "--offload-arch=gfx950", "-x", "hip", *COMMON_FLAGS, *extra, "-shared", "-o", path, *srcs, "-ldl"]  # RCCL is dlopen'ed on first use (csrc/host/multi.cpp)
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
     cli_srcs = [s for s in CLI_SOURCES if os.path.exists(s)]
     if cli_srcs and (force or rebuilt or not _newer(CLI_PATH, deps)):  # the CLI goes with the library it was built against
         cmd = [_hipcc(), "--offload-arch=gfx950", "-x", "hip", *COMMON_FLAGS, "-o", CLI_PATH, *cli_srcs,

@@ -81,6 +81,8 @@ int main(int argc, char* argv[]) {
         fgoicp_multi* m = nullptr;
         icp::check_status(fgoicp_multi_create(&pct.data()->x, pct.size(), &pcs.data()->x, pcs.size(), config.params.lut_resolution, config.params.mse_threshold, &o,
                                               devices.data(), (int)devices.size(), transport, &m), "fgoicp_multi_create");
+        // rank 0's log events: every rank holds the same incumbents (SERIAL and the cooperative flow: the same refinements too)
+        icp::check_status(fgoicp_solver_set_log(fgoicp_multi_solver(m, 0), &icp::FastGoICP::log_line, nullptr), "fgoicp_solver_set_log");
         auto start = std::chrono::high_resolution_clock::now();
         icp::check_status(fgoicp_multi_run(m, R.data(), &t.x), "fgoicp_multi_run");
         elapsed_seconds = std::chrono::high_resolution_clock::now() - start;
@@ -95,6 +97,7 @@ int main(int argc, char* argv[]) {
         }
         icp::check_status(fgoicp_solver_best_error(fgoicp_multi_solver(m, 0), &best_error), "fgoicp_solver_best_error");
         fgoicp_multi_destroy(m);
+        icp::Logger(icp::LogLevel::Info) << "Searching over! Best Error: " << best_error << "\n\tRotation:\n" << R << "\n\tTranslation: " << t;  // fgoicp.cpp:25-27
     } else {
         icp::FastGoICP fgoicp(std::move(pct), std::move(pcs), config.params.lut_resolution, config.params.mse_threshold, schedule,
                               config.params.round_width, 0, config.params.trim_fraction);
@@ -104,8 +107,6 @@ int main(int argc, char* argv[]) {
         st = fgoicp.stats();
         best_error = fgoicp.get_best_error();
     }
-    icp::Logger(icp::LogLevel::Info) << "Initial ICP best error: " << st.initial_icp_sse;
-    icp::Logger(icp::LogLevel::Info) << "Searching over! Best Error: " << best_error << "\n\tRotation:\n" << R << "\n\tTranslation: " << t;
     icp::Logger(icp::LogLevel::Debug) << "Subcubes: " << st.trans_cubes << ", rotation cubes: " << st.rot_cubes << ", ICP runs: " << st.icp_runs;
     icp::Logger(icp::LogLevel::Info) << "Fast Go-ICP finished, time elapsed: " << std::fixed << std::setprecision(3) << elapsed_seconds.count() << " seconds";
     if (!config.io.output.empty()) cli::write_result_toml(config.io.output, R, t, best_error, pcs_in.size(), elapsed_seconds.count(), st);

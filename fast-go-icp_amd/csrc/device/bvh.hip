@@ -1,5 +1,6 @@
 // Host-side construction and upload of the implicit bounding-volume tree (bvh.hpp).
 #include "bvh.hpp"
+#include "../host/knobs.hpp"
 
 #include <cfloat>
 #include <cmath>
@@ -13,7 +14,7 @@
 namespace fgoicp {
 
 bool bvh_kd_order() {
-    static const bool kd = [] { const char* e = std::getenv("FGOICP_BVH_ORDER"); return !e || std::atoi(e) != 0; }();  // tuning knob / A-B
+    static const bool kd = [] { const char* e = dev_env("FGOICP_BVH_ORDER"); return !e || std::atoi(e) != 0; }();  // tuning knob / A-B
     return kd;
 }
 
@@ -62,7 +63,7 @@ BvhHost bvh_build_host(const float4* p, size_t n, std::vector<uint32_t>* order) 
     // noise amplitudes apart.  Per leaf: n = the direction of least variance of its points (|n| <= 1 after rounding), [a, b] = the range of
     // n.p over them, widened by the rounding of both sides.  max(box distance, slab distance) is still a lower bound of the distance to
     // every point of the leaf (kernels.hip box_walk refines its per-query test with it).
-    static const bool want_slab = [] { const char* e = std::getenv("FGOICP_BVH_SLAB"); return !e || std::atoi(e) != 0; }();  // tuning knob / A-B
+    static const bool want_slab = [] { const char* e = dev_env("FGOICP_BVH_SLAB"); return !e || std::atoi(e) != 0; }();  // tuning knob / A-B
     if (want_slab) {
         h.slab.assign(2 * nleaf, make_float4(0.f, 0.f, 0.f, 0.f));
         const size_t nreal = (n + kBvhLeaf - 1) / kBvhLeaf;

@@ -16,6 +16,7 @@
 
 #include "../../../include/fgoicp_amd.h"
 #include "../host/math3.hpp"
+#include "../host/knobs.hpp"
 #include "ctx.hpp"
 #include "kernels.hpp"
 #include "morton.hpp"
@@ -39,7 +40,7 @@ int ctx_flush_profile(fgoicp_ctx* c) {
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, c->ev_start[i], c->ev_stop[i]));
         c->prof_ms += ms;
-        static const bool tick_log = std::getenv("FGOICP_TICK_LOG") != nullptr;  // debugging aid: one line per bounds launch on stderr
+        static const bool tick_log = dev_env("FGOICP_TICK_LOG") != nullptr;  // debugging aid: one line per bounds launch on stderr
         if (tick_log && i < (int)c->ev_evals.size()) std::fprintf(stderr, "[tick] evals %d us %.1f\n", c->ev_evals[i], ms * 1e3);
         if (c->ev_has_sel[i]) {  // trimmed mode: the selection kernel of the same window (side stream)
             HIPCHK(hipEventSynchronize(c->ev_sel_stop[i]));
@@ -59,7 +60,7 @@ int ctx_flush_profile(fgoicp_ctx* c) {
 // -------------------------------------------------------------------------------------------
 namespace {
 struct TickTiming {  // FGOICP_TIMING=1: where a tick's wall time goes (host side), printed at context destruction
-    bool on = std::getenv("FGOICP_TIMING") != nullptr;
+    bool on = dev_env("FGOICP_TIMING") != nullptr;
     double pack = 0, enqueue = 0, wait = 0, copyout = 0;
     uint64_t ticks = 0;
 };
@@ -83,7 +84,7 @@ static int tick_launch_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
     *sl.h_sort_err = 0u;
     if (!small) {
         // descriptors + locality sort on the slot's side stream (overlaps the other slot's bounds kernel); the main stream joins behind it
-        static const int upload_kernel = [] { const char* e = std::getenv("FGOICP_UPLOAD_KERNEL"); return e ? std::atoi(e) : 1; }();  // tuning knob: 0 = two hipMemcpyAsync
+        static const int upload_kernel = [] { const char* e = dev_env("FGOICP_UPLOAD_KERNEL"); return e ? std::atoi(e) : 1; }();  // tuning knob: 0 = two hipMemcpyAsync
         if (upload_kernel) {
             launch_tick_upload(sl.hd_groups, sl.d_groups, ng, sl.hd_subs, sl.d_subs, neval, sl.sort_stream);
         } else {
@@ -494,7 +495,7 @@ static int procrustes_enqueue(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const uint3
     }
     L.cov_on_host = false;
     if (part != 2) {
-        static const bool fold_move = [] { const char* e = std::getenv("FGOICP_ICP_FOLD_MOVE"); return !e || std::atoi(e) != 0; }();  // tuning knob / A-B
+        static const bool fold_move = [] { const char* e = dev_env("FGOICP_ICP_FOLD_MOVE"); return !e || std::atoi(e) != 0; }();  // tuning knob / A-B
         const bool fold = move9 && fold_move && !c->brute_force_nn && !(c->inliers && c->trim_skip);
         if (move9 && !fold) launch_transform_inplace(L.d_work, ns, move9, move3, st);
         // kernFindNearestNeighbor (icp3d.cu:11-28): min distance, tie set, lowest index
@@ -1138,8 +1139,8 @@ int ctx_set_inliers(fgoicp_ctx* c, size_t k) {
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         const size_t budget = std::max<size_t>((size_t)3 << 29, std::min<size_t>((size_t)12 << 30, free_b / 6));
-        if (const char* e = std::getenv("FGOICP_TRIM_SAMPLE")) c->trim_samp_shift = std::max(0, std::min(10, std::atoi(e)));  // tuning knob: 0 = two-pass selection, no sample
-        if (const char* e = std::getenv("FGOICP_TRIM_MARGIN")) c->trim_margin_sd = (float)std::atof(e);                          // tuning knob: bracket half-width (standard deviations)
+        if (const char* e = dev_env("FGOICP_TRIM_SAMPLE")) c->trim_samp_shift = std::max(0, std::min(10, std::atoi(e)));  // tuning knob: 0 = two-pass selection, no sample
+        if (const char* e = dev_env("FGOICP_TRIM_MARGIN")) c->trim_margin_sd = (float)std::atof(e);                          // tuning knob: bracket half-width (standard deviations)
         c->erow = (c->ns + 3) & ~(size_t)3;  // rows start 16-byte aligned
         if (c->trim_samp_shift > 0)  // + the row's sample (trim_store); rows and samples then start on 256-byte boundaries
             c->erow = ((c->ns + 63) & ~(size_t)63) + (((((c->ns + ((size_t)1 << c->trim_samp_shift) - 1) >> c->trim_samp_shift)) + 63) & ~(size_t)63);
@@ -1157,7 +1158,7 @@ int ctx_set_inliers(fgoicp_ctx* c, size_t k) {
             if (!L.d_nn_ub2) HIPCHK(hipMalloc(&L.d_nn_ub2, sizeof(float) * c->ns));
             if (!L.d_sel) HIPCHK(hipMalloc(&L.d_sel, sizeof(uint32_t) * 16));
             if (!L.d_eq) HIPCHK(hipMalloc(&L.d_eq, sizeof(uint32_t)));
-            const char* e = std::getenv("FGOICP_SELECT_WIDE");  // tuning knob: 0 = always the one-block selection for single rows
+            const char* e = dev_env("FGOICP_SELECT_WIDE");  // tuning knob: 0 = always the one-block selection for single rows
             if (!(e && std::atoi(e) == 0)) {
                 if (!L.d_sel_wide) HIPCHK(hipMalloc(&L.d_sel_wide, 65536));
                 if (!L.d_sel_wide2) HIPCHK(hipMalloc(&L.d_sel_wide2, 65536));
@@ -1191,7 +1192,8 @@ using namespace fgoicp;
 extern "C" {
 
 const char* fgoicp_last_error(void) { return g_last_error.c_str(); }
-const char* fgoicp_version(void) { return "fgoicp_amd 0.1 (gfx950)"; }
+const char* fgoicp_version(void) { return kDevKnobs ? "fgoicp_amd 0.4 (gfx950, development build)" : "fgoicp_amd 0.4 (gfx950)"; }
+int fgoicp_dev_knobs(void) { return kDevKnobs ? 1 : 0; }
 
 static int ctx_create_impl(const float* tgt_xyz, size_t nt, const float* src_xyz, size_t ns, const float* bounds6, float lut_resolution, int device, unsigned flags,
                            fgoicp_ctx** out, fgoicp_ctx** partial);
@@ -1250,9 +1252,9 @@ static int ctx_create_impl(const float* tgt_xyz, size_t nt, const float* src_xyz
             c->tgt_box6[2 * a] = std::min(c->tgt_box6[2 * a], v);
             c->tgt_box6[2 * a + 1] = std::max(c->tgt_box6[2 * a + 1], v);
         }
-    if (const char* e = std::getenv("FGOICP_TRIM_SKIP")) c->trim_skip = std::atoi(e) != 0;        // tuning knob
-    if (const char* e = std::getenv("FGOICP_SORT_XCD")) c->sort_xcd = std::atoi(e) != 0;          // tuning knob
-    if (const char* e = std::getenv("FGOICP_SORT_CHECK")) c->sort_check = std::atoi(e) != 0;      // tuning knob: 0 = no permutation check of the tick sort
+    if (const char* e = dev_env("FGOICP_TRIM_SKIP")) c->trim_skip = std::atoi(e) != 0;        // tuning knob
+    if (const char* e = dev_env("FGOICP_SORT_XCD")) c->sort_xcd = std::atoi(e) != 0;          // tuning knob
+    if (const char* e = dev_env("FGOICP_SORT_CHECK")) c->sort_check = std::atoi(e) != 0;      // tuning knob: 0 = no permutation check of the tick sort
     auto fail = [&](int rc) { fgoicp_ctx_destroy(c); *partial = nullptr; return rc; };
 #define CHK(expr) do { hipError_t e2_ = (expr); if (e2_ != hipSuccess) { set_error(std::string(#expr) + " failed: " + hipGetErrorString(e2_)); return fail(e2_ == hipErrorOutOfMemory ? FGOICP_ERR_OOM : FGOICP_ERR_HIP); } } while (0)
     CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -1284,7 +1286,7 @@ static int ctx_create_impl(const float* tgt_xyz, size_t nt, const float* src_xyz
         // compact cell instead of a run that straddles curve cells), 5540 -> 5324 us on the dragon shape, ICP iteration 222 -> 169 us
         // at 437k points; with 20 % volume outliers (1M trimmed) the cells grow tails along the surface normal and the trimmed ICP is
         // 13 % SLOWER — hence the flag.  FGOICP_POINT_CURVE overrides: 2 = k-d, 1 = Hilbert, 0 = Z-order.
-        static const int forced = [] { const char* e = std::getenv("FGOICP_POINT_CURVE"); return e ? std::atoi(e) : -1; }();  // tuning knob
+        static const int forced = [] { const char* e = dev_env("FGOICP_POINT_CURVE"); return e ? std::atoi(e) : -1; }();  // tuning knob
         const int mode = forced >= 0 ? forced : ((flags & FGOICP_FLAG_CURVE_ORDER) ? 1 : 2);
         c->perm = point_order(src_xyz, ns, 3, 64, mode);
         c->source_order = mode;
@@ -1334,7 +1336,7 @@ static int ctx_create_impl(const float* tgt_xyz, size_t nt, const float* src_xyz
             // 169 -> 170 us at 437k, trimmed 1M ICP 463 -> 465 ms): the triangle bound's slack is not what makes the scans of a far state
             // expensive — the leaf BOXES a large ball cuts are (tools/kd_sim.py-style count: 5.4 -> 16 leaves per query group 20 degrees
             // off the optimum even with exact bounds).  OFF by default; FGOICP_LUT_INDEX=1 builds and uses it.
-            static const bool want_idx = [] { const char* e = std::getenv("FGOICP_LUT_INDEX"); return e && std::atoi(e) != 0; }();  // tuning knob / A-B
+            static const bool want_idx = [] { const char* e = dev_env("FGOICP_LUT_INDEX"); return e && std::atoi(e) != 0; }();  // tuning knob / A-B
             if (e3 == hipSuccess && want_idx && hipMalloc(&c->d_lut_idx, total * sizeof(uint32_t)) != hipSuccess) { c->d_lut_idx = nullptr; (void)hipGetLastError(); }
             if (e3 == hipSuccess) {
                 launch_lut_build_scan(shifted.view(), g, scratch, c->d_lut, c->stream, c->d_lut_idx);
@@ -1356,8 +1358,8 @@ static int ctx_create_impl(const float* tgt_xyz, size_t nt, const float* src_xyz
         // patch of base voxels; 21.3 instead of 16 B per node) — bounds kernel -1.1 % on the bunny shape, three A/B pairs
         const size_t apron_bytes = (size_t)((g.px + 2) / 3) * ((g.py + 1) / 2) * g.pz * 8 * sizeof(float4);
         if (layout == 2 && apron_bytes <= ((size_t)16 << 30)) layout = 4;
-        if (const char* e = std::getenv("FGOICP_LUT_ZPAIR")) layout = std::atoi(e);  // tuning knob
-        const char* units_env = std::getenv("FGOICP_UNITS");
+        if (const char* e = dev_env("FGOICP_LUT_ZPAIR")) layout = std::atoi(e);  // tuning knob
+        const char* units_env = dev_env("FGOICP_UNITS");
         const bool units_on = units_env && (std::atoi(units_env) == 4 || std::atoi(units_env) == 8);
         if (layout == 3 && (g.px > 1023 || g.py > 1023 || g.pz > 1023 || c->inliers)) layout = 2;  // the bricked copy packs indices in 10 bits
         if (layout == 4 && (g.px > 1023 || g.py > 1023 || g.pz > 1023 || units_on)) layout = 2;     // the apron copy too; no sibling-unit kernel for it
@@ -1386,7 +1388,7 @@ static int ctx_create_impl(const float* tgt_xyz, size_t nt, const float* src_xyz
     {
         int P = 8;
         while (P > 1 && ((ns + (size_t)kBlock * P - 1) / ((size_t)kBlock * P)) * kMaxBatch < 2048) P >>= 1;
-        if (const char* e = std::getenv("FGOICP_PTS_PER_THREAD")) {  // tuning knob: 1, 2, 4 or 8
+        if (const char* e = dev_env("FGOICP_PTS_PER_THREAD")) {  // tuning knob: 1, 2, 4 or 8
             const int v = std::atoi(e);
             if (v == 1 || v == 2 || v == 4 || v == 8) P = v;
         }
@@ -1404,7 +1406,7 @@ static int ctx_create_impl(const float* tgt_xyz, size_t nt, const float* src_xyz
                 const double face_voxels = (double)g.dx * g.dy + (double)g.dy * g.dz + (double)g.dx * g.dz;
                 const double density = (double)ns / face_voxels;
                 c->chunk_pts = density >= 1.0 ? 2048 : density >= 0.5 ? 1024 : density >= 0.25 ? 512 : 256;
-                if (const char* e = std::getenv("FGOICP_CHUNK_PTS")) {  // tuning knob
+                if (const char* e = dev_env("FGOICP_CHUNK_PTS")) {  // tuning knob
                     const int v = std::atoi(e);
                     if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024 || v == 2048 || v == 4096) c->chunk_pts = v;  // 64 / 128 need FGOICP_BOUNDS_VARIANT 4 / 3
                 }
@@ -1412,7 +1414,7 @@ static int ctx_create_impl(const float* tgt_xyz, size_t nt, const float* src_xyz
             const size_t nchunk1 = (ns + c->chunk_pts - 1) / c->chunk_pts;
             const size_t fit = ((size_t)4 << 30) / (nchunk1 * (sizeof(double2) + 2 * sizeof(unsigned) + sizeof(unsigned short)));
             c->max_subcubes = (int)std::max<size_t>(4096, std::min<size_t>(131072, fit));
-            if (const char* e = std::getenv("FGOICP_MAX_SUBCUBES")) c->max_subcubes = std::max(kMaxBatch, std::min(1 << 18, std::atoi(e)));  // tuning knob: subcubes per window
+            if (const char* e = dev_env("FGOICP_MAX_SUBCUBES")) c->max_subcubes = std::max(kMaxBatch, std::min(1 << 18, std::atoi(e)));  // tuning knob: subcubes per window
             // one launch = one workgroup per (subcube, chunk) item: keep items x 256 threads inside the 32-bit grid
             const size_t launch_fit = (((size_t)1 << 24) - 1) / nchunk1;
             if (launch_fit < (size_t)kMaxBatch) {
@@ -1429,15 +1431,15 @@ static int ctx_create_impl(const float* tgt_xyz, size_t nt, const float* src_xyz
     }
     // locality-sorted whole-tick path
     {
-        if (const char* e = std::getenv("FGOICP_BOUNDS_SORTED")) c->sorted_bounds = std::atoi(e) != 0;
+        if (const char* e = dev_env("FGOICP_BOUNDS_SORTED")) c->sorted_bounds = std::atoi(e) != 0;
         c->nchunk1 = (int)((ns + c->chunk_pts - 1) / c->chunk_pts);
         c->max_groups = std::max(512, c->max_subcubes / 8);
-        if (const char* e = std::getenv("FGOICP_FINALIZE_SIDE")) c->finalize_on_side = std::atoi(e) != 0;  // tuning knob
-        if (const char* e = std::getenv("FGOICP_ICP_SEED")) c->icp_seeding = std::atoi(e) != 0;             // tuning knob
-        if (const char* e = std::getenv("FGOICP_COOP_SPLIT_MIN")) c->coop_split_min = c->coop_split_trim_min = (size_t)std::max(0L, std::atol(e));  // tuning knob (both thresholds)
-        if (const char* e = std::getenv("FGOICP_UNITS")) { const int v = std::atoi(e); c->unit_m = (v == 4 || v == 8) ? v : 0; }  // tuning knob: siblings per work item
+        if (const char* e = dev_env("FGOICP_FINALIZE_SIDE")) c->finalize_on_side = std::atoi(e) != 0;  // tuning knob
+        if (const char* e = dev_env("FGOICP_ICP_SEED")) c->icp_seeding = std::atoi(e) != 0;             // tuning knob
+        if (const char* e = dev_env("FGOICP_COOP_SPLIT_MIN")) c->coop_split_min = c->coop_split_trim_min = (size_t)std::max(0L, std::atol(e));  // tuning knob (both thresholds)
+        if (const char* e = dev_env("FGOICP_UNITS")) { const int v = std::atoi(e); c->unit_m = (v == 4 || v == 8) ? v : 0; }  // tuning knob: siblings per work item
         if (c->lut_layout == 4) c->unit_m = 0;  // the apron layout has no sibling-unit kernel
-        if (const char* e = std::getenv("FGOICP_SMALL_TICK")) c->small_tick_items = std::max(0, std::atoi(e));  // tuning knob: items
+        if (const char* e = dev_env("FGOICP_SMALL_TICK")) c->small_tick_items = std::max(0, std::atoi(e));  // tuning knob: items
         int maxd = std::max(g.dx, std::max(g.dy, g.dz));
         c->cell_shift = 0;
         while ((maxd >> c->cell_shift) > 32) ++c->cell_shift;  // 5 bits per axis
@@ -1469,10 +1471,10 @@ static int ctx_create_impl(const float* tgt_xyz, size_t nt, const float* src_xyz
             sl.stream = c->stream;
             CHK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
             {
-                const char* e = std::getenv("FGOICP_SORT_STREAM");  // tuning knob: 0 = sort on the main stream
+                const char* e = dev_env("FGOICP_SORT_STREAM");  // tuning knob: 0 = sort on the main stream
                 if (e && std::atoi(e) == 0) sl.sort_stream = c->stream;
                 else {
-                    const char* pe = std::getenv("FGOICP_SIDE_PRIORITY");  // tuning knob: -1 = the side streams (sort, finalize / selection) above the bounds kernels' stream, 1 = below
+                    const char* pe = dev_env("FGOICP_SIDE_PRIORITY");  // tuning knob: -1 = the side streams (sort, finalize / selection) above the bounds kernels' stream, 1 = below
                     const int pri = pe ? std::atoi(pe) : 0;
                     int least = 0, greatest = 0;
                     if (pri) CHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -1516,13 +1518,13 @@ static int ctx_create_impl(const float* tgt_xyz, size_t nt, const float* src_xyz
     // exact-NN / ICP scratch
     {
         int nl = 4;  // concurrent ICP runs (ctx_icp_batch); lane 0 shares the context's main stream
-        if (const char* e = std::getenv("FGOICP_ICP_LANES")) nl = std::max(1, std::min(16, std::atoi(e)));  // tuning knob
-        if (const char* e = std::getenv("FGOICP_ICP_OVERLAP")) c->icp_overlap = std::atoi(e) != 0;       // tuning knob
-        if (const char* e = std::getenv("FGOICP_ICP_DEVICE")) c->icp_device = std::atoi(e) != 0;         // tuning knob / A-B: 1 = loop advanced on the device (measured slower)
-        if (const char* e = std::getenv("FGOICP_ICP_DUAL")) c->icp_dual_env = std::atoi(e) != 0 ? 1 : 0; // tuning knob / A-B: 1 = one walk for both scans of an iteration, 0 = two scans on two streams
-        if (const char* e = std::getenv("FGOICP_ICP_GATED")) c->icp_gated = std::atoi(e) != 0;           // tuning knob / A-B: 1 = iterations pre-enqueued behind stream gates
-        if (const char* e = std::getenv("FGOICP_ICP_FUSE")) c->icp_fuse = std::atoi(e) != 0;             // tuning knob / A-B: 0 = separate reduction kernels
-        if (const char* e = std::getenv("FGOICP_ICP_AHEAD")) c->icp_ahead = std::max(1, std::min(6, std::atoi(e)));  // tuning knob
+        if (const char* e = dev_env("FGOICP_ICP_LANES")) nl = std::max(1, std::min(16, std::atoi(e)));  // tuning knob
+        if (const char* e = dev_env("FGOICP_ICP_OVERLAP")) c->icp_overlap = std::atoi(e) != 0;       // tuning knob
+        if (const char* e = dev_env("FGOICP_ICP_DEVICE")) c->icp_device = std::atoi(e) != 0;         // tuning knob / A-B: 1 = loop advanced on the device (measured slower)
+        if (const char* e = dev_env("FGOICP_ICP_DUAL")) c->icp_dual_env = std::atoi(e) != 0 ? 1 : 0; // tuning knob / A-B: 1 = one walk for both scans of an iteration, 0 = two scans on two streams
+        if (const char* e = dev_env("FGOICP_ICP_GATED")) c->icp_gated = std::atoi(e) != 0;           // tuning knob / A-B: 1 = iterations pre-enqueued behind stream gates
+        if (const char* e = dev_env("FGOICP_ICP_FUSE")) c->icp_fuse = std::atoi(e) != 0;             // tuning knob / A-B: 0 = separate reduction kernels
+        if (const char* e = dev_env("FGOICP_ICP_AHEAD")) c->icp_ahead = std::max(1, std::min(6, std::atoi(e)));  // tuning knob
         c->lanes.resize((size_t)nl);
         for (int l = 0; l < nl; ++l) {
             fgoicp_ctx::IcpLane& L = c->lanes[(size_t)l];
@@ -1595,7 +1597,7 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
                      1e6 * g_tt.pack / g_tt.ticks, 1e6 * g_tt.enqueue / g_tt.ticks, 1e6 * g_tt.wait / g_tt.ticks, 1e6 * g_tt.copyout / g_tt.ticks);
         g_tt = TickTiming{};
     }
-    if (c->unit_m > 1 && std::getenv("FGOICP_UNITS_STATS"))
+    if (c->unit_m > 1 && dev_env("FGOICP_UNITS_STATS"))
         std::fprintf(stderr, "[fgoicp units] M = %d: %llu of %llu evaluations in sibling units (%.1f %%)\n", c->unit_m, (unsigned long long)c->unit_evals,
                      (unsigned long long)c->unit_total, c->unit_total ? 100.0 * (double)c->unit_evals / (double)c->unit_total : 0.0);
     (void)hipSetDevice(c->device);

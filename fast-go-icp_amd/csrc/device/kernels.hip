@@ -15,6 +15,8 @@
 #include <cstdlib>
 
 #include "../host/math3.hpp"
+#include "../host/knobs.hpp"
+#include "slab.hpp"
 #include "bvh.hpp"
 
 namespace fgoicp {
@@ -596,6 +598,8 @@ __device__ __forceinline__ void trim_store(float* __restrict__ evals, size_t row
     evals[row_base + (size_t)i] = e;
     if (samp_shift > 0 && trim_is_sample(i, samp_shift, ns)) evals[row_base + trim_sample_offset(ns) + (size_t)(i >> samp_shift)] = e;
 }
+
+#include "bounds_item.hpp"   // round 4: the bounds kernel of the sorted path (bounds_item_kernel)
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 // FGOICP_BOUNDS_WAVES (development builds, tools/ab_waves.sh): ask the register allocator for that many resident waves per SIMD
@@ -1978,12 +1982,7 @@ __device__ unsigned long long g_scan_times[4096 * 4];  // per block of the last 
 // (0: the leaf cannot matter to this lane), leaf(point, flags) = what to do with each of the leaf's points.
 // refine(flags, n.x, n.y, n.z, a, b) = the lane's flags again after the leaf's SLAB test (bvh.hpp: a <= n.p <= b for every point p of the leaf) —
 // only called for a leaf whose box some lane could not rule out, with the slab read through the scalar unit next to the leaf's points.
-__device__ __forceinline__ float slab_d2(float nx, float ny, float nz, float a, float b, float qx, float qy, float qz) {
-    const float nq = fma_(nz, qz, fma_(ny, qy, nx * qx));
-    float s = fmaxf(nq - b, a - nq);                                         // distance of q from the slab along n (|n| <= 1: never more than the true one)
-    s -= 2e-6f * fmaxf(fabsf(nq), fmaxf(fabsf(a), fabsf(b)));                // the rounding of n.q, relative to the magnitudes involved
-    return s > 0.0f ? s * s : 0.0f;
-}
+// slab_d2: slab.hpp (shared with the host so that its rounding allowance can be tested against exact arithmetic)
 template <class RadiusFn, class TestFn, class LeafFn, class RefineFn>
 __device__ __forceinline__ void box_walk(const BvhView t, const float (&wl)[3], const float (&wh)[3], int part, int nparts, RadiusFn radius, TestFn test, LeafFn leaf, RefineFn refine,
                                          int* claim_ctr /* LDS word, zero on entry, when nparts > 1 (nullptr: round-robin) */,
@@ -2915,9 +2914,9 @@ void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, con
                       int allow_xcd, unsigned* check_err, int inject_fault, hipStream_t s, int nunits, int unit_m) {
     const size_t nitems = (size_t)(nsub - nunits * (unit_m - 1)) * nchunk;
     const unsigned kb = (unsigned)std::min<size_t>((nitems + 63) / 64, 8192);  // `hist` / `hist_xcd` are zero here: the scan / fold kernels re-zero them
-    static const int hilbert = [] { const char* e = std::getenv("FGOICP_SORT_CURVE"); return e ? std::atoi(e) : 1; }();  // tuning knob: 1 = Hilbert (default), 0 = Z-order
-    static const int use_ranks = [] { const char* e = std::getenv("FGOICP_SORT_RANKS"); return e ? std::atoi(e) : 1; }();  // tuning knob
-    static const int orient = [] { const char* e = std::getenv("FGOICP_SORT_ORIENT"); return e ? std::atoi(e) : 0; }();  // tuning knob (experimental): orientation bits in the sort key
+    static const int hilbert = [] { const char* e = dev_env("FGOICP_SORT_CURVE"); return e ? std::atoi(e) : 1; }();  // tuning knob: 1 = Hilbert (default), 0 = Z-order
+    static const int use_ranks = [] { const char* e = dev_env("FGOICP_SORT_RANKS"); return e ? std::atoi(e) : 1; }();  // tuning knob
+    static const int orient = [] { const char* e = dev_env("FGOICP_SORT_ORIENT"); return e ? std::atoi(e) : 0; }();  // tuning knob (experimental): orientation bits in the sort key
     const bool xcd = allow_xcd && use_ranks && hist_xcd && xoff;  // allow_xcd: FGOICP_SORT_XCD per context, cleared by a failed permutation check
     if (xcd) {
         if (hilbert) hipLaunchKernelGGL((tick_keys_kernel<1, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd, check_err ? sorted : nullptr, nunits, unit_m, orient);
@@ -2936,13 +2935,16 @@ void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, con
     if (check_err) hipLaunchKernelGGL(tick_check_kernel, dim3(kb), dim3(64), 0, s, sorted, nitems, check_err);
 }
 
-void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* zp, int layout, const LutGeom& g, int nchunk, int chunk_pts,
-                          const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials, float* evals, size_t erow, int samp_shift,
-                          hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s, int nunits, int unit_m) {
+#ifdef FGOICP_DEV_KNOBS
+// Round 3's launch logic with every variant behind its knob; false = nothing launched (the shipped kernel follows).
+static bool launch_bounds_sorted_dev(const float4* src, int ns, const float* lut, const float2* zp, int layout, const LutGeom& g, int nchunk, int chunk_pts,
+                                     const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials, float* evals, size_t erow, int samp_shift,
+                                     hipStream_t s, int nunits, int unit_m) {
+    const hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // (recorded by the caller)
     const size_t nitems = (size_t)(nsub - nunits * (unit_m - 1)) * nchunk;
-    const int lds_rows = [] { const char* e = std::getenv("FGOICP_LDS_TILES"); return e ? std::atoi(e) : 0; }();  // tuning knob / A-B (read per launch: tests toggle it): 128 or 192 rows of 16 floats per wave
+    const int lds_rows = [] { const char* e = dev_env("FGOICP_LDS_TILES"); return e ? std::atoi(e) : 0; }();  // tuning knob / A-B (read per launch: tests toggle it): 128 or 192 rows of 16 floats per wave
     if (nunits == 0 && (lds_rows == 128 || lds_rows == 192) && lut) {
-        static unsigned* d_stat = [] { unsigned* p = nullptr; if (std::getenv("FGOICP_LDS_STATS")) { (void)hipMalloc(&p, 8); (void)hipMemset(p, 0, 8); } return p; }();
+        static unsigned* d_stat = [] { unsigned* p = nullptr; if (dev_env("FGOICP_LDS_STATS")) { (void)hipMalloc(&p, 8); (void)hipMemset(p, 0, 8); } return p; }();
         if (ev_start) (void)hipEventRecord(ev_start, s);
         const dim3 lgrid((unsigned)nitems);
         if (evals) {
@@ -2962,7 +2964,7 @@ void launch_bounds_sorted(const float4* src, int ns, const float* lut, const flo
                 std::fprintf(stderr, "[fgoicp lds tiles] %u of %u passes staged (%.1f %%)\n", h[0], h[1], h[1] ? 100.0 * h[0] / h[1] : 0.0);
             }
         }
-        return;
+        return true;
     }
     if (nunits > 0) {  // sibling units (dense clouds): the z-pair or plain layouts, one wave per item, 4 points per lane
         if (ev_start) (void)hipEventRecord(ev_start, s);
@@ -2979,16 +2981,20 @@ void launch_bounds_sorted(const float4* src, int ns, const float* lut, const flo
         }
 #undef FGOICP_LAUNCH_UNITS
         if (ev_stop) (void)hipEventRecord(ev_stop, s);
-        return;
+        return true;
     }
+    // FGOICP_BOUNDS_ITEM (default 1): 0 = round 3's kernel family below instead of bounds_item_kernel; the variants further down imply it
+    const int item_kernel = [] { const char* e = dev_env("FGOICP_BOUNDS_ITEM"); return e ? std::atoi(e) : 1; }();  // (read per launch: tests toggle it)
+    const bool other_variant = dev_env("FGOICP_BOUNDS_VARIANT") || dev_env("FGOICP_ITEMS_PER_WG") || dev_env("FGOICP_NT_SOURCE") || dev_env("FGOICP_TRIM_VARIANT") || dev_env("FGOICP_QUAD_PAIRED") ||
+                               dev_env("FGOICP_LDS_PAD") || !zp || layout == 3;
+    if (item_kernel && !other_variant) return false;
     const TickGroup* gp = groups;
     const TickSub* sp = subs;
-    if (ev_start) (void)hipEventRecord(ev_start, s);
-    static const int variant = [] { const char* e = std::getenv("FGOICP_BOUNDS_VARIANT"); return e ? std::atoi(e) : 2; }();  // tuning knob (2 = default: one wave, 4 points per lane)
+    static const int variant = [] { const char* e = dev_env("FGOICP_BOUNDS_VARIANT"); return e ? std::atoi(e) : 2; }();  // tuning knob (2 = default: one wave, 4 points per lane)
     const dim3 grid((unsigned)nitems);
-    static const int wpg = [] { const char* e = std::getenv("FGOICP_ITEMS_PER_WG"); return e ? std::atoi(e) : 1; }();   // tuning knob: 1, 2 or 4 one-wave items per workgroup
-    static const int nt_src = [] { const char* e = std::getenv("FGOICP_NT_SOURCE"); return e ? std::atoi(e) : 0; }();   // tuning knob: non-temporal source loads
-    static const unsigned lds_pad = [] { const char* e = std::getenv("FGOICP_LDS_PAD"); return e ? (unsigned)std::atoi(e) : 0u; }();  // tuning knob: unused dynamic LDS per workgroup = fewer resident waves per CU
+    static const int wpg = [] { const char* e = dev_env("FGOICP_ITEMS_PER_WG"); return e ? std::atoi(e) : 1; }();   // tuning knob: 1, 2 or 4 one-wave items per workgroup
+    static const int nt_src = [] { const char* e = dev_env("FGOICP_NT_SOURCE"); return e ? std::atoi(e) : 0; }();   // tuning knob: non-temporal source loads
+    static const unsigned lds_pad = [] { const char* e = dev_env("FGOICP_LDS_PAD"); return e ? (unsigned)std::atoi(e) : 0u; }();  // tuning knob: unused dynamic LDS per workgroup = fewer resident waves per CU
 #define FGOICP_LAUNCH_SORTED(T, PP, Z, TR) \
     hipLaunchKernelGGL((bounds_sorted_kernel<T, PP, Z, TR>), grid, dim3(T), lds_pad, s, src, ns, lut, zp, g, gp, sp, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems)
 #define FGOICP_LAUNCH_WPG(Z, W, N) \
@@ -2999,10 +3005,10 @@ void launch_bounds_sorted(const float4* src, int ns, const float* lut, const flo
         if (z == 3) { if (wpg == 4 && nt_src) FGOICP_LAUNCH_WPG(3, 4, 1); else if (wpg == 4) FGOICP_LAUNCH_WPG(3, 4, 0); else if (wpg == 2 && nt_src) FGOICP_LAUNCH_WPG(3, 2, 1); else if (wpg == 2) FGOICP_LAUNCH_WPG(3, 2, 0); else if (nt_src) FGOICP_LAUNCH_WPG(3, 1, 1); else done = false; }
         else if (z == 1) { if (wpg == 4 && nt_src) FGOICP_LAUNCH_WPG(1, 4, 1); else if (wpg == 4) FGOICP_LAUNCH_WPG(1, 4, 0); else if (wpg == 2 && nt_src) FGOICP_LAUNCH_WPG(1, 2, 1); else if (wpg == 2) FGOICP_LAUNCH_WPG(1, 2, 0); else if (nt_src) FGOICP_LAUNCH_WPG(1, 1, 1); else done = false; }
         else done = false;
-        if (done) { if (ev_stop) (void)hipEventRecord(ev_stop, s); return; }
+        if (done) return true;
     }
     if (evals) {
-        static const int trim_variant = [] { const char* e = std::getenv("FGOICP_TRIM_VARIANT"); return e ? std::atoi(e) : 2; }();  // tuning knob (2 = 64x4, default)
+        static const int trim_variant = [] { const char* e = dev_env("FGOICP_TRIM_VARIANT"); return e ? std::atoi(e) : 2; }();  // tuning knob (2 = 64x4, default)
         if (trim_variant == 2) {
             if (zp && layout == 4) FGOICP_LAUNCH_SORTED(64, 4, 5, 1); else
             if (zp && layout == 2) FGOICP_LAUNCH_SORTED(64, 4, 3, 1); else if (zp) FGOICP_LAUNCH_SORTED(64, 4, 1, 1); else FGOICP_LAUNCH_SORTED(64, 4, 0, 1);
@@ -3012,7 +3018,7 @@ void launch_bounds_sorted(const float4* src, int ns, const float* lut, const flo
     } else if (zp && layout == 4) {
         FGOICP_LAUNCH_SORTED(64, 4, 5, 0);
     } else if (zp && layout == 2) {
-        static const int paired = [] { const char* e = std::getenv("FGOICP_QUAD_PAIRED"); return e ? std::atoi(e) : 1; }();  // tuning knob (1 = default)
+        static const int paired = [] { const char* e = dev_env("FGOICP_QUAD_PAIRED"); return e ? std::atoi(e) : 1; }();  // tuning knob (1 = default)
         if (variant == 2 && paired) FGOICP_LAUNCH_SORTED(64, 4, 3, 0); else
         if (variant == 0) FGOICP_LAUNCH_SORTED(256, 1, 2, 0); else if (variant == 2) FGOICP_LAUNCH_SORTED(64, 4, 2, 0);
         else if (variant == 3) FGOICP_LAUNCH_SORTED(64, 2, 2, 0); else if (variant == 4) FGOICP_LAUNCH_SORTED(64, 1, 2, 0); else FGOICP_LAUNCH_SORTED(128, 2, 2, 0);
@@ -3024,6 +3030,52 @@ void launch_bounds_sorted(const float4* src, int ns, const float* lut, const flo
     }
 #undef FGOICP_LAUNCH_SORTED
 #undef FGOICP_LAUNCH_WPG
+    return true;
+}
+
+#endif  // FGOICP_DEV_KNOBS
+
+// The bounds kernel of a window.  Shipped: bounds_item_kernel (bounds_item.hpp), one instantiation per packed layout x trimmed x wide
+// addressing x weight quantisation.  Development build: FGOICP_BOUNDS_ITEM=0 runs round 3's bounds_sorted_kernel family instead (the
+// bit reference of tests/test_gpu_ops.py::test_item_kernel_keeps_every_bit), and the variants that were measured and rejected —
+// sibling units, LDS tiles, several items per workgroup, other thread / point shapes — stay selectable by their knobs (NOTES.md).
+template <int LAYOUT, int TRIM>
+static void launch_item(const float4* src, int ns, const char* lutp, const LutGeom& g, bool wide, const TickGroup* groups, const TickSub* subs, const unsigned* sorted, int nchunk,
+                        int chunk_pts, double2* partials, float* evals, size_t erow, int samp_shift, unsigned nitems, hipStream_t s) {
+    const dim3 grid(nitems), block(64);
+#define FGOICP_ITEM(W, Q) hipLaunchKernelGGL((bounds_item_kernel<LAYOUT, TRIM, W, Q>), grid, block, 0, s, src, ns, lutp, g, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, nitems)
+    if (wide) { if (g.quantize) FGOICP_ITEM(true, true); else FGOICP_ITEM(true, false); }
+    else { if (g.quantize) FGOICP_ITEM(false, true); else FGOICP_ITEM(false, false); }
+#undef FGOICP_ITEM
+}
+
+void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* zp, int layout, const LutGeom& g, int nchunk, int chunk_pts,
+                          const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials, float* evals, size_t erow, int samp_shift,
+                          hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s, int nunits, int unit_m) {
+    const size_t nitems = (size_t)(nsub - nunits * (unit_m - 1)) * nchunk;
+    if (ev_start) (void)hipEventRecord(ev_start, s);
+    bool done = false;
+#ifdef FGOICP_DEV_KNOBS
+    done = launch_bounds_sorted_dev(src, ns, lut, zp, layout, g, nchunk, chunk_pts, groups, subs, nsub, sorted, partials, evals, erow, samp_shift, s, nunits, unit_m);
+#endif
+    if (!done && zp && (layout == 1 || layout == 2 || layout == 4) && nunits == 0) {
+        const size_t nodes = (size_t)g.px * g.py * g.pz;
+        // 32-bit texel addressing: the row number (z * py + y) must fit the signed 24-bit multiply and the byte offsets of the packed copy 32 bits
+        const size_t bytes = layout == 4 ? (size_t)((g.px + 2) / 3) * ((g.py + 1) / 2) * g.pz * 8 * sizeof(float4) : nodes * (layout == 2 ? sizeof(float4) : sizeof(float2));
+        const bool wide = (size_t)g.py * g.pz > ((size_t)1 << 23) || bytes + 64 > ((size_t)1 << 32);
+        const char* lutp = reinterpret_cast<const char*>(zp);
+        if (evals) {
+            if (layout == 1) launch_item<1, 1>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, s);
+            else if (layout == 2) launch_item<3, 1>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, s);
+            else launch_item<5, 1>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, s);
+        } else {
+            if (layout == 1) launch_item<1, 0>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, s);
+            else if (layout == 2) launch_item<3, 0>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, s);
+            else launch_item<5, 0>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, s);
+        }
+        done = true;
+    }
+    if (!done) std::fprintf(stderr, "fgoicp: no bounds kernel for packed layout %d in this build\n", layout);  // (ctx_create only chooses layouts 1, 2, 4 outside the development build)
     if (ev_stop) (void)hipEventRecord(ev_stop, s);
 }
 
@@ -3110,13 +3162,13 @@ void launch_nn_scan(const float4* pts, int n, const BvhView& t, const float* lut
     // chip is already full (measured: 437k queries 1 -> 4 waves 1.75x faster, 40k queries 4 -> 8 waves +4 %, 16 waves slower).
     int nparts = 4;
     while (nparts < 8 && groups * nparts < 4096) nparts <<= 1;
-    static const int forced = [] { const char* e = std::getenv("FGOICP_NN_PARTS"); const int v = e ? std::atoi(e) : 0; return v; }();  // tuning knob
+    static const int forced = [] { const char* e = dev_env("FGOICP_NN_PARTS"); const int v = e ? std::atoi(e) : 0; return v; }();  // tuning knob
     if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16) nparts = forced;
     // candidate leaves claimed dynamically by the waves of a block while the grid does not fill the device (the scan then lasts as long as its
     // slowest block: 40k points, -3 %), dealt round-robin when it does (437k / 1M points: the LDS claims cost 1-2 % and buy nothing)
-    static const int dyn_env = [] { const char* e = std::getenv("FGOICP_NN_CLAIM"); return e ? std::atoi(e) : -1; }();  // tuning knob / A-B: 0 / 1 force
+    static const int dyn_env = [] { const char* e = dev_env("FGOICP_NN_CLAIM"); return e ? std::atoi(e) : -1; }();  // tuning knob / A-B: 0 / 1 force
     const int dyn = dyn_env >= 0 ? dyn_env : (groups * nparts <= 8192 ? 1 : 0);
-    const int flat = [] { const char* e = std::getenv("FGOICP_NN_FLAT"); return e ? std::atoi(e) : 0; }();  // tuning knob / A-B (read per launch): 1 = flat form of the walk for targets of <= 2048 leaves (measured slower: off)
+    const int flat = [] { const char* e = dev_env("FGOICP_NN_FLAT"); return e ? std::atoi(e) : 0; }();  // tuning knob / A-B (read per launch): 1 = flat form of the walk for targets of <= 2048 leaves (measured slower: off)
     if (want_index) hipLaunchKernelGGL(nn_scan_kernel<1>, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, skip_lb, skip_u, out, writeback, rt_dev, done, wsum, dyn, flat);
     else hipLaunchKernelGGL(nn_scan_kernel<0>, dim3(groups), dim3(64 * nparts), 0, s, pts, n, t, lut, g, make_rt(R9, t3), apply, tgt, nt, seed_idx, skip_lb, skip_u, out, writeback, rt_dev, done, wsum, dyn, flat);
 }
@@ -3127,9 +3179,9 @@ void launch_nn_scan_dual(const float4* ptsA, const float* RA9, const float* tA3,
     const int groups = (n + 63) / 64;
     int nparts = 4;
     while (nparts < 8 && groups * nparts < 4096) nparts <<= 1;
-    static const int forced = [] { const char* e = std::getenv("FGOICP_NN_PARTS"); const int v = e ? std::atoi(e) : 0; return v; }();  // tuning knob
+    static const int forced = [] { const char* e = dev_env("FGOICP_NN_PARTS"); const int v = e ? std::atoi(e) : 0; return v; }();  // tuning knob
     if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16) nparts = forced;
-    static const int dyn_env = [] { const char* e = std::getenv("FGOICP_NN_CLAIM"); return e ? std::atoi(e) : -1; }();  // tuning knob / A-B
+    static const int dyn_env = [] { const char* e = dev_env("FGOICP_NN_CLAIM"); return e ? std::atoi(e) : -1; }();  // tuning knob / A-B
     const int dyn = dyn_env >= 0 ? dyn_env : (groups * nparts <= 8192 ? 1 : 0);
     hipLaunchKernelGGL(nn_scan_dual_kernel, dim3(groups), dim3(64 * nparts), 0, s, ptsA, make_rt(RA9, tA3), applyA, ptsB, make_rt(RB9, tB3), n, t, lut, g, tgt, nt, seed_idx,
                        skip_lbA, skip_uA, skip_lbB, skip_uB, out_idx, out_min, writeback, wsumA, wsumB, dyn);

@@ -4,6 +4,7 @@
 // run that straddles a power-of-two boundary is two patches far apart), FGOICP_POINT_CURVE=0 selects
 // Z-order.  Only locality depends on the order, results do not.
 #pragma once
+#include "../host/knobs.hpp"
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
@@ -43,7 +44,7 @@ inline uint32_t hilbert30(uint32_t x, uint32_t y, uint32_t z) {
 
 // xyz: n points with the given float stride (3 for packed xyz, 4 for float4)
 inline std::vector<uint32_t> morton_order(const float* xyz, size_t n, size_t stride) {
-    static const bool hilbert = [] { const char* e = std::getenv("FGOICP_POINT_CURVE"); return e ? std::atoi(e) != 0 : true; }();  // tuning knob
+    static const bool hilbert = [] { const char* e = dev_env("FGOICP_POINT_CURVE"); return e ? std::atoi(e) != 0 : true; }();  // tuning knob
     std::vector<uint32_t> perm(n);
     std::iota(perm.begin(), perm.end(), 0u);
     if (n == 0) return perm;
@@ -215,7 +216,7 @@ inline std::vector<uint32_t> mixed_order(const float* xyz, size_t n, size_t stri
 inline std::vector<uint32_t> point_order(const float* xyz, size_t n, size_t stride, size_t leaf, int mode) {
     // inside a 64-point run: median splits down to pairs, so that neighbouring lanes hold neighbouring points (their gathers share LUT
     // lines): dragon-shape bounds kernel 5240 -> 5084 us per launch, bunny shape unchanged (profiles/r03_ab_kd_order.txt)
-    static const bool fine = [] { const char* e = std::getenv("FGOICP_KD_FINE"); return !e || std::atoi(e) != 0; }();  // tuning knob / A-B
+    static const bool fine = [] { const char* e = dev_env("FGOICP_KD_FINE"); return !e || std::atoi(e) != 0; }();  // tuning knob / A-B
     return mode == 3 ? mixed_order(xyz, n, stride, leaf, fine) : mode == 2 ? kd_order(xyz, n, stride, leaf, fine) : morton_order(xyz, n, stride);
 }
 

@@ -41,6 +41,7 @@
 #include <vector>
 
 #include "math3.hpp"
+#include "knobs.hpp"
 
 namespace fgoicp {
 
@@ -358,6 +359,11 @@ public:
     }
 
     void set_exchange(const Exchange& ex) { ex_ = ex; }
+    // The reference's log lines as events (fgoicp.cpp:15-17 "Initial ICP best error", :85-87 "New best error" after EVERY triggered ICP,
+    // improved or not): 0 = the initial ICP's (sse, R, t) as it returned them, 1 = the incumbent after a triggered ICP.  Called on the
+    // thread that runs run(); under SERIAL in the reference's order.
+    enum { kLogInitialIcp = 0, kLogNewBest = 1 };
+    void set_log(std::function<void(int, float, const Mat3f&, const Vec3f&)> fn) { log_ = std::move(fn); }
     const DriverStats& stats() const { return stats_; }
 
     float best_sse() const { std::lock_guard<std::mutex> g(mu_); return best_sse_; }
@@ -381,6 +387,7 @@ public:
         if (rc) return rc;
         set_best_sse_only(sse);  // :14 — only the error is adopted
         stats_.initial_icp_sse = sse;
+        if (log_) log_(kLogInitialIcp, sse, R, t);  // :15-17
         const auto t_bnb = clock::now();
         rc = schedule_ == kScheduleSerial ? bnb_so3_serial() : bnb_so3_round();
         stats_.seconds_bnb = seconds_since(t_bnb);
@@ -443,6 +450,12 @@ private:
         return coop_icp_ < 0 ? ns_ >= coop_min_points_ : coop_icp_ != 0;
     }
     void set_best_sse_only(float sse) { std::lock_guard<std::mutex> g(mu_); best_sse_ = sse; }
+    void log_new_best() {
+        if (!log_) return;
+        float e; Mat3f R; Vec3f t;
+        { std::lock_guard<std::mutex> g(mu_); e = best_sse_; R = best_R_; t = best_t_; }
+        log_(kLogNewBest, e, R, t);
+    }
     void set_last(const Mat3f& R, const Vec3f& t) { std::lock_guard<std::mutex> g(mu_); last_R_ = R; last_t_ = t; }
 
     // -------------------------------------------------------------------------------------------
@@ -487,13 +500,13 @@ private:
     }
 
     int bnb_so3_serial() {
-        static const int mode = [] { const char* e = std::getenv("FGOICP_SERIAL_SPECULATE"); return e ? std::atoi(e) : 2; }();
+        static const int mode = [] { const char* e = dev_env("FGOICP_SERIAL_SPECULATE"); return e ? std::atoi(e) : 2; }();
         // width cap: 256 nodes per rank (the evaluations of a speculation are dealt over the ranks: the same tick sizes per rank at any world size)
-        static const int spec_cap_env = [] { const char* e = std::getenv("FGOICP_SERIAL_WIDTH"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 0; }();  // tuning knob
+        static const int spec_cap_env = [] { const char* e = dev_env("FGOICP_SERIAL_WIDTH"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 0; }();  // tuning knob
         const int spec_cap = spec_cap_env > 0 ? spec_cap_env : 256 * (serial_sharded() ? ex_.world : 1);
         // how the width grows while the incumbent stands and where it restarts when it improves (tuning knobs; the trajectory does not depend on them)
-        static const int spec_grow = [] { const char* e = std::getenv("FGOICP_SERIAL_GROW"); const int v = e ? std::atoi(e) : 0; return v >= 2 && v <= 16 ? v : 2; }();
-        static const int spec_start = [] { const char* e = std::getenv("FGOICP_SERIAL_START"); const int v = e ? std::atoi(e) : 0; return v >= 1 && v <= 256 ? v : 1; }();
+        static const int spec_grow = [] { const char* e = dev_env("FGOICP_SERIAL_GROW"); const int v = e ? std::atoi(e) : 0; return v >= 2 && v <= 16 ? v : 2; }();
+        static const int spec_start = [] { const char* e = dev_env("FGOICP_SERIAL_START"); const int v = e ? std::atoi(e) : 0; return v >= 1 && v <= 256 ? v : 1; }();
         std::priority_queue<RotCube> rcand;
         rcand.push(RotCube(0.f, 0.f, 0.f, 1.0f, 0.f, best_sse()));
         std::map<SpecKey, SpecNode> cache;
@@ -584,6 +597,7 @@ private:
                         for (auto it = cache.begin(); it != cache.end();)  // ... and every other cached node
                             it = it->second.epoch != epoch ? cache.erase(it) : std::next(it);
                     }
+                    log_new_best();  // :85-87
                 }
                 if (!sp.valid[2 * k + 1]) { int rc = evaluate({&sp}, {2 * k + 1}); if (rc) return rc; }
                 commit(sp.tk[2 * k + 1]);
@@ -792,6 +806,7 @@ private:
                         rc = icp(children[i].q.R, bt, 0.005f, sse, R, t);
                         if (rc) return rc;
                         if (sse < loc_sse) { loc_sse = sse; loc_R = R; loc_t = t; }
+                        if (log_) log_(kLogNewBest, loc_sse, loc_R, loc_t);  // :85-87, the running best of the round
                     }
                 }
                 if (loc_sse < best_sse()) { std::lock_guard<std::mutex> g(mu_); best_sse_ = loc_sse; best_R_ = loc_R; best_t_ = loc_t; }
@@ -829,6 +844,7 @@ private:
                     rc = icp(ch.q.R, bt, 0.005f, sse, R, t);
                     if (rc) return rc;
                     if (sse < loc_sse) { loc_sse = sse; loc_R = R; loc_t = t; }
+                    if (log_) log_(kLogNewBest, loc_sse, loc_R, loc_t);  // :85-87, this rank's running best
                 }
             }
 
@@ -1217,22 +1233,22 @@ private:
     Ops& ops_;
     double t_pop_ = 0, t_ops_ = 0, t_push_ = 0;
     double t_prep_[3] = {0, 0, 0};  // FGOICP_TIMING: pops / pair matching / packing inside prepare_half
-    const bool timing_ = std::getenv("FGOICP_TIMING") != nullptr;  // host-side timing lines on stderr
-    const bool serial_shard_ = [] { const char* e = std::getenv("FGOICP_SERIAL_SHARD"); return !e || std::atoi(e) != 0; }();  // tuning knob / A-B: 0 = SERIAL on N ranks runs replicated
-    const int coop_icp_ = [] { const char* e = std::getenv("FGOICP_COOP_ICP"); return e ? (std::atoi(e) != 0 ? 1 : 0) : -1; }();  // tuning knob / A-B: 0 = every rank refines its own children alone, 1 = cooperative rounds, unset = by size
-    const size_t coop_min_points_ = [] { const char* e = std::getenv("FGOICP_COOP_MIN_POINTS"); return e ? (size_t)std::max(0L, std::atol(e)) : (size_t)131072; }();  // tuning knob
-    const int late_icp_ = [] { const char* e = std::getenv("FGOICP_LATE_ICP"); return e ? std::atoi(e) : 0; }();  // tuning knob (ROUND): 0 = off (default: measured slower, see above), 1 = with an exchange (world > 1), 2 = always
-    bool use_twins_ = [] { const char* e = std::getenv("FGOICP_TWINS"); return !e || std::atoi(e) != 0; }();  // tuning knob
-    const size_t round_batch_ = [] { const char* e = std::getenv("FGOICP_ROUND_BATCH"); const int v = e ? std::atoi(e) : 48; return (size_t)(v >= 8 && v <= 64 ? v : 48); }();  // tuning knob (ROUND only; SERIAL keeps the reference's 32)
-    const int serial_ahead_ = [] { const char* e = std::getenv("FGOICP_SERIAL_AHEAD"); return e ? std::max(0, std::atoi(e)) : 480; }();  // tuning knob: look-ahead nodes of a SERIAL task in the tail of an evaluation (0 = off)
-    const size_t serial_ahead_tasks_ = [] { const char* e = std::getenv("FGOICP_SERIAL_AHEAD_TASKS"); const int v = e ? std::atoi(e) : 0; return (size_t)(v > 0 ? v : 0); }();  // ... while its half holds at most this many tasks (0 = by cloud size: 512 / 32)
-    const size_t tick_rows_ = [] { const char* e = std::getenv("FGOICP_TICK_ROWS"); const int v = e ? std::atoi(e) : 0; return (size_t)(v > 0 ? v : 0); }();  // tuning knob (ROUND): rows a tick should carry (0 = the stepwise tail rule)
-    const size_t deal_block_ = [] { const char* e = std::getenv("FGOICP_DEAL_BLOCK"); const int v = e ? std::atoi(e) : 0; return (size_t)(v >= 1 && v <= 64 ? v : 1); }();  // tuning knob (ROUND on N ranks): consecutive children dealt to one rank
-    const bool tail_batch_fixed_ = std::getenv("FGOICP_TAIL_BATCH") != nullptr;
-    const size_t tail_batch_ = [] { const char* e = std::getenv("FGOICP_TAIL_BATCH"); const int v = e ? std::atoi(e) : 128; return (size_t)(v >= 8 && v <= 512 ? v : 0); }();  // tuning knob (ROUND): batch of a half with few tasks left (0 = off)
-    const size_t tail_tasks_ = [] { const char* e = std::getenv("FGOICP_TAIL_TASKS"); const int v = e ? std::atoi(e) : 32; return (size_t)(v >= 0 ? v : 32); }();  // ... "few" = at most this many
-    bool use_memo_ = [] { const char* e = std::getenv("FGOICP_MEMO"); return !e || std::atoi(e) != 0; }();    // tuning knob: memo of the twin task's evaluations
-    const bool overlap_stats_ = std::getenv("FGOICP_OVERLAP_STATS") != nullptr;  // diagnostic: how many nodes both tasks of a rotation cube evaluate
+    const bool timing_ = dev_env("FGOICP_TIMING") != nullptr;  // host-side timing lines on stderr
+    const bool serial_shard_ = [] { const char* e = dev_env("FGOICP_SERIAL_SHARD"); return !e || std::atoi(e) != 0; }();  // tuning knob / A-B: 0 = SERIAL on N ranks runs replicated
+    const int coop_icp_ = [] { const char* e = dev_env("FGOICP_COOP_ICP"); return e ? (std::atoi(e) != 0 ? 1 : 0) : -1; }();  // tuning knob / A-B: 0 = every rank refines its own children alone, 1 = cooperative rounds, unset = by size
+    const size_t coop_min_points_ = [] { const char* e = dev_env("FGOICP_COOP_MIN_POINTS"); return e ? (size_t)std::max(0L, std::atol(e)) : (size_t)131072; }();  // tuning knob
+    const int late_icp_ = [] { const char* e = dev_env("FGOICP_LATE_ICP"); return e ? std::atoi(e) : 0; }();  // tuning knob (ROUND): 0 = off (default: measured slower, see above), 1 = with an exchange (world > 1), 2 = always
+    bool use_twins_ = [] { const char* e = dev_env("FGOICP_TWINS"); return !e || std::atoi(e) != 0; }();  // tuning knob
+    const size_t round_batch_ = [] { const char* e = dev_env("FGOICP_ROUND_BATCH"); const int v = e ? std::atoi(e) : 48; return (size_t)(v >= 8 && v <= 64 ? v : 48); }();  // tuning knob (ROUND only; SERIAL keeps the reference's 32)
+    const int serial_ahead_ = [] { const char* e = dev_env("FGOICP_SERIAL_AHEAD"); return e ? std::max(0, std::atoi(e)) : 480; }();  // tuning knob: look-ahead nodes of a SERIAL task in the tail of an evaluation (0 = off)
+    const size_t serial_ahead_tasks_ = [] { const char* e = dev_env("FGOICP_SERIAL_AHEAD_TASKS"); const int v = e ? std::atoi(e) : 0; return (size_t)(v > 0 ? v : 0); }();  // ... while its half holds at most this many tasks (0 = by cloud size: 512 / 32)
+    const size_t tick_rows_ = [] { const char* e = dev_env("FGOICP_TICK_ROWS"); const int v = e ? std::atoi(e) : 0; return (size_t)(v > 0 ? v : 0); }();  // tuning knob (ROUND): rows a tick should carry (0 = the stepwise tail rule)
+    const size_t deal_block_ = [] { const char* e = dev_env("FGOICP_DEAL_BLOCK"); const int v = e ? std::atoi(e) : 0; return (size_t)(v >= 1 && v <= 64 ? v : 1); }();  // tuning knob (ROUND on N ranks): consecutive children dealt to one rank
+    const bool tail_batch_fixed_ = dev_env("FGOICP_TAIL_BATCH") != nullptr;
+    const size_t tail_batch_ = [] { const char* e = dev_env("FGOICP_TAIL_BATCH"); const int v = e ? std::atoi(e) : 128; return (size_t)(v >= 8 && v <= 512 ? v : 0); }();  // tuning knob (ROUND): batch of a half with few tasks left (0 = off)
+    const size_t tail_tasks_ = [] { const char* e = dev_env("FGOICP_TAIL_TASKS"); const int v = e ? std::atoi(e) : 32; return (size_t)(v >= 0 ? v : 32); }();  // ... "few" = at most this many
+    bool use_memo_ = [] { const char* e = dev_env("FGOICP_MEMO"); return !e || std::atoi(e) != 0; }();    // tuning knob: memo of the twin task's evaluations
+    const bool overlap_stats_ = dev_env("FGOICP_OVERLAP_STATS") != nullptr;  // diagnostic: how many nodes both tasks of a rotation cube evaluate
     uint64_t ov_ub_ = 0, ov_lb_ = 0, ov_both_ = 0;
     bool account_submissions_ = true;   // false while SERIAL speculates: work is accounted per committed task instead
     std::unique_ptr<WorkerPool> pool_;
@@ -1240,6 +1256,7 @@ private:
     size_t ns_;
     int schedule_, round_width_;
     Exchange ex_;
+    std::function<void(int, float, const Mat3f&, const Vec3f&)> log_;
     DriverStats stats_;
     mutable std::mutex mu_;
     float best_sse_ = kHostInf;

@@ -39,7 +39,7 @@ struct HipOps {
     int icp_background(const float* R0, const float* t0, size_t max_iter, float thr, float* sse, float* R9, float* t3, int* iters) {
         return ctx_icp_lane(ctx, 1, R0, t0, max_iter, thr, sse, R9, t3, iters);
     }
-    bool pipeline = std::getenv("FGOICP_PIPELINE") ? std::atoi(std::getenv("FGOICP_PIPELINE")) != 0 : true;  // tuning knob
+    bool pipeline = [] { const char* e = dev_env("FGOICP_PIPELINE"); return e ? std::atoi(e) != 0 : true; }();  // tuning knob
 };
 
 }  // namespace fgoicp
@@ -139,6 +139,18 @@ int fgoicp_solver_set_exchange(fgoicp_solver* s, const fgoicp_exchange* ex) {
         s->has_ex = false;
     }
     s->driver->set_exchange(e);
+    return FGOICP_OK;
+}
+
+int fgoicp_solver_set_log(fgoicp_solver* s, fgoicp_log_fn cb, void* user) {
+    if (!s) return FGOICP_ERR_INVALID_ARG;
+    if (!cb) { s->driver->set_log(nullptr); return FGOICP_OK; }
+    s->driver->set_log([s, cb, user](int event, float sse, const Mat3f& R, const Vec3f& t) {
+        // the initial ICP's translation is printed as returned (fgoicp.cpp:17), the incumbent's restored (:87, fgoicp.hpp:87-90)
+        const Vec3f tr = event == FGOICP_LOG_NEW_BEST ? t / s->scaling_factor + R * s->offset_pcs - s->offset_pct : t;
+        const float t3[3] = {tr.x, tr.y, tr.z};
+        cb(event, sse, R.m, t3, user);
+    });
     return FGOICP_OK;
 }
 

@@ -16,6 +16,7 @@ public:
         fgoicp_solver_opts o{schedule, round_width, 0u, device, trim_fraction};
         check_status(fgoicp_solver_create(&pct.data()->x, pct.size(), &pcs.data()->x, pcs.size(), lut_resolution, mse_threshold, &o, &s_),
                      "fgoicp_solver_create");
+        check_status(fgoicp_solver_set_log(s_, &FastGoICP::log_line, nullptr), "fgoicp_solver_set_log");
     }
     ~FastGoICP() { fgoicp_solver_destroy(s_); }
     FastGoICP(const FastGoICP&) = delete;
@@ -26,6 +27,7 @@ public:
         mat3 R;
         vec3 t;
         check_status(fgoicp_solver_run(s_, R.data(), &t.x), "fgoicp_solver_run");
+        Logger(LogLevel::Info) << "Searching over! Best Error: " << get_best_error() << "\n\tRotation:\n" << R << "\n\tTranslation: " << t;  // fgoicp.cpp:25-27
         return {R, t};
     }
     // interfaces for visualisation, fgoicp.hpp:31-43 (safe to poll from another thread)
@@ -35,6 +37,14 @@ public:
 
     fgoicp_run_stats stats() const { fgoicp_run_stats st{}; check_status(fgoicp_solver_stats(s_, &st), "fgoicp_solver_stats"); return st; }
     fgoicp_solver* handle() const { return s_; }
+    // the reference's own lines while the search runs (fgoicp.cpp:15-17 Info, :85-87 Debug), from the driver's log events
+    static void log_line(int event, float sse, const float* R9, const float* t3, void*) {
+        mat3 R;
+        for (int k = 0; k < 9; ++k) R.data()[k] = R9[k];
+        const vec3 t{t3[0], t3[1], t3[2]};
+        if (event == FGOICP_LOG_INITIAL_ICP) Logger(LogLevel::Info) << "Initial ICP best error: " << sse << "\n\tRotation:\n" << R << "\n\tTranslation: " << t;
+        else Logger(LogLevel::Debug) << "New best error: " << sse << "\n\tRotation:\n" << R << "\n\tTranslation: " << t;
+    }
 private:
     fgoicp_solver* s_ = nullptr;
 };

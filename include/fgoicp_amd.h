@@ -38,6 +38,10 @@ typedef enum fgoicp_status {
 /* Thread-local description of the last failure on the calling thread ("" if none). */
 const char* fgoicp_last_error(void);
 const char* fgoicp_version(void);
+/* 1 = this is the development build (-DFGOICP_DEV_KNOBS, libfgoicp_amd_dev.so): it reads the FGOICP_* tuning / A-B variables of
+ * NOTES.md from the environment and carries the kernel variants that were measured and rejected.  0 = the shipped build: it reads
+ * FGOICP_HOST_THREADS / FGOICP_HOST_SPIN only and no stray variable can change its code path. */
+int fgoicp_dev_knobs(void);
 
 /* ------------------------------------------------------------------------------------------
  * Operator level: icp::Registration + icp::NearestNeighborLUT + icp::IterativeClosestPoint3D
@@ -253,6 +257,17 @@ int fgoicp_solver_create(const float* tgt_xyz, size_t nt, const float* src_xyz, 
 void fgoicp_solver_destroy(fgoicp_solver* s);
 /* Installs the multi-GPU exchange (NULL = single process). */
 int fgoicp_solver_set_exchange(fgoicp_solver* s, const fgoicp_exchange* ex);
+/* The log lines FastGoICP::run() and branch_and_bound_SO3 emit while they run (fgoicp.cpp:15-17, :85-87), as a callback on the thread
+ * that called fgoicp_solver_run:
+ *   FGOICP_LOG_INITIAL_ICP  once, after the initial ICP: its (sse, R, t) as it returned them (t in the solver's scaled frame, as the
+ *                           reference prints it);
+ *   FGOICP_LOG_NEW_BEST     after EVERY refinement the search triggers (improved or not, as the reference): the incumbent's error and
+ *                           rotation and its translation RESTORED to the callers' frame (restore_translation, fgoicp.hpp:87-90).
+ * Under FGOICP_SCHEDULE_SERIAL the events come in the reference's order.  cb = NULL removes the hook.  icp::FastGoICP (include/fgoicp/
+ * fgoicp.hpp) installs one that prints the reference's lines through icp::Logger. */
+enum { FGOICP_LOG_INITIAL_ICP = 0, FGOICP_LOG_NEW_BEST = 1 };
+typedef void (*fgoicp_log_fn)(int event, float sse, const float* R9, const float* t3, void* user);
+int fgoicp_solver_set_log(fgoicp_solver* s, fgoicp_log_fn cb, void* user);
 /* Replaces FastGoICP::run() (fgoicp.cpp:10-30): returns R and the restored translation
  * (fgoicp.hpp:87-90). */
 int fgoicp_solver_run(fgoicp_solver* s, float* R_out9, float* t_out3);

@@ -26,6 +26,40 @@ except Exception:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "dev_knobs: sets FGOICP_* A/B knobs, which only the development build reads (libfgoicp_amd_dev.so; "
+                            "tests/test_gpu_dev_build.py runs these in one child process with FGOICP_LIB pointing at it)")
+
+
+# What the SHIPPED library still reads from the environment (csrc/host/knobs.hpp); setting anything else is an A/B knob.
+_DEPLOYMENT_VARS = {"FGOICP_HOST_THREADS", "FGOICP_HOST_SPIN", "FGOICP_MULTI_DEVICES", "FGOICP_LIB", "FGOICP_ORACLE_THREADS", "FGOICP_EXTRA_CXXFLAGS"}
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU tests that set an FGOICP_* knob (monkeypatch.setenv / an env dict) exercise variants the shipped build does not carry or
+    thresholds it does not read: they get the `dev_knobs` marker, and are skipped unless the loaded library is the development build."""
+    import inspect
+    import re
+    dev = None
+    for item in items:
+        if item.get_closest_marker("gpu") is None:
+            continue
+        fn = getattr(item, "function", None)
+        try:
+            src = inspect.getsource(fn) if fn is not None else ""
+        except (OSError, TypeError):
+            src = ""
+        knobs = set(re.findall(r"setenv\(\s*\"(FGOICP_[A-Z_0-9]+)\"", src)) - _DEPLOYMENT_VARS
+        if knobs and item.get_closest_marker("dev_knobs") is None:
+            item.add_marker(pytest.mark.dev_knobs)
+        if item.get_closest_marker("dev_knobs") is not None:
+            if dev is None:
+                try:
+                    import fgoicp_amd
+                    dev = fgoicp_amd.dev_knobs()
+                except Exception:
+                    dev = False
+            if not dev:
+                item.add_marker(pytest.mark.skip(reason="needs the development build (FGOICP_LIB=.../libfgoicp_amd_dev.so): run by tests/test_gpu_dev_build.py"))
 
 
 def _has_gpu():

@@ -18,10 +18,11 @@ def build():
     from oracle import pyoracle
     pyoracle.build()
     deps = [os.path.join(_DIR, "harness.cpp"), os.path.join(_REPO, "fast-go-icp_amd/csrc/host/driver.hpp"), os.path.join(_REPO, "fast-go-icp_amd/csrc/device/morton.hpp"),
-            os.path.join(_REPO, "fast-go-icp_amd/csrc/host/math3.hpp"), os.path.join(_REPO, "oracle/libgoicp_oracle.so")]
+            os.path.join(_REPO, "fast-go-icp_amd/csrc/host/math3.hpp"), os.path.join(_REPO, "oracle/libgoicp_oracle.so"),
+            os.path.join(_DIR, "oracle_ops.hpp"), os.path.join(_REPO, "fast-go-icp_amd/csrc/device/slab.hpp"), os.path.join(_REPO, "fast-go-icp_amd/csrc/host/knobs.hpp")]
     if not os.path.exists(_SO) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps):
         tmp = f"{_SO}.{os.getpid()}.tmp"  # several ranks of a world-size-N test may get here together: build aside, rename atomically
-        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fopenmp", "-shared", "-o", tmp,
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-DFGOICP_DEV_KNOBS", "-fopenmp", "-shared", "-o", tmp,
                         os.path.join(_DIR, "harness.cpp"), "-L" + os.path.join(_REPO, "oracle"), "-lgoicp_oracle",
                         "-Wl,-rpath," + os.path.join(_REPO, "oracle")], check=True)
         os.replace(tmp, _SO)
@@ -118,6 +119,17 @@ def point_order(xyz, leaf=64, mode=2, fine=True):
     L.harness_point_order.restype = None
     L.harness_point_order(_f(xyz), len(xyz), int(leaf), int(mode), int(bool(fine)), perm.ctypes.data_as(C.POINTER(C.c_uint32)))
     return perm
+
+
+def slab_d2(n3, a, b, q):
+    """csrc/device/slab.hpp: squared slab distance (with its rounding allowance) of the queries q (m, 3) from {p: a <= n.p <= b}"""
+    n3 = np.ascontiguousarray(n3, np.float32); q = np.ascontiguousarray(q, np.float32)
+    out = np.empty(len(q), np.float32)
+    L = lib()
+    L.harness_slab_d2.argtypes = [_fp, C.c_float, C.c_float, _fp, C.c_size_t, _fp]
+    L.harness_slab_d2.restype = None
+    L.harness_slab_d2(_f(n3), float(a), float(b), _f(q), len(q), _f(out))
+    return out
 
 
 def rotation(x, y, z):

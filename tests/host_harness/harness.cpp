@@ -3,6 +3,7 @@
 // multi-rank exchange) can be checked without a GPU.  This translation unit lives under tests/ and
 // is never part of libfgoicp_amd.so; the product instantiates the template with HIP only.
 #include "oracle_ops.hpp"
+#include "../../fast-go-icp_amd/csrc/device/slab.hpp"
 
 using namespace host_harness;
 
@@ -88,6 +89,10 @@ void harness_svd3(const double* A9, double* U9, double* S3, double* V9) {
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) A[i][j] = A9[3 * i + j];
     svd3_jacobi(A, U, S3, V);
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { U9[3 * i + j] = U[i][j]; V9[3 * i + j] = V[i][j]; }
+}
+// the leaf-slab test of the exact scans (csrc/device/slab.hpp), n queries against one slab
+void harness_slab_d2(const float* n3, float a, float b, const float* q_xyz, size_t n, float* out) {
+    for (size_t i = 0; i < n; ++i) out[i] = fgoicp::slab_d2(n3[0], n3[1], n3[2], a, b, q_xyz[3 * i], q_xyz[3 * i + 1], q_xyz[3 * i + 2]);
 }
 // the point orders of csrc/device/morton.hpp (host code): mode 1 = curve, 2 = k-d cells of `leaf` points (+ in-leaf order), 3 = density split
 void harness_point_order(const float* xyz, size_t n, size_t leaf, int mode, int fine, uint32_t* perm_out) {

@@ -36,6 +36,13 @@ def test_cli_runs_and_matches_library(fg, gpu_required, tmp_path):
     for needle in ("Reading configurations from cfg.toml", "Fast Go-ICP Configurations", "Target point cloud (700) loaded from",
                    "Source point cloud (", "Initial ICP best error:", "Searching over! Best Error:", "Fast Go-ICP finished, time elapsed:"):
         assert needle in out, needle
+    # the reference's lines in the reference's order (fgoicp.cpp:15-17, :85-87, :25-27): the initial ICP with its rotation and translation
+    # BEFORE the search, a Debug "New best error" block after every refinement the search triggers, then "Searching over!"
+    plain = re.sub(r"\x1b\[[0-9;]*m", "", out)
+    i0, i1 = plain.index("Initial ICP best error:"), plain.index("Searching over! Best Error:")
+    assert re.search(r"Initial ICP best error: [0-9.eE+-]+\n\tRotation:\n(\t[-0-9.]+\t[-0-9.]+\t[-0-9.]+\n){3}\tTranslation: [-0-9.]+\t[-0-9.]+\t[-0-9.]+", plain)
+    news = [m.start() for m in re.finditer(r"\[Debug [0-9:]+\] New best error: [0-9.eE+-]+\n\tRotation:\n", plain)]
+    assert news and all(i0 < k < i1 for k in news)
     ns = int(re.search(r"Source point cloud \((\d+)\)", out).group(1))
     assert 150 < ns <= 250  # source_subsample clamps to 0.5: floor(500 * 0.5) kept at most
     txt = (tmp_path / "out.toml").read_text()
@@ -63,6 +70,7 @@ def test_cli_runs_and_matches_library(fg, gpu_required, tmp_path):
     rot = np.array([[float(v) for v in re.findall(r"[-+0-9.eE]+", line)] for line in re.search(r"rotation = \[\n(.*?)\n\]", txt, re.S).group(1).splitlines()], np.float64)
     tr = np.array([float(v) for v in re.findall(r"[-+0-9.eE]+", re.search(r"^translation = \[(.*)\]$", txt, re.M).group(1))])
     assert sse == pytest.approx(float(o["best_sse"]), rel=1e-5) and np.allclose(rot, o["R"], atol=1e-5) and np.allclose(tr, o["t"], atol=1e-5)
+    assert len(news) == int(re.search(r"^icp_runs = (\d+)$", txt, re.M).group(1)) - 2  # every ICP but the initial and the final one is a triggered refinement
     st_sub = int(re.search(r"^subcubes = (\d+)$", txt, re.M).group(1))
     assert st_sub == o["stats"]["trans_cubes"]  # the CLI's default schedule follows the reference's exploration order
     # missing config -> usage + non-zero exit; bad extension -> runtime_error (uncaught upstream too)

@@ -660,6 +660,56 @@ def test_packed_lut_layouts_keep_every_bit(fg, gpu_required, monkeypatch, worklo
             assert np.array_equal(lb0.view(np.uint32), lb1.view(np.uint32)) and np.array_equal(ub0.view(np.uint32), ub1.view(np.uint32)), layout
 
 
+@pytest.mark.parametrize("flags", [0, "noquant"])
+@pytest.mark.parametrize("workload,res,chunk", [("tiny", 0.05, "256"), ("small", 0.02, "256"), ("small", 0.013, "1024")])
+def test_item_kernel_keeps_every_bit(fg, gpu_required, monkeypatch, workload, res, chunk, flags):
+    """bounds_item_kernel (round 4: the shipped bounds kernel — packed fp32, 32-bit texel addressing, per-pass item kinds; csrc/device/bounds_item.hpp)
+    against round 3's bounds_sorted_kernel family (development build, FGOICP_BOUNDS_ITEM=0) on the same submission: every bound bit for bit —
+    under the z-pair, yz-quad and apron layouts, trimmed or not, twins (dual items) included, multi-pass items, a cloud whose size is not a multiple
+    of a pass (the tail pass with missing points), CUDA's 1.8 fixed-point weights on and off (FGOICP_FLAG_NO_WEIGHT_QUANT)."""
+    import ctypes as C
+    tgt, src, R_gt, t_gt = fg.synth.workload(workload, angle_deg=30.0)
+    pct, pcs, off_t, off_s, scale, bounds = fg.synth.preprocess(tgt, src)
+    pcs = pcs[:len(pcs) - 3]  # never a whole number of passes
+    monkeypatch.setenv("FGOICP_SMALL_TICK", "0")
+    monkeypatch.setenv("FGOICP_CHUNK_PTS", chunk)
+    lib = fg._lib.load()
+    rng = np.random.default_rng(21)
+    rn = [fg.RotNode(0.125, -0.25, 0.375, 0.25), fg.RotNode(-0.375, 0.125, 0.25, 0.125)]
+    ta, tb, tc, td = _tnodes(rng, 20, 0.25), _tnodes(rng, 24, 0.25), _tnodes(rng, 9, 0.125), _tnodes(rng, 7, 0.125)
+    tb[3:15] = ta[5:17]  # twelve twins between group 0 (fix_rot) and group 1
+    R9 = np.concatenate([fg.nodes.to_glm(n.q.R) for n in (rn[0], rn[0], rn[1], rn[1])]).astype(np.float32)
+    spans = np.array([rn[0].span, rn[0].span, rn[1].span, rn[1].span], np.float32)
+    fix = np.array([1, 0, 1, 0], np.int32)
+    offs = np.array([0, 20, 44, 53, 60], np.int32)
+    tn4 = np.ascontiguousarray(np.concatenate([ta, tb, tc, td]), np.float32)
+    twin = np.full(60, -1, np.int32)
+    for k in range(12):
+        twin[5 + k], twin[20 + 3 + k] = 20 + 3 + k, 5 + k
+    fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
+    out = {}
+    for layout in ("1", "2", "4"):
+        monkeypatch.setenv("FGOICP_LUT_ZPAIR", layout)
+        for trim in (False, True):
+            for item in ("1", "0"):
+                monkeypatch.setenv("FGOICP_BOUNDS_ITEM", item)
+                reg = fg.Registration(pct, pcs, bounds, res, flags=fg.FLAG_NO_WEIGHT_QUANT if flags else 0)
+                if trim:
+                    reg.set_inliers(int(0.8 * len(pcs)))
+                lb, ub = np.zeros(60, np.float32), np.zeros(60, np.float32)
+                assert lib.fgoicp_bounds_submit_twins(reg._h, 0, 4, R9.ctypes.data_as(fp), spans.ctypes.data_as(fp), fix.ctypes.data_as(ip), offs.ctypes.data_as(ip),
+                                                      tn4.ctypes.data_as(fp), twin.ctypes.data_as(ip)) == 0
+                assert lib.fgoicp_bounds_collect(reg._h, 0, lb.ctypes.data_as(fp), ub.ctypes.data_as(fp)) == 0
+                out[(layout, trim, item)] = (lb, ub)
+                reg.close()
+            a, b = out[(layout, trim, "1")], out[(layout, trim, "0")]
+            assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), (layout, trim)
+            assert float(a[1].max()) > 0
+    for trim in (False, True):  # and the layouts among each other
+        for layout in ("2", "4"):
+            assert np.array_equal(out[("1", trim, "1")][1].view(np.uint32), out[(layout, trim, "1")][1].view(np.uint32))
+
+
 def test_sibling_units_whole_run(fg, gpu_required, monkeypatch):
     """A whole FastGoICP::run() with and without sibling units: same counters, same result bits (twins and the memo included)."""
     tgt, src, R_gt, t_gt = fg.synth.workload("small", angle_deg=150.0, min_angle_deg=110.0)

@@ -218,3 +218,48 @@ def test_density_split_order_puts_scattered_points_last():
     r = np.linalg.norm(p[perm], axis=1)
     on_surface = np.abs(r - 1.0) < 1e-3
     assert on_surface[:19000].mean() > 0.93 and on_surface[-4000:].mean() < 0.05  # an outlier that shares its grid cell counts as dense
+
+
+def test_leaf_slab_distance_never_exceeds_the_exact_one():
+    """csrc/device/slab.hpp: the slab test of the exact scans prunes a leaf when slab_d2(q) exceeds the query's bound, so in
+    fp32 it must stay a LOWER bound of the exact squared distance of q from the slab along n — also when the three products of n.q cancel:
+    a plane through the origin at 45 degrees, clouds with a large common offset (+100), queries placed right on the pruning boundary.  Exact
+    side: numpy longdouble on the same fp32 inputs."""
+    from tests.host_harness import slab_d2
+    rng = np.random.default_rng(11)
+    f32, ld = np.float32, np.longdouble
+    worst = 0.0
+    cases = []
+    for off in (0.0, 1.0, 100.0, 1000.0):
+        for _ in range(40):
+            n = rng.normal(size=3)
+            cases.append((n / np.linalg.norm(n), off))
+        cases.append((np.array([1.0, 1.0, 0.0]) / np.sqrt(2.0), off))      # 45 degrees
+        cases.append((np.array([1.0, -1.0, 1.0]) / np.sqrt(3.0), off))
+    for n, off in cases:
+        nf = (n * (1.0 - 1e-6)).astype(f32)                                  # bvh.hip: |n| <= 1 after rounding
+        c = rng.uniform(-1, 1, 3) + off                                      # the leaf's centre; off: a cloud far from the origin
+        if off == 0.0 and rng.random() < 0.5:
+            c = c - n * (n @ c)                                              # a plane through the origin: n.c = 0, the products cancel
+        pts = (c + rng.normal(scale=0.01, size=(32, 3)) - n * rng.normal(scale=1e-4, size=(32, 1))).astype(f32)
+        pr = (pts.astype(ld) * nf.astype(ld)).sum(axis=1)
+        a, b = f32(np.nextafter(f32(pr.min()), f32(-np.inf))), f32(np.nextafter(f32(pr.max()), f32(np.inf)))  # outward, as bvh.hip stores them
+        # queries: everywhere, and a batch a hair outside either plane (where an over-estimate flips the decision)
+        q_far = (c + rng.normal(scale=2.0, size=(400, 3))).astype(f32)
+        t = rng.normal(scale=1.0, size=(400, 3))
+        t -= np.outer(t @ n, n)                                              # in-plane offsets
+        eps = np.concatenate([rng.uniform(0, 1e-5, 200), rng.uniform(0, 1e-7, 200)]) * max(1.0, off)
+        sign = np.where(rng.random(400) < 0.5, 1.0, -1.0)
+        q_edge = (c + t + np.outer(sign * (0.02 + eps), n)).astype(f32)
+        for qi, q in enumerate((q_far, q_edge)):
+            got = slab_d2(nf, a, b, q).astype(ld)
+            nq = (q.astype(ld) * nf.astype(ld)).sum(axis=1)
+            s = np.maximum(nq - ld(b), ld(a) - nq)
+            exact = np.where(s > 0, s * s, ld(0))
+            assert np.all(got <= exact), (nf, off, float((got - exact).max()))
+            pos = exact > 1e-2  # (far queries only: right at the boundary the allowance rightly leaves nothing)
+            if qi == 0 and pos.any():
+                worst = max(worst, float(np.max(1 - np.sqrt(got[pos] / exact[pos]))))
+    assert worst < 0.05  # the allowance costs the far queries (the ones the slab exists for) less than 5 % of their distance even at offset 1000
+    # and it does prune: a query two leaf sizes away along n is still separated
+    assert slab_d2(np.array([0, 0, 1], f32) * f32(1 - 1e-6), -0.01, 0.01, np.array([[0.3, 0.2, 0.5]], f32))[0] > 0.2

@@ -20,7 +20,7 @@ def build():
     if os.path.exists(EXE) and all(os.path.getmtime(s) <= os.path.getmtime(EXE) for s in SOURCES):
         return
     subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-ffp-contract=off",
-                    "-fopenmp", "-o", EXE, SOURCES[0], SOURCES[2]], check=True, cwd=HERE)
+                    "-DFGOICP_DEV_KNOBS", "-fopenmp", "-o", EXE, SOURCES[0], SOURCES[2]], check=True, cwd=HERE)
 
 
 def test_multi_rank_core_is_clean_under_asan_and_ubsan():
