@@ -10,7 +10,7 @@ c_int_p = C.POINTER(C.c_int)
 
 
 class CtxInfo(C.Structure):
-    _fields_ = [("lut_dims", C.c_int * 3), ("lut_layout", C.c_int), ("lut_nodes", C.c_uint64), ("lut_bytes", C.c_uint64),
+    _fields_ = [("struct_size", C.c_size_t), ("lut_dims", C.c_int * 3), ("lut_layout", C.c_int), ("lut_nodes", C.c_uint64), ("lut_bytes", C.c_uint64),
                 ("source_points_per_face_voxel", C.c_double), ("points_per_item", C.c_int), ("items_per_evaluation", C.c_int),
                 ("max_subcubes_per_window", C.c_int), ("source_order", C.c_int), ("tree_order", C.c_int)]
 
@@ -24,8 +24,19 @@ class Exchange(C.Structure):
     ALLREDUCE_MIN = C.CFUNCTYPE(C.c_int, c_float_p, C.c_size_t, C.c_void_p)
     ALLGATHER = C.CFUNCTYPE(C.c_int, c_float_p, c_float_p, C.c_size_t, C.c_void_p)
     ALLGATHER_DEVICE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
-    _fields_ = [("rank", C.c_int), ("world_size", C.c_int), ("allreduce_min", ALLREDUCE_MIN),
+    _fields_ = [("struct_size", C.c_size_t), ("rank", C.c_int), ("world_size", C.c_int), ("allreduce_min", ALLREDUCE_MIN),
                 ("allgather", ALLGATHER), ("user", C.c_void_p), ("allgather_device", ALLGATHER_DEVICE)]  # the last one optional (NULL: no cooperative ICP)
+
+    def __init__(self, rank=0, world_size=1, allreduce_min=None, allgather=None, user=None, allgather_device=None):
+        super().__init__()
+        self.struct_size = C.sizeof(Exchange)  # ABI 2: the library reads no byte beyond it
+        self.rank, self.world_size, self.user = rank, world_size, user
+        if allreduce_min is not None:
+            self.allreduce_min = allreduce_min
+        if allgather is not None:
+            self.allgather = allgather
+        if allgather_device is not None:
+            self.allgather_device = allgather_device
 
 
 class SolverOpts(C.Structure):
@@ -54,6 +65,7 @@ _SIGS = {
     "fgoicp_last_error": (C.c_char_p, []),
     "fgoicp_version": (C.c_char_p, []),
     "fgoicp_dev_knobs": (C.c_int, []),
+    "fgoicp_abi_version": (C.c_int, []),
     "fgoicp_ctx_create": (C.c_int, [c_float_p, C.c_size_t, c_float_p, C.c_size_t, c_float_p, C.c_float, C.c_int, C.c_uint,
                                     C.POINTER(C.c_void_p)]),
     "fgoicp_ctx_destroy": (None, [C.c_void_p]),

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -564,20 +565,26 @@ int ctx_procrustes_device(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, Mat3f* R_out, V
 // iteration k, so they run next to each other — both are latency chains that fill half the device at 40k points.  The pass of
 // iteration k+1 is speculative (the loop may end on the SSE of iteration k); it is drained before returning.  Same kernels,
 // same arithmetic, same order of every sum as the one-stream loop (FGOICP_ICP_OVERLAP=0).
+#ifdef FGOICP_DEV_KNOBS
 static int lane_icp_device(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9,
                            float* t_out3, int* iters_out);
-static int lane_icp_dual(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9,
-                         float* t_out3, int* iters_out);
 static int lane_icp_gated(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9,
                           float* t_out3, int* iters_out);
+#endif
+static int lane_icp_dual(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9,
+                         float* t_out3, int* iters_out);
 static int lane_icp(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3,
                     int* iters_out) {
+#ifdef FGOICP_DEV_KNOBS
     if (c->icp_device && c->icp_overlap && !c->brute_force_nn && !c->inliers) return lane_icp_device(c, L, R0, t0, max_iter, thr, sse_out, R_out9, t_out3, iters_out);
+#endif
     // one walk for both scans where the device is full anyway (clouds beyond 262 144 points, trimmed runs: -3 ... -5 % of the ICP time); below
     // that the two scans of an iteration overlap on two streams and a wave carrying both query sets only lengthens the chain (40k points:
     // 51-53 -> 55-56 us per iteration) — FGOICP_ICP_DUAL = 1 / 0 forces either
+#ifdef FGOICP_DEV_KNOBS
     if (c->icp_gated && c->icp_gate_ok && c->icp_dual_env <= 0 && c->icp_overlap && icp_fused(c) && L.sig_b && L.sig_a)
         return lane_icp_gated(c, L, R0, t0, max_iter, thr, sse_out, R_out9, t_out3, iters_out);
+#endif
     const bool dual = c->icp_dual_env >= 0 ? c->icp_dual_env != 0 : !icp_fused(c);
     if (dual && c->icp_overlap && !c->brute_force_nn) return lane_icp_dual(c, L, R0, t0, max_iter, thr, sse_out, R_out9, t_out3, iters_out);
     HIPCHK(hipSetDevice(c->device));  // per host thread
@@ -665,6 +672,7 @@ static int lane_icp(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0, cons
     return FGOICP_OK;
 }
 
+#ifdef FGOICP_DEV_KNOBS
 // The same loop advanced ON THE DEVICE (kernels.hip, icp_step_kernel): no host round trip inside the loop.  Per iteration j the
 // host enqueues, without waiting for anything,
 //   stream B:  step_j   (waits for the SSE partials of iteration j-1: loop test of :94, then SVD, compose -> state)
@@ -747,6 +755,8 @@ static int lane_icp_device(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R
     return FGOICP_OK;
 }
 
+#endif  // FGOICP_DEV_KNOBS (device-resident loop)
+
 int ctx_icp(fgoicp_ctx* c, const float* R0, const float* t0, size_t max_iter, float thr, float* sse_out, float* R_out9, float* t_out3, int* iters_out) {
     return lane_icp(c, c->lanes[0], R0, t0, max_iter, thr, sse_out, R_out9, t_out3, iters_out);
 }
@@ -774,12 +784,18 @@ int ctx_icp_coop(fgoicp_ctx* c, int rank, int world, int (*gather)(void* dev_buf
         (void)hipFree(c->d_coop);
         c->d_coop = nullptr;
         c->coop_cap = 0;
-        HIPCHK(hipMalloc(&c->d_coop, sizeof(uint32_t) * 2 * per * world));
-        HIPCHK(hipMemset(c->d_coop, 0, sizeof(uint32_t) * 2 * per * world));
+        HIPCHK(hipMalloc(&c->d_coop, sizeof(uint32_t) * 3 * per * world));
+        HIPCHK(hipMemset(c->d_coop, 0, sizeof(uint32_t) * 3 * per * world));
         c->coop_cap = per * world;
     }
-    uint32_t* idx = c->d_coop;
-    uint32_t* mins = c->d_coop + c->coop_cap;
+    // the gathered correspondences are double-buffered, like idx[cur] / idx[cur ^ 1] of the one-GPU loop: a pass reads its seeds from the
+    // buffer the pass before it wrote and writes the other one (round 3 used ONE buffer as seed and output of the same kernel: with skip
+    // lists the kernel wrote 0x7fffffff to a slot before every wave of the block had read its seed — results stayed exact, a seed only
+    // tightens a bound, but the work done varied from run to run)
+    uint32_t* idx_buf[2] = {c->d_coop, c->d_coop + c->coop_cap};
+    int cur = 0;
+    uint32_t* idx = idx_buf[cur];
+    uint32_t* mins = c->d_coop + 2 * c->coop_cap;
     const int qb = (int)std::min<size_t>((size_t)ns, per * rank), nq = (int)std::min<size_t>((size_t)ns, per * (rank + 1)) - qb;
     const bool seeding = c->icp_seeding;
     hipStream_t S = L.stream;
@@ -853,6 +869,7 @@ int ctx_icp_coop(fgoicp_ctx* c, int rank, int world, int (*gather)(void* dev_buf
         launch_transform_inplace(L.d_work, ns, Rn.m, tn3, S);    // :100 (the whole cloud: the reductions read all of it)
         const bool next = iter < max_iter;
         const uint32_t* seed = seeding ? idx : nullptr;          // the gathered correspondences of the pass the host has just consumed
+        uint32_t* idx_out = idx_buf[cur ^ 1];                    // where the pass riding along writes (never the buffer the seeds come from)
         const float *lbA = nullptr, *lbB = nullptr;
         const uint32_t *uA = nullptr, *uB = nullptr;
         if (skip) {  // trimmed: brackets and cuts of both query sets, whole cloud, as lane_icp_dual
@@ -868,16 +885,16 @@ int ctx_icp_coop(fgoicp_ctx* c, int rank, int world, int (*gather)(void* dev_buf
         if (nq > 0) {
             if (next)  // compute_sse_error(R, t) (:103) of this iteration and the correspondences of the next: one walk, my share
                 launch_nn_scan_dual(L.d_work + qb, nullptr, nullptr, 0, c->d_src + qb, R.m, t3, nq, c->bvh_tgt.view(), c->d_lut, c->geom, c->d_tgt, nt, seed ? seed + qb : nullptr,
-                                    lbA, uA, lbB, uB, idx + qb, mins + qb, nullptr, nullptr, nullptr, S);
+                                    lbA, uA, lbB, uB, idx_out + qb, mins + qb, nullptr, nullptr, nullptr, S);
             else       // the last iteration the loop can make: no pass rides along
                 launch_nn_scan(c->d_src + qb, nq, c->bvh_tgt.view(), c->d_lut, c->geom, R.m, t3, 1, 0, c->d_tgt, nt, seed ? seed + qb : nullptr, lbB, uB, mins + qb, S);
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(S));
-        if (next && gather(idx, sizeof(uint32_t) * per, user)) return FGOICP_ERR_EXCHANGE;
+        if (next && gather(idx_out, sizeof(uint32_t) * per, user)) return FGOICP_ERR_EXCHANGE;
         if (gather(mins, sizeof(uint32_t) * per, user)) return FGOICP_ERR_EXCHANGE;
         int rc = FGOICP_OK;
-        if (next) { rc = reduce_pass(); pending = true; }  // speculative, as on one GPU (the loop may end on this iteration's SSE)
+        if (next) { cur ^= 1; idx = idx_buf[cur]; rc = reduce_pass(); pending = true; }  // speculative, as on one GPU (the loop may end on this iteration's SSE)
         if (rc) return rc;
         rc = sse_sum();
         if (rc) return rc;
@@ -981,6 +998,7 @@ static int lane_icp_dual(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0,
     return FGOICP_OK;
 }
 
+#ifdef FGOICP_DEV_KNOBS
 // (FGOICP_ICP_GATED=1; measured SLOWER than paying the launches — 50-53 -> 53-56 us per iteration at 40k points: the command processor's
 // wait-value poll and the two extra stream operations per iteration cost more than the launch latency they hide — so this is a knob, off by default.)
 // The two-stream loop of small clouds with the launch latency taken off the iteration's chain (round 3).  An iteration's kernels depend on the
@@ -1091,6 +1109,8 @@ static int lane_icp_gated(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0
     return FGOICP_OK;
 }
 
+#endif  // FGOICP_DEV_KNOBS (gated loop)
+
 // One ICP run on a lane of its own (lane >= 1: own scratch, own two streams — nothing of it queues on the context's main stream,
 // where the bounds kernels run): the late-joining refinement of the ROUND schedule (driver.hpp) calls this from a background
 // host thread while the main thread keeps submitting bounds ticks.  Same kernels and sums as ctx_icp.
@@ -1194,6 +1214,7 @@ extern "C" {
 const char* fgoicp_last_error(void) { return g_last_error.c_str(); }
 const char* fgoicp_version(void) { return kDevKnobs ? "fgoicp_amd 0.4 (gfx950, development build)" : "fgoicp_amd 0.4 (gfx950)"; }
 int fgoicp_dev_knobs(void) { return kDevKnobs ? 1 : 0; }
+int fgoicp_abi_version(void) { return FGOICP_ABI_VERSION; }
 
 static int ctx_create_impl(const float* tgt_xyz, size_t nt, const float* src_xyz, size_t ns, const float* bounds6, float lut_resolution, int device, unsigned flags,
                            fgoicp_ctx** out, fgoicp_ctx** partial);
@@ -1669,6 +1690,12 @@ int fgoicp_lut_dims(const fgoicp_ctx* c, int* dims3) {
 
 int fgoicp_ctx_get_info(const fgoicp_ctx* c, fgoicp_ctx_info* out) {
     if (!c || !out) return FGOICP_ERR_INVALID_ARG;
+    // the caller says how large ITS struct is; everything is assembled in a full-size local and only that many bytes are copied out
+    const size_t caller = out->struct_size;
+    if (caller < offsetof(fgoicp_ctx_info, lut_layout)) { set_error("fgoicp_ctx_get_info: set struct_size = sizeof(fgoicp_ctx_info) before the call"); return FGOICP_ERR_INVALID_ARG; }
+    fgoicp_ctx_info full{};
+    fgoicp_ctx_info* const user_out = out;
+    out = &full;
     const LutGeom& g = c->geom;
     *out = fgoicp_ctx_info{};
     out->lut_dims[0] = g.dx; out->lut_dims[1] = g.dy; out->lut_dims[2] = g.dz;
@@ -1688,6 +1715,8 @@ int fgoicp_ctx_get_info(const fgoicp_ctx* c, fgoicp_ctx_info* out) {
     out->max_subcubes_per_window = c->max_subcubes;
     out->source_order = c->source_order;
     out->tree_order = c->tree_order;
+    full.struct_size = caller < sizeof(full) ? caller : sizeof(full);
+    std::memcpy(user_out, &full, full.struct_size);
     return FGOICP_OK;
 }
 

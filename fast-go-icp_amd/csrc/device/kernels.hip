@@ -2899,6 +2899,9 @@ int nn_slices(int nq, int nt) {
 // ---------------------------------------------------------------------------------------------
 void launch_bounds(const float4* src, int ns, const float* lut, const LutGeom& g, const BoundsArgs& a, double2* partials, int nchunk,
                    int P, hipStream_t s) {
+#ifndef FGOICP_DEV_KNOBS
+    (void)src; (void)ns; (void)lut; (void)g; (void)a; (void)partials; (void)nchunk; (void)P; (void)s;  // the per-rotation-node kernel is the development build's A/B reference (FGOICP_BOUNDS_SORTED=0)
+#else
     dim3 grid((unsigned)nchunk * (unsigned)a.B), block(kBlock);
     switch (P) {
         case 1: hipLaunchKernelGGL(bounds_kernel<1>, grid, block, 0, s, src, ns, lut, g, a, partials, nchunk); break;
@@ -2906,6 +2909,7 @@ void launch_bounds(const float4* src, int ns, const float* lut, const LutGeom& g
         case 4: hipLaunchKernelGGL(bounds_kernel<4>, grid, block, 0, s, src, ns, lut, g, a, partials, nchunk); break;
         default: hipLaunchKernelGGL(bounds_kernel<8>, grid, block, 0, s, src, ns, lut, g, a, partials, nchunk); break;
     }
+#endif
 }
 
 // The locality sort of one tick (descriptors must already be on the device): keys + histogram, scan, scatter.
@@ -2914,23 +2918,39 @@ void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, con
                       int allow_xcd, unsigned* check_err, int inject_fault, hipStream_t s, int nunits, int unit_m) {
     const size_t nitems = (size_t)(nsub - nunits * (unit_m - 1)) * nchunk;
     const unsigned kb = (unsigned)std::min<size_t>((nitems + 63) / 64, 8192);  // `hist` / `hist_xcd` are zero here: the scan / fold kernels re-zero them
+#ifdef FGOICP_DEV_KNOBS
     static const int hilbert = [] { const char* e = dev_env("FGOICP_SORT_CURVE"); return e ? std::atoi(e) : 1; }();  // tuning knob: 1 = Hilbert (default), 0 = Z-order
     static const int use_ranks = [] { const char* e = dev_env("FGOICP_SORT_RANKS"); return e ? std::atoi(e) : 1; }();  // tuning knob
     static const int orient = [] { const char* e = dev_env("FGOICP_SORT_ORIENT"); return e ? std::atoi(e) : 0; }();  // tuning knob (experimental): orientation bits in the sort key
-    const bool xcd = allow_xcd && use_ranks && hist_xcd && xoff;  // allow_xcd: FGOICP_SORT_XCD per context, cleared by a failed permutation check
+#else
+    constexpr int orient = 0;  // shipped: Hilbert keys, ranks from the histogram atomic (the scatter needs no atomics of its own)
+#endif
+    const bool xcd = allow_xcd != 0 && hist_xcd && xoff
+#ifdef FGOICP_DEV_KNOBS
+                     && use_ranks != 0
+#endif
+        ;  // allow_xcd: per context, cleared by a failed permutation check
     if (xcd) {
-        if (hilbert) hipLaunchKernelGGL((tick_keys_kernel<1, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd, check_err ? sorted : nullptr, nunits, unit_m, orient);
-        else hipLaunchKernelGGL((tick_keys_kernel<0, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd, check_err ? sorted : nullptr, nunits, unit_m, orient);
+#ifdef FGOICP_DEV_KNOBS
+        if (!hilbert) hipLaunchKernelGGL((tick_keys_kernel<0, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd, check_err ? sorted : nullptr, nunits, unit_m, orient);
+        else
+#endif
+        hipLaunchKernelGGL((tick_keys_kernel<1, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd, check_err ? sorted : nullptr, nunits, unit_m, orient);
         hipLaunchKernelGGL(tick_fold_sums_kernel, dim3(kScanBlocks), dim3(64), 0, s, hist_xcd, xoff, hist, block_sums);
     } else {
-        if (hilbert) hipLaunchKernelGGL((tick_keys_kernel<1, 0>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist, check_err ? sorted : nullptr, nunits, unit_m, orient);
-        else hipLaunchKernelGGL((tick_keys_kernel<0, 0>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist, check_err ? sorted : nullptr, nunits, unit_m, orient);
+#ifdef FGOICP_DEV_KNOBS
+        if (!hilbert) hipLaunchKernelGGL((tick_keys_kernel<0, 0>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist, check_err ? sorted : nullptr, nunits, unit_m, orient);
+        else
+#endif
+        hipLaunchKernelGGL((tick_keys_kernel<1, 0>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist, check_err ? sorted : nullptr, nunits, unit_m, orient);
     }
     if (!xcd) hipLaunchKernelGGL(tick_scan_sums_kernel, dim3(kScanBlocks), dim3(64), 0, s, hist, block_sums);
     hipLaunchKernelGGL(tick_scan_apply_kernel, dim3(kScanBlocks), dim3(64), 0, s, hist, block_sums, cursor);
     if (xcd) hipLaunchKernelGGL(tick_scatter_xcd_kernel, dim3(kb), dim3(64), 0, s, keys, ranks, nitems, cursor, xoff, sorted);
-    else if (use_ranks) hipLaunchKernelGGL(tick_scatter_kernel, dim3(kb), dim3(64), 0, s, keys, ranks, nitems, cursor, sorted);
-    else hipLaunchKernelGGL(tick_scatter_atomic_kernel, dim3(kb), dim3(64), 0, s, keys, nitems, cursor, sorted);
+#ifdef FGOICP_DEV_KNOBS
+    else if (!use_ranks) hipLaunchKernelGGL(tick_scatter_atomic_kernel, dim3(kb), dim3(64), 0, s, keys, nitems, cursor, sorted);
+#endif
+    else hipLaunchKernelGGL(tick_scatter_kernel, dim3(kb), dim3(64), 0, s, keys, ranks, nitems, cursor, sorted);
     if (inject_fault) hipLaunchKernelGGL(tick_fault_kernel, dim3(1), dim3(1), 0, s, sorted);
     if (check_err) hipLaunchKernelGGL(tick_check_kernel, dim3(kb), dim3(64), 0, s, sorted, nitems, check_err);
 }
@@ -3098,7 +3118,11 @@ void launch_lut_build(const float4* tgt_shifted, int nt, const LutGeom& g, float
 }
 
 void launch_lut_quad_bricked(const float* lut_padded, const LutGeom& g, float4* qd, hipStream_t s) {
+#ifdef FGOICP_DEV_KNOBS   // layout 3 (2 x 2 x 2 quad bricks): measured slower, development build only
     hipLaunchKernelGGL(lut_quad_bricked_kernel, dim3(8192), dim3(kBlock), 0, s, lut_padded, g, qd);
+#else
+    (void)lut_padded; (void)g; (void)qd; (void)s;
+#endif
 }
 
 void launch_lut_quad_apron(const float* lut_padded, const LutGeom& g, float4* qd, hipStream_t s) {
@@ -3255,6 +3279,7 @@ void launch_icp_cov_cen(const float4* work, const float4* tgt, const uint32_t* i
     hipLaunchKernelGGL(icp_cov_cen_kernel, dim3(nblocks), dim3(kBlock), 0, s, work, tgt, idx, n, nt, sums_bp, sums_nblocks, from_waves, cen_out, bp, done);
 }
 
+#ifdef FGOICP_DEV_KNOBS   // the device-resident ICP loop (measured slower than the host loop): development build only
 void launch_icp_init(IcpDevState* st, const float* R9, const float* t3, int max_iter, float thr, IcpHostResult* res, hipStream_t s) {
     hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(64), 0, s, st, make_rt(R9, t3), max_iter, thr, res);
 }
@@ -3262,6 +3287,7 @@ void launch_icp_init(IcpDevState* st, const float* R9, const float* t3, int max_
 void launch_icp_step(IcpDevState* st, const double* bp_cov, int nb_cov, const double* bp_sse, int nb_sse, const float* cen, IcpHostResult* res, hipStream_t s) {
     hipLaunchKernelGGL(icp_step_kernel, dim3(1), dim3(640), 0, s, st, bp_cov, nb_cov, bp_sse, nb_sse, cen, res);
 }
+#endif
 
 // trimmed bounds of a window: out_ub[row] / out_lb[row] from the row's k smallest e (trim_rows_kernel)
 void launch_trim_rows(const float* evals, size_t erow, int n, int k, int rows, const float* row_span, float* out_ub, float* out_lb, hipStream_t s,

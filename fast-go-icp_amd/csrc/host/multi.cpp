@@ -343,6 +343,7 @@ int fgoicp_rccl_comm_count(fgoicp_rccl* x, int* count) {
 
 int fgoicp_rccl_exchange(fgoicp_rccl* x, fgoicp_exchange* out) {
     if (!x || !out) return FGOICP_ERR_INVALID_ARG;
+    out->struct_size = sizeof(fgoicp_exchange);
     out->rank = x->rank;
     out->world_size = x->world;
     out->allreduce_min = rccl_allreduce_min;

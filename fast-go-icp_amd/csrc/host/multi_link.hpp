@@ -270,7 +270,7 @@ public:
         l->dg = &dg;
         l->mem = Backend::mem();
         l->device = devices[(size_t)r];
-        fgoicp_exchange ex{r, ndev, link_allreduce_min, link_allgather, l.get(), link_allgather_device};
+        fgoicp_exchange ex{sizeof(fgoicp_exchange), r, ndev, link_allreduce_min, link_allgather, l.get(), link_allgather_device};
         const int rc = Backend::set_exchange(solvers[(size_t)r], ndev > 1 ? &ex : nullptr);
         if (rc) return rc;
         links.push_back(std::move(l));

@@ -1,6 +1,7 @@
 // Driver-level C ABI: icp::FastGoICP (reference fgoicp/fgoicp.hpp:13-43) over the HIP operator
 // context.  The driver template is instantiated with the HIP backend ONLY — there is no CPU
 // backend in this library.
+#include <cstddef>
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
@@ -119,10 +120,16 @@ void fgoicp_solver_destroy(fgoicp_solver* s) {
     delete s;
 }
 
-int fgoicp_solver_set_exchange(fgoicp_solver* s, const fgoicp_exchange* ex) {
+int fgoicp_solver_set_exchange(fgoicp_solver* s, const fgoicp_exchange* ex_in) {
     if (!s) return FGOICP_ERR_INVALID_ARG;
     Exchange e;
-    if (ex) {
+    if (ex_in) {
+        // only the bytes the caller's struct has are read (struct_size, ABI 2): members it does not know stay NULL
+        fgoicp_exchange x{};
+        const size_t n = ex_in->struct_size;
+        if (n < offsetof(fgoicp_exchange, user) + sizeof(void*) || n > 4096) { set_error("fgoicp_solver_set_exchange: set struct_size = sizeof(fgoicp_exchange)"); return FGOICP_ERR_INVALID_ARG; }
+        std::memcpy(&x, ex_in, n < sizeof(x) ? n : sizeof(x));
+        const fgoicp_exchange* ex = &x;
         if (ex->world_size < 1 || ex->rank < 0 || ex->rank >= ex->world_size || (ex->world_size > 1 && (!ex->allreduce_min || !ex->allgather))) {
             set_error("fgoicp_solver_set_exchange: invalid exchange");
             return FGOICP_ERR_INVALID_ARG;

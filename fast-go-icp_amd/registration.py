@@ -81,6 +81,7 @@ class Registration:
         """fgoicp_ctx_get_info: LUT size and layout, source density per LUT face voxel, points per work item (what the context
         derived from the clouds' statistics)."""
         i = _lib.CtxInfo()
+        i.struct_size = C.sizeof(_lib.CtxInfo)
         _lib.check(self._lib.fgoicp_ctx_get_info(self._h, C.byref(i)), "fgoicp_ctx_get_info")
         return dict(lut_dims=tuple(i.lut_dims), lut_layout=i.lut_layout, lut_nodes=i.lut_nodes, lut_bytes=i.lut_bytes,
                     source_points_per_face_voxel=i.source_points_per_face_voxel, points_per_item=i.points_per_item,

@@ -42,6 +42,11 @@ const char* fgoicp_version(void);
  * NOTES.md from the environment and carries the kernel variants that were measured and rejected.  0 = the shipped build: it reads
  * FGOICP_HOST_THREADS / FGOICP_HOST_SPIN only and no stray variable can change its code path. */
 int fgoicp_dev_knobs(void);
+/* The ABI revision of this header.  2 (round 4): fgoicp_exchange and fgoicp_ctx_info start with `struct_size` (members may be appended
+ * from now on without breaking callers built against this revision); fgoicp_solver_set_log, fgoicp_rccl_create_ex added.  A caller
+ * built against revision 1 (no struct_size) must be rebuilt: INTEGRATION.md "ABI revisions". */
+#define FGOICP_ABI_VERSION 2
+int fgoicp_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
  * Operator level: icp::Registration + icp::NearestNeighborLUT + icp::IterativeClosestPoint3D
@@ -78,6 +83,8 @@ int fgoicp_lut_read(fgoicp_ctx* ctx, float* out, size_t capacity_floats);
  * clouds' stats, normalize (For scalability)", TODO.md:7): LUT size in every layout it keeps, source points per voxel of the LUT's
  * faces (the density that picks the packed layout and the points per work item), work items per evaluation. */
 typedef struct fgoicp_ctx_info {
+    size_t struct_size;          /* IN: sizeof(fgoicp_ctx_info) as the CALLER was compiled (ABI 2).  fgoicp_ctx_get_info writes no byte beyond it, so a caller
+                                    built against an older, shorter struct is not overrun when members are appended; 0 is refused */
     int lut_dims[3];
     int lut_layout;              /* next to the plain fp32 LUT: 1 = z-pair copy (8 B per node), 2 = yz-quad copy (16 B per node), 4 = apron-bricked yz-quad copy (21.3 B per node) */
     uint64_t lut_nodes;
@@ -211,6 +218,8 @@ typedef enum fgoicp_schedule {
  * Both return 0 on success.
  */
 typedef struct fgoicp_exchange {
+    size_t struct_size;  /* sizeof(fgoicp_exchange) as the caller was compiled (ABI 2): members beyond it are taken as NULL / 0, so a struct from an older
+                            header (without allgather_device, say) never hands the library a garbage pointer; 0 is refused */
     int rank;
     int world_size;
     int (*allreduce_min)(float* buf, size_t n, void* user);

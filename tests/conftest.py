@@ -48,7 +48,11 @@ def pytest_collection_modifyitems(config, items):
             src = inspect.getsource(fn) if fn is not None else ""
         except (OSError, TypeError):
             src = ""
-        knobs = set(re.findall(r"setenv\(\s*\"(FGOICP_[A-Z_0-9]+)\"", src)) - _DEPLOYMENT_VARS
+        # every FGOICP_* name the test mentions (a knob may be set through a variable: for name, val in env.items(): monkeypatch.setenv(name, val)),
+        # minus the deployment variables and the ABI's constants
+        knobs = {k for k in re.findall(r"FGOICP_[A-Z][A-Z_0-9]+", src) if not re.match(r"FGOICP_(FLAG|ERR|OK|SCHEDULE|TRANSPORT|LOG|ABI)(_|$)", k)} - _DEPLOYMENT_VARS
+        if "monkeypatch" not in src and "env=" not in src and "environ" not in src:
+            knobs = set()
         if knobs and item.get_closest_marker("dev_knobs") is None:
             item.add_marker(pytest.mark.dev_knobs)
         if item.get_closest_marker("dev_knobs") is not None:

@@ -39,6 +39,19 @@ int main(int argc, char** argv) {
     const float sse = reg.compute_sse_error(rn.q.R, icp::vec3(0.01f, -0.02f, 0.005f));
     icp::IterativeClosestPoint3D icp3d(reg, pct, pcs, 100, 0.005f, rn.q.R, icp::vec3(0.01f, -0.02f, 0.005f));
     auto [icp_sse, icp_R, icp_t] = icp3d.run();
+    // driver level first (raw clouds: argv[5], argv[6]) — FastGoICP::run() prints the reference's log lines (fgoicp.cpp:15-17, :25-27)
+    // on stdout while it runs; the JSON record follows as the last line
+    bool have_run = false;
+    float run_sse = 0.f;
+    icp::mat3 run_R;
+    icp::vec3 run_t;
+    if (argc >= 7) {
+        icp::FastGoICP solver(read_txt(argv[5]), read_txt(argv[6]), res, 1e-3f);
+        std::tie(run_R, run_t) = solver.run();
+        run_sse = solver.get_best_error();
+        have_run = true;
+    }
+    std::cout.flush();
     std::printf("{\"dims\": [%d, %d, %d], \"lb\": [", dims[0], dims[1], dims[2]);
     for (size_t i = 0; i < lb.size(); ++i) std::printf("%s%.9g", i ? ", " : "", lb[i]);
     std::printf("], \"ub\": [");
@@ -46,13 +59,10 @@ int main(int argc, char** argv) {
     std::printf("], \"sse\": %.9g, \"icp_sse\": %.9g, \"icp_iters\": %d, \"icp_R\": [", sse, icp_sse, icp3d.iterations());
     for (int i = 0; i < 9; ++i) std::printf("%s%.9g", i ? ", " : "", icp_R.data()[i]);
     std::printf("], \"icp_t\": [%.9g, %.9g, %.9g]", icp_t.x, icp_t.y, icp_t.z);
-    // driver level: raw clouds (argv[5], argv[6])
-    if (argc >= 7) {
-        icp::FastGoICP solver(read_txt(argv[5]), read_txt(argv[6]), res, 1e-3f);
-        auto [R, t] = solver.run();
-        std::printf(", \"run_sse\": %.9g, \"run_R\": [", solver.get_best_error());
-        for (int i = 0; i < 9; ++i) std::printf("%s%.9g", i ? ", " : "", R.data()[i]);
-        std::printf("], \"run_t\": [%.9g, %.9g, %.9g]", t.x, t.y, t.z);
+    if (have_run) {
+        std::printf(", \"run_sse\": %.9g, \"run_R\": [", run_sse);
+        for (int i = 0; i < 9; ++i) std::printf("%s%.9g", i ? ", " : "", run_R.data()[i]);
+        std::printf("], \"run_t\": [%.9g, %.9g, %.9g]", run_t.x, run_t.y, run_t.z);
     }
     std::printf("}\n");
     return 0;

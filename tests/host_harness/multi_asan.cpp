@@ -108,7 +108,7 @@ int scenario(const char* name, int world, int schedule, int round_width, bool co
         if (m->connect(r, nullptr)) return fail(name, "connect");
     if (!coop)  // the private flow: the exchange offers no device all-gather
         for (int r = 0; r < world; ++r) {
-            fgoicp_exchange ex{r, world, fgoicp::link_allreduce_min, fgoicp::link_allgather, m->links[(size_t)r].get(), nullptr};
+            fgoicp_exchange ex{sizeof(fgoicp_exchange), r, world, fgoicp::link_allreduce_min, fgoicp::link_allgather, m->links[(size_t)r].get(), nullptr};
             CpuBackend::set_exchange(m->solvers[(size_t)r], world > 1 ? &ex : nullptr);
         }
     float R[9], t[3];

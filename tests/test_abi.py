@@ -33,7 +33,7 @@ def test_library_builds_and_exports_every_declared_symbol(fg):
 def test_library_contains_gfx950_code_object(fg):
     path = fg.build.build()
     data = open(path, "rb").read()
-    assert b"gfx950" in data and b"bounds_kernel" in data
+    assert b"gfx950" in data and b"bounds_item_kernel" in data
 
 
 def test_product_does_not_reference_the_oracle(fg):
@@ -140,3 +140,21 @@ def test_cloud_statistics_run_on_the_host(fg):
     pct, pcs, off_t, off_s, scale, bounds = fg.synth.preprocess(p[:3000], p[3000:])
     assert float(scale) == pytest.approx(1.0 / fg.cloud_stats(p[3000:])["max_abs_centred"], rel=2e-6)
 
+
+
+def test_abi_revision_and_shipped_build(fg):
+    """ABI 2: struct_size leads fgoicp_exchange / fgoicp_ctx_info; the library the package loads by default is the shipped build (no A/B knobs)."""
+    import ctypes as C
+    import os
+    lib = fg._lib.load()
+    assert lib.fgoicp_abi_version() == 2
+    assert C.sizeof(fg._lib.Exchange) == 48 and fg._lib.Exchange().struct_size == 48
+    if not os.environ.get("FGOICP_LIB"):
+        assert not fg.dev_knobs()
+        # the shipped library carries no knob names (csrc/host/knobs.hpp): what it reads from the environment is FGOICP_HOST_THREADS / _SPIN
+        data = open(fg._lib.lib_path(), "rb").read()
+        import re
+        names = set(re.findall(rb"FGOICP_[A-Z][A-Z_0-9]+", data))
+        assert names <= {b"FGOICP_HOST_THREADS", b"FGOICP_HOST_SPIN", b"FGOICP_TRANSPORT_IN_PROCESS", b"FGOICP_BOUNDS_SORTED"}, names
+        dev = open(fg.build.DEV_LIB, "rb").read()
+        assert len(set(re.findall(rb"FGOICP_[A-Z][A-Z_0-9]+", dev))) > 40

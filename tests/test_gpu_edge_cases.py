@@ -177,3 +177,34 @@ def test_non_finite_coordinates_are_refused(fg, gpu_required):
     pcs = pcs.copy(); pcs[3, 0] = np.nan
     with pytest.raises(fg.FgoicpError, match="non-finite"):
         fg.Registration(pct, pcs, bounds, 0.02)
+
+
+def test_struct_size_guards_the_extensible_structs(fg, gpu_required):
+    """ABI 2: fgoicp_ctx_get_info writes no byte beyond the caller's struct_size, fgoicp_solver_set_exchange reads none — a
+    caller compiled against a shorter struct neither gets overrun nor hands the library a garbage allgather_device."""
+    import ctypes as C
+    lib = fg._lib.load()
+    tgt, src, _, _ = fg.synth.workload("tiny", angle_deg=20.0)
+    s = fg.FastGoICP(tgt, src, 0.05, 1e-3)
+    ctx = C.c_void_p(lib.fgoicp_solver_ctx(s._h))
+    buf = (C.c_ubyte * 256)(*([0xAB] * 256))
+    info = C.cast(buf, C.POINTER(fg._lib.CtxInfo))
+    info.contents.struct_size = 0
+    assert lib.fgoicp_ctx_get_info(ctx, info) == fg._lib.load().fgoicp_ctx_get_info(ctx, info) != 0  # refused: struct_size not set
+    short = fg._lib.CtxInfo.lut_nodes.offset  # a caller that knows the struct up to lut_layout only
+    info.contents.struct_size = short
+    assert lib.fgoicp_ctx_get_info(ctx, info) == 0 and info.contents.lut_dims[0] > 0 and info.contents.lut_layout in (1, 2, 4)
+    assert all(b == 0xAB for b in bytes(buf)[short:])  # nothing beyond the caller's struct was touched
+    info.contents.struct_size = C.sizeof(fg._lib.CtxInfo)
+    assert lib.fgoicp_ctx_get_info(ctx, info) == 0 and info.contents.points_per_item in (256, 512, 1024, 2048)
+    calls = []
+    ar = fg._lib.Exchange.ALLREDUCE_MIN(lambda b, n, u: calls.append("ar") or 0)
+    ag = fg._lib.Exchange.ALLGATHER(lambda a, b, n, u: calls.append("ag") or 0)
+    ex = fg._lib.Exchange(0, 1, ar, ag, None)
+    ex.allgather_device = C.cast(0xDEAD0000, fg._lib.Exchange.ALLGATHER_DEVICE)  # garbage where an older caller's struct has already ended
+    ex.struct_size = fg._lib.Exchange.allgather_device.offset
+    assert lib.fgoicp_solver_set_exchange(s._h, C.byref(ex)) == 0
+    R, t = s.run()  # world 1: no collective; above all nothing calls the garbage pointer
+    ex.struct_size = 0
+    assert lib.fgoicp_solver_set_exchange(s._h, C.byref(ex)) != 0 and b"struct_size" in lib.fgoicp_last_error()
+    s.close()

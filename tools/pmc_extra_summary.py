@@ -12,6 +12,7 @@ Derived figures (cycle-based ones come from the profiled pass itself and do not 
   l1_pending_stall_frac      TCP_PENDING_STALL_CYCLES / (256 TCPs x cycles)
   ta_busy_frac               TA_BUSY_avr / cycles           (average over the texture addressers)
   ta_addr_stalled_frac       TA_ADDR_STALLED_BY_TC_CYCLES / (256 x cycles)
+  l1_accesses_per_clock_cu   TCP_TOTAL_CACHE_ACCESSES / (256 TCPs x cycles): cache-line accesses the L1 of a CU handles per clock
   wave_wait_frac             SQ_WAIT_ANY / SQ_WAVE_CYCLES   (share of wave lifetime parked in s_waitcnt / barriers)
   wave_issue_stall_frac      SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES"""
 import json
@@ -29,12 +30,12 @@ def main():
         c = {}
         for f in files.split(","):
             d = json.load(open(f))
-            for k, v in d.get("bounds_sorted_kernel", {}).items():
+            for k, v in (d.get("bounds_item_kernel") or d.get("bounds_sorted_kernel") or {}).items():
                 c[k] = v["per_dispatch"]
         if not c:
             continue
         cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
-        e = {"kernel": "bounds_sorted_kernel", "source": [os.path.relpath(f, REPO) for f in files.split(",")], "cycles_per_launch": cyc, "counters_per_launch": c}
+        e = {"kernel": "bounds_item_kernel", "source": [os.path.relpath(f, REPO) for f in files.split(",")], "cycles_per_launch": cyc, "counters_per_launch": c}
         g = c.get
         if g("SQ_INSTS_VALU") and cyc:
             e["valu_insts_per_launch"] = g("SQ_INSTS_VALU")
@@ -46,6 +47,8 @@ def main():
         if g("TCP_TOTAL_CACHE_ACCESSES_sum"):
             e["l1_accesses_per_launch"] = g("TCP_TOTAL_CACHE_ACCESSES_sum")
             e["l1_hit_rate"] = 1.0 - g("TCP_TCC_READ_REQ_sum", 0.0) / g("TCP_TOTAL_CACHE_ACCESSES_sum")
+            if cyc:
+                e["l1_accesses_per_clock_cu"] = g("TCP_TOTAL_CACHE_ACCESSES_sum") / (256.0 * cyc)
         if g("TCP_TCC_READ_REQ_sum"):
             e["l1_miss_latency_cycles"] = g("TCP_TCC_READ_REQ_LATENCY_sum", 0.0) / g("TCP_TCC_READ_REQ_sum")
         if g("TCP_PENDING_STALL_CYCLES_sum") and cyc:
@@ -54,6 +57,8 @@ def main():
             e["ta_busy_frac"] = g("TA_BUSY_avr") / cyc
         if g("TA_ADDR_STALLED_BY_TC_CYCLES_sum") and cyc:
             e["ta_addr_stalled_frac"] = g("TA_ADDR_STALLED_BY_TC_CYCLES_sum") / (256.0 * cyc)
+        if g("TA_DATA_STALLED_BY_TC_CYCLES_sum") and cyc:
+            e["ta_data_stalled_frac"] = g("TA_DATA_STALLED_BY_TC_CYCLES_sum") / (256.0 * cyc)
         if g("SQ_WAVE_CYCLES"):
             if g("SQ_WAIT_ANY"):
                 e["wave_wait_frac"] = g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES")

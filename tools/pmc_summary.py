@@ -16,7 +16,7 @@ import os
 import re
 import sys
 
-KERNELS = ("bounds_sorted_kernel", "bounds_kernel", "trim_rows_kernel", "nn_scan_kernel", "tick_keys_kernel", "tick_scatter_xcd_kernel")
+KERNELS = ("bounds_item_kernel", "bounds_sorted_kernel", "bounds_kernel", "trim_rows_sampled_kernel", "trim_rows_kernel", "nn_scan_kernel", "tick_keys_kernel", "tick_scatter_xcd_kernel")
 
 
 def load(dirs):
@@ -51,15 +51,16 @@ def main():
             if "TCC_HIT_sum_sum" in o:
                 o["l2_hit_rate"] = o["TCC_HIT_sum_sum"] / (o["TCC_HIT_sum_sum"] + o["TCC_MISS_sum_sum"])
         summary[leg] = ks
-        dom = "bounds_sorted_kernel" if "bounds_sorted_kernel" in ks else "bounds_kernel"
+        dom = next((k for k in ("bounds_item_kernel", "bounds_sorted_kernel", "bounds_kernel") if k in ks), "bounds_item_kernel")
         if dom in ks and "read_bytes_per_launch" in ks[dom]:
             b = ks[dom]
             e = {"kernel": dom, "hbm_bytes_per_launch": b["read_bytes_per_launch"] + b.get("write_bytes_per_launch", 0.0),
                  "read_bytes_per_launch": b["read_bytes_per_launch"], "write_bytes_per_launch": b.get("write_bytes_per_launch"), "l2_hit_rate": b.get("l2_hit_rate"),
                  "fetch_size_read_factor": factor,
                  "source": f"profiles/{tag}_bench_pmc_summary.json [{leg}]: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- python3 bench.py --only {leg} --steps 1 --warmup 1"}
-            if "trim_rows_kernel" in ks and "read_bytes_per_launch" in ks["trim_rows_kernel"]:
-                t = ks["trim_rows_kernel"]
+            sel = next((k for k in ("trim_rows_sampled_kernel", "trim_rows_kernel") if k in ks and "read_bytes_per_launch" in ks[k]), None)
+            if sel:
+                t = ks[sel]
                 e["select_kernel_read_bytes_per_launch"] = t["read_bytes_per_launch"]
                 e["select_kernel_write_bytes_per_launch"] = t.get("write_bytes_per_launch")
             bench[leg] = e
