@@ -37,7 +37,10 @@ work is fixed, so "scaling" is "strong".
 it runs on (fgoicp_ctx_profile).  `achieved` = algorithmic bytes of the EVALUATIONS the launches did
 (ns * (32 + 12/32) B each; a node both tasks of a rotation cube need is two subcubes and one evaluation) / the launches'
 duration; `traffic` = HBM bytes per launch from separate rocprofv3 --pmc passes of `--only LEG`
-(profiles/bench_pmc.json, see tools/gpu_profile.sh); `hbm_actual_GBps` = traffic / duration."""
+(profiles/bench_pmc.json, see tools/gpu_profile.sh) — `traffic_measured_in_this_run` says so; `hbm_actual_GBps` = traffic / this run's duration.
+One `frac` per leg and none above 1: the headline and the trimmed leg are priced against the HBM roof with the measured HBM fraction next
+to it; the dense dragon leg, whose per-evaluation byte model is no roof (texels are shared between points and evaluations out of L1 / L2), against the
+busiest unit its counters name (`bound`: "ta" texture addresser / "l1" / "valu" / "hbm"; `busiest_unit_fracs` lists the candidates)."""
 import argparse
 import json
 import os
@@ -51,7 +54,6 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy rate)
-HBM_COPY_GBS = 6290.0
 LEGS = ("headline", "default_threshold", "serial", "dragon", "trimmed", "cpu_baseline")
 
 
@@ -206,16 +208,17 @@ def roofline(leg, pmc, extra=None):
         return None
     ub = unit_bytes(ns)
     ach = p["evaluations"] * ub / (kms * 1e-3) / 1e9
-    served = leg["subcubes_rank"] * ub / (kms * 1e-3) / 1e9  # subcubes the tasks consumed (`count`, fgoicp.cpp:132) — twins and memo hits included
-    r = {"bound": "hbm", "kernel": "bounds_sorted_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-         "traffic": None, "frac_of_measured_copy_rate": ach / HBM_COPY_GBS,
+    r = {"bound": "hbm", "kernel": "bounds_item_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+         "traffic": None, "traffic_measured_in_this_run": False,
          "avg_launch_us": kms * 1e3 / launches, "launches": int(launches), "evaluations_per_launch": p["evaluations"] / launches,
          "subcubes_per_launch": leg["subcubes_rank"] / launches, "output_rows_per_launch": p["subcubes"] / launches, "algorithmic_bytes_per_evaluation": ub,
          "algorithmic_bytes_per_launch": p["evaluations"] * ub / launches,
-         "achieved_per_subcube_served": served, "frac_per_subcube_served": served / HBM_PEAK_GBS,
+         "subcubes_served_per_evaluation": leg["subcubes_rank"] / max(1.0, float(p["evaluations"])),
          "note": "achieved = algorithmic bytes of the EVALUATIONS (SURVEY 8d unit x evaluations per launch) / launch duration, HIP events on the kernel's own stream; a "
                  "translation node that both the UB and the LB task of a rotation cube need is evaluated once for both (same tick: twin; later: the LB task takes it from "
-                 "its memo) — two subcubes served by one evaluation (achieved_per_subcube_served); output rows include the memo's look-ahead rows"}
+                 "its memo) — subcubes_served_per_evaluation; output rows include the memo's look-ahead rows.  `traffic` and everything under `utilisation` are per-launch "
+                 "counter figures of separate rocprofv3 --pmc passes of the same deterministic step on this tree (profiles/bench_pmc.json, bench_pmc_extra.json), NOT measured "
+                 "in this run; rates derived from them use this run's launch duration"}
     if pmc:
         r["traffic"] = pmc.get("hbm_bytes_per_launch")
         r["traffic_source"] = pmc.get("source")
@@ -250,91 +253,19 @@ def utilisation(r, x):
         u["valu"] = {"achieved": ach, "peak": VALU_PEAK_GINST, "unit": "G wave64 VALU instructions/s", "frac": ach / VALU_PEAK_GINST,
                      "frac_cycle_based": x.get("valu_issue_utilisation"), "insts_per_launch": x["valu_insts_per_launch"],
                      "insts_per_point_evaluation": x["valu_insts_per_launch"] * 64.0 / (r["evaluations_per_launch"] * r["algorithmic_bytes_per_evaluation"] / 32.375)}
-    for k in ("l1_hit_rate", "l1_miss_latency_cycles", "l1_pending_stall_frac", "ta_busy_frac", "ta_addr_stalled_frac", "wave_wait_frac", "wave_issue_stall_frac"):
+    for k in ("l1_hit_rate", "l1_miss_latency_cycles", "l1_pending_stall_frac", "l1_accesses_per_clock_cu", "ta_busy_frac", "ta_addr_stalled_frac", "ta_data_stalled_frac", "wave_wait_frac",
+              "wave_issue_stall_frac"):
         if x.get(k) is not None:
             u[k] = x[k]
     if x.get("l1_accesses_per_launch"):
         u["l1_accesses_per_point_evaluation"] = x["l1_accesses_per_launch"] / (r["evaluations_per_launch"] * r["algorithmic_bytes_per_evaluation"] / 32.375)
     r["utilisation"] = u
-    cands = {"hbm": r.get("hbm_actual_frac") or 0.0, "valu": (u.get("valu") or {}).get("frac_cycle_based") or (u.get("valu") or {}).get("frac") or 0.0, "ta": u.get("ta_busy_frac") or 0.0}
-    r["busiest_unit"] = max(cands, key=cands.get)
+    # every candidate is a fraction of something that cannot exceed 1: HBM bytes moved / peak, VALU issue cycles / cycles, texture-addresser busy cycles / cycles,
+    # L1 cache-line accesses per clock and CU (the TCP looks up one line per clock)
+    cands = {"hbm": r.get("hbm_actual_frac") or 0.0, "valu": (u.get("valu") or {}).get("frac_cycle_based") or (u.get("valu") or {}).get("frac") or 0.0, "ta": u.get("ta_busy_frac") or 0.0,
+             "l1": u.get("l1_accesses_per_clock_cu") or 0.0}
     r["busiest_unit_fracs"] = cands
-
-
-def unique_line_model(fg, tgt, src, res, layout_bytes, samples=6, seed=0):
-    """Dense clouds: neighbouring points share LUT texels, so 8 private texels per point over-count what a subcube needs.
-    Counts, for sampled rigid motions, the distinct 128-byte lines of the packed LUT (z-pair: 8 B per node, rows y0 and y0+1;
-    yz-quad: 16 B per node) one evaluation touches — the compulsory traffic of a subcube with perfect re-use inside it and
-    none across subcubes.  numpy restatement of lut_address (kernels.hip) on the pre-processed clouds."""
-    pct, pcs, *_, bounds = fg.synth.preprocess(tgt, src)
-    b = np.asarray(bounds, np.float64)
-    d = [int(np.ceil(np.float32(np.float32(b[a, 1] - b[a, 0]) / np.float32(res)))) for a in range(3)]
-    px, py = d[0] + 2, d[1] + 2
-    rng = np.random.default_rng(seed)
-    out = []
-    for _ in range(samples):
-        R = fg.synth.random_rotation(rng)
-        t = rng.uniform(-0.25, 0.25, 3)
-        q = pcs.astype(np.float64) @ R.T + t
-        idx = []
-        for a in range(3):
-            u = (q[:, a] - b[a, 0]) / res - 0.5
-            idx.append(np.clip(np.floor(u), -1, d[a] - 1).astype(np.int64) + 1)
-        o = (idx[2] * py + idx[1]) * px + idx[0]
-        if layout_bytes == 8:   # z-pair: two 16-byte gathers, rows y0 and y0 + 1
-            addr = np.concatenate([o * 8, o * 8 + 15, (o + px) * 8, (o + px) * 8 + 15])
-        else:                   # yz-quad: 32 contiguous bytes
-            addr = np.concatenate([o * 16, o * 16 + 31])
-        out.append(len(np.unique(addr >> 7)) * 128.0 + len(pcs) * 16.0 / 32.0)
-    return float(np.mean(out))
-
-
-def cpu_baseline(fg, reg, tgt, src, res, mse, sched_id, K, seconds, gpu_leg):
-    """The reference has no CPU path, so the baseline is the product's host driver over the CPU oracle's operators
-    (tests/host_harness: same driver template, thresholds and LUT semantics) with a uniform-grid exact nearest-neighbour search
-    standing in for the nanoflann kd-tree the reference's README names.  A full run() to the optimum at the reference's default
-    threshold on the host's cores (kind "port"); its LUT is filled from the device LUT (bit-identical; the O(nodes * nt) CPU
-    build would take hours and is outside the timed span on the GPU side as well).  Plus the bounds operator on ONE core for a
-    bounded sample."""
-    from oracle import pyoracle
-    from tests import host_harness as hh
-    os.environ["FGOICP_HOST_SPIN"] = "0"     # the CPU run's driver shares the cores with the oracle's OpenMP team, which does the parallel work:
-    os.environ["FGOICP_HOST_THREADS"] = "1"  # no polling worker threads next to it
-    pyoracle.build()
-    cores = int(pyoracle.lib().orc_num_threads())
-    h = hh.HostDriver(tgt, src, res, mse, schedule=sched_id, round_width=K, build_lut=False, use_grid=True)
-    assert h.lut_dims() == tuple(reg.lut_dims())
-    h.lut_set(reg.lut_read())
-    t0 = time.perf_counter()
-    r = h.run()
-    wall = time.perf_counter() - t0
-    secs = h.seconds()
-    same = bool(abs(float(r["best_sse"]) - gpu_leg["best_sse"]) <= 1e-5 * gpu_leg["best_sse"] and np.allclose(r["R"], gpu_leg["R"], atol=1e-5))
-    # the bounds operator on ONE core, bounded sample of the same workload
-    pct, pcs, *_, bounds = fg.synth.preprocess(tgt, src)
-    orc = pyoracle.Registration(pct, pcs, bounds, res, build_lut=False)
-    orc.lut_set(reg.lut_read())
-    rng = np.random.default_rng(0)
-    rn = fg.RotNode(0.25, -0.125, 0.375, 0.125)
-    pyoracle.lib().orc_set_num_threads(1)
-    done1, t1 = 0, time.perf_counter()
-    while True:
-        tn = np.concatenate([rng.uniform(-0.5, 0.5, (32, 3)), np.full((32, 1), 0.125)], axis=1).astype(np.float32)
-        orc.compute_bounds(rn.q.R, rn.span, tn, False)
-        done1 += 32
-        dt1 = time.perf_counter() - t1
-        if dt1 >= seconds:
-            break
-    pyoracle.lib().orc_set_num_threads(cores)
-    sub = r["stats"]["trans_cubes"]
-    return {"value": sub / wall, "unit": "subcubes/s", "cores": cores, "kind": "port",
-            "sample": f"one full run() to the optimum: bunny-shape pair, mse_threshold={mse} (the reference's default), {sub} subcubes, "
-                      f"{r['stats']['icp_runs']} ICP runs ({r['stats']['icp_iters']} iterations), OpenMP over points/queries on {cores} threads",
-            "wall_clock_to_optimum_s": wall, "seconds_bnb": secs["bnb"], "seconds_icp": secs["icp"], "subcubes": int(sub),
-            "same_optimum_as_gpu": same, "best_sse": float(r["best_sse"]),
-            "gpu_wall_clock_to_optimum_s_same_run": gpu_leg["elapsed"] / gpu_leg["steps"],
-            "value_1_core": done1 / dt1, "sample_1_core": f"bounds operator only, {done1} subcubes (batches of 32, fix_rot=0) in {dt1:.1f}s on one thread",
-            "nearest_neighbour": "uniform grid over the target (oracle/goicp_oracle.cpp GridNN; exact, identical to the O(n*m) loops)"}
+    r["busiest_unit"] = max(cands, key=cands.get)
 
 
 def icp_latency(leg):
@@ -454,50 +385,37 @@ def main():
         tgt_d, src_d, R_gt_d, t_gt_d = fg.synth.workload("dragon", angle_deg=150.0, min_angle_deg=110.0)
         dr = run_leg(env, fg, tgt_d, src_d, a.lut_resolution, 5e-6, sched, K, 1, 0)  # ns*mse = 2.2 < residual 3.0
         s = leg_summary(dr, R_gt_d, t_gt_d, f"dragon-shape synthetic pair (nt={len(tgt_d)}, ns={len(src_d)}), mse_threshold=5e-06, one step, no warm-up")
-        extra = None
+        r = None
         if rank == 0:
-            uniq = unique_line_model(fg, tgt_d, src_d, a.lut_resolution, 8)
-            p = dr["prof"]
-            ach_u = p["evaluations"] * uniq / (p["kernel_ms"] * 1e-3) / 1e9 if p["kernel_ms"] > 0 else 0.0
-            extra = {"private_texel_model_GBps": None, "unique_line_bytes_per_evaluation": uniq,
-                     "model": "dense cloud (>= 1 source point per LUT voxel face): neighbouring points share texels, so the byte model counts the distinct 128-B lines of the "
-                              "z-pair LUT one evaluation touches (sampled rigid motions, numpy) + the source read; 8 private texels per point (SURVEY 8d) is reported as "
-                              "private_texel_model_GBps and is NOT a roof here"}
-            r = roofline(dr, pmc_all.get("dragon"), extra)
+            r = roofline(dr, pmc_all.get("dragon"), {})
             if r:
-                r["private_texel_model_GBps"] = r["achieved"]
-                r["unique_line_model_GBps"] = ach_u
                 utilisation(r, pmc_extra.get("dragon"))
                 u = r.get("utilisation") or {}
-                # Neither per-evaluation byte model is a roof for this kernel (both exceed the HBM peak: LUT lines are shared ACROSS the evaluations of a
-                # tick, out of the L2s): `bound` names the unit the counters show busiest, `achieved / peak` are in that unit's terms, and the HBM side
-                # is reported as what it is — measured traffic per launch / launch duration.
+                # Dense cloud: neighbouring points share texels and the LUT lines are re-used ACROSS the evaluations of a tick out of L1 / L2, so the per-evaluation
+                # byte model of SURVEY 8d (8 private texels per point) is not a roof here (priced that way the kernel would "exceed" the HBM peak).  One `frac`: the
+                # busiest unit the counters of this kernel name (profiles/bench_pmc_extra.json [dragon]); the HBM side as what it is, measured traffic / duration.
+                r["algorithmic_model_GBps_not_a_roof"] = r["achieved"]
                 if r.get("hbm_actual_GBps"):
                     r["hbm"] = {"achieved": r["hbm_actual_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["hbm_actual_frac"],
-                                "definition": "measured HBM bytes per launch (rocprofv3 PMC, FETCH_SIZE x 2 + WRITE_SIZE) / launch duration"}
-                if u.get("valu") and r.get("busiest_unit") in ("valu", "ta"):
-                    if r["busiest_unit"] == "valu":
-                        r["bound"] = "valu"
-                        r["achieved"], r["peak"], r["unit"] = u["valu"]["achieved"], u["valu"]["peak"], u["valu"]["unit"]
-                        r["frac"] = u["valu"]["frac"]
-                        r["achieved_definition"] = "SQ_INSTS_VALU per launch (profiles/bench_pmc_extra.json) / launch duration of this run, against 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction"
-                    else:
-                        r["bound"] = "ta"
-                        r["achieved"], r["peak"], r["unit"], r["frac"] = u["ta_busy_frac"], 1.0, "texture-addresser busy fraction", u["ta_busy_frac"]
-                    r.pop("frac_of_measured_copy_rate", None)
-                    r["limited_by"] = (f"VALU issue {100 * (u['valu'].get('frac_cycle_based') or u['valu']['frac']):.0f} % of the SIMDs' slots ({u['valu']['insts_per_point_evaluation']:.0f} VALU instructions per point: IEEE sqrt, "
-                                       f"1.8 fixed-point weights, fp64 accumulation are the contract), L1 hit rate {100 * u.get('l1_hit_rate', 0):.0f} %, "
-                                       f"L1 miss latency {u.get('l1_miss_latency_cycles', 0):.0f} cycles, measured HBM traffic {100 * (r.get('hbm_actual_frac') or 0):.0f} % of the peak "
-                                       "(profiles/bench_pmc_extra.json: round-3 counters of this kernel)")
+                                "definition": "measured HBM bytes per launch (rocprofv3 PMC, FETCH_SIZE x 2 + WRITE_SIZE; not measured in this run) / this run's launch duration"}
+                b = r.get("busiest_unit")
+                if b == "ta" and u.get("ta_busy_frac"):
+                    r["bound"], r["achieved"], r["peak"], r["unit"], r["frac"] = "ta", u["ta_busy_frac"], 1.0, "texture-addresser busy cycles / cycle (TA_BUSY, average over the 256 TAs)", u["ta_busy_frac"]
+                elif b == "l1" and u.get("l1_accesses_per_clock_cu"):
+                    r["bound"], r["achieved"], r["peak"], r["unit"], r["frac"] = "l1", u["l1_accesses_per_clock_cu"], 1.0, "L1 cache-line accesses per clock and CU (TCP_TOTAL_CACHE_ACCESSES)", u["l1_accesses_per_clock_cu"]
+                elif b == "valu" and u.get("valu"):
+                    v = u["valu"]
+                    r["bound"], r["achieved"], r["peak"], r["unit"], r["frac"] = "valu", v["achieved"], v["peak"], v["unit"], v.get("frac_cycle_based") or v["frac"]
                 elif r.get("hbm_actual_GBps"):
-                    r["achieved"] = r["hbm_actual_GBps"]
-                    r["frac"] = r["hbm_actual_frac"]
-                    r["frac_of_measured_copy_rate"] = r["hbm_actual_GBps"] / HBM_COPY_GBS
-                    r["achieved_definition"] = "measured HBM bytes per launch (rocprofv3 PMC, FETCH_SIZE x 2 + WRITE_SIZE) / launch duration"
-                else:
-                    r["achieved"] = ach_u
-                    r["frac"] = ach_u / HBM_PEAK_GBS
-                    r["model_exceeds_peak"] = bool(ach_u > HBM_PEAK_GBS)
+                    r["achieved"], r["frac"] = r["hbm_actual_GBps"], r["hbm_actual_frac"]
+                else:  # no counter file for this tree: nothing to price against — say so instead of printing a model above the peak
+                    r["bound"], r["achieved"], r["frac"] = "unpriced (no counter passes of this tree)", None, None
+                if u:
+                    r["limited_by"] = (f"the L1 / texture path: TA busy {100 * (u.get('ta_busy_frac') or 0):.0f} % of the cycles ({100 * (u.get('ta_addr_stalled_frac') or 0):.0f} % stalled by the L1), "
+                                       f"{(u.get('l1_accesses_per_clock_cu') or 0):.2f} cache-line accesses per clock and CU ({(u.get('l1_accesses_per_point_evaluation') or 0):.2f} per point-evaluation, hit rate "
+                                       f"{100 * (u.get('l1_hit_rate') or 0):.0f} %), VALU issue {100 * ((u.get('valu') or {}).get('frac_cycle_based') or 0):.0f} % "
+                                       f"({(u.get('valu') or {}).get('insts_per_point_evaluation', 0):.0f} VALU instructions per point-evaluation: round 4 cut them from 120 to 77 with packed fp32 and the launch "
+                                       f"did not get shorter — profiles/r04_ab_item_kernel_dragon_trimmed.txt), measured HBM traffic {100 * (r.get('hbm_actual_frac') or 0):.0f} % of the peak")
             s["roofline"] = r
         s["icp_latency"] = icp_latency(dr)
         line["dragon_shape"] = s
