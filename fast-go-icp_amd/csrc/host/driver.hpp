@@ -766,9 +766,66 @@ private:
             }
             const auto t_round = clock::now();
             const uint64_t calls_before = stats_.bounds_calls, cubes_before = stats_.trans_cubes;
+            const double icp_before = stats_.seconds_icp;
+            // OVERLAPPED REFINEMENTS (round 4).  The triggers of a round (fgoicp.cpp:74-88) read nothing but the UB tasks' results — child by child,
+            // against the running best — and the LB tasks of a ROUND round read nothing of the refinements (they prune against the round-start error,
+            // see above).  So the refinements do not have to wait for the LB tasks, which are five times the work: a second host thread applies the
+            // rule in child order as the UB tasks end and runs each triggered ICP on an ICP lane of its own (own scratch and streams) while this
+            // thread keeps ticking the remaining tasks.  Same rule, same order, same inputs: the bits of the sequential flow; the round ends when both
+            // have ended.  (Not to be confused with round 3's late-joining variant, which let the refinements LAG a round and lost.)
+            // MEASURED (profiles/r04_ab_overlap_icp.txt): bit-identical, and no gain — default-threshold bunny step 15.3 -> 15.1 ms, headline 0.351 -> 0.350 s,
+            // trimmed 1M and dragon within noise.  The timing lines say why: with the tail batches the UB tasks of a small round need as many device round trips as
+            // the LB tasks (8 of the round's 8.5 per half), so the first trigger is known 5.4 ms into a 5.7-ms task phase, and in big rounds the refinements are
+            // 3 % of the time.  OFF by default (development knob FGOICP_OVERLAP_ICP=1).
+            struct Overlapped {
+                std::thread th;
+                std::atomic<size_t> ub_ready{0};   // UB tasks of my children [0, ub_ready) have ended
+                std::atomic<bool> stop{false};
+                float sse = 0.f; Mat3f R{}; Vec3f t{0, 0, 0};
+                int rc = kDriverOk;
+                bool active = false;
+                ~Overlapped() { stop.store(true); if (th.joinable()) th.join(); }
+            } ov;
+            const bool overlapped = overlap_icp_ && !coop() && !(late_icp_ > 0 && (world > 1 || late_icp_ > 1)) && !mine.empty();
+            if (overlapped) {
+                { std::lock_guard<std::mutex> g(mu_); ov.sse = best_sse_; ov.R = best_R_; ov.t = best_t_; }
+                ov.active = true;
+                tick_hook_ = [&] {
+                    size_t k = ov.ub_ready.load(std::memory_order_relaxed);
+                    while (k < mine.size() && boxes[2 * k].done) ++k;
+                    ov.ub_ready.store(k, std::memory_order_release);
+                };
+                ov.th = std::thread([&] {
+                    for (size_t k = 0; k < mine.size(); ++k) {
+                        for (unsigned spins = 0; ov.ub_ready.load(std::memory_order_acquire) <= k; ++spins) {
+                            if (ov.stop.load(std::memory_order_acquire)) return;
+                            if (spins < 64) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(10));
+                        }
+                        const RotCube& ch = children[mine[k]];
+                        const float ub = boxes[2 * k].best_ub;
+                        const Vec3f bt = boxes[2 * k].best_t;
+                        set_last(ch.q.R, bt);
+                        if (timing_ && mine.size() <= 64) std::fprintf(stderr, "[fgoicp timing] overlapped: UB task of child %zu ended %.3f ms into the round (%llu batches)\n", k, seconds_since(t_round) * 1e3, (unsigned long long)boxes[2 * k].batches);
+                        if (ub < ov.sse * 1.8) {  // fgoicp.cpp:74
+                            float sse; Mat3f R; Vec3f t;
+                            const int r = icp(ch.q.R, bt, 0.005f, sse, R, t, true);
+                            if (r) { ov.rc = r; return; }
+                            if (sse < ov.sse) { ov.sse = sse; ov.R = R; ov.t = t; }
+                            if (log_) log_(kLogNewBest, ov.sse, ov.R, ov.t);  // :85-87, this rank's running best
+                        }
+                    }
+                });
+            }
             int rc = run_task_list(tasks, cubes);
+            if (overlapped) {
+                tick_hook_();          // every task has ended
+                tick_hook_ = nullptr;
+                if (rc) ov.stop.store(true);
+                ov.th.join();
+                if (!rc) rc = ov.rc;
+            }
             if (rc) return rc;
-            const double s_tasks = seconds_since(t_round), icp_before = stats_.seconds_icp;
+            const double s_tasks = seconds_since(t_round);
 
             // ICP triggers in child order against the running local best (fgoicp.cpp:74-88), one run after another: a successful run
             // tightens the trigger of the next child, and after the first success most children no longer qualify.  (Refining every
@@ -833,6 +890,8 @@ private:
                         }
                     });
                 }
+            } else if (ov.active) {
+                loc_sse = ov.sse; loc_R = ov.R; loc_t = ov.t;  // the refinements ran next to the tasks (above)
             } else
             for (size_t k = 0; k < mine.size(); ++k) {
                 const RotCube& ch = children[mine[k]];
@@ -1197,7 +1256,9 @@ private:
                     h[k].live.clear();
                     const auto tc = clock::now();
                     rebalance(h[k], h[1 - k]);
-                    if (!h[k].members.empty() && prepare_half(h[k], tasks, cubes, par, ops_.twins())) {
+                    const bool more = !h[k].members.empty() && prepare_half(h[k], tasks, cubes, par, ops_.twins());
+                    if (tick_hook_) tick_hook_();  // (tasks that have just ended are marked done by now)
+                    if (more) {
                         int rc = ops_.bounds_submit(k, (int)h[k].live.size(), h[k].R9.data(), h[k].spans.data(), h[k].fix.data(), h[k].offsets.data(), h[k].tn4.data(), h[k].twin.data());
                         if (rc) return rc;
                         h[k].inflight = true;
@@ -1216,7 +1277,9 @@ private:
         for (size_t i = 0; i < tasks.size(); ++i) h.members.push_back(i);
         for (;;) {
             const auto ta = clock::now();
-            if (!prepare_half(h, tasks, cubes, par, false)) return kDriverOk;
+            const bool more = prepare_half(h, tasks, cubes, par, false);
+            if (tick_hook_) tick_hook_();
+            if (!more) return kDriverOk;
             const auto tb = clock::now();
             int rc = ops_.bounds_multi((int)h.live.size(), h.R9.data(), h.spans.data(), h.fix.data(), h.offsets.data(), h.tn4.data(), h.lb.data(), h.ub.data());
             if (rc) return rc;
@@ -1251,6 +1314,8 @@ private:
     const bool overlap_stats_ = dev_env("FGOICP_OVERLAP_STATS") != nullptr;  // diagnostic: how many nodes both tasks of a rotation cube evaluate
     uint64_t ov_ub_ = 0, ov_lb_ = 0, ov_both_ = 0;
     bool account_submissions_ = true;   // false while SERIAL speculates: work is accounted per committed task instead
+    std::function<void()> tick_hook_;   // called by the task loop's thread after every batch preparation (ROUND: the overlapped refinements watch the UB tasks end)
+    const bool overlap_icp_ = [] { const char* e = dev_env("FGOICP_OVERLAP_ICP"); return e && std::atoi(e) != 0; }();  // development knob: 1 = a round's refinements next to its tasks (measured: no gain, see bnb_so3_round)
     std::unique_ptr<WorkerPool> pool_;
     float sse_threshold_;
     size_t ns_;

@@ -12,7 +12,7 @@ OUT=gpurun_out/r04b_ab_item_kernel.txt
 for leg in dragon headline trimmed; do
   for item in 0 1 0 1; do
     echo "== leg $leg FGOICP_BOUNDS_ITEM=$item" | tee -a $OUT
-    FGOICP_LIB=$DEV FGOICP_BOUNDS_ITEM=$item timeout -k 10 300 python3 bench.py --only $leg --steps 3 --warmup 1 2>/dev/null | python3 -c "
+    FGOICP_LIB=$DEV FGOICP_BOUNDS_ITEM=$item timeout -k 10 300 python3 bench.py --only $leg --steps 3 --warmup 1 2>gpurun_out/r04b_err.txt | python3 -c "
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):

@@ -13,7 +13,7 @@ cd /tmp
 SET4="TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE"
 for layout in 1 2 4 1 2 4; do
   echo "== dragon leg, FGOICP_LUT_ZPAIR=$layout" | tee -a $OUT
-  FGOICP_LIB=$DEV FGOICP_LUT_ZPAIR=$layout timeout -k 10 300 python3 $REPO/bench.py --only dragon --steps 1 --warmup 0 2>/dev/null | python3 $REPO/tools/bench_pick.py | tee -a $OUT
+  FGOICP_LIB=$DEV FGOICP_LUT_ZPAIR=$layout timeout -k 10 300 python3 $REPO/bench.py --only dragon --steps 1 --warmup 0 2>gpurun_out/r04b_err.txt | python3 $REPO/tools/bench_pick.py | tee -a $OUT
 done
 for layout in 2 4; do
   rm -rf /tmp/p4_l$layout

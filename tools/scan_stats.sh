@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 MODE=${1:-1}   # 1: counters, 2: cycle stamps only
 LIB=/tmp/libfgoicp_stats$MODE.so
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -x hip -DFGOICP_SCAN_STATS=$MODE -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -shared -o $LIB \
-   fast-go-icp_amd/csrc/device/kernels.hip fast-go-icp_amd/csrc/device/ctx.hip fast-go-icp_amd/csrc/device/bvh.hip fast-go-icp_amd/csrc/host/solver.cpp fast-go-icp_amd/csrc/host/multi.cpp -ldl 2>/dev/null || exit 1
+   fast-go-icp_amd/csrc/device/kernels.hip fast-go-icp_amd/csrc/device/ctx.hip fast-go-icp_amd/csrc/device/bvh.hip fast-go-icp_amd/csrc/host/solver.cpp fast-go-icp_amd/csrc/host/multi.cpp -ldl 2> gpurun_out/scan_stats_build.err || { tail -20 gpurun_out/scan_stats_build.err; exit 1; }
 FGOICP_LIB=$LIB python - <<'PY'
 import ctypes as C, numpy as np, sys, os
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
