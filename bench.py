@@ -268,6 +268,54 @@ def utilisation(r, x):
     r["busiest_unit"] = max(cands, key=cands.get)
 
 
+def cpu_baseline(fg, reg, tgt, src, res, mse, sched_id, K, seconds, gpu_leg):
+    """The reference has no CPU path, so the baseline is the product's host driver over the CPU oracle's operators
+    (tests/host_harness: same driver template, thresholds and LUT semantics) with a uniform-grid exact nearest-neighbour search
+    standing in for the nanoflann kd-tree the reference's README names.  A full run() to the optimum at the reference's default
+    threshold on the host's cores (kind "port"); its LUT is filled from the device LUT (bit-identical; the O(nodes * nt) CPU
+    build would take hours and is outside the timed span on the GPU side as well).  Plus the bounds operator on ONE core for a
+    bounded sample."""
+    from oracle import pyoracle
+    from tests import host_harness as hh
+    os.environ["FGOICP_HOST_SPIN"] = "0"     # the CPU run's driver shares the cores with the oracle's OpenMP team, which does the parallel work:
+    os.environ["FGOICP_HOST_THREADS"] = "1"  # no polling worker threads next to it
+    pyoracle.build()
+    cores = int(pyoracle.lib().orc_num_threads())
+    h = hh.HostDriver(tgt, src, res, mse, schedule=sched_id, round_width=K, build_lut=False, use_grid=True)
+    assert h.lut_dims() == tuple(reg.lut_dims())
+    h.lut_set(reg.lut_read())
+    t0 = time.perf_counter()
+    r = h.run()
+    wall = time.perf_counter() - t0
+    secs = h.seconds()
+    same = bool(abs(float(r["best_sse"]) - gpu_leg["best_sse"]) <= 1e-5 * gpu_leg["best_sse"] and np.allclose(r["R"], gpu_leg["R"], atol=1e-5))
+    # the bounds operator on ONE core, bounded sample of the same workload
+    pct, pcs, *_, bounds = fg.synth.preprocess(tgt, src)
+    orc = pyoracle.Registration(pct, pcs, bounds, res, build_lut=False)
+    orc.lut_set(reg.lut_read())
+    rng = np.random.default_rng(0)
+    rn = fg.RotNode(0.25, -0.125, 0.375, 0.125)
+    pyoracle.lib().orc_set_num_threads(1)
+    done1, t1 = 0, time.perf_counter()
+    while True:
+        tn = np.concatenate([rng.uniform(-0.5, 0.5, (32, 3)), np.full((32, 1), 0.125)], axis=1).astype(np.float32)
+        orc.compute_bounds(rn.q.R, rn.span, tn, False)
+        done1 += 32
+        dt1 = time.perf_counter() - t1
+        if dt1 >= seconds:
+            break
+    pyoracle.lib().orc_set_num_threads(cores)
+    sub = r["stats"]["trans_cubes"]
+    return {"value": sub / wall, "unit": "subcubes/s", "cores": cores, "kind": "port",
+            "sample": f"one full run() to the optimum: bunny-shape pair, mse_threshold={mse} (the reference's default), {sub} subcubes, "
+                      f"{r['stats']['icp_runs']} ICP runs ({r['stats']['icp_iters']} iterations), OpenMP over points/queries on {cores} threads",
+            "wall_clock_to_optimum_s": wall, "seconds_bnb": secs["bnb"], "seconds_icp": secs["icp"], "subcubes": int(sub),
+            "same_optimum_as_gpu": same, "best_sse": float(r["best_sse"]),
+            "gpu_wall_clock_to_optimum_s_same_run": gpu_leg["elapsed"] / gpu_leg["steps"],
+            "value_1_core": done1 / dt1, "sample_1_core": f"bounds operator only, {done1} subcubes (batches of 32, fix_rot=0) in {dt1:.1f}s on one thread",
+            "nearest_neighbour": "uniform grid over the target (oracle/goicp_oracle.cpp GridNN; exact, identical to the O(n*m) loops)"}
+
+
 def icp_latency(leg):
     """The ICP path of a leg (IterativeClosestPoint3D::run, icp3d.cu:80-108; exact SSE registration.cu:62-86) is a chain of dependent
     passes, not a bandwidth kernel: per iteration one correspondence scan of the working cloud (+ the move of the cloud and the
