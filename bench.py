@@ -110,8 +110,8 @@ class Env:
             # The trimmed leg's cooperative refinements would split their scans over the ranks through an in-place RCCL all-gather on device
             # memory (fgoicp_exchange.allgather_device) — a collective no multi-GPU node has executed yet (tests: in-process ranks on one
             # device, gloo).  The scaling run's headline must not depend on it: refinements run replicated here unless the caller opts in
-            # (FGOICP_COOP_SPLIT_MIN set in the environment, e.g. 262144 = the library's default for trimmed contexts).
-            os.environ.setdefault("FGOICP_COOP_SPLIT_MIN", str(1 << 62))
+            # (FGOICP_BENCH_SPLIT_SCANS=1 keeps the library's default: trimmed contexts of at least 262144 points split; fgoicp_ctx_set_coop_split).
+            self.split_scans = os.environ.get("FGOICP_BENCH_SPLIT_SCANS", "0") != "0"  # opt in: run_leg() then leaves the library's default (trimmed contexts split)
             import torch.distributed as dist
             self.dist = dist
             if a.rehearse_on_one_gpu:
@@ -173,6 +173,8 @@ def run_leg(env, fg, tgt, src, res, mse, sched, K, steps, warmup, trim=0.0):
     if env.ex is not None:
         solver.set_exchange(env.ex)
     reg = solver.registration
+    if env.world > 1 and not getattr(env, "split_scans", False):
+        reg.set_coop_split(None, None)  # N > 1: refinements replicated on every rank (see Env)
     for _ in range(warmup):
         solver.run()
     reg.set_profile(True)  # HIP events around every bounds kernel of the timed region (~2 % of a step)
@@ -414,91 +416,121 @@ def main():
         line["default_threshold_subcubes_per_step"] = s["subcubes_per_step"]
         line["icp_latency"] = icp_latency(dflt)
 
+    # Secondary legs.  On N > 1 ranks a leg that fails (a collective on a node nobody has run on before) must not cost the run its headline:
+    # the failure is recorded in the line, the exchange is aborted for every rank (the peers' runs then fail fast instead of waiting) and the
+    # remaining secondary legs are skipped.  On one rank an exception propagates as before.
+    state = {"failed": None}
+
+    def guarded(name, fn):
+        if state["failed"]:
+            line.setdefault("skipped_after_failure", []).append(name)
+            return
+        if world == 1:
+            fn()
+            return
+        try:
+            fn()
+        except Exception as e:  # noqa: BLE001
+            state["failed"] = name
+            line[name + "_error"] = repr(e)[:500]
+            print(f"[bench] rank {rank}: leg {name} failed: {e!r}", file=sys.stderr, flush=True)
+            try:
+                if env.ex is not None and hasattr(env.ex, "abort"):
+                    env.ex.abort()
+            except Exception:
+                pass
+
     # the reference's own exploration order (the drop-in classes' default schedule)
     if want("serial") and not a.no_serial:
-        ser = run_leg(env, fg, tgt, src, a.lut_resolution, a.mse_threshold, fg.SCHEDULE_SERIAL, 1, 1, 1)
-        if world > 1:  # SERIAL on N ranks: the trajectory is replicated, every rank's counters are the whole run's — not to be summed
-            ser["subcubes"] = ser["subcubes"] / world
-        s = leg_summary(ser, R_gt, t_gt, f"{a.workload}-shape pair, mse_threshold={a.mse_threshold}, SERIAL schedule (the reference's pops, pushes and counters — "
-                                          "checked against the oracle's literal driver in tests), one step after 1 warm-up"
-                                          + (f"; the inner BnBs of every speculative evaluation dealt over {world} ranks, one all-gather per evaluation" if world > 1 else ""))
-        if head is not None:
-            s["same_optimum_as_headline"] = bool(np.allclose(ser["R"], head["R"], atol=1e-5) and abs(ser["best_sse"] - head["best_sse"]) <= 1e-5 * head["best_sse"])
-        s["roofline"] = roofline(ser, None)
-        line["serial_reference_order"] = s
-        ser["solver"].close()
+        def _leg_serial():
+            ser = run_leg(env, fg, tgt, src, a.lut_resolution, a.mse_threshold, fg.SCHEDULE_SERIAL, 1, 1, 1)
+            if world > 1:  # SERIAL on N ranks: the trajectory is replicated, every rank's counters are the whole run's — not to be summed
+                ser["subcubes"] = ser["subcubes"] / world
+            s = leg_summary(ser, R_gt, t_gt, f"{a.workload}-shape pair, mse_threshold={a.mse_threshold}, SERIAL schedule (the reference's pops, pushes and counters — "
+                                              "checked against the oracle's literal driver in tests), one step after 1 warm-up"
+                                              + (f"; the inner BnBs of every speculative evaluation dealt over {world} ranks, one all-gather per evaluation" if world > 1 else ""))
+            if head is not None:
+                s["same_optimum_as_headline"] = bool(np.allclose(ser["R"], head["R"], atol=1e-5) and abs(ser["best_sse"] - head["best_sse"]) <= 1e-5 * head["best_sse"])
+            s["roofline"] = roofline(ser, None)
+            line["serial_reference_order"] = s
+            ser["solver"].close()
+        guarded("serial", _leg_serial)
 
     # dragon shape (BASELINE configs[2]/[3]; nt = ns = 437 645), certify regime, one step
     if want("dragon") and not a.no_dragon and a.workload == "bunny":
-        tgt_d, src_d, R_gt_d, t_gt_d = fg.synth.workload("dragon", angle_deg=150.0, min_angle_deg=110.0)
-        dr = run_leg(env, fg, tgt_d, src_d, a.lut_resolution, 5e-6, sched, K, 1, 0)  # ns*mse = 2.2 < residual 3.0
-        s = leg_summary(dr, R_gt_d, t_gt_d, f"dragon-shape synthetic pair (nt={len(tgt_d)}, ns={len(src_d)}), mse_threshold=5e-06, one step, no warm-up")
-        r = None
-        if rank == 0:
-            r = roofline(dr, pmc_all.get("dragon"), {})
-            if r:
-                utilisation(r, pmc_extra.get("dragon"))
-                u = r.get("utilisation") or {}
-                # Dense cloud: neighbouring points share texels and the LUT lines are re-used ACROSS the evaluations of a tick out of L1 / L2, so the per-evaluation
-                # byte model of SURVEY 8d (8 private texels per point) is not a roof here (priced that way the kernel would "exceed" the HBM peak).  One `frac`: the
-                # busiest unit the counters of this kernel name (profiles/bench_pmc_extra.json [dragon]); the HBM side as what it is, measured traffic / duration.
-                r["algorithmic_model_GBps_not_a_roof"] = r["achieved"]
-                if r.get("hbm_actual_GBps"):
-                    r["hbm"] = {"achieved": r["hbm_actual_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["hbm_actual_frac"],
-                                "definition": "measured HBM bytes per launch (rocprofv3 PMC, FETCH_SIZE x 2 + WRITE_SIZE; not measured in this run) / this run's launch duration"}
-                b = r.get("busiest_unit")
-                if b == "ta" and u.get("ta_busy_frac"):
-                    r["bound"], r["achieved"], r["peak"], r["unit"], r["frac"] = "ta", u["ta_busy_frac"], 1.0, "texture-addresser busy cycles / cycle (TA_BUSY, average over the 256 TAs)", u["ta_busy_frac"]
-                elif b == "l1" and u.get("l1_accesses_per_clock_cu"):
-                    r["bound"], r["achieved"], r["peak"], r["unit"], r["frac"] = "l1", u["l1_accesses_per_clock_cu"], 1.0, "L1 cache-line accesses per clock and CU (TCP_TOTAL_CACHE_ACCESSES)", u["l1_accesses_per_clock_cu"]
-                elif b == "valu" and u.get("valu"):
-                    v = u["valu"]
-                    r["bound"], r["achieved"], r["peak"], r["unit"], r["frac"] = "valu", v["achieved"], v["peak"], v["unit"], v.get("frac_cycle_based") or v["frac"]
-                elif r.get("hbm_actual_GBps"):
-                    r["achieved"], r["frac"] = r["hbm_actual_GBps"], r["hbm_actual_frac"]
-                else:  # no counter file for this tree: nothing to price against — say so instead of printing a model above the peak
-                    r["bound"], r["achieved"], r["frac"] = "unpriced (no counter passes of this tree)", None, None
-                if u:
-                    r["limited_by"] = (f"the L1 / texture path: TA busy {100 * (u.get('ta_busy_frac') or 0):.0f} % of the cycles ({100 * (u.get('ta_addr_stalled_frac') or 0):.0f} % stalled by the L1), "
-                                       f"{(u.get('l1_accesses_per_clock_cu') or 0):.2f} cache-line accesses per clock and CU ({(u.get('l1_accesses_per_point_evaluation') or 0):.2f} per point-evaluation, hit rate "
-                                       f"{100 * (u.get('l1_hit_rate') or 0):.0f} %), VALU issue {100 * ((u.get('valu') or {}).get('frac_cycle_based') or 0):.0f} % "
-                                       f"({(u.get('valu') or {}).get('insts_per_point_evaluation', 0):.0f} VALU instructions per point-evaluation: round 4 cut them from 120 to 77 with packed fp32 and the launch "
-                                       f"did not get shorter — profiles/r04_ab_item_kernel_dragon_trimmed.txt), measured HBM traffic {100 * (r.get('hbm_actual_frac') or 0):.0f} % of the peak")
-            s["roofline"] = r
-        s["icp_latency"] = icp_latency(dr)
-        line["dragon_shape"] = s
-        dr["solver"].close()
+        def _leg_dragon():
+            tgt_d, src_d, R_gt_d, t_gt_d = fg.synth.workload("dragon", angle_deg=150.0, min_angle_deg=110.0)
+            dr = run_leg(env, fg, tgt_d, src_d, a.lut_resolution, 5e-6, sched, K, 1, 0)  # ns*mse = 2.2 < residual 3.0
+            s = leg_summary(dr, R_gt_d, t_gt_d, f"dragon-shape synthetic pair (nt={len(tgt_d)}, ns={len(src_d)}), mse_threshold=5e-06, one step, no warm-up")
+            r = None
+            if rank == 0:
+                r = roofline(dr, pmc_all.get("dragon"), {})
+                if r:
+                    utilisation(r, pmc_extra.get("dragon"))
+                    u = r.get("utilisation") or {}
+                    # Dense cloud: neighbouring points share texels and the LUT lines are re-used ACROSS the evaluations of a tick out of L1 / L2, so the per-evaluation
+                    # byte model of SURVEY 8d (8 private texels per point) is not a roof here (priced that way the kernel would "exceed" the HBM peak).  One `frac`: the
+                    # busiest unit the counters of this kernel name (profiles/bench_pmc_extra.json [dragon]); the HBM side as what it is, measured traffic / duration.
+                    r["algorithmic_model_GBps_not_a_roof"] = r["achieved"]
+                    if r.get("hbm_actual_GBps"):
+                        r["hbm"] = {"achieved": r["hbm_actual_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["hbm_actual_frac"],
+                                    "definition": "measured HBM bytes per launch (rocprofv3 PMC, FETCH_SIZE x 2 + WRITE_SIZE; not measured in this run) / this run's launch duration"}
+                    b = r.get("busiest_unit")
+                    if b == "ta" and u.get("ta_busy_frac"):
+                        r["bound"], r["achieved"], r["peak"], r["unit"], r["frac"] = "ta", u["ta_busy_frac"], 1.0, "texture-addresser busy cycles / cycle (TA_BUSY, average over the 256 TAs)", u["ta_busy_frac"]
+                    elif b == "l1" and u.get("l1_accesses_per_clock_cu"):
+                        r["bound"], r["achieved"], r["peak"], r["unit"], r["frac"] = "l1", u["l1_accesses_per_clock_cu"], 1.0, "L1 cache-line accesses per clock and CU (TCP_TOTAL_CACHE_ACCESSES)", u["l1_accesses_per_clock_cu"]
+                    elif b == "valu" and u.get("valu"):
+                        v = u["valu"]
+                        r["bound"], r["achieved"], r["peak"], r["unit"], r["frac"] = "valu", v["achieved"], v["peak"], v["unit"], v.get("frac_cycle_based") or v["frac"]
+                    elif r.get("hbm_actual_GBps"):
+                        r["achieved"], r["frac"] = r["hbm_actual_GBps"], r["hbm_actual_frac"]
+                    else:  # no counter file for this tree: nothing to price against — say so instead of printing a model above the peak
+                        r["bound"], r["achieved"], r["frac"] = "unpriced (no counter passes of this tree)", None, None
+                    if u:
+                        r["limited_by"] = (f"the L1 / texture path: TA busy {100 * (u.get('ta_busy_frac') or 0):.0f} % of the cycles ({100 * (u.get('ta_addr_stalled_frac') or 0):.0f} % stalled by the L1), "
+                                           f"{(u.get('l1_accesses_per_clock_cu') or 0):.2f} cache-line accesses per clock and CU ({(u.get('l1_accesses_per_point_evaluation') or 0):.2f} per point-evaluation, hit rate "
+                                           f"{100 * (u.get('l1_hit_rate') or 0):.0f} %), VALU issue {100 * ((u.get('valu') or {}).get('frac_cycle_based') or 0):.0f} % "
+                                           f"({(u.get('valu') or {}).get('insts_per_point_evaluation', 0):.0f} VALU instructions per point-evaluation: round 4 cut them from 120 to 77 with packed fp32 and the launch "
+                                           f"did not get shorter — profiles/r04_ab_item_kernel_dragon_trimmed.txt), measured HBM traffic {100 * (r.get('hbm_actual_frac') or 0):.0f} % of the peak")
+                s["roofline"] = r
+            s["icp_latency"] = icp_latency(dr)
+            line["dragon_shape"] = s
+            dr["solver"].close()
+        guarded("dragon", _leg_dragon)
 
     # BASELINE configs[4] — 1M points, 20 % uniform outliers, trimmed Go-ICP (an extension: the reference parses `trim` and ignores it)
     if want("trimmed") and not a.no_trimmed and a.workload == "bunny":
-        tgt_m, src_m, R_gt_m, t_gt_m = fg.synth.workload("synthetic1m_outliers", angle_deg=150.0, min_angle_deg=110.0)
-        tr = run_leg(env, fg, tgt_m, src_m, a.lut_resolution, 1e-3, sched, K, 1, 0, trim=0.2)
-        s = leg_summary(tr, R_gt_m, t_gt_m, f"1M-point synthetic pair, 20 % of the source replaced by uniform outliers (nt={len(tgt_m)}, ns={len(src_m)}), trim_fraction=0.2, "
-                                             "mse_threshold=0.001, one step, no warm-up")
-        p = tr["prof"]
-        shift = int(os.environ.get("FGOICP_TRIM_SAMPLE", "5"))
-        sel_rows, sel_fallbacks, sel_members = tr["solver"].registration.trim_stats()
-        one_pass = shift > 0 and sel_rows > 0
-        frac_fb = sel_fallbacks / sel_rows if sel_rows else 0.0
-        samp = 1.0 / (1 << shift) if shift > 0 else 0.0
-        extra = {"select_kernel": "trim_rows_sampled_kernel" if one_pass else "trim_rows_kernel", "select_kernel_ms": p["select_ms"], "bounds_kernel_ms": p["kernel_ms"],
-                 # one pass over the row + its 1/2^shift sample (+ two more passes for a row whose bracket failed its exact check) | two passes
-                 "select_bytes_per_row": (4.0 * tr["ns"] * (1.0 + samp + 2.0 * frac_fb)) if one_pass else 2 * 4.0 * tr["ns"],
-                 "bounds_write_bytes_per_row": 4.0 * tr["ns"] * (1.0 + (samp if one_pass else 0.0)),
-                 "select_rows": sel_rows, "select_rows_done_again_in_two_passes": sel_fallbacks,
-                 "select_bracket_members_per_row": (sel_members / max(1, sel_rows - sel_fallbacks)) if one_pass else None,
-                 "bnb_without_icp_GBps_algorithmic_rank0": tr["stats"]["trans_cubes"] * unit_bytes(tr["ns"]) / (tr["stats"]["seconds_total"] - tr["stats"]["seconds_icp"]) / 1e9,
-                 "model": "algorithmic bytes as for the untrimmed operator (SURVEY 8d); on top of them the trimmed path writes 4 B per point-row (e = max(d, 0)) plus a 1/32 "
-                          "sample of it, and the selection kernel, which runs NEXT TO the bounds kernel on a side stream, reads the sample and then the row ONCE "
-                          "(bracket from the sample, verified exactly; round 2 read every row twice)" if one_pass else
-                          "algorithmic bytes as for the untrimmed operator (SURVEY 8d); on top of them the trimmed path writes 4 B per point-row (e = max(d, 0)) and the "
-                          "selection kernel, which runs NEXT TO the bounds kernel on a side stream, reads each row twice"}
-        extra["limited_by"] = "closest of the three to the HBM roof: measured traffic (LUT lines + 4 B written per point-row) at ~0.7 of the peak, ~0.9 of the measured copy rate"
-        s["roofline"] = roofline(tr, pmc_all.get("trimmed"), extra)
-        utilisation(s["roofline"], pmc_extra.get("trimmed"))
-        s["icp_latency"] = icp_latency(tr)
-        line["trimmed_1m_outliers"] = s
-        tr["solver"].close()
+        def _leg_trimmed():
+            tgt_m, src_m, R_gt_m, t_gt_m = fg.synth.workload("synthetic1m_outliers", angle_deg=150.0, min_angle_deg=110.0)
+            tr = run_leg(env, fg, tgt_m, src_m, a.lut_resolution, 1e-3, sched, K, 1, 0, trim=0.2)
+            s = leg_summary(tr, R_gt_m, t_gt_m, f"1M-point synthetic pair, 20 % of the source replaced by uniform outliers (nt={len(tgt_m)}, ns={len(src_m)}), trim_fraction=0.2, "
+                                                 "mse_threshold=0.001, one step, no warm-up")
+            p = tr["prof"]
+            shift = int(os.environ.get("FGOICP_TRIM_SAMPLE", "5"))
+            sel_rows, sel_fallbacks, sel_members = tr["solver"].registration.trim_stats()
+            one_pass = shift > 0 and sel_rows > 0
+            frac_fb = sel_fallbacks / sel_rows if sel_rows else 0.0
+            samp = 1.0 / (1 << shift) if shift > 0 else 0.0
+            extra = {"select_kernel": "trim_rows_sampled_kernel" if one_pass else "trim_rows_kernel", "select_kernel_ms": p["select_ms"], "bounds_kernel_ms": p["kernel_ms"],
+                     # one pass over the row + its 1/2^shift sample (+ two more passes for a row whose bracket failed its exact check) | two passes
+                     "select_bytes_per_row": (4.0 * tr["ns"] * (1.0 + samp + 2.0 * frac_fb)) if one_pass else 2 * 4.0 * tr["ns"],
+                     "bounds_write_bytes_per_row": 4.0 * tr["ns"] * (1.0 + (samp if one_pass else 0.0)),
+                     "select_rows": sel_rows, "select_rows_done_again_in_two_passes": sel_fallbacks,
+                     "select_bracket_members_per_row": (sel_members / max(1, sel_rows - sel_fallbacks)) if one_pass else None,
+                     "bnb_without_icp_GBps_algorithmic_rank0": tr["stats"]["trans_cubes"] * unit_bytes(tr["ns"]) / (tr["stats"]["seconds_total"] - tr["stats"]["seconds_icp"]) / 1e9,
+                     "model": "algorithmic bytes as for the untrimmed operator (SURVEY 8d); on top of them the trimmed path writes 4 B per point-row (e = max(d, 0)) plus a 1/32 "
+                              "sample of it, and the selection kernel, which runs NEXT TO the bounds kernel on a side stream, reads the sample and then the row ONCE "
+                              "(bracket from the sample, verified exactly; round 2 read every row twice)" if one_pass else
+                              "algorithmic bytes as for the untrimmed operator (SURVEY 8d); on top of them the trimmed path writes 4 B per point-row (e = max(d, 0)) and the "
+                              "selection kernel, which runs NEXT TO the bounds kernel on a side stream, reads each row twice"}
+            extra["limited_by"] = "closest of the three to the HBM roof: measured traffic (LUT lines + 4 B written per point-row) at ~0.7 of the peak, ~0.9 of the measured copy rate"
+            s["roofline"] = roofline(tr, pmc_all.get("trimmed"), extra)
+            utilisation(s["roofline"], pmc_extra.get("trimmed"))
+            s["icp_latency"] = icp_latency(tr)
+            line["trimmed_1m_outliers"] = s
+            tr["solver"].close()
+        guarded("trimmed", _leg_trimmed)
 
     if rank == 0:
         if world == 1 and want("cpu_baseline") and not a.no_cpu_baseline and a.only in (None, "cpu_baseline"):

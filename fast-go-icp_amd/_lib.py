@@ -93,6 +93,7 @@ _SIGS = {
     "fgoicp_ctx_profile_evaluations": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "fgoicp_ctx_profile_select_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "fgoicp_ctx_trim_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]),
+    "fgoicp_ctx_set_coop_split": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t]),
     "fgoicp_ctx_set_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "fgoicp_ctx_ns": (C.c_size_t, [C.c_void_p]),
     "fgoicp_ctx_nt": (C.c_size_t, [C.c_void_p]),
@@ -108,6 +109,7 @@ _SIGS = {
     "fgoicp_solver_stats": (C.c_int, [C.c_void_p, C.POINTER(RunStats)]),
     "fgoicp_solver_preproc": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_float_p]),
     "fgoicp_solver_ctx": (C.c_void_p, [C.c_void_p]),
+    "fgoicp_rccl_library": (C.c_char_p, []),
     "fgoicp_rccl_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "fgoicp_rccl_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.POINTER(C.c_void_p)]),
     "fgoicp_rccl_create_ex": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),

@@ -1929,6 +1929,13 @@ int fgoicp_ctx_profile_evaluations(fgoicp_ctx* c, uint64_t* evaluations) {
     return FGOICP_OK;
 }
 
+int fgoicp_ctx_set_coop_split(fgoicp_ctx* c, size_t min_points_untrimmed, size_t min_points_trimmed) {
+    if (!c) return FGOICP_ERR_INVALID_ARG;
+    c->coop_split_min = min_points_untrimmed;
+    c->coop_split_trim_min = min_points_trimmed;
+    return FGOICP_OK;
+}
+
 int fgoicp_ctx_set_profile(fgoicp_ctx* c, int enabled) {
     if (!c) return FGOICP_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(c->device));

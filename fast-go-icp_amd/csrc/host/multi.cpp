@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>   // types and prototypes only: the library is loaded on first use (RcclApi below), not linked
 #include <dlfcn.h>
+#include <link.h>   // dl_iterate_phdr: is a librccl already mapped into the process?
 
 #include <atomic>
 #include <chrono>
@@ -30,6 +31,7 @@
 #include "../../../include/fgoicp_amd.h"
 #include "abi_guard.hpp"
 #include "multi_link.hpp"
+#include "knobs.hpp"
 
 namespace fgoicp {
 int ctx_icp_coop(fgoicp_ctx* c, int rank, int world, int (*gather)(void* dev_buf, size_t bytes_per_rank, void* user), void* user, const float* R0,
@@ -73,16 +75,39 @@ struct RcclApi {
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
-    std::string error;
+    std::string error, path;
     bool ok = false;
 };
+// Which librccl?  A process may already hold one: PyTorch-ROCm bundles its own librccl.so and librocm_smi64.so under torch/lib.  Loading the
+// system's /opt/rocm/lib/librccl.so.1 next to it puts a SECOND librocm_smi64 into the process, both copies export the same C++ globals
+// (amd::smi::...), the dynamic linker binds both to the copy that was loaded first, and that copy's objects are then constructed and
+// DESTROYED TWICE: glibc aborts with "double free or corruption (!prev)" in the exit handlers, after main() has returned (round 3's and round
+// 4's recorded heap abort: the destructor of a std::map<amd::smi::DevInfoTypes, const char*> of librocm_smi64.so.1 — profiles/
+// r04_exit_abort_rocm_smi.txt; it needs both libraries in one process, which is why only the replays that also imported torch hit it).
+// So: (1) if the process already has a librccl mapped, that instance is used — one RCCL, one SMI; (2) otherwise the system library is loaded
+// RTLD_LOCAL | RTLD_DEEPBIND (round 3: RTLD_GLOBAL), so that its dependencies bind to themselves and a copy that something else loads later
+// neither sees their symbols nor overrides them.
+static int find_loaded_rccl(struct dl_phdr_info* info, size_t, void* out) {
+    const char* name = info->dlpi_name;
+    if (!name || !*name) return 0;
+    const char* base = std::strrchr(name, '/');
+    base = base ? base + 1 : name;
+    if (std::strncmp(base, "librccl.so", 10) != 0) return 0;
+    *static_cast<std::string*>(out) = name;
+    return 1;
+}
 const RcclApi& rccl_api() {
     static const RcclApi api = [] {
         RcclApi a;
         void* h = nullptr;
+        std::string loaded;
+        const char* legacy = fgoicp::dev_env("FGOICP_RCCL_LOAD_GLOBAL");  // development build only: round 3's loading (system library, RTLD_GLOBAL) — the A/B that shows the exit abort
+        const bool old_way = legacy && std::atoi(legacy) != 0;
+        if (!old_way) (void)dl_iterate_phdr(find_loaded_rccl, &loaded);
+        if (!loaded.empty()) h = dlopen(loaded.c_str(), RTLD_NOW | RTLD_NOLOAD);  // the instance the process already runs (e.g. PyTorch's)
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (h) break;
+            h = dlopen(name, old_way ? (RTLD_NOW | RTLD_GLOBAL) : (RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND));
         }
         if (!h) { a.error = std::string("RCCL is not installed (dlopen librccl.so.1: ") + dlerror() + ")"; return a; }
         bool all = true;
@@ -91,6 +116,7 @@ const RcclApi& rccl_api() {
         sym(a.CommGetAsyncError, "ncclCommGetAsyncError"); sym(a.CommDestroy, "ncclCommDestroy"); sym(a.CommAbort, "ncclCommAbort");
         sym(a.CommCount, "ncclCommCount"); sym(a.AllReduce, "ncclAllReduce"); sym(a.AllGather, "ncclAllGather"); sym(a.GetErrorString, "ncclGetErrorString");
         if (!all) { a.error = "librccl.so lacks an entry point this library uses"; return a; }
+        a.path = !loaded.empty() ? loaded + " (already in the process)" : old_way ? "librccl.so.1 (loaded by libfgoicp_amd, RTLD_GLOBAL: round 3's way)" : "librccl.so.1 (loaded by libfgoicp_amd, RTLD_LOCAL | RTLD_DEEPBIND)";
         a.ok = true;
         return a;
     }();
@@ -352,6 +378,9 @@ int fgoicp_rccl_exchange(fgoicp_rccl* x, fgoicp_exchange* out) {
     out->allgather_device = rccl_allgather_device;
     return FGOICP_OK;
 }
+
+// Which librccl the transport uses (diagnostic; bench.py prints it): the instance already mapped into the process, or the one this library loaded.
+const char* fgoicp_rccl_library(void) { return rccl_api().ok ? rccl_api().path.c_str() : rccl_api().error.c_str(); }
 
 int fgoicp_rccl_calls(const fgoicp_rccl* x, uint64_t* calls) {
     if (!x || !calls) return FGOICP_ERR_INVALID_ARG;

@@ -77,6 +77,12 @@ class Registration:
         _lib.check(self._lib.fgoicp_lut_dims(self._h, d), "fgoicp_lut_dims")
         return tuple(d)
 
+    def set_coop_split(self, min_points_untrimmed=None, min_points_trimmed=None):
+        """fgoicp_ctx_set_coop_split: from how many source points a cooperative refinement splits its scans over the ranks (None = never)"""
+        never = (1 << 64) - 1
+        _lib.check(self._lib.fgoicp_ctx_set_coop_split(self._h, never if min_points_untrimmed is None else int(min_points_untrimmed),
+                                                       never if min_points_trimmed is None else int(min_points_trimmed)), "fgoicp_ctx_set_coop_split")
+
     def info(self):
         """fgoicp_ctx_get_info: LUT size and layout, source density per LUT face voxel, points per work item (what the context
         derived from the clouds' statistics)."""

@@ -195,6 +195,11 @@ int fgoicp_ctx_profile_select_ms(fgoicp_ctx* ctx, double* select_ms);
  * sampled bracket failed its exact check and that were done again in two passes, bracket members gathered}.  No submission may
  * be in flight. */
 int fgoicp_ctx_trim_stats(fgoicp_ctx* ctx, uint64_t* out3, int reset);
+/* Multi-rank runs: from how many source points a cooperative refinement (fgoicp_exchange.allgather_device) splits its exact scans over the
+ * ranks instead of running replicated on every rank.  Defaults: untrimmed never ((size_t)-1: measured no faster at 437k points on 8 ranks),
+ * trimmed contexts from 262 144 points (their iterations are long: 8-rank replay 1.84x -> 2.69x).  A deployment choice (it trades an
+ * in-place device all-gather of 4 B per source point, twice per ICP iteration, against the replicated scan), hence an option, not a knob. */
+int fgoicp_ctx_set_coop_split(fgoicp_ctx* ctx, size_t min_points_untrimmed, size_t min_points_trimmed);
 /* Turns the HIP-event bracketing on or off at run time (events are created on first use). */
 int fgoicp_ctx_set_profile(fgoicp_ctx* ctx, int enabled);
 size_t fgoicp_ctx_ns(const fgoicp_ctx* ctx);
@@ -312,6 +317,10 @@ typedef struct fgoicp_rccl fgoicp_rccl;
  * fgoicp_rccl_create (ncclCommInitRank — blocks until all ranks have joined) and installs fgoicp_rccl_exchange's struct with
  * fgoicp_solver_set_exchange.  The collectives run on device buffers over xGMI, on a stream of their own. */
 int fgoicp_rccl_unique_id(unsigned char* id128);
+/* Which librccl the transport runs on (loads it on first use): the instance already mapped into the process — PyTorch-ROCm brings its own
+ * librccl.so + librocm_smi64.so, and a second copy next to it makes the process abort in its exit handlers (two librocm_smi64 destroying
+ * the same globals) — or the system's librccl.so.1, loaded RTLD_LOCAL | RTLD_DEEPBIND.  Returns a description (or the load error). */
+const char* fgoicp_rccl_library(void);
 int fgoicp_rccl_create(int rank, int world_size, const unsigned char* id128, int device, fgoicp_rccl** out);
 /* The same with the kind of communicator chosen: nonblocking != 0 creates it with ncclConfig_t.blocking = 0 (what fgoicp_multi_create
  * does for its rank threads, so that a rank can abandon the set-up when a peer fails); every collective on such a communicator may

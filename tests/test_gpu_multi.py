@@ -253,6 +253,39 @@ def test_rccl_nonblocking_communicator_settles_every_collective(fg, gpu_required
     ex.close()
 
 
+@pytest.mark.parametrize("torch_first", [True, False])
+def test_process_exit_is_clean_with_torch_and_rccl_in_one_process(fg, gpu_required, torch_first):
+    """The recorded heap abort of rounds 3 and 4 (`double free or corruption (!prev)` AFTER main() had returned): PyTorch-ROCm bundles its own
+    librccl.so + librocm_smi64.so; the library used to dlopen the system's librccl.so.1 RTLD_GLOBAL next to them, two librocm_smi64 then
+    destroyed the same C++ globals in the exit handlers (profiles/r04_exit_abort_rocm_smi.txt).  Now the transport uses the librccl the process
+    already has, or loads the system one RTLD_LOCAL | RTLD_DEEPBIND: a child process that uses torch on the GPU AND the library's RCCL
+    transport, in either order, must exit with status 0 and an empty heap-checker."""
+    import subprocess
+    import sys
+    code = f"""
+import sys
+sys.path.insert(0, {REPO!r})
+import fgoicp_amd as fg
+def use_torch():
+    import torch
+    t = torch.arange(1024, device="cuda:0", dtype=torch.float32)
+    assert float(t.sum()) == 523776.0
+def use_rccl():
+    ex = fg.RcclExchange(0, 1, fg.rccl_unique_id(), 0)
+    assert ex.warmup()
+    print("rccl:", fg._lib.load().fgoicp_rccl_library().decode())
+    ex.close()
+for f in ({'use_torch, use_rccl' if torch_first else 'use_rccl, use_torch'}):
+    f()
+print("done", flush=True)
+"""
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, (p.returncode, p.stdout[-500:], p.stderr[-1500:])
+    assert "done" in p.stdout and "double free" not in p.stderr and "corruption" not in p.stderr
+    if torch_first:
+        assert "already in the process" in p.stdout  # torch's own librccl was reused: one RCCL, one SMI library
+
+
 def test_rccl_transport_with_one_rank(fg, gpu_required):
     """ncclCommInitRank + all-reduce(min) + all-gather on device buffers (world size 1 is all a one-GPU box can form)."""
     ident = fg.rccl_unique_id()

@@ -26,6 +26,11 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
 
+def note(msg):
+    """progress on stderr (the runner keeps it in a file under gpurun_out/: a long, silent run is taken for hung on the GPU box)"""
+    print(f"[scale_replay {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     import fgoicp_amd as fg
     world = int(sys.argv[1]); workload = sys.argv[2] if len(sys.argv) > 2 else "bunny"
@@ -35,6 +40,7 @@ def main():
     serial = os.environ.get("FGOICP_REPLAY_SCHEDULE", "round") == "serial"
     sched = fg.SCHEDULE_SERIAL if serial else fg.SCHEDULE_ROUND
     trim = float(os.environ.get("FGOICP_REPLAY_TRIM", "0"))  # e.g. 0.2 with the workload synthetic1m_outliers (BASELINE configs[4])
+    note(f"workload {workload} generated; creating the one-GPU solver")
     one = fg.FastGoICP(tgt, src, res, mse, schedule=sched, round_width=1 if serial else 0, device=0, trim_fraction=trim)
     t1 = 1e30
     for _ in range(repeats + 1):
@@ -42,15 +48,19 @@ def main():
     st1 = one.stats()
     e1 = float(one.get_best_error())
     one.close()
+    note(f"one GPU: {t1:.3f} s; creating {world} ranks on device 0")
     m = fg.MultiGoICP(tgt, src, res, mse, devices=[0] * world, transport=fg.TRANSPORT_IN_PROCESS, schedule=sched, round_width=1 if serial else 0, trim_fraction=trim)
     m.set_record(True)
+    note("ranks created; recorded run of all ranks together")
     t0 = time.perf_counter(); R, t = m.run(); together = time.perf_counter() - t0
+    note(f"together: {together:.3f} s; replaying every rank alone")
     times, subs, icps, rounds, iters_rank = [], [], [], None, []
     for r in range(world):
         best = 1e30
         for _ in range(repeats + 1):  # the first pass warms up
             best = min(best, m.replay_rank(r))
         st = m.stats(r)
+        note(f"rank {r} alone: {best:.3f} s")
         times.append(best); subs.append(int(st["trans_cubes"])); icps.append(float(st["seconds_icp"])); rounds = int(st["rounds"]); iters_rank.append(int(st.get("icp_iters", 0)))
     host_ex = [m.recorded(r)[0] for r in range(world)]
     dev_gathers = m.recorded(0)[1]
@@ -79,7 +89,9 @@ def main():
         buf = torch.zeros(per_bytes * world, dtype=torch.uint8, device="cuda:0")
         torch.cuda.synchronize()
         t_dev = timed(lambda: ex.struct.allgather_device(buf.data_ptr(), per_bytes * world, ex.struct.user))  # world 1: the whole buffer is this rank's chunk
+    note("closing the one-rank RCCL communicator")
     ex.close()
+    note("communicator closed")
     band = 1e-5 if (late == "0" or coop) else 2e-3
     t_wire = per_bytes * (world - 1) / 50e9
     t_host = max(t_ar, t_ag)  # every recorded host-side collective is charged the dearer of the two
@@ -97,8 +109,11 @@ def main():
            "note": "each rank's share replayed alone on one GPU against the recorded exchange results (fgoicp_multi_replay_rank); "
                    "estimated_speedup excludes the collectives, estimated_speedup_with_collectives adds the measured RCCL software-path latency per exchange"}
     print(json.dumps(out), flush=True)
+    note("closing the multi-rank object")
     m.close()
+    note("multi-rank object closed; leaving main()")
 
 
 if __name__ == "__main__":
     main()
+    note("main() returned; interpreter exit follows")
