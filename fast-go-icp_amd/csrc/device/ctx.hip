@@ -36,6 +36,41 @@ void set_error(const std::string& s) { g_last_error = s; }
         }                                                                                              \
     } while (0)
 
+// Waiting for the device with the host's latency in mind.  hipEventSynchronize / hipStreamSynchronize park the thread in the runtime (the wake-up
+// costs 5-8 us on this image); the ICP loop pays that twice per iteration and an iteration is 45-55 us at 40k points.  These poll the event /
+// stream for a bounded time first (an iteration's kernels are tens of microseconds) and fall back to the blocking call for long waits.
+// MEASURED (profiles/r04_ab_spin_sync.txt): nothing — 54.7-55.9 us per ICP iteration blocking against 54.7-60.3 polling, every bench leg within noise: the
+// runtime's own wait is not what an iteration's 18-us host turn-around consists of.  OFF (0) by default; FGOICP_SPIN_SYNC_US=<us> is the development knob.
+static const int g_spin_sync_us = [] { const char* e = dev_env("FGOICP_SPIN_SYNC_US"); return e ? std::atoi(e) : 0; }();
+static hipError_t wait_event(hipEvent_t ev) {
+    if (g_spin_sync_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; ++spins) {
+            const hipError_t q = hipEventQuery(ev);
+            if (q != hipErrorNotReady) return q;
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+            if ((spins & 15u) == 15u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(g_spin_sync_us)) break;
+        }
+    }
+    return hipEventSynchronize(ev);
+}
+static hipError_t wait_stream(hipStream_t st) {
+    if (g_spin_sync_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; ++spins) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q != hipErrorNotReady) return q;
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+            if ((spins & 15u) == 15u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(g_spin_sync_us)) break;
+        }
+    }
+    return hipStreamSynchronize(st);
+}
+
 int ctx_flush_profile(fgoicp_ctx* c) {
     for (int i = 0; i < c->ev_used; ++i) {
         float ms = 0.f;
@@ -256,7 +291,7 @@ static int tick_enqueue_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl, int G, c
 
 static int tick_wait_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
     const double t2 = g_tt.on ? now_s() : 0;
-    HIPCHK(hipEventSynchronize(sl.done));
+    HIPCHK(wait_event(sl.done));
     if (*sl.h_sort_err) {
         // The tick's `sorted` was not a permutation: the XCD-private histogram (workgroup-scope atomics, see kernels.hip) is
         // not a single point of coherence on this device.  Switch this context to device-scope atomics for good and repeat
@@ -619,7 +654,7 @@ static int lane_icp(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0, cons
         Mat3f Rn;
         Vec3f tn;
         if (overlap) {
-            HIPCHK(hipEventSynchronize(L.icp_ev_b));
+            HIPCHK(wait_event(L.icp_ev_b));
             chain_pending = false;
             procrustes_finish(L, &Rn, &tn, nullptr, nullptr);
         } else {
@@ -652,7 +687,7 @@ static int lane_icp(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0, cons
             chain_pending = true;
             rc = sse_enqueue(c, L, R.m, t3, seed, A, 2);
             if (rc) return rc;
-            HIPCHK(hipStreamSynchronize(A));
+            HIPCHK(wait_stream(A));
             sse = sse_result(c, L);
         } else {
             launch_transform_inplace(L.d_work, ns, Rn.m, tn3, A);  // :100
@@ -946,7 +981,7 @@ static int lane_icp_dual(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0,
         last_sse = sse;
         last_R = R;
         last_t = t;
-        HIPCHK(hipStreamSynchronize(S));  // first iteration: pass 1; later: a no-op (the SSE's sync below drained the stream)
+        HIPCHK(wait_stream(S));  // first iteration: pass 1; later: a no-op (the SSE's sync below drained the stream)
         pending = false;
         Mat3f Rn;
         Vec3f tn;
@@ -983,7 +1018,7 @@ static int lane_icp_dual(fgoicp_ctx* c, fgoicp_ctx::IcpLane& L, const float* R0,
             if (rc) return rc;
         }
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(S));
+        HIPCHK(wait_stream(S));
         sse = sse_result(c, L);
         ++iters;
     }

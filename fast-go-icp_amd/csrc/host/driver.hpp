@@ -816,9 +816,31 @@ private:
                     }
                 });
             }
-            int rc = run_task_list(tasks, cubes);
+            // UB TASKS FIRST in a small round (round 4, FGOICP_UB_FIRST, development knob — see the measurement below): a round of a few cubes is a chain of
+            // device round trips, every UB task needs one per level of its translation tree (5-8), and next to the LB tasks a round trip carries five times the
+            // rows.  Run alone, the UB tasks end in a fraction of the task phase; the triggers are then known and the refinements run on the second thread
+            // (above) next to the LB tasks.  The twin / memo sharing between a cube's two tasks is given up for such a round (a few hundred subcubes).
+            // MEASURED (profiles/r04_ab_ub_first.txt): nothing — default-threshold step 15.3 -> 15.3-15.5 ms, headline and trimmed within noise.  A tick of a few
+            // hundred subcubes is not shorter than one of a thousand: its 245 us are the chain of eight dependent launches (upload, keys, fold, scan, scatter, check,
+            // bounds, finalize), so the UB tasks alone still need their 5-8 round trips of that length and the LB tasks theirs AFTER them.
+            const bool ub_first = overlapped && ub_first_max_ > 0 && mine.size() <= ub_first_max_;
+            int rc = kDriverOk;
+            if (ub_first) {
+                std::vector<Task*> ubt, lbt;
+                std::vector<const RotCube*> ubc, lbc;
+                for (size_t k = 0; k < mine.size(); ++k) {
+                    ubt.push_back(tasks[2 * k]); ubc.push_back(cubes[2 * k]);
+                    lbt.push_back(tasks[2 * k + 1]); lbc.push_back(cubes[2 * k + 1]);
+                }
+                tick_hook_ = nullptr;  // (the hook is keyed to the combined task list)
+                rc = run_task_list(ubt, ubc);
+                ov.ub_ready.store(rc ? 0 : mine.size(), std::memory_order_release);
+                if (!rc) rc = run_task_list(lbt, lbc);
+            } else {
+                rc = run_task_list(tasks, cubes);
+            }
             if (overlapped) {
-                tick_hook_();          // every task has ended
+                if (!ub_first) tick_hook_();   // every task has ended
                 tick_hook_ = nullptr;
                 if (rc) ov.stop.store(true);
                 ov.th.join();
@@ -1315,6 +1337,7 @@ private:
     uint64_t ov_ub_ = 0, ov_lb_ = 0, ov_both_ = 0;
     bool account_submissions_ = true;   // false while SERIAL speculates: work is accounted per committed task instead
     std::function<void()> tick_hook_;   // called by the task loop's thread after every batch preparation (ROUND: the overlapped refinements watch the UB tasks end)
+    const size_t ub_first_max_ = [] { const char* e = dev_env("FGOICP_UB_FIRST"); const int v = e ? std::atoi(e) : 0; return (size_t)(v > 0 ? v : 0); }();  // development knob: rounds of at most this many children run their UB tasks first (needs FGOICP_OVERLAP_ICP=1)
     const bool overlap_icp_ = [] { const char* e = dev_env("FGOICP_OVERLAP_ICP"); return e && std::atoi(e) != 0; }();  // development knob: 1 = a round's refinements next to its tasks (measured: no gain, see bnb_so3_round)
     std::unique_ptr<WorkerPool> pool_;
     float sse_threshold_;

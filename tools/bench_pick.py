@@ -15,6 +15,10 @@ for line in sys.stdin:
     if not line.startswith("{"):
         continue
     d = json.loads(line)
+    if d.get("default_threshold_ms_per_step") is not None:
+        il = d.get("icp_latency") or {}
+        print(json.dumps({"where": "/default_threshold", "ms_per_step": round(d["default_threshold_ms_per_step"], 3), "icp_us_per_iteration": round(il.get("us_per_iteration", 0.0), 2),
+                          "icp_iterations": il.get("iterations"), "seconds_icp": il.get("seconds_icp")}))
     for path, r in walk(d):
         parent = d
         for k in [p for p in path.split("/") if p][:-1]:
