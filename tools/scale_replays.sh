@@ -12,6 +12,7 @@ mkdir -p gpurun_out
 OUT=gpurun_out/${TAG}_scale_replay.jsonl
 : > "$OUT"
 PRE=""
+[ -f tools/abort_bt.so ] || gcc -O1 -g -shared -fPIC -o tools/abort_bt.so tools/abort_bt.c 2>/dev/null || true
 [ -f tools/abort_bt.so ] && PRE="$PWD/tools/abort_bt.so"
 n=0
 for spec in "$@"; do
