@@ -217,10 +217,18 @@ template <int LAYOUT, int TRIM, bool WIDE, bool QUANT>
 __global__ __launch_bounds__(64) void bounds_item_kernel(const float4* __restrict__ src, int ns, const char* __restrict__ lutp, LutGeom g,
                                                          const TickGroup* __restrict__ groups, const TickSub* __restrict__ subs, const unsigned* __restrict__ sorted,
                                                          int nchunk, int chunk_pts, double2* __restrict__ partials, float* __restrict__ evals, size_t erow, int samp_shift,
-                                                         unsigned nitems) {
+                                                         unsigned nitems, unsigned* __restrict__ sort_err) {
     const unsigned slot = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned item = sorted ? sorted[slot] : slot;  // small ticks come unsorted
-    if (item >= nitems) return;  // never taken when `sorted` is a permutation (tick_check_kernel verifies that on the device)
+    // The sort's check, folded into its only consumer.  `sorted` was filled with 0xFFFFFFFF before the scatter and every in-range rank
+    // is written by exactly the item that drew it, so if no slot still holds an out-of-range value every slot was written, hence written
+    // once: `sorted` is a permutation of the items.  The grid reads every slot exactly once (xcd_remap is a bijection), so a slot that
+    // was never written (two items drew the same rank: the XCD-private histogram's workgroup-scope atomics did not behave as one point
+    // of coherence) is seen here; *sort_err is pinned host memory and the context then repeats the window with device-scope atomics.
+    if (item >= nitems) {
+        if (sort_err && threadIdx.x == 0) *sort_err = 1u;
+        return;
+    }
     const int s = (int)(item / (unsigned)nchunk);
     const int chunk = (int)(item - (unsigned)s * (unsigned)nchunk);
     const TickSub sb = subs[s];

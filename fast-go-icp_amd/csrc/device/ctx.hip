@@ -118,6 +118,7 @@ static int tick_launch_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
     const TickGroup* dev_groups = small ? sl.hd_groups : sl.d_groups;
     const TickSub* dev_subs = small ? sl.hd_subs : sl.d_subs;
     *sl.h_sort_err = 0u;
+    unsigned* fused_err = !small && c->sort_check ? sl.hd_sort_err : nullptr;  // the bounds kernel checks the permutation it walks
     if (!small) {
         // descriptors + locality sort on the slot's side stream (overlaps the other slot's bounds kernel); the main stream joins behind it
         static const int upload_kernel = [] { const char* e = dev_env("FGOICP_UPLOAD_KERNEL"); return e ? std::atoi(e) : 1; }();  // tuning knob: 0 = two hipMemcpyAsync
@@ -129,8 +130,11 @@ static int tick_launch_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
         }
         ++c->sorted_ticks;
         const int fault = c->sort_fault_tick && c->sorted_ticks == (uint64_t)c->sort_fault_tick;
+        // FGOICP_SEPARATE_CHECK=1 (development build): the permutation check as round 3's launch behind the scatter instead of inside the bounds kernel
+        static const bool separate_check = [] { const char* e = dev_env("FGOICP_SEPARATE_CHECK"); return e && std::atoi(e) != 0; }();
         launch_tick_sort(c->geom, c->d_chunk_cen, c->nchunk1, sl.d_groups, sl.d_subs, neval, c->cell_shift, sl.d_keys, sl.d_ranks, sl.d_hist, sl.d_hist_xcd, sl.d_xoff, sl.d_block_sums, sl.d_cursor, sl.d_sorted,
-                         c->sort_xcd ? 1 : 0, c->sort_check ? sl.hd_sort_err : nullptr, fault, sl.sort_stream, sl.win_units, um);
+                         c->sort_xcd ? 1 : 0, c->sort_check ? 1 : 0, separate_check && c->sort_check ? sl.hd_sort_err : nullptr, fault, sl.sort_stream, sl.win_units, um);
+        if (separate_check) fused_err = nullptr;
         HIPCHK(hipEventRecord(sl.sorted_ev, sl.sort_stream));
         HIPCHK(hipStreamWaitEvent(sl.stream, sl.sorted_ev, 0));
     }
@@ -151,7 +155,7 @@ static int tick_launch_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
         c->prof_evals += neval;  // a twin pair is two subcubes and one evaluation
     }
     launch_bounds_sorted(c->d_src, (int)c->ns, c->d_lut, c->d_lut_zp, c->lut_layout, c->geom, c->nchunk1, c->chunk_pts, dev_groups, dev_subs, neval, small ? nullptr : sl.d_sorted, sl.d_partials,
-                         c->inliers ? sl.d_evals : nullptr, c->erow, c->trim_samp_shift, e0, e1, sl.stream, sl.win_units, um);
+                         c->inliers ? sl.d_evals : nullptr, c->erow, c->trim_samp_shift, fused_err, e0, e1, sl.stream, sl.win_units, um);
     // the per-subcube sums run on the slot's side stream, so the main stream holds nothing but bounds kernels back to back
     hipStream_t fin = c->finalize_on_side ? sl.sort_stream : sl.stream;
     if (fin != sl.stream) {

@@ -399,7 +399,7 @@ template <int HILBERT, int XCD>
 __global__ __launch_bounds__(64) void tick_keys_kernel(const float4* __restrict__ chunk_cen, int nchunk, const TickGroup* __restrict__ groups,
                                                            const TickSub* __restrict__ subs, int nsub, LutGeom g, int cell_shift,
                                                            unsigned short* __restrict__ keys, unsigned* __restrict__ ranks, unsigned* __restrict__ hist,
-                                                           unsigned* __restrict__ prefill /* optional: `sorted`, filled with 0xFFFFFFFF for tick_check_kernel */,
+                                                           unsigned* __restrict__ prefill /* optional: `sorted`, filled with 0xFFFFFFFF for the permutation check of the bounds kernel */,
                                                            int nunits, int unit_m /* sibling units: the first nunits * unit_m evaluations, unit_m per item */,
                                                            int orient /* experimental: 1 = 12-bit cell index + 3 bits of the rotated patch normal (chunk_cen[nchunk + c]) */) {
     const size_t unit_items = (size_t)nunits * nchunk;
@@ -539,15 +539,14 @@ __global__ __launch_bounds__(64) void tick_scatter_xcd_kernel(const unsigned sho
         sorted[cursor[k] + xoff[(size_t)(r >> 28) * kNumKeys + k] + (r & 0x0FFFFFFFu)] = (unsigned)i;
     }
 }
-// `sorted` was filled with 0xFFFFFFFF before the scatter, which stores exactly nitems values into its nitems slots: if no slot
-// still holds an out-of-range value every slot was written, hence written exactly once — `sorted` is a permutation of the
-// items.  Anything else (two items drew the same rank: the XCD-private histogram's workgroup-scope atomics did not behave
-// as one point of coherence) raises *err (pinned host memory); the context then repeats the tick with device-scope atomics.
+#ifdef FGOICP_DEV_KNOBS
+// The permutation check as a launch of its own, for round 3's bounds kernels (bounds_item_kernel carries it itself: see there).
 __global__ __launch_bounds__(64) void tick_check_kernel(const unsigned* __restrict__ sorted, size_t nitems, unsigned* __restrict__ err) {
     bool bad = false;
     for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < nitems; i += (size_t)gridDim.x * 64) bad = bad || sorted[i] >= nitems;
     if (__any(bad) && threadIdx.x == 0) *err = 1u;
 }
+#endif
 // The tick's descriptors from the pinned staging buffers into device memory: one launch instead of two hipMemcpyAsync calls (each
 // costs the submitting thread ~10 us; the bytes — <= 150 KB — cross PCIe either way).
 __global__ __launch_bounds__(64) void tick_upload_kernel(const uint4* __restrict__ hg, uint4* __restrict__ dg, unsigned ng16, const uint4* __restrict__ hs,
@@ -2915,7 +2914,7 @@ void launch_bounds(const float4* src, int ns, const float* lut, const LutGeom& g
 // The locality sort of one tick (descriptors must already be on the device): keys + histogram, scan, scatter.
 void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, const TickGroup* groups, const TickSub* subs, int nsub, int cell_shift,
                       unsigned short* keys, unsigned* ranks, unsigned* hist, unsigned* hist_xcd, unsigned* xoff, unsigned* block_sums, unsigned* cursor, unsigned* sorted,
-                      int allow_xcd, unsigned* check_err, int inject_fault, hipStream_t s, int nunits, int unit_m) {
+                      int allow_xcd, int prefill, unsigned* check_err, int inject_fault, hipStream_t s, int nunits, int unit_m) {
     const size_t nitems = (size_t)(nsub - nunits * (unit_m - 1)) * nchunk;
     const unsigned kb = (unsigned)std::min<size_t>((nitems + 63) / 64, 8192);  // `hist` / `hist_xcd` are zero here: the scan / fold kernels re-zero them
 #ifdef FGOICP_DEV_KNOBS
@@ -2932,17 +2931,17 @@ void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, con
         ;  // allow_xcd: per context, cleared by a failed permutation check
     if (xcd) {
 #ifdef FGOICP_DEV_KNOBS
-        if (!hilbert) hipLaunchKernelGGL((tick_keys_kernel<0, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd, check_err ? sorted : nullptr, nunits, unit_m, orient);
+        if (!hilbert) hipLaunchKernelGGL((tick_keys_kernel<0, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd, prefill ? sorted : nullptr, nunits, unit_m, orient);
         else
 #endif
-        hipLaunchKernelGGL((tick_keys_kernel<1, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd, check_err ? sorted : nullptr, nunits, unit_m, orient);
+        hipLaunchKernelGGL((tick_keys_kernel<1, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd, prefill ? sorted : nullptr, nunits, unit_m, orient);
         hipLaunchKernelGGL(tick_fold_sums_kernel, dim3(kScanBlocks), dim3(64), 0, s, hist_xcd, xoff, hist, block_sums);
     } else {
 #ifdef FGOICP_DEV_KNOBS
-        if (!hilbert) hipLaunchKernelGGL((tick_keys_kernel<0, 0>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist, check_err ? sorted : nullptr, nunits, unit_m, orient);
+        if (!hilbert) hipLaunchKernelGGL((tick_keys_kernel<0, 0>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist, prefill ? sorted : nullptr, nunits, unit_m, orient);
         else
 #endif
-        hipLaunchKernelGGL((tick_keys_kernel<1, 0>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist, check_err ? sorted : nullptr, nunits, unit_m, orient);
+        hipLaunchKernelGGL((tick_keys_kernel<1, 0>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist, prefill ? sorted : nullptr, nunits, unit_m, orient);
     }
     if (!xcd) hipLaunchKernelGGL(tick_scan_sums_kernel, dim3(kScanBlocks), dim3(64), 0, s, hist, block_sums);
     hipLaunchKernelGGL(tick_scan_apply_kernel, dim3(kScanBlocks), dim3(64), 0, s, hist, block_sums, cursor);
@@ -2952,7 +2951,9 @@ void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, con
 #endif
     else hipLaunchKernelGGL(tick_scatter_kernel, dim3(kb), dim3(64), 0, s, keys, ranks, nitems, cursor, sorted);
     if (inject_fault) hipLaunchKernelGGL(tick_fault_kernel, dim3(1), dim3(1), 0, s, sorted);
-    if (check_err) hipLaunchKernelGGL(tick_check_kernel, dim3(kb), dim3(64), 0, s, sorted, nitems, check_err);
+#ifdef FGOICP_DEV_KNOBS
+    if (check_err) hipLaunchKernelGGL(tick_check_kernel, dim3(kb), dim3(64), 0, s, sorted, nitems, check_err);  // FGOICP_SEPARATE_CHECK=1 (ctx.hip)
+#endif
 }
 
 #ifdef FGOICP_DEV_KNOBS
@@ -3061,9 +3062,9 @@ static bool launch_bounds_sorted_dev(const float4* src, int ns, const float* lut
 // sibling units, LDS tiles, several items per workgroup, other thread / point shapes — stay selectable by their knobs (NOTES.md).
 template <int LAYOUT, int TRIM>
 static void launch_item(const float4* src, int ns, const char* lutp, const LutGeom& g, bool wide, const TickGroup* groups, const TickSub* subs, const unsigned* sorted, int nchunk,
-                        int chunk_pts, double2* partials, float* evals, size_t erow, int samp_shift, unsigned nitems, hipStream_t s) {
+                        int chunk_pts, double2* partials, float* evals, size_t erow, int samp_shift, unsigned nitems, unsigned* sort_err, hipStream_t s) {
     const dim3 grid(nitems), block(64);
-#define FGOICP_ITEM(W, Q) hipLaunchKernelGGL((bounds_item_kernel<LAYOUT, TRIM, W, Q>), grid, block, 0, s, src, ns, lutp, g, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, nitems)
+#define FGOICP_ITEM(W, Q) hipLaunchKernelGGL((bounds_item_kernel<LAYOUT, TRIM, W, Q>), grid, block, 0, s, src, ns, lutp, g, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, nitems, sort_err)
     if (wide) { if (g.quantize) FGOICP_ITEM(true, true); else FGOICP_ITEM(true, false); }
     else { if (g.quantize) FGOICP_ITEM(false, true); else FGOICP_ITEM(false, false); }
 #undef FGOICP_ITEM
@@ -3071,12 +3072,14 @@ static void launch_item(const float4* src, int ns, const char* lutp, const LutGe
 
 void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* zp, int layout, const LutGeom& g, int nchunk, int chunk_pts,
                           const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials, float* evals, size_t erow, int samp_shift,
-                          hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s, int nunits, int unit_m) {
+                          unsigned* sort_err, hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s, int nunits, int unit_m) {
     const size_t nitems = (size_t)(nsub - nunits * (unit_m - 1)) * nchunk;
     if (ev_start) (void)hipEventRecord(ev_start, s);
     bool done = false;
 #ifdef FGOICP_DEV_KNOBS
     done = launch_bounds_sorted_dev(src, ns, lut, zp, layout, g, nchunk, chunk_pts, groups, subs, nsub, sorted, partials, evals, erow, samp_shift, s, nunits, unit_m);
+    // round 3's kernels do not look at the values they read from `sorted`: their check is a launch of its own
+    if (done && sorted && sort_err) hipLaunchKernelGGL(tick_check_kernel, dim3((unsigned)std::min<size_t>((nitems + 63) / 64, 4096)), dim3(64), 0, s, sorted, nitems, sort_err);
 #endif
     if (!done && zp && (layout == 1 || layout == 2 || layout == 4) && nunits == 0) {
         const size_t nodes = (size_t)g.px * g.py * g.pz;
@@ -3085,13 +3088,13 @@ void launch_bounds_sorted(const float4* src, int ns, const float* lut, const flo
         const bool wide = (size_t)g.py * g.pz > ((size_t)1 << 23) || bytes + 64 > ((size_t)1 << 32);
         const char* lutp = reinterpret_cast<const char*>(zp);
         if (evals) {
-            if (layout == 1) launch_item<1, 1>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, s);
-            else if (layout == 2) launch_item<3, 1>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, s);
-            else launch_item<5, 1>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, s);
+            if (layout == 1) launch_item<1, 1>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, s);
+            else if (layout == 2) launch_item<3, 1>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, s);
+            else launch_item<5, 1>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, s);
         } else {
-            if (layout == 1) launch_item<1, 0>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, s);
-            else if (layout == 2) launch_item<3, 0>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, s);
-            else launch_item<5, 0>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, s);
+            if (layout == 1) launch_item<1, 0>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, s);
+            else if (layout == 2) launch_item<3, 0>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, s);
+            else launch_item<5, 0>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, s);
         }
         done = true;
     }

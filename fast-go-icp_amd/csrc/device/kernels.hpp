@@ -67,7 +67,8 @@ void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, con
                       unsigned short* keys, unsigned* ranks /* per item, like keys */, unsigned* hist /* kTickNumKeys, zero on entry and on exit */,
                       unsigned* hist_xcd /* 16 x kTickNumKeys, zero on entry and on exit (optional) */, unsigned* xoff /* 16 x kTickNumKeys (optional) */,
                       unsigned* block_sums /* 64 */, unsigned* cursor, unsigned* sorted,
-                      int allow_xcd /* 0: device-scope histogram atomics */, unsigned* check_err /* optional, host-visible: set to 1 unless `sorted` is a permutation */,
+                      int allow_xcd /* 0: device-scope histogram atomics */, int prefill /* 1: `sorted` is filled with 0xFFFFFFFF first, for the permutation check in launch_bounds_sorted */,
+                      unsigned* check_err /* development build, A/B only: the check as a launch of its own behind the scatter */,
                       int inject_fault /* test hook */, hipStream_t s,
                       int nunits = 0, int unit_m = 1 /* sibling units: the first nunits * unit_m evaluations form nunits items per chunk (bounds_units_kernel) */);
 // descriptors of a tick: pinned staging (device-visible addresses) -> device arrays, one launch
@@ -76,6 +77,7 @@ void launch_bounds_sorted(const float4* src, int ns, const float* lut, const flo
                           int chunk_pts /* 256 .. 2048 points per item */, const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials,
                           float* evals_or_null /* trimmed mode: row r = the per-point e = max(d, 0) of output row r */, size_t erow /* floats per row, multiple of 4 */,
                           int samp_shift /* trimmed mode: > 0 = every 2^samp_shift-th point once more in the sample behind the row (offset: ns rounded up to 64 floats) */,
+                          unsigned* sort_err /* optional, host-visible: set to 1 unless `sorted` (prefilled, see launch_tick_sort) is a permutation of the items */,
                           hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s, int nunits = 0, int unit_m = 1);
 // EXTENSION (trimmed Go-ICP): per output row the sums of ub = e*e and lb = max(e - sqrt3*span, 0)^2 over the row's k smallest e
 // (one exact selection per row, kernels.hip trim_rows_kernel); row_span[r] = translation span of row r (device-readable)
