@@ -70,6 +70,8 @@ def parse():
     ap.add_argument("--only", default=None, choices=LEGS, help="run ONE leg (profiling); the headline keys then describe that leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-default-threshold-run", action="store_true")
+    ap.add_argument("--no-full-evaluation", action="store_true", help="skip the headline's comparison run with the early exit off")
+    ap.add_argument("--no-early-exit", action="store_true", help="A/B: every leg evaluates every subcube in full (fgoicp_solver_set_early_exit(0)); not the product's default")
     ap.add_argument("--no-serial", action="store_true")
     ap.add_argument("--no-dragon", action="store_true", help="skip the secondary dragon-shape (437k points) measurement")
     ap.add_argument("--no-trimmed", action="store_true", help="skip the secondary 1M-point trimmed Go-ICP measurement (20 %% outliers)")
@@ -102,6 +104,7 @@ class Env:
             self.local_rank = 0
         torch.cuda.set_device(self.local_rank)
         self.dist = None
+        self.no_early_exit = bool(a.no_early_exit)
         self.red_dev = "cuda"
         self.ex = None
         self.transport = None
@@ -164,14 +167,17 @@ class Env:
         return t.tolist(), m.tolist()
 
 
-def run_leg(env, fg, tgt, src, res, mse, sched, K, steps, warmup, trim=0.0):
-    """W warm-up + exactly `steps` timed run()s bracketed by barrier + synchronize; wall = max over ranks, subcubes = sum."""
+def run_leg(env, fg, tgt, src, res, mse, sched, K, steps, warmup, trim=0.0, early_exit=True):
+    """W warm-up + exactly `steps` timed run()s bracketed by barrier + synchronize; wall = max over ranks, subcubes = sum.
+    early_exit (the library's default): the inner BnBs hand their thresholds to the bounds operator, which stops evaluating a subcube
+    the search drops anyway (fgoicp_bounds_submit_cut; same trajectory, counters and result as evaluating everything in full)."""
     t0 = time.perf_counter()
     solver = fg.FastGoICP(tgt, src, res, mse, schedule=sched, round_width=K, device=env.local_rank, trim_fraction=trim)
     env.torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
     if env.ex is not None:
         solver.set_exchange(env.ex)
+    solver.set_early_exit(early_exit and not env.no_early_exit)
     reg = solver.registration
     if env.world > 1 and not getattr(env, "split_scans", False):
         reg.set_coop_split(None, None)  # N > 1: refinements replicated on every rank (see Env)
@@ -179,6 +185,7 @@ def run_leg(env, fg, tgt, src, res, mse, sched, K, steps, warmup, trim=0.0):
         solver.run()
     reg.set_profile(True)  # HIP events around every bounds kernel of the timed region (~2 % of a step)
     reg.profile(reset=True)
+    reg.cut_stats(reset=True)
     sub, stats, R, t = 0, None, None, None
     env.barrier()
     t0 = time.perf_counter()
@@ -189,6 +196,7 @@ def run_leg(env, fg, tgt, src, res, mse, sched, K, steps, warmup, trim=0.0):
     env.barrier()
     elapsed = time.perf_counter() - t0
     prof = reg.profile(reset=True)
+    prof["work_items_offered"], prof["work_items_not_evaluated"] = reg.cut_stats(reset=True)
     reg.set_profile(False)
     sums, maxes = env.sum_max([sub, elapsed])
     if stats is not None and steps > 1:  # ICP figures over all timed steps (stats() describes the last run only)
@@ -209,14 +217,20 @@ def roofline(leg, pmc, extra=None):
     if not launches or kms <= 0:
         return None
     ub = unit_bytes(ns)
-    ach = p["evaluations"] * ub / (kms * 1e-3) / 1e9
+    # early exit: the kernel is priced on the work items (evaluation x chunk of source points) it EVALUATED, counted on the device
+    offered, skipped = p.get("work_items_offered", 0), p.get("work_items_not_evaluated", 0)
+    done_frac = 1.0 - skipped / offered if offered else 1.0
+    ach = p["evaluations"] * done_frac * ub / (kms * 1e-3) / 1e9
     r = {"bound": "hbm", "kernel": "bounds_item_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
          "traffic": None, "traffic_measured_in_this_run": False,
          "avg_launch_us": kms * 1e3 / launches, "launches": int(launches), "evaluations_per_launch": p["evaluations"] / launches,
          "subcubes_per_launch": leg["subcubes_rank"] / launches, "output_rows_per_launch": p["subcubes"] / launches, "algorithmic_bytes_per_evaluation": ub,
-         "algorithmic_bytes_per_launch": p["evaluations"] * ub / launches,
+         "algorithmic_bytes_per_launch": p["evaluations"] * done_frac * ub / launches,
+         "work_items_evaluated_frac": done_frac,
          "subcubes_served_per_evaluation": leg["subcubes_rank"] / max(1.0, float(p["evaluations"])),
-         "note": "achieved = algorithmic bytes of the EVALUATIONS (SURVEY 8d unit x evaluations per launch) / launch duration, HIP events on the kernel's own stream; a "
+         "note": "achieved = algorithmic bytes of the EVALUATIONS (SURVEY 8d unit x evaluations per launch x the fraction of their work items the kernel evaluated: a subcube "
+                 "whose lower bound has reached the threshold its inner BnB drops it at is not evaluated further, fgoicp_bounds_submit_cut; counted on the device) / launch duration, "
+                 "HIP events on the kernel's own stream; a "
                  "translation node that both the UB and the LB task of a rotation cube need is evaluated once for both (same tick: twin; later: the LB task takes it from "
                  "its memo) — subcubes_served_per_evaluation; output rows include the memo's look-ahead rows.  `traffic` and everything under `utilisation` are per-launch "
                  "counter figures of separate rocprofv3 --pmc passes of the same deterministic step on this tree (profiles/bench_pmc.json, bench_pmc_extra.json), NOT measured "
@@ -392,6 +406,18 @@ def main():
         line["result"] = {"best_sse": head["best_sse"], "rotation_error_deg_vs_ground_truth": s["rotation_error_deg_vs_ground_truth"],
                           "translation_error_vs_ground_truth": s["translation_error_vs_ground_truth"]}
         line["roofline"] = roofline(head, pmc_all.get("headline"), {})
+        if a.only in (None, "headline") and not a.no_full_evaluation and world == 1:
+            # the same steps with every subcube evaluated in full, as the reference evaluates them (fgoicp_solver_set_early_exit(0)): the
+            # same trajectory, counters and incumbent — checked here — at the price of the point evaluations the search never looks at
+            full = run_leg(env, fg, tgt, src, a.lut_resolution, a.mse_threshold, sched, K, a.steps, 1, early_exit=False)
+            rf = roofline(full, None)
+            line["full_evaluation"] = {
+                "what": "the headline steps with the early exit off: every subcube evaluated in full (the reference's kernComputeBounds does; same search, same result)",
+                "value": full["subcubes"] / full["elapsed"], "unit": "subcubes/s", "ms_per_step": full["elapsed"] / a.steps * 1e3,
+                "same_counters_as_headline": bool(all(full["stats"][k] == head["stats"][k] for k in ("trans_cubes", "rot_cubes", "icp_runs", "icp_iters", "inner_bnb", "rounds"))),
+                "same_incumbent_bits_as_headline": bool(np.array_equal(full["R"], head["R"]) and np.array_equal(full["t"], head["t"]) and full["best_sse"] == head["best_sse"]),
+                "roofline": None if rf is None else {k: rf[k] for k in ("achieved", "peak", "unit", "frac", "avg_launch_us", "launches", "evaluations_per_launch", "work_items_evaluated_frac")}}
+            full["solver"].close()
         utilisation(line["roofline"], pmc_extra.get("headline"))
         u = line["roofline"].get("utilisation") or {}
         if u.get("valu"):  # the counters of THIS kernel build (profiles/bench_pmc_extra.json [headline]), not a remembered figure

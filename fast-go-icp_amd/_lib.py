@@ -83,6 +83,9 @@ _SIGS = {
                                       c_float_p]),
     "fgoicp_bounds_submit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_float_p, c_float_p, c_int_p, c_int_p, c_float_p]),
     "fgoicp_bounds_submit_twins": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_float_p, c_float_p, c_int_p, c_int_p, c_float_p, c_int_p]),
+    "fgoicp_bounds_submit_cut": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_float_p, c_float_p, c_int_p, c_int_p, c_float_p, c_int_p, c_float_p]),
+    "fgoicp_ctx_cut_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
+    "fgoicp_solver_set_early_exit": (C.c_int, [C.c_void_p, C.c_int]),
     "fgoicp_bounds_collect": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p]),
     "fgoicp_sse": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_float_p]),
     "fgoicp_icp": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_size_t, C.c_float, c_float_p, c_float_p, c_float_p, c_int_p]),

@@ -19,6 +19,9 @@
 //     the instruction COUNT falls further than the time does.
 #pragma once
 
+constexpr float kCutNone = 3.0e38f;       // thresholds at or above this (fgoicp_bounds_submit_cut: +inf) switch the early exit off
+constexpr double kCutMargin = 1.000001;   // see bounds_item_kernel
+
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 
@@ -217,7 +220,7 @@ template <int LAYOUT, int TRIM, bool WIDE, bool QUANT>
 __global__ __launch_bounds__(64) void bounds_item_kernel(const float4* __restrict__ src, int ns, const char* __restrict__ lutp, LutGeom g,
                                                          const TickGroup* __restrict__ groups, const TickSub* __restrict__ subs, const unsigned* __restrict__ sorted,
                                                          int nchunk, int chunk_pts, double2* __restrict__ partials, float* __restrict__ evals, size_t erow, int samp_shift,
-                                                         unsigned nitems, unsigned* __restrict__ sort_err) {
+                                                         unsigned nitems, unsigned* __restrict__ sort_err, TickCut cut) {
     const unsigned slot = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned item = sorted ? sorted[slot] : slot;  // small ticks come unsorted
     // The sort's check, folded into its only consumer.  `sorted` was filled with 0xFFFFFFFF before the scatter and every in-range rank
@@ -231,7 +234,44 @@ __global__ __launch_bounds__(64) void bounds_item_kernel(const float4* __restric
     }
     const int s = (int)(item / (unsigned)nchunk);
     const int chunk = (int)(item - (unsigned)s * (unsigned)nchunk);
+    // (read next to the descriptor, not behind it: an item that ends early is three dependent L2 round trips — slot, descriptor + hint, partial)
+    const unsigned done_hint = (!TRIM && cut.acc && !(cut.probe & 4)) ? __builtin_nontemporal_load(&cut.done[s]) : 0u;
     const TickSub sb = subs[s];
+    const int lane = (int)threadIdx.x;
+    // Early exit (fgoicp_bounds_submit_cut).  Every term of the lower-bound sum is >= 0, so once the partial sums of the evaluation's
+    // FINISHED items have reached the caller's threshold the whole sum has, and the caller has said that it only needs to know that
+    // much (the inner BnB drops such a node whatever its exact bounds are: fgoicp.cpp:151): the remaining items leave a partial that
+    // keeps the row at or above the threshold and end.  Which items get here early depends on timing; what is reported does not —
+    // bounds_finalize_kernel returns {T, T} for EVERY row whose lower bound is >= T, cut short or not.  The margin keeps the decision
+    // on the safe side of the two summation orders (this running sum: finished items in any order; the reported one: the fixed tree).
+    bool cutting = false;
+    if (!TRIM && cut.acc) {
+        if (chunk == 0 && lane == 0) {
+            cut.row_cut[sb.out0] = sb.cut0;
+            if (sb.dual) cut.row_cut[sb.out1] = sb.cut1;
+        }
+        cutting = sb.cut0 < kCutNone && (!sb.dual || sb.cut1 < kCutNone);
+        if (cutting) {
+            // The running sums live at the device's point of coherence (the eight XCDs' L2s are not coherent with each other): reading
+            // them costs a trip to memory, ~2 us.  Once an item has found its evaluation finished it says so in `done`, an ordinary
+            // cached word: the later items of that evaluation ON THE SAME XCD (whose L2 holds that store) end after an L2 hit instead.
+            // A stale 0 — another XCD's L2, a line not refreshed yet — only sends the item down the slow path.
+            bool reached = done_hint != 0u;
+            if (!__builtin_amdgcn_readfirstlane((int)reached) && !(cut.probe & 1)) {
+                const double a0 = __hip_atomic_load(&cut.acc[2 * (size_t)s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double a1 = sb.dual ? __hip_atomic_load(&cut.acc[2 * (size_t)s + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                reached = a0 >= (double)sb.cut0 * kCutMargin && (!sb.dual || a1 >= (double)sb.cut1 * kCutMargin);
+                if (reached && lane == 0) cut.done[s] = 1u;
+            }
+            if (__builtin_amdgcn_readfirstlane((int)reached)) {
+                if (lane == 0) {  // (the negative upper-bound partial marks the item as not evaluated: bounds_finalize_kernel counts them)
+                    partials[(size_t)sb.out0 * nchunk + chunk] = make_double2(-1.0, (double)sb.cut0);
+                    if (sb.dual) partials[(size_t)sb.out1 * nchunk + chunk] = make_double2(0.0, (double)sb.cut1);
+                }
+                return;
+            }
+        }
+    }
     const TickGroup gr = groups[sb.group];  // by value: the rotation node of the item, read once
     float R[9];
 #pragma unroll
@@ -239,7 +279,6 @@ __global__ __launch_bounds__(64) void bounds_item_kernel(const float4* __restric
     const ItemGeom G = item_geom(g);
     const float trans_radius = kSqrt3 * sb.span;  // registration.cu:33
     const f2v t_xy = f2v{sb.tx, sb.ty};
-    const int lane = (int)threadIdx.x;
     const int base = chunk * chunk_pts;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     float* row0 = TRIM ? evals + (size_t)sb.out0 * erow : nullptr;
@@ -255,8 +294,13 @@ __global__ __launch_bounds__(64) void bounds_item_kernel(const float4* __restric
         if (lane == 0) {
             partials[(size_t)sb.out0 * nchunk + chunk] = make_double2(r0, r1);
             partials[(size_t)sb.out1 * nchunk + chunk] = make_double2(r2, r3);
+            if (cutting && !(cut.probe & 2)) {
+                unsafeAtomicAdd(&cut.acc[2 * (size_t)s], r1);
+                unsafeAtomicAdd(&cut.acc[2 * (size_t)s + 1], r3);
+            }
         }
     } else if (lane == 0) {
         partials[(size_t)sb.out0 * nchunk + chunk] = make_double2(r0, r1);
+        if (cutting && !(cut.probe & 2)) unsafeAtomicAdd(&cut.acc[2 * (size_t)s], r1);
     }
 }

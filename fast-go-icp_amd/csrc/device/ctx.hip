@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <limits>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -101,6 +102,7 @@ struct TickTiming {  // FGOICP_TIMING=1: where a tick's wall time goes (host sid
     uint64_t ticks = 0;
 };
 TickTiming g_tt;
+constexpr float kNoCut = std::numeric_limits<float>::infinity();  // TickSub::cut0 / cut1 of a group without a threshold
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }  // namespace
 
@@ -154,8 +156,13 @@ static int tick_launch_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
         c->prof_subcubes += rows;
         c->prof_evals += neval;  // a twin pair is two subcubes and one evaluation
     }
-    launch_bounds_sorted(c->d_src, (int)c->ns, c->d_lut, c->d_lut_zp, c->lut_layout, c->geom, c->nchunk1, c->chunk_pts, dev_groups, dev_subs, neval, small ? nullptr : sl.d_sorted, sl.d_partials,
-                         c->inliers ? sl.d_evals : nullptr, c->erow, c->trim_samp_shift, fused_err, e0, e1, sl.stream, sl.win_units, um);
+    TickCut cut;  // early exit of evaluations that have reached their group's threshold (fgoicp_bounds_submit_cut)
+    if (sl.win_cut) { cut.acc = sl.d_cut_acc; cut.done = sl.d_cut_done; cut.row_cut = sl.d_row_cut; cut.stat = c->d_cut_stat; }
+    static const int cut_probe = [] { const char* e = dev_env("FGOICP_CUT_PROBE"); return e ? std::atoi(e) : 0; }();  // measurement of the early exit's own cost (tools/op_bench.py)
+    cut.probe = cut_probe;
+    const bool cut_on = launch_bounds_sorted(c->d_src, (int)c->ns, c->d_lut, c->d_lut_zp, c->lut_layout, c->geom, c->nchunk1, c->chunk_pts, dev_groups, dev_subs, neval, small ? nullptr : sl.d_sorted,
+                                             sl.d_partials, c->inliers ? sl.d_evals : nullptr, c->erow, c->trim_samp_shift, fused_err, cut, e0, e1, sl.stream, sl.win_units, um);
+    if (cut_on) c->cut_items_offered += nitems;
     // the per-subcube sums run on the slot's side stream, so the main stream holds nothing but bounds kernels back to back
     hipStream_t fin = c->finalize_on_side ? sl.sort_stream : sl.stream;
     if (fin != sl.stream) {
@@ -168,7 +175,7 @@ static int tick_launch_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
         launch_trim_rows(sl.d_evals, c->erow, (int)c->ns, (int)c->inliers, rows, sl.hd_row_span, sl.hd_ub, sl.hd_lb, fin, c->trim_samp_shift, c->trim_margin, c->d_trim_stat);
         if (pi >= 0) HIPCHK(hipEventRecord(c->ev_sel_stop[pi], fin));
     } else
-        launch_bounds_finalize(sl.d_partials, c->nchunk1, rows, sl.hd_lb, sl.hd_ub, fin);
+        launch_bounds_finalize(sl.d_partials, c->nchunk1, rows, sl.hd_lb, sl.hd_ub, cut_on ? cut : TickCut(), fin);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(sl.done, fin));
     return FGOICP_OK;
@@ -177,7 +184,7 @@ static int tick_launch_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
 // Enqueues the window [pos, pos+rows) of a submission on its slot: packs the descriptors (host), then tick_launch_window.
 // Returns the window end.
 static int tick_enqueue_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl, int G, const float* R9, const float* rot_span, const int* fix_rot,
-                               const int* offsets, const float* tn4, const int* twin, int pos, int* end_out) {
+                               const int* offsets, const float* tn4, const int* twin, const float* cut_above, int pos, int* end_out) {
     const double t0 = g_tt.on ? now_s() : 0;
     int g = 0;
     while (g < G && offsets[g + 1] <= pos) ++g;
@@ -222,6 +229,10 @@ static int tick_enqueue_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl, int G, c
                 ts.out0 = a.fix_rot ? r : j - pos;  // the fix_rot = 1 variant belongs to the fix_rot group's row
                 ts.out1 = a.fix_rot ? j - pos : r;
                 ts.dual = 1;
+                const float ca = cut_above ? cut_above[a.pad_] : kNoCut, cb = cut_above ? cut_above[b.pad_] : kNoCut;  // (pad_: the submission's group index)
+                ts.cut0 = a.fix_rot ? ca : cb;
+                ts.cut1 = a.fix_rot ? cb : ca;
+                ts.pad_[0] = ts.pad_[1] = 0;
                 continue;
             }
         }
@@ -231,7 +242,10 @@ static int tick_enqueue_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl, int G, c
         ts.out0 = r;
         ts.out1 = r;
         ts.dual = 0;
+        ts.cut0 = ts.cut1 = cut_above ? cut_above[sl.h_groups[gi].pad_] : kNoCut;
+        ts.pad_[0] = ts.pad_[1] = 0;
     }
+    sl.win_cut = cut_above != nullptr && !c->inliers;
     for (int k = 0; k < ng; ++k) sl.h_groups[k].pad_ = 0;
     // Sibling units (bounds_units_kernel): the eight children of a translation node carry one queue key (fgoicp.cpp:157-168), so the
     // inner BnB pops them together and they sit next to each other here.  A run of 8 evaluations of one group, one span and one
@@ -319,7 +333,7 @@ static int tick_wait_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
 
 // fgoicp_bounds_submit: all windows but the last are completed here, the last one stays in flight.
 int ctx_bounds_submit(fgoicp_ctx* c, int slot, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets,
-                      const float* tn4, const int* twin) {
+                      const float* tn4, const int* twin, const float* cut_above) {
     HIPCHK(hipSetDevice(c->device));
     fgoicp_ctx::TickSlot& sl = c->slots[slot];
     if (sl.inflight) { set_error("fgoicp_bounds_submit: slot still in flight (collect it first)"); return FGOICP_ERR_INVALID_ARG; }
@@ -330,7 +344,7 @@ int ctx_bounds_submit(fgoicp_ctx* c, int slot, int G, const float* R9, const flo
     int pos = 0;
     while (pos < sl.total) {
         int end = pos;
-        int rc = tick_enqueue_window(c, sl, G, R9, rot_span, fix_rot, offsets, tn4, twin, pos, &end);
+        int rc = tick_enqueue_window(c, sl, G, R9, rot_span, fix_rot, offsets, tn4, twin, cut_above, pos, &end);
         if (rc) return rc;
         if (end <= pos) break;
         pos = end;
@@ -341,6 +355,23 @@ int ctx_bounds_submit(fgoicp_ctx* c, int slot, int G, const float* R9, const flo
         }
     }
     sl.inflight = true;
+    return FGOICP_OK;
+}
+
+// Items (evaluation x chunk of source points) of the windows submitted with thresholds since the last reset, and how many of
+// them the early exit did not evaluate.  Call between submissions (it synchronises the context's streams).
+int ctx_cut_stats(fgoicp_ctx* c, uint64_t* items_offered, uint64_t* items_cut, int reset) {
+    HIPCHK(hipSetDevice(c->device));
+    unsigned long long now = 0;
+    if (c->d_cut_stat) {
+        unsigned long long part[kCutStatSlots];
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(part, c->d_cut_stat, sizeof(part), hipMemcpyDeviceToHost));
+        for (unsigned long long v : part) now += v;
+    }
+    if (items_offered) *items_offered = c->cut_items_offered;
+    if (items_cut) *items_cut = (uint64_t)now - c->cut_stat_base;
+    if (reset) { c->cut_items_offered = 0; c->cut_stat_base = (uint64_t)now; }
     return FGOICP_OK;
 }
 
@@ -363,8 +394,8 @@ int ctx_bounds_collect(fgoicp_ctx* c, int slot, float* lb_out, float* ub_out) {
 }
 
 static int ctx_bounds_multi_sorted(fgoicp_ctx* c, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets,
-                                   const float* tn4, float* lb_out, float* ub_out) {
-    int rc = ctx_bounds_submit(c, 0, G, R9, rot_span, fix_rot, offsets, tn4, nullptr);
+                                   const float* tn4, float* lb_out, float* ub_out, const float* cut_above) {
+    int rc = ctx_bounds_submit(c, 0, G, R9, rot_span, fix_rot, offsets, tn4, nullptr, cut_above);
     if (rc) return rc;
     return ctx_bounds_collect(c, 0, lb_out, ub_out);
 }
@@ -373,9 +404,9 @@ static int ctx_bounds_multi_sorted(fgoicp_ctx* c, int G, const float* R9, const 
 // Registration::compute_sse_error(RotNode&, vector<TransNode>&, bool, StreamPool&) for G groups.
 // -------------------------------------------------------------------------------------------
 int ctx_bounds_multi(fgoicp_ctx* c, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets,
-                     const float* tn4, float* lb_out, float* ub_out) {
+                     const float* tn4, float* lb_out, float* ub_out, const float* cut_above) {
     HIPCHK(hipSetDevice(c->device));
-    if (c->sorted_bounds) return ctx_bounds_multi_sorted(c, G, R9, rot_span, fix_rot, offsets, tn4, lb_out, ub_out);
+    if (c->sorted_bounds) return ctx_bounds_multi_sorted(c, G, R9, rot_span, fix_rot, offsets, tn4, lb_out, ub_out, cut_above);  // (the per-node path below ignores cut_above: exact rows)
     if (c->inliers) { set_error("trimmed bounds need the sorted bounds path (FGOICP_BOUNDS_SORTED=0 is set)"); return FGOICP_ERR_INVALID_ARG; }
     struct Piece { int g, pos, B; };
     std::vector<Piece> pieces;
@@ -417,7 +448,7 @@ int ctx_bounds_multi(fgoicp_ctx* c, int G, const float* R9, const float* rot_spa
             rows += pc.B;
             ++pi;
         }
-        launch_bounds_finalize(c->d_partials, c->nchunk, rows, c->hd_lb, c->hd_ub, c->stream);
+        launch_bounds_finalize(c->d_partials, c->nchunk, rows, c->hd_lb, c->hd_ub, TickCut(), c->stream);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c->stream));
         std::memcpy(lb_out + first, c->h_lb, sizeof(float) * rows);
@@ -1566,6 +1597,15 @@ static int ctx_create_impl(const float* tgt_xyz, size_t nt, const float* src_xyz
             CHK(hipMalloc(&sl.d_cursor, sizeof(unsigned) * kTickNumKeys));
             CHK(hipMalloc(&sl.d_sorted, sizeof(unsigned) * max_items));
             CHK(hipMalloc(&sl.d_partials, sizeof(double2) * max_items));
+            CHK(hipMalloc(&sl.d_cut_acc, sizeof(double) * 2 * (size_t)c->max_subcubes));
+            CHK(hipMemset(sl.d_cut_acc, 0, sizeof(double) * 2 * (size_t)c->max_subcubes));  // bounds_finalize_kernel re-zeroes what a window used
+            CHK(hipMalloc(&sl.d_row_cut, sizeof(float) * (size_t)c->max_subcubes));
+            CHK(hipMalloc(&sl.d_cut_done, sizeof(unsigned) * (size_t)c->max_subcubes));
+            CHK(hipMemset(sl.d_cut_done, 0, sizeof(unsigned) * (size_t)c->max_subcubes));
+            if (k == 0 && !c->d_cut_stat) {
+                CHK(hipMalloc(&c->d_cut_stat, sizeof(unsigned long long) * kCutStatSlots));
+                CHK(hipMemset(c->d_cut_stat, 0, sizeof(unsigned long long) * kCutStatSlots));
+            }
             if (k == 0) { sl.h_lb = c->h_lb; sl.h_ub = c->h_ub; sl.hd_lb = c->hd_lb; sl.hd_ub = c->hd_ub; }
             else {
                 CHK(hipHostMalloc((void**)&sl.h_lb, sizeof(float) * c->max_subcubes, hipHostMallocMapped));
@@ -1668,6 +1708,7 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
     for (auto& e : c->ev_sel_stop) if (e) (void)hipEventDestroy(e);
     (void)hipFree(c->d_src); (void)hipFree(c->d_tgt); (void)hipFree(c->d_lut); (void)hipFree(c->d_lut_idx); (void)hipFree(c->d_lut_zp);
     (void)hipFree(c->d_partials);
+    (void)hipFree(c->d_cut_stat);
     for (auto& L : c->lanes) {
         if (L.stream && L.stream != c->stream) { (void)hipStreamSynchronize(L.stream); (void)hipStreamDestroy(L.stream); }
         if (L.icp_stream) { (void)hipStreamSynchronize(L.icp_stream); (void)hipStreamDestroy(L.icp_stream); }
@@ -1709,7 +1750,7 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
         if (sl.h_row_span) (void)hipHostFree(sl.h_row_span);
         if (sl.h_sort_err) (void)hipHostFree(sl.h_sort_err);
         (void)hipFree(sl.d_groups); (void)hipFree(sl.d_subs); (void)hipFree(sl.d_keys); (void)hipFree(sl.d_ranks); (void)hipFree(sl.d_hist);
-        (void)hipFree(sl.d_cursor); (void)hipFree(sl.d_block_sums); (void)hipFree(sl.d_hist_xcd); (void)hipFree(sl.d_xoff); (void)hipFree(sl.d_sorted); (void)hipFree(sl.d_partials);
+        (void)hipFree(sl.d_cursor); (void)hipFree(sl.d_block_sums); (void)hipFree(sl.d_hist_xcd); (void)hipFree(sl.d_xoff); (void)hipFree(sl.d_sorted); (void)hipFree(sl.d_partials); (void)hipFree(sl.d_cut_acc); (void)hipFree(sl.d_row_cut); (void)hipFree(sl.d_cut_done);
         if (sl.h_groups) (void)hipHostFree(sl.h_groups);
         if (sl.h_subs) (void)hipHostFree(sl.h_subs);
         if (k == 1 && sl.h_lb) (void)hipHostFree(sl.h_lb);
@@ -1819,13 +1860,23 @@ int fgoicp_bounds_multi(fgoicp_ctx* c, int G, const float* R9, const float* rot_
 
 int fgoicp_bounds_submit_twins(fgoicp_ctx* c, int slot, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets,
                                const float* tn4, const int* twin) {
+    return fgoicp_bounds_submit_cut(c, slot, G, R9, rot_span, fix_rot, offsets, tn4, twin, nullptr);
+}
+
+int fgoicp_bounds_submit_cut(fgoicp_ctx* c, int slot, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets,
+                             const float* tn4, const int* twin, const float* cut_above) {
     if (!c || slot < 0 || slot > 1 || G < 0 || (G > 0 && (!R9 || !rot_span || !fix_rot || !offsets || !tn4))) return FGOICP_ERR_INVALID_ARG;
     if (!c->sorted_bounds) { set_error("fgoicp_bounds_submit needs the sorted bounds path (FGOICP_BOUNDS_SORTED=0 is set)"); return FGOICP_ERR_INVALID_ARG; }
     static const int zero[1] = {0};
     if (G == 0) offsets = zero;
     for (int g = 0; g < G; ++g)
         if (offsets[g + 1] < offsets[g] || offsets[0] != 0) { set_error("fgoicp_bounds_submit: offsets must start at 0 and be non-decreasing"); return FGOICP_ERR_INVALID_ARG; }
-    return ctx_bounds_submit(c, slot, G, R9, rot_span, fix_rot, offsets, tn4, twin);
+    return ctx_bounds_submit(c, slot, G, R9, rot_span, fix_rot, offsets, tn4, twin, cut_above);
+}
+
+int fgoicp_ctx_cut_stats(fgoicp_ctx* c, uint64_t* items_offered, uint64_t* items_cut, int reset) {
+    if (!c) return FGOICP_ERR_INVALID_ARG;
+    return ctx_cut_stats(c, items_offered, items_cut, reset);
 }
 
 int fgoicp_bounds_submit(fgoicp_ctx* c, int slot, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets,

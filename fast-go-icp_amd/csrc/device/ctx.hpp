@@ -57,6 +57,10 @@ struct fgoicp_ctx {
         unsigned *d_hist = nullptr, *d_block_sums = nullptr, *d_cursor = nullptr, *d_sorted = nullptr;
         unsigned *d_hist_xcd = nullptr, *d_xoff = nullptr;   // per-XCD histograms of the tick sort and their offsets inside a bin
         double2* d_partials = nullptr;           // [max_subcubes][nchunk1]
+        double* d_cut_acc = nullptr;             // early exit (fgoicp_bounds_submit_cut): 2 running sums per evaluation, zero between windows
+        float* d_row_cut = nullptr;              // ... and the threshold of every output row
+        unsigned* d_cut_done = nullptr;          // ... and the cached "finished" hint per evaluation
+        bool win_cut = false;                    // the window in flight carries thresholds
         float *h_lb = nullptr, *h_ub = nullptr, *hd_lb = nullptr, *hd_ub = nullptr;  // pinned results of the window in flight
         float* d_evals = nullptr;                // trimmed mode: per-point e = max(d, 0) of every output row, [vals_rows][erow]
         float *h_row_span = nullptr, *hd_row_span = nullptr;   // translation span of every output row of the window (pinned)
@@ -70,6 +74,9 @@ struct fgoicp_ctx {
         int total = 0, win_pos = 0, win_rows = 0;
         bool inflight = false;
     };
+    unsigned long long* d_cut_stat = nullptr;    // items the early exit did not evaluate, since creation (device counter)
+    uint64_t cut_items_offered = 0;              // items of the windows submitted with thresholds
+    uint64_t cut_stat_base = 0;                  // value of *d_cut_stat at the last reset
     bool sorted_bounds = true;
     bool sort_xcd = true;                    // XCD-private histograms for the tick sort (cleared for good if a permutation check fails)
     bool sort_check = true;                  // verify on the device that every tick's `sorted` is a permutation
@@ -165,9 +172,10 @@ namespace fgoicp {
 void set_error(const std::string& s);
 
 int ctx_bounds_multi(fgoicp_ctx* c, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets,
-                     const float* tn4, float* lb_out, float* ub_out);
+                     const float* tn4, float* lb_out, float* ub_out, const float* cut_above = nullptr);
+int ctx_cut_stats(fgoicp_ctx* c, uint64_t* items_offered, uint64_t* items_cut, int reset);
 int ctx_bounds_submit(fgoicp_ctx* c, int slot, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets, const float* tn4,
-                      const int* twin = nullptr);
+                      const int* twin = nullptr, const float* cut_above = nullptr);
 int ctx_bounds_collect(fgoicp_ctx* c, int slot, float* lb_out, float* ub_out);
 int ctx_set_inliers(fgoicp_ctx* c, size_t k);
 int ctx_sse(fgoicp_ctx* c, const float* R9, const float* t3, float* sse_out, const uint32_t* seed_idx = nullptr);

@@ -1693,22 +1693,35 @@ __global__ __launch_bounds__(1024) void icp_inlier_ties_kernel(int n, const uint
 
 // One block (one wave) per subcube: fixed-order sum of its chunk partials, rounded once to fp32.
 __global__ __launch_bounds__(64) void bounds_finalize_kernel(const double2* __restrict__ partials, int nchunk, int total,
-                                                             float* __restrict__ out_lb, float* __restrict__ out_ub) {
+                                                             float* __restrict__ out_lb, float* __restrict__ out_ub, TickCut cut) {
     const int s = blockIdx.x;
     if (s >= total) return;
     const double2* row = partials + (size_t)s * nchunk;
     double u = 0.0, l = 0.0;
+    unsigned skipped = 0;  // work items the early exit did not evaluate (their upper-bound partial is -1; such a row reports its threshold below)
     for (int c = threadIdx.x; c < nchunk; c += 64) {
         const double2 v = row[c];
+        skipped += v.x < 0.0 ? 1u : 0u;
         u += v.x;
         l += v.y;
     }
     u = wave_sum(u);
     l = wave_sum(l);
-    if (threadIdx.x == 0) {
-        out_ub[s] = (float)u;
-        out_lb[s] = (float)l;
+    if (cut.stat) {
+        for (int off = 32; off > 0; off >>= 1) skipped += __shfl_down(skipped, off);
+        if (threadIdx.x == 0 && skipped) atomicAdd(&cut.stat[s & (kCutStatSlots - 1)], (unsigned long long)skipped);
     }
+    if (threadIdx.x == 0) {
+        float ubf = (float)u, lbf = (float)l;
+        if (cut.row_cut) {  // fgoicp_bounds_submit_cut: a row at or above its threshold T reports {T, T}, whether the bounds kernel cut it short or not
+            const float T = cut.row_cut[s];
+            if (lbf >= T) lbf = ubf = T;
+        }
+        out_ub[s] = ubf;
+        out_lb[s] = lbf;
+    }
+    if (cut.acc && threadIdx.x == 2) cut.done[s] = 0u;
+    if (cut.acc && threadIdx.x < 2) cut.acc[2 * (size_t)s + threadIdx.x] = 0.0;  // evaluations <= rows: the running sums are zero again for the slot's next window
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3062,20 +3075,20 @@ static bool launch_bounds_sorted_dev(const float4* src, int ns, const float* lut
 // sibling units, LDS tiles, several items per workgroup, other thread / point shapes — stay selectable by their knobs (NOTES.md).
 template <int LAYOUT, int TRIM>
 static void launch_item(const float4* src, int ns, const char* lutp, const LutGeom& g, bool wide, const TickGroup* groups, const TickSub* subs, const unsigned* sorted, int nchunk,
-                        int chunk_pts, double2* partials, float* evals, size_t erow, int samp_shift, unsigned nitems, unsigned* sort_err, hipStream_t s) {
+                        int chunk_pts, double2* partials, float* evals, size_t erow, int samp_shift, unsigned nitems, unsigned* sort_err, const TickCut& cut, hipStream_t s) {
     const dim3 grid(nitems), block(64);
-#define FGOICP_ITEM(W, Q) hipLaunchKernelGGL((bounds_item_kernel<LAYOUT, TRIM, W, Q>), grid, block, 0, s, src, ns, lutp, g, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, nitems, sort_err)
+#define FGOICP_ITEM(W, Q) hipLaunchKernelGGL((bounds_item_kernel<LAYOUT, TRIM, W, Q>), grid, block, 0, s, src, ns, lutp, g, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, nitems, sort_err, cut)
     if (wide) { if (g.quantize) FGOICP_ITEM(true, true); else FGOICP_ITEM(true, false); }
     else { if (g.quantize) FGOICP_ITEM(false, true); else FGOICP_ITEM(false, false); }
 #undef FGOICP_ITEM
 }
 
-void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* zp, int layout, const LutGeom& g, int nchunk, int chunk_pts,
+bool launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* zp, int layout, const LutGeom& g, int nchunk, int chunk_pts,
                           const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials, float* evals, size_t erow, int samp_shift,
-                          unsigned* sort_err, hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s, int nunits, int unit_m) {
+                          unsigned* sort_err, const TickCut& cut, hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s, int nunits, int unit_m) {
     const size_t nitems = (size_t)(nsub - nunits * (unit_m - 1)) * nchunk;
     if (ev_start) (void)hipEventRecord(ev_start, s);
-    bool done = false;
+    bool done = false, item_kernel = false;
 #ifdef FGOICP_DEV_KNOBS
     done = launch_bounds_sorted_dev(src, ns, lut, zp, layout, g, nchunk, chunk_pts, groups, subs, nsub, sorted, partials, evals, erow, samp_shift, s, nunits, unit_m);
     // round 3's kernels do not look at the values they read from `sorted`: their check is a launch of its own
@@ -3088,18 +3101,19 @@ void launch_bounds_sorted(const float4* src, int ns, const float* lut, const flo
         const bool wide = (size_t)g.py * g.pz > ((size_t)1 << 23) || bytes + 64 > ((size_t)1 << 32);
         const char* lutp = reinterpret_cast<const char*>(zp);
         if (evals) {
-            if (layout == 1) launch_item<1, 1>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, s);
-            else if (layout == 2) launch_item<3, 1>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, s);
-            else launch_item<5, 1>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, s);
+            if (layout == 1) launch_item<1, 1>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, cut, s);
+            else if (layout == 2) launch_item<3, 1>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, cut, s);
+            else launch_item<5, 1>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, cut, s);
         } else {
-            if (layout == 1) launch_item<1, 0>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, s);
-            else if (layout == 2) launch_item<3, 0>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, s);
-            else launch_item<5, 0>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, s);
+            if (layout == 1) launch_item<1, 0>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, cut, s);
+            else if (layout == 2) launch_item<3, 0>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, cut, s);
+            else launch_item<5, 0>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, cut, s);
         }
-        done = true;
+        done = item_kernel = true;
     }
     if (!done) std::fprintf(stderr, "fgoicp: no bounds kernel for packed layout %d in this build\n", layout);  // (ctx_create only chooses layouts 1, 2, 4 outside the development build)
     if (ev_stop) (void)hipEventRecord(ev_stop, s);
+    return item_kernel && cut.acc && !evals;  // the early exit was in force (round 3's kernels in the development build do not know it: exact rows then)
 }
 
 void launch_tick_upload(const TickGroup* h_groups, TickGroup* d_groups, int ngroups, const TickSub* h_subs, TickSub* d_subs, int nsubs, hipStream_t s) {
@@ -3109,8 +3123,8 @@ void launch_tick_upload(const TickGroup* h_groups, TickGroup* d_groups, int ngro
                        reinterpret_cast<uint4*>(d_groups), ng16, reinterpret_cast<const uint4*>(h_subs), reinterpret_cast<uint4*>(d_subs), ns16);
 }
 
-void launch_bounds_finalize(const double2* partials, int nchunk, int total, float* out_lb, float* out_ub, hipStream_t s) {
-    hipLaunchKernelGGL(bounds_finalize_kernel, dim3(total), dim3(64), 0, s, partials, nchunk, total, out_lb, out_ub);
+void launch_bounds_finalize(const double2* partials, int nchunk, int total, float* out_lb, float* out_ub, const TickCut& cut, hipStream_t s) {
+    hipLaunchKernelGGL(bounds_finalize_kernel, dim3(total), dim3(64), 0, s, partials, nchunk, total, out_lb, out_ub, cut);
 }
 
 void launch_lut_build(const float4* tgt_shifted, int nt, const LutGeom& g, float* lut_padded, hipStream_t s) {

@@ -46,7 +46,7 @@ struct BoundsArgs {
 void launch_bounds(const float4* src, int ns, const float* lut, const LutGeom& g, const BoundsArgs& a, double2* partials,
                    int nchunk, int pts_per_thread, hipStream_t s);
 // Whole-tick variant: all subcubes of all rotation nodes in ONE launch, work items ordered by LUT locality
-// (kernels.hip).  groups/subs are device arrays of TickGroup (48 B) / TickSub (32 B); partials is indexed
+// (kernels.hip).  groups/subs are device arrays of TickGroup (48 B) / TickSub (48 B); partials is indexed
 // [s * nchunk + chunk] with 256-point chunks; events (optional) bracket the bounds kernel only.
 struct TickGroup {   // one rotation node
     float R[9];
@@ -61,6 +61,21 @@ struct TickSub {     // one EVALUATION: a translation node + its rotation node, 
     int out1;        // dual only: output row of the fix_rot = 0 variant
     int dual;        // 1 = the UB task and the LB task of one rotation cube both hold this translation node in the same
                      // submission: one lookup per point, both variants of the bound formulae (registration.cu:39-58)
+    float cut0;      // cut_above of out0's group (fgoicp_bounds_submit_cut; +inf = none): once the lower-bound sums of the evaluation's
+    float cut1;      // finished items reach it, the remaining items are not evaluated (dual: both variants must have reached theirs)
+    int pad_[2];
+};
+static_assert(sizeof(TickSub) == 48, "TickSub is copied in 16-byte units");
+// Early exit (fgoicp_bounds_submit_cut): acc = 2 doubles per evaluation (sum of the lower-bound partials of its finished items, per
+// variant; zero on entry, re-zeroed by bounds_finalize_kernel), row_cut = the threshold of every output row (written by the
+// bounds kernel, applied by bounds_finalize_kernel), stat = {items not evaluated} (optional).  acc == nullptr: off.
+constexpr int kCutStatSlots = 64;  // the counter is spread over this many words (one atomic per output row with skipped items)
+struct TickCut {
+    double* acc = nullptr;
+    unsigned* done = nullptr;             // per evaluation: 1 = an item has seen the running sums at their thresholds (a cached hint, zero between windows)
+    float* row_cut = nullptr;
+    unsigned long long* stat = nullptr;   // [kCutStatSlots]
+    int probe = 0;                        // development build, FGOICP_CUT_PROBE: 1 = the running sums are not read (nothing is ever cut), 2 = not added to, 4 = no `done` hint
 };
 constexpr int kTickNumKeys = 1 << 15;
 void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, const TickGroup* groups, const TickSub* subs, int nsub, int cell_shift,
@@ -73,11 +88,12 @@ void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, con
                       int nunits = 0, int unit_m = 1 /* sibling units: the first nunits * unit_m evaluations form nunits items per chunk (bounds_units_kernel) */);
 // descriptors of a tick: pinned staging (device-visible addresses) -> device arrays, one launch
 void launch_tick_upload(const TickGroup* hd_groups, TickGroup* d_groups, int ngroups, const TickSub* hd_subs, TickSub* d_subs, int nsubs, hipStream_t s);
-void launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* packed_or_null, int layout /* 1 z-pair, 2 yz-quad */, const LutGeom& g, int nchunk,
+bool launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* packed_or_null, int layout /* 1 z-pair, 2 yz-quad */, const LutGeom& g, int nchunk,
                           int chunk_pts /* 256 .. 2048 points per item */, const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials,
                           float* evals_or_null /* trimmed mode: row r = the per-point e = max(d, 0) of output row r */, size_t erow /* floats per row, multiple of 4 */,
                           int samp_shift /* trimmed mode: > 0 = every 2^samp_shift-th point once more in the sample behind the row (offset: ns rounded up to 64 floats) */,
                           unsigned* sort_err /* optional, host-visible: set to 1 unless `sorted` (prefilled, see launch_tick_sort) is a permutation of the items */,
+                          const TickCut& cut /* early exit of evaluations whose lower bound has reached its group's cut_above */,
                           hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s, int nunits = 0, int unit_m = 1);
 // EXTENSION (trimmed Go-ICP): per output row the sums of ub = e*e and lb = max(e - sqrt3*span, 0)^2 over the row's k smallest e
 // (one exact selection per row, kernels.hip trim_rows_kernel); row_span[r] = translation span of row r (device-readable)
@@ -91,7 +107,7 @@ void launch_trim_select(const float* vals, int n, int k, float* out, uint32_t* s
 void launch_icp_inliers(const float4* work, const float4* tgt, const uint32_t* idx, int n, int nt, int k, float* d2, uint32_t* sel_info,
                         uint32_t* equal_count, const uint32_t* orig_of_slot, unsigned char* use, uint32_t* wide_scratch, hipStream_t s);
 // out_lb[i], out_ub[i] = float(sum over chunks), fixed order → bit-reproducible
-void launch_bounds_finalize(const double2* partials, int nchunk, int total, float* out_lb, float* out_ub, hipStream_t s);
+void launch_bounds_finalize(const double2* partials, int nchunk, int total, float* out_lb, float* out_ub, const TickCut& cut, hipStream_t s);
 
 void launch_lut_build(const float4* tgt_shifted, int nt, const LutGeom& g, float* lut_padded, hipStream_t s);
 // zp[o] = {lut[o], lut[o + one z-slice]}: the z-paired copy the sorted bounds kernel gathers from (kernels.hip)

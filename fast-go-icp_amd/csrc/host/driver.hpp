@@ -2,8 +2,8 @@
 // branch-and-bound of icp::FastGoICP (reference fgoicp/fgoicp.hpp:13-110, fgoicp/fgoicp.cpp:10-287,
 // fgoicp/common.hpp:30-128), written against an abstract operator backend `Ops`:
 //
-//     int    Ops::bounds_multi(G, R9, rot_span, fix_rot, offsets, tnodes4, lb, ub)   (fgoicp_bounds_multi)
-//     int    Ops::bounds_submit(slot, G, ...tnodes4, twin) / bounds_collect(slot, lb, ub)  (fgoicp_bounds_submit_twins / _collect)
+//     int    Ops::bounds_multi(G, R9, rot_span, fix_rot, offsets, tnodes4, lb, ub, cut_above)   (fgoicp_bounds_multi)
+//     int    Ops::bounds_submit(slot, G, ...tnodes4, twin, cut_above) / bounds_collect(slot, lb, ub)  (fgoicp_bounds_submit_cut / _collect)
 //     bool   Ops::async()                                                            two slots available?
 //     bool   Ops::twins()                                                            does bounds_submit evaluate a twin pair once? (then the memo is free)
 //     int    Ops::icp(R0, t0, max_iter, thr, &sse, R9, t3, &iters)                   (fgoicp_icp)
@@ -139,6 +139,7 @@ struct InnerTask {
     float best_error = 0.f;
     Vec3f best_t{0.f, 0.f, 0.f};
     float best_ub = kHostInf;
+    float start_sse = 0.f;  // the job's best error when the task started (:104)
     uint64_t count = 0;
     std::priority_queue<TransCube> cand;
     std::vector<TransCube> batch;
@@ -148,6 +149,7 @@ struct InnerTask {
     void start(bool fix, float best_sse, float rnode_ub) {
         fix_rot = fix;
         best_error = best_sse;  // :104
+        start_sse = best_sse;
         best_t = Vec3f{0.f, 0.f, 0.f};
         best_ub = kHostInf;
         count = 0;
@@ -169,6 +171,20 @@ struct InnerTask {
         }
         count += batch.size();  // :132
         return true;
+    }
+    // What this task does not need to know exactly (fgoicp_bounds_submit_cut): a node whose lower bound is >= the value returned here
+    // may come back as {T, T} instead of {lb, ub}.  Every use of a node's bounds is a comparison that both answers decide alike:
+    //   * the node itself: dropped when lb >= best_error (:151), its ub counted only when < best_error (:143) — and T >= best_error,
+    //     ub >= lb >= T; best_error only falls while the task runs, so the threshold of the submission also holds for a node that
+    //     is looked up LATER (memo rows, look-ahead rows);
+    //   * the task's result best_ub = min of all ub (:142): a pass with rotation uncertainty (fix_rot = 0) hands it to the outer loop as
+    //     the cube's lower bound, which is compared with best_sse <= start_sse (:92) and stored only when below — T = best_error;
+    //     the pass with the rotation fixed hands it to the trigger rule `ub < best_sse * 1.8` (:74) — T = 1.8 * start_sse, rounded up.
+    // Both are exact whenever the outer loop looks at more than the comparison.  The child nodes (:163-166) inherit exact bounds:
+    // they exist only below the threshold.
+    float cut_above() const {
+        if (!fix_rot) return best_error;
+        return std::nextafter((float)((double)start_sse * 1.8), kHostInf);
     }
     // consumes the operator's {lb, ub} of the current batch (:139-169)
     void consume(const float* lb, const float* ub) {
@@ -364,6 +380,7 @@ public:
     // thread that runs run(); under SERIAL in the reference's order.
     enum { kLogInitialIcp = 0, kLogNewBest = 1 };
     void set_log(std::function<void(int, float, const Mat3f&, const Vec3f&)> fn) { log_ = std::move(fn); }
+    void set_use_cut(bool on) { use_cut_ = on; }
     const DriverStats& stats() const { return stats_; }
 
     float best_sse() const { std::lock_guard<std::mutex> g(mu_); return best_sse_; }
@@ -1022,6 +1039,7 @@ private:
         std::vector<int> live;         // members with a batch in this submission
         std::vector<float> R9, spans, tn4, lb, ub;
         std::vector<int> fix, offsets;
+        std::vector<float> cut;        // per group: InnerTask::cut_above() of its task
         std::vector<int> twin;         // per subcube: the same translation node in the paired task's batch (or -1)
         std::vector<std::vector<std::pair<int, int>>> pair_twins;  // per (UB, LB) pair: {row in the UB group, row in the LB group}
         bool inflight = false;
@@ -1159,12 +1177,14 @@ private:
         for (size_t a = 0; a < G; ++a) h.offsets.push_back(h.offsets.back() + tasks[h.live[a]]->nrows + (int)tasks[h.live[a]]->phantom.size());
         const size_t total = (size_t)h.offsets.back();
         h.R9.resize(9 * G); h.spans.resize(G); h.fix.resize(G); h.tn4.resize(4 * total);
+        h.cut.resize(G);
         const std::function<void(size_t)> pack_fn = [&](size_t a) {  // groups are independent: packed in parallel
             const int i = h.live[a];
             const Task& tk = *tasks[i];
             std::memcpy(&h.R9[9 * a], cubes[i]->q.R.m, 9 * sizeof(float));
             h.spans[a] = cubes[i]->span;
             h.fix[a] = tk.fix_rot ? 1 : 0;
+            h.cut[a] = tk.cut_above();
             float* base = &h.tn4[4 * (size_t)h.offsets[a]];
             for (size_t q = 0; q < tk.batch.size(); ++q) {
                 if (tk.brow[q] < 0) continue;
@@ -1281,7 +1301,7 @@ private:
                     const bool more = !h[k].members.empty() && prepare_half(h[k], tasks, cubes, par, ops_.twins());
                     if (tick_hook_) tick_hook_();  // (tasks that have just ended are marked done by now)
                     if (more) {
-                        int rc = ops_.bounds_submit(k, (int)h[k].live.size(), h[k].R9.data(), h[k].spans.data(), h[k].fix.data(), h[k].offsets.data(), h[k].tn4.data(), h[k].twin.data());
+                        int rc = ops_.bounds_submit(k, (int)h[k].live.size(), h[k].R9.data(), h[k].spans.data(), h[k].fix.data(), h[k].offsets.data(), h[k].tn4.data(), h[k].twin.data(), use_cut_ ? h[k].cut.data() : nullptr);
                         if (rc) return rc;
                         h[k].inflight = true;
                     }
@@ -1303,7 +1323,7 @@ private:
             if (tick_hook_) tick_hook_();
             if (!more) return kDriverOk;
             const auto tb = clock::now();
-            int rc = ops_.bounds_multi((int)h.live.size(), h.R9.data(), h.spans.data(), h.fix.data(), h.offsets.data(), h.tn4.data(), h.lb.data(), h.ub.data());
+            int rc = ops_.bounds_multi((int)h.live.size(), h.R9.data(), h.spans.data(), h.fix.data(), h.offsets.data(), h.tn4.data(), h.lb.data(), h.ub.data(), use_cut_ ? h.cut.data() : nullptr);
             if (rc) return rc;
             const auto tc = clock::now();
             consume_half(h, tasks, par);
@@ -1323,6 +1343,7 @@ private:
     const int coop_icp_ = [] { const char* e = dev_env("FGOICP_COOP_ICP"); return e ? (std::atoi(e) != 0 ? 1 : 0) : -1; }();  // tuning knob / A-B: 0 = every rank refines its own children alone, 1 = cooperative rounds, unset = by size
     const size_t coop_min_points_ = [] { const char* e = dev_env("FGOICP_COOP_MIN_POINTS"); return e ? (size_t)std::max(0L, std::atol(e)) : (size_t)131072; }();  // tuning knob
     const int late_icp_ = [] { const char* e = dev_env("FGOICP_LATE_ICP"); return e ? std::atoi(e) : 0; }();  // tuning knob (ROUND): 0 = off (default: measured slower, see above), 1 = with an exchange (world > 1), 2 = always
+    bool use_cut_ = true;   // hand every task's cut_above() to the operator (set_use_cut: the A/B and the exact-rows mode of the tests)
     bool use_twins_ = [] { const char* e = dev_env("FGOICP_TWINS"); return !e || std::atoi(e) != 0; }();  // tuning knob
     const size_t round_batch_ = [] { const char* e = dev_env("FGOICP_ROUND_BATCH"); const int v = e ? std::atoi(e) : 48; return (size_t)(v >= 8 && v <= 64 ? v : 48); }();  // tuning knob (ROUND only; SERIAL keeps the reference's 32)
     const int serial_ahead_ = [] { const char* e = dev_env("FGOICP_SERIAL_AHEAD"); return e ? std::max(0, std::atoi(e)) : 480; }();  // tuning knob: look-ahead nodes of a SERIAL task in the tail of an evaluation (0 = off)

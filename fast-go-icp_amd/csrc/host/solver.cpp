@@ -18,12 +18,12 @@ namespace fgoicp {
 struct HipOps {
     fgoicp_ctx* ctx = nullptr;
     int bounds_multi(int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets, const float* tn4, float* lb,
-                     float* ub) {
-        return ctx_bounds_multi(ctx, G, R9, rot_span, fix_rot, offsets, tn4, lb, ub);
+                     float* ub, const float* cut_above) {
+        return ctx_bounds_multi(ctx, G, R9, rot_span, fix_rot, offsets, tn4, lb, ub, cut_above);
     }
     int bounds_submit(int slot, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets, const float* tn4,
-                      const int* twin) {
-        return ctx_bounds_submit(ctx, slot, G, R9, rot_span, fix_rot, offsets, tn4, twin);
+                      const int* twin, const float* cut_above) {
+        return ctx_bounds_submit(ctx, slot, G, R9, rot_span, fix_rot, offsets, tn4, twin, cut_above);
     }
     int bounds_collect(int slot, float* lb, float* ub) { return ctx_bounds_collect(ctx, slot, lb, ub); }
     bool async() const { return ctx->sorted_bounds && pipeline; }
@@ -158,6 +158,12 @@ int fgoicp_solver_set_log(fgoicp_solver* s, fgoicp_log_fn cb, void* user) {
         const float t3[3] = {tr.x, tr.y, tr.z};
         cb(event, sse, R.m, t3, user);
     });
+    return FGOICP_OK;
+}
+
+int fgoicp_solver_set_early_exit(fgoicp_solver* s, int on) {
+    if (!s) return FGOICP_ERR_INVALID_ARG;
+    s->driver->set_use_cut(on != 0);
     return FGOICP_OK;
 }
 

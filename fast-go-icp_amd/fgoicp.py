@@ -38,6 +38,10 @@ class FastGoICP:
         ptr = C.byref(exchange.struct) if exchange is not None else None
         _lib.check(self._lib.fgoicp_solver_set_exchange(self._h, ptr), "fgoicp_solver_set_exchange")
 
+    def set_early_exit(self, on=True):
+        """False: every subcube is evaluated in full, as the reference does (same trajectory and result; fgoicp_solver_set_early_exit)."""
+        _lib.check(self._lib.fgoicp_solver_set_early_exit(self._h, int(bool(on))), "fgoicp_solver_set_early_exit")
+
     def run(self):
         """-> (R (3,3), t (3,)) with t restored to the callers' frame (fgoicp.cpp:29)."""
         R = np.empty(9, np.float32); t = np.empty(3, np.float32)

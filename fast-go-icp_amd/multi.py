@@ -107,6 +107,10 @@ class MultiGoICP:
                                               float(convergence_threshold), _fp(sse), _fp(R), _fp(t), it.ctypes.data_as(_lib.c_int_p)), "fgoicp_multi_icp")
         return np.float32(sse[0]), from_glm(R), t, int(it[0])
 
+    def set_early_exit(self, on=True):
+        for r in range(self.world):
+            _lib.check(self._lib.fgoicp_solver_set_early_exit(C.c_void_p(self._lib.fgoicp_multi_solver(self._h, r)), int(bool(on))), "fgoicp_solver_set_early_exit")
+
     def test_fault(self, rank, call):
         """TEST HOOK: the call-th exchange of `rank` in the next run fails, once."""
         _lib.check(self._lib.fgoicp_multi_test_fault(self._h, int(rank), int(call)), "fgoicp_multi_test_fault")

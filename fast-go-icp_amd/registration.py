@@ -154,6 +154,34 @@ class Registration:
                    "fgoicp_bounds_multi")
         return [(lb[offs[g]:offs[g + 1]], ub[offs[g]:offs[g + 1]]) for g in range(G)]
 
+    def compute_bounds_cut(self, Rs, rot_spans, fix_rots, tnode_groups, cut_above, twin=None, slot=0):
+        """fgoicp_bounds_submit_cut + fgoicp_bounds_collect: as compute_bounds_multi, but a subcube of group g whose lower bound is
+        >= cut_above[g] comes back as lb = ub = cut_above[g] (np.inf: exact).  twin: optional array over all subcubes (-1 = none)."""
+        G = len(Rs)
+        Rg = np.concatenate([to_glm(R) for R in Rs]).astype(np.float32) if G else np.zeros(0, np.float32)
+        spans = np.asarray(rot_spans, dtype=np.float32)
+        fr = np.asarray([int(bool(f)) for f in fix_rots], dtype=np.int32)
+        packed = [pack_tnodes(t) for t in tnode_groups]
+        offs = np.zeros(G + 1, dtype=np.int32)
+        offs[1:] = np.cumsum([len(p) for p in packed])
+        tn = np.ascontiguousarray(np.concatenate(packed) if G else np.zeros((0, 4), np.float32))
+        cut = None if cut_above is None else np.ascontiguousarray(cut_above, dtype=np.float32)
+        assert cut is None or len(cut) == G
+        tw = None if twin is None else np.ascontiguousarray(twin, dtype=np.int32)
+        lb = np.empty(len(tn), dtype=np.float32)
+        ub = np.empty(len(tn), dtype=np.float32)
+        _lib.check(self._lib.fgoicp_bounds_submit_cut(self._h, int(slot), G, _fp(Rg), _fp(spans), fr.ctypes.data_as(_lib.c_int_p), offs.ctypes.data_as(_lib.c_int_p),
+                                                      _fp(tn), None if tw is None else tw.ctypes.data_as(_lib.c_int_p), None if cut is None else _fp(cut)),
+                   "fgoicp_bounds_submit_cut")
+        _lib.check(self._lib.fgoicp_bounds_collect(self._h, int(slot), _fp(lb), _fp(ub)), "fgoicp_bounds_collect")
+        return [(lb[offs[g]:offs[g + 1]], ub[offs[g]:offs[g + 1]]) for g in range(G)]
+
+    def cut_stats(self, reset=False):
+        """(work items of the submissions that carried thresholds, work items the early exit did not evaluate) since the last reset"""
+        a = C.c_uint64(); b = C.c_uint64()
+        _lib.check(self._lib.fgoicp_ctx_cut_stats(self._h, C.byref(a), C.byref(b), int(reset)), "fgoicp_ctx_cut_stats")
+        return a.value, b.value
+
     def procrustes(self, working):
         """One IterativeClosestPoint3D::procrustes() step (icp3d.cu:140-172) on `working` (ns, 3)."""
         w = _cloud(working)

@@ -138,7 +138,22 @@ int fgoicp_bounds_submit(fgoicp_ctx* ctx, int slot, int G, const float* R9, cons
  */
 int fgoicp_bounds_submit_twins(fgoicp_ctx* ctx, int slot, int G, const float* R9, const float* rot_span, const int* fix_rot,
                                const int* offsets, const float* tnodes4, const int* twin);
+/*
+ * The same with what the caller does NOT need to know: cut_above[g] = T (one per group; +inf, or cut_above = NULL: everything) says
+ * that for a subcube of group g whose lower bound is >= T the exact bounds do not matter — the inner branch-and-bound drops such a node
+ * whatever they are (fgoicp.cpp:151, with T = its running best error) and its result takes part in comparisons only (:74, :92;
+ * csrc/host/driver.hpp InnerTask::cut_above).  Such a row comes back as lb = ub = T.  All terms of the lower-bound sum are >= 0 and the
+ * evaluation of a subcube is spread over many work items (chunks of source points), so the kernel stops evaluating a subcube once the
+ * sums of its finished items have reached T: on a certify run two thirds of all point evaluations belong to such subcubes
+ * (profiles/r04_early_exit_*).  Rows below their threshold are bit-identical to fgoicp_bounds_submit_twins; the answer for a row at or
+ * above it is {T, T} whether the kernel got to cut it short or not (deterministic).  Trimmed contexts ignore cut_above.
+ */
+int fgoicp_bounds_submit_cut(fgoicp_ctx* ctx, int slot, int G, const float* R9, const float* rot_span, const int* fix_rot,
+                             const int* offsets, const float* tnodes4, const int* twin, const float* cut_above);
 int fgoicp_bounds_collect(fgoicp_ctx* ctx, int slot, float* lb_out, float* ub_out);
+/* Work items (subcube x chunk of source points) of the submissions that carried thresholds since the last reset, and how many of them
+ * the early exit did not evaluate (measurement: bench.py prices the kernel on the items it evaluated).  Call between submissions. */
+int fgoicp_ctx_cut_stats(fgoicp_ctx* ctx, uint64_t* items_offered, uint64_t* items_cut, int reset);
 
 /* Replaces float Registration::compute_sse_error(glm::mat3 R, glm::vec3 t)
  * (registration.hpp:96, registration.cu:62-86; kernels :14-25, :154-174): exact nearest
@@ -282,6 +297,9 @@ int fgoicp_solver_set_exchange(fgoicp_solver* s, const fgoicp_exchange* ex);
 enum { FGOICP_LOG_INITIAL_ICP = 0, FGOICP_LOG_NEW_BEST = 1 };
 typedef void (*fgoicp_log_fn)(int event, float sse, const float* R9, const float* t3, void* user);
 int fgoicp_solver_set_log(fgoicp_solver* s, fgoicp_log_fn cb, void* user);
+/* on = 1 (default): the inner branch-and-bounds hand their thresholds to the bounds operator (fgoicp_bounds_submit_cut); 0: every
+ * subcube is evaluated in full, as the reference does.  Same trajectory, counters and result either way. */
+int fgoicp_solver_set_early_exit(fgoicp_solver* s, int on);
 /* Replaces FastGoICP::run() (fgoicp.cpp:10-30): returns R and the restored translation
  * (fgoicp.hpp:87-90). */
 int fgoicp_solver_run(fgoicp_solver* s, float* R_out9, float* t_out3);

@@ -47,6 +47,8 @@ def lib():
         L.harness_seconds.argtypes = [C.c_void_p, C.c_int]
         L.harness_seconds.restype = C.c_double
         L.harness_destroy.argtypes = [C.c_void_p]
+        L.harness_set_cut.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.harness_set_cut.restype = None
         L.harness_set_exchange.argtypes = [C.c_void_p, C.c_int, C.c_int, AR, AG]
         L.harness_set_exchange_coop.argtypes = [C.c_void_p, C.c_int, C.c_int, AR, AG, C.c_int]
         L.harness_preproc.argtypes = [C.c_void_p, _fp, _fp, _fp]
@@ -89,6 +91,11 @@ class HostDriver:
         if getattr(self, "_h", None):
             lib().harness_destroy(self._h)
             self._h = None
+
+    def set_cut(self, driver_passes_thresholds=True, oracle_applies_them=False):
+        """Early exit (fgoicp_bounds_submit_cut): whether the tasks' thresholds reach the operator, and whether the oracle operator then
+        answers {T, T} for a row at or above its threshold, as the device does."""
+        lib().harness_set_cut(self._h, int(bool(driver_passes_thresholds)), int(bool(oracle_applies_them)))
 
     def set_exchange(self, rank, world, allreduce_min, allgather, coop=False):
         """coop: cooperative rounds (the driver flow a device all-gather switches on; the CPU backend runs every ICP replicated)"""

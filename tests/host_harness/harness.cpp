@@ -37,6 +37,13 @@ void* harness_create(const float* tgt, size_t nt, const float* src, size_t ns, f
     return harness_create_trim(tgt, nt, src, ns, lut_res, mse_thr, schedule, round_width, 0.0f);
 }
 void harness_destroy(void* p) { delete static_cast<Harness*>(p); }
+// early exit (fgoicp_bounds_submit_cut): does the driver hand its tasks' thresholds to the operator, and does the oracle operator then
+// answer {T, T} for a row at or above its threshold as the device does (it evaluates every row in full either way)
+void harness_set_cut(void* p, int driver_passes_thresholds, int oracle_applies_them) {
+    auto* h = static_cast<Harness*>(p);
+    h->drv->set_use_cut(driver_passes_thresholds != 0);
+    h->ops.apply_cut = oracle_applies_them != 0;
+}
 void harness_set_exchange(void* p, int rank, int world, ar_fn ar, ag_fn ag) {
     Exchange e; e.rank = rank; e.world = world; e.allreduce_min = ar; e.allgather = ag; e.user = nullptr;
     static_cast<Harness*>(p)->drv->set_exchange(e);

@@ -18,8 +18,11 @@ struct OracleOps {
     const orc::Registration* reg = nullptr;
     const orc::PointCloud* pct = nullptr;
     const orc::PointCloud* pcs = nullptr;
+    // cut_above (fgoicp_bounds_submit_cut): the oracle always evaluates every subcube in full; with apply_cut it then reports a row whose
+    // lower bound has reached its group's threshold T as {T, T}, like the device — the driver must not be able to tell (tests/test_host_logic.py)
+    bool apply_cut = false;
     int bounds_multi(int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets, const float* tn4, float* lb,
-                     float* ub) {
+                     float* ub, const float* cut_above = nullptr) {
         for (int g = 0; g < G; ++g) {
             orc::RotNode rn(0, 0, 0, rot_span[g], 0, 0);
             std::memcpy(rn.q.R.c, R9 + 9 * g, sizeof(float) * 9);
@@ -27,6 +30,9 @@ struct OracleOps {
             for (int i = offsets[g]; i < offsets[g + 1]; ++i) tns.emplace_back(tn4[4 * i], tn4[4 * i + 1], tn4[4 * i + 2], tn4[4 * i + 3], 0.f, 0.f);
             auto [l, u] = reg->compute_sse_error(rn, tns, fix_rot[g] != 0);
             for (size_t k = 0; k < tns.size(); ++k) { lb[offsets[g] + k] = l[k]; ub[offsets[g] + k] = u[k]; }
+            if (apply_cut && cut_above)
+                for (size_t k = 0; k < tns.size(); ++k)
+                    if (lb[offsets[g] + k] >= cut_above[g]) lb[offsets[g] + k] = ub[offsets[g] + k] = cut_above[g];
         }
         return 0;
     }
@@ -36,10 +42,10 @@ struct OracleOps {
     bool async() const { return use_async; }
     bool twins() const { return claim_twins; }  // the oracle evaluates every row; claiming twins only switches the driver's memo logic on (schedule 4, 5)
     int bounds_submit(int slot, int G, const float* R9, const float* rot_span, const int* fix_rot, const int* offsets, const float* tn4,
-                      const int* /*twin: a device-side saving, the oracle evaluates every subcube*/) {
+                      const int* /*twin: a device-side saving, the oracle evaluates every subcube*/, const float* cut_above = nullptr) {
         slot_lb[slot].assign(offsets[G], 0.f);
         slot_ub[slot].assign(offsets[G], 0.f);
-        return bounds_multi(G, R9, rot_span, fix_rot, offsets, tn4, slot_lb[slot].data(), slot_ub[slot].data());
+        return bounds_multi(G, R9, rot_span, fix_rot, offsets, tn4, slot_lb[slot].data(), slot_ub[slot].data(), cut_above);
     }
     int bounds_collect(int slot, float* lb, float* ub) {
         std::memcpy(lb, slot_lb[slot].data(), slot_lb[slot].size() * sizeof(float));

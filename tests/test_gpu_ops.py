@@ -744,3 +744,43 @@ def test_serial_look_ahead_changes_no_counter_on_the_device(fg, gpu_required, mo
         s.close()
     a, b = out["0"], out["480"]
     assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3].view(np.uint32) == b[3].view(np.uint32)
+
+
+def test_early_exit_reports_exact_rows_below_the_threshold_and_the_threshold_above(fg, bunny_full):
+    """fgoicp_bounds_submit_cut on the benchmark's clouds (157 work items per subcube): a subcube whose lower bound is below its
+    group's threshold T comes back bit for bit as without thresholds, every other one as {T, T} — the same answer in every repetition,
+    whichever items the kernel happened to skip; +inf and NULL switch the early exit off; twins keep working; the counters say that
+    items were skipped at all."""
+    reg = bunny_full["reg"]
+    rng = np.random.default_rng(77)
+    rn = [fg.RotNode(0.125, -0.25, 0.375, 0.25), fg.RotNode(-0.375, 0.125, 0.25, 0.125), fg.RotNode(0.25, 0.25, -0.125, 0.0625)]
+    groups = [_tnodes(rng, 260, 0.25), _tnodes(rng, 300, 0.25), _tnodes(rng, 200, 0.125), _tnodes(rng, 240, 0.5)]
+    groups[1][40:200] = groups[0][10:170]          # 160 nodes held by the fix_rot group AND the other group of the same rotation
+    Rs = [rn[0].q.R, rn[0].q.R, rn[1].q.R, rn[2].q.R]
+    spans = [rn[0].span, rn[0].span, rn[1].span, rn[2].span]
+    fixes = [True, False, False, True]
+    offs = np.concatenate([[0], np.cumsum([len(g) for g in groups])])
+    twin = np.full(offs[-1], -1, np.int32)
+    for k in range(160):
+        twin[10 + k] = offs[1] + 40 + k
+        twin[offs[1] + 40 + k] = 10 + k
+    exact = reg.compute_bounds_multi(Rs, spans, fixes, groups)
+    assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(exact, reg.compute_bounds_cut(Rs, spans, fixes, groups, None, twin=twin)))
+    cut = np.array([np.median(exact[0][0]), np.quantile(exact[1][0], 0.25), np.inf, np.quantile(exact[3][0], 0.1)], np.float32)
+    reg.cut_stats(reset=True)
+    first = None
+    for rep in range(3):
+        got = reg.compute_bounds_cut(Rs, spans, fixes, groups, cut, twin=twin if rep != 1 else None, slot=rep & 1)
+        for g, ((lb, ub), (lbx, ubx)) in enumerate(zip(got, exact)):
+            below = lbx < cut[g]
+            assert np.array_equal(lb[below], lbx[below]) and np.array_equal(ub[below], ubx[below]), g
+            assert np.all(lb[~below] == cut[g]) and np.all(ub[~below] == cut[g]), g
+        assert not np.isinf(cut[2]) or (np.array_equal(got[2][0], exact[2][0]) and np.array_equal(got[2][1], exact[2][1]))
+        if first is None:
+            first = got
+        assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(first, got))
+    offered, skipped = reg.cut_stats(reset=True)
+    evaluations = 2 * (1000 - 160) + 1000      # two submissions with 160 twin pairs evaluated once, one without the hint
+    assert offered > 0 and offered % evaluations == 0 and offered // evaluations > 16   # (work items per evaluation: chunks of the source cloud)
+    assert 0 < skipped < offered
+    assert reg.cut_stats() == (0, 0)

@@ -145,6 +145,28 @@ def test_twin_task_memo_changes_nothing_a_task_can_see():
     assert [b["stats"][k] for k in KEYS] == list(G[pre + "stats"])  # schedule 5: the oracle's counters
 
 
+@pytest.mark.parametrize("pre", ["runsyn_", "runbun_"])
+def test_early_exit_answers_change_nothing_the_search_can_see(pre):
+    """fgoicp_bounds_submit_cut: every inner branch-and-bound hands the operator the value T above which it does not need a subcube's
+    exact bounds (driver.hpp InnerTask::cut_above: its running best error; 1.8 x the job's best error for the pass whose result feeds
+    the trigger rule), and the device answers {T, T} for such a subcube.  Here the ORACLE operator gives exactly those answers
+    (OracleOps::apply_cut) — under every schedule the run must be the run with exact answers: same counters, same bits.  SERIAL is
+    moreover the golden record of the oracle's literal restatement of fgoicp.cpp, which knows nothing of thresholds."""
+    args = (G[pre + "tgt"], G[pre + "src"], float(G[pre + "res"]), float(G[pre + "mse"]))
+    for sched, K in ((0, 1), (3, 1), (5, 1), (1, 3), (2, 4), (4, 0)):
+        runs = []
+        for passes, applies in ((False, False), (True, True)):
+            h = hh.HostDriver(*args, schedule=sched, round_width=K)
+            h.set_cut(passes, applies)
+            runs.append(h.run())
+        a, b = runs
+        assert np.array_equal(a["R"], b["R"]) and np.array_equal(a["t"], b["t"]) and a["best_sse"] == b["best_sse"], sched
+        assert a["stats"] == b["stats"], sched
+        if sched in (0, 3, 5):
+            assert [b["stats"][k] for k in KEYS] == list(G[pre + "stats"])
+            assert np.array_equal(b["R"], G[pre + "R"]) and np.array_equal(b["t"], G[pre + "t"]) and b["best_sse"] == G[pre + "sse"]
+
+
 def test_serial_speculation_modes_walk_the_same_trajectory(tmp_path):
     """FGOICP_SERIAL_SPECULATE = 0 (literal, one task at a time), 1 (inside the popped node), 2 (across the tops of the queue,
     default): the same pops, counters and result — speculation only changes how many tasks share an operator submission."""

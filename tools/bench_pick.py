@@ -25,4 +25,4 @@ for line in sys.stdin:
             parent = parent[k]
         wall = parent.get("wall_clock_to_optimum_s") if isinstance(parent, dict) else None
         print(json.dumps({"where": path, "wall_s": wall if wall is not None else d.get("wall_clock_to_optimum_s"), "avg_launch_us": round(r["avg_launch_us"], 1), "launches": r["launches"],
-                          "evals_per_launch": round(r["evaluations_per_launch"], 1), "bound": r.get("bound"), "frac": r.get("frac")}))
+                          "evals_per_launch": round(r["evaluations_per_launch"], 1), "bound": r.get("bound"), "frac": r.get("frac"), "work_items_evaluated_frac": r.get("work_items_evaluated_frac")}))

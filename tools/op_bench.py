@@ -1,7 +1,9 @@
 """Operator-level timing of the bounds kernel on a FIXED tick (results do not feed back into a search, so builds that change the
 arithmetic — tools/ablate.sh — stay comparable):  python tools/op_bench.py [workload] [groups] [reps]
 G random rotation nodes (span 0.125) x 32 translation nodes (span 0.0625) scattered within +-0.15 of the ground-truth translation in
-the scaled frame; fix_rot alternates.  Prints ns per evaluation and the algorithmic GB/s of the kernel."""
+the scaled frame; fix_rot alternates.  Prints ns per evaluation and the algorithmic GB/s of the kernel.
+OP_BENCH_CUT=q: the tick goes through fgoicp_bounds_submit_cut with every group's threshold at the q-quantile of its exact lower bounds
+(q = 2: thresholds nothing reaches — the early exit's bookkeeping alone; development build: FGOICP_CUT_PROBE takes it apart)."""
 import json
 import os
 import sys
@@ -30,12 +32,18 @@ while len(nodes) < G:
     groups.append(tn)
     fixes.append(bool(len(nodes) % 2))
 args = ([n.q.R for n in nodes], [n.span for n in nodes], fixes, groups)
-reg.compute_bounds_multi(*args)  # warm-up
-reg.set_profile(True); reg.profile(reset=True)
+exact = reg.compute_bounds_multi(*args)  # warm-up
+q = os.environ.get("OP_BENCH_CUT")
+cut = None
+if q is not None:
+    cut = np.array([1e30 if float(q) > 1 else np.quantile(e[0], float(q)) for e in exact], np.float32)
+reg.set_profile(True); reg.profile(reset=True); reg.cut_stats(reset=True)
 for _ in range(reps):
-    out = reg.compute_bounds_multi(*args)
+    out = reg.compute_bounds_multi(*args) if cut is None else reg.compute_bounds_cut(*args, cut)
 p = reg.profile(reset=True)
+p["work_items"], p["work_items_not_evaluated"] = reg.cut_stats(reset=True)
 ns_eval = p["kernel_ms"] * 1e6 / p["evaluations"]
-print(json.dumps({"workload": wl, "groups": G, "evaluations": p["evaluations"], "launches": p["launches"], "ns_per_evaluation": ns_eval,
+print(json.dumps({"workload": wl, "groups": G, "cut_quantile": q, "probe": os.environ.get("FGOICP_CUT_PROBE"), "work_items": p["work_items"], "not_evaluated": p["work_items_not_evaluated"],
+                  "evaluations": p["evaluations"], "launches": p["launches"], "kernel_us_per_launch": p["kernel_ms"] * 1e3 / p["launches"], "ns_per_evaluation": ns_eval,
                   "algorithmic_GBps": reg.ns * 32.375 / ns_eval, "checksum_ub": float(np.sum([o[1].astype(np.float64).sum() for o in out]))}))
 reg.close()

@@ -1,0 +1,19 @@
+#!/bin/bash
+# What the early exit's own bookkeeping costs (fixed tick, development build): thresholds nothing reaches, parts switched off one by one.
+set -u -o pipefail
+cd "$GRAFT_REPO_ROOT"
+export FGOICP_LIB=$PWD/fast-go-icp_amd/lib/libfgoicp_amd_dev.so
+WL=${1:-bunny}; G=${2:-256}
+OUT=gpurun_out/r04q_cut_cost_$WL.txt
+: > $OUT
+run() { echo "== $*" | tee -a $OUT; env "$@" timeout -k 10 300 python3 tools/op_bench.py $WL $G 5 2>>gpurun_out/r04q.err | tee -a $OUT; }
+run A=exact
+run OP_BENCH_CUT=2
+run OP_BENCH_CUT=2 FGOICP_CUT_PROBE=1
+run OP_BENCH_CUT=2 FGOICP_CUT_PROBE=2
+run OP_BENCH_CUT=2 FGOICP_CUT_PROBE=3
+run OP_BENCH_CUT=2 FGOICP_CUT_PROBE=7
+run OP_BENCH_CUT=0.5
+run OP_BENCH_CUT=0.5 FGOICP_CUT_PROBE=4
+run OP_BENCH_CUT=0.1
+run OP_BENCH_CUT=0.0
