@@ -216,11 +216,11 @@ __device__ __forceinline__ void item_walk(const float4* __restrict__ src, int ns
     }
 }
 
-template <int LAYOUT, int TRIM, bool WIDE, bool QUANT>
+template <int LAYOUT, int TRIM, bool WIDE, bool QUANT, bool SPAN /* several chunks per item: its own instantiation, the loop costs the one-chunk kernel 1-2 % */>
 __global__ __launch_bounds__(64) void bounds_item_kernel(const float4* __restrict__ src, int ns, const char* __restrict__ lutp, LutGeom g,
                                                          const TickGroup* __restrict__ groups, const TickSub* __restrict__ subs, const unsigned* __restrict__ sorted,
                                                          int nchunk, int chunk_pts, double2* __restrict__ partials, float* __restrict__ evals, size_t erow, int samp_shift,
-                                                         unsigned nitems, unsigned* __restrict__ sort_err, TickCut cut) {
+                                                         unsigned nitems, unsigned* __restrict__ sort_err, TickCut cut, int span /* chunks per work item (1: the rule) */) {
     const unsigned slot = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned item = sorted ? sorted[slot] : slot;  // small ticks come unsorted
     // The sort's check, folded into its only consumer.  `sorted` was filled with 0xFFFFFFFF before the scatter and every in-range rank
@@ -232,8 +232,13 @@ __global__ __launch_bounds__(64) void bounds_item_kernel(const float4* __restric
         if (sort_err && threadIdx.x == 0) *sort_err = 1u;
         return;
     }
-    const int s = (int)(item / (unsigned)nchunk);
-    const int chunk = (int)(item - (unsigned)s * (unsigned)nchunk);
+    // A work item is `span` consecutive chunks of one evaluation (one chunk, except in windows with thresholds on sparse clouds: an item
+    // that ends early costs a workgroup dispatch — 0.21 ns each on this chip, profiles/r04_dispatch_rate.txt — and little else, so
+    // such windows take two chunks per wave).  The sums stay per chunk: same partials, same bits, whatever the span.
+    const unsigned per_eval = SPAN ? ((unsigned)nchunk + (unsigned)span - 1u) / (unsigned)span : (unsigned)nchunk;
+    const int s = (int)(item / per_eval);
+    const int chunk0 = (int)(item - (unsigned)s * per_eval) * (SPAN ? span : 1);
+    const int nsub = SPAN ? min(span, nchunk - chunk0) : 1;
     // (read next to the descriptor, not behind it: an item that ends early is three dependent L2 round trips — slot, descriptor + hint, partial)
     const unsigned done_hint = (!TRIM && cut.acc && !(cut.probe & 4)) ? __builtin_nontemporal_load(&cut.done[s]) : 0u;
     const TickSub sb = subs[s];
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(64) void bounds_item_kernel(const float4* __restric
     // on the safe side of the two summation orders (this running sum: finished items in any order; the reported one: the fixed tree).
     bool cutting = false;
     if (!TRIM && cut.acc) {
-        if (chunk == 0 && lane == 0) {
+        if (chunk0 == 0 && lane == 0) {
             cut.row_cut[sb.out0] = sb.cut0;
             if (sb.dual) cut.row_cut[sb.out1] = sb.cut1;
         }
@@ -264,9 +269,9 @@ __global__ __launch_bounds__(64) void bounds_item_kernel(const float4* __restric
                 if (reached && lane == 0) cut.done[s] = 1u;
             }
             if (__builtin_amdgcn_readfirstlane((int)reached)) {
-                if (lane == 0) {  // (the negative upper-bound partial marks the item as not evaluated: bounds_finalize_kernel counts them)
-                    partials[(size_t)sb.out0 * nchunk + chunk] = make_double2(-1.0, (double)sb.cut0);
-                    if (sb.dual) partials[(size_t)sb.out1 * nchunk + chunk] = make_double2(0.0, (double)sb.cut1);
+                if (lane < nsub) {  // (the negative upper-bound partial marks a chunk as not evaluated: bounds_finalize_kernel counts them)
+                    partials[(size_t)sb.out0 * nchunk + chunk0 + lane] = make_double2(-1.0, (double)sb.cut0);
+                    if (sb.dual) partials[(size_t)sb.out1 * nchunk + chunk0 + lane] = make_double2(0.0, (double)sb.cut1);
                 }
                 return;
             }
@@ -279,28 +284,33 @@ __global__ __launch_bounds__(64) void bounds_item_kernel(const float4* __restric
     const ItemGeom G = item_geom(g);
     const float trans_radius = kSqrt3 * sb.span;  // registration.cu:33
     const f2v t_xy = f2v{sb.tx, sb.ty};
-    const int base = chunk * chunk_pts;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
     float* row0 = TRIM ? evals + (size_t)sb.out0 * erow : nullptr;
     float* row1 = TRIM ? evals + (size_t)sb.out1 * erow : nullptr;
-    if (sb.dual) item_walk<LAYOUT, TRIM, WIDE, QUANT, 2>(src, ns, lutp, G, R, t_xy, sb.tz, gr.sin_half, trans_radius, base, chunk_pts, lane, acc, row0, row1, samp_shift);
-    else if (gr.fix_rot) item_walk<LAYOUT, TRIM, WIDE, QUANT, 0>(src, ns, lutp, G, R, t_xy, sb.tz, gr.sin_half, trans_radius, base, chunk_pts, lane, acc, row0, row1, samp_shift);
-    else item_walk<LAYOUT, TRIM, WIDE, QUANT, 1>(src, ns, lutp, G, R, t_xy, sb.tz, gr.sin_half, trans_radius, base, chunk_pts, lane, acc, row0, row1, samp_shift);
-    if (TRIM) return;
-    // the wave tree of block_sum with one wave (bounds_sorted_kernel<64, ...>: same operands, same order), lane 0 writes
-    const double r0 = wave_sum(acc[0]), r1 = wave_sum(acc[1]);
-    if (sb.dual) {
-        const double r2 = wave_sum(acc[2]), r3 = wave_sum(acc[3]);
-        if (lane == 0) {
-            partials[(size_t)sb.out0 * nchunk + chunk] = make_double2(r0, r1);
-            partials[(size_t)sb.out1 * nchunk + chunk] = make_double2(r2, r3);
-            if (cutting && !(cut.probe & 2)) {
-                unsafeAtomicAdd(&cut.acc[2 * (size_t)s], r1);
-                unsafeAtomicAdd(&cut.acc[2 * (size_t)s + 1], r3);
+    double lb_fix = 0.0, lb_rot = 0.0;  // what this item adds to the evaluation's running sums
+    for (int sub = 0; sub < (SPAN ? nsub : 1); ++sub) {
+        const int chunk = chunk0 + sub;
+        const int base = chunk * chunk_pts;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        if (sb.dual) item_walk<LAYOUT, TRIM, WIDE, QUANT, 2>(src, ns, lutp, G, R, t_xy, sb.tz, gr.sin_half, trans_radius, base, chunk_pts, lane, acc, row0, row1, samp_shift);
+        else if (gr.fix_rot) item_walk<LAYOUT, TRIM, WIDE, QUANT, 0>(src, ns, lutp, G, R, t_xy, sb.tz, gr.sin_half, trans_radius, base, chunk_pts, lane, acc, row0, row1, samp_shift);
+        else item_walk<LAYOUT, TRIM, WIDE, QUANT, 1>(src, ns, lutp, G, R, t_xy, sb.tz, gr.sin_half, trans_radius, base, chunk_pts, lane, acc, row0, row1, samp_shift);
+        if (TRIM) continue;
+        // the wave tree of block_sum with one wave (bounds_sorted_kernel<64, ...>: same operands, same order), lane 0 writes
+        const double r0 = wave_sum(acc[0]), r1 = wave_sum(acc[1]);
+        lb_fix += r1;
+        if (sb.dual) {
+            const double r2 = wave_sum(acc[2]), r3 = wave_sum(acc[3]);
+            lb_rot += r3;
+            if (lane == 0) {
+                partials[(size_t)sb.out0 * nchunk + chunk] = make_double2(r0, r1);
+                partials[(size_t)sb.out1 * nchunk + chunk] = make_double2(r2, r3);
             }
+        } else if (lane == 0) {
+            partials[(size_t)sb.out0 * nchunk + chunk] = make_double2(r0, r1);
         }
-    } else if (lane == 0) {
-        partials[(size_t)sb.out0 * nchunk + chunk] = make_double2(r0, r1);
-        if (cutting && !(cut.probe & 2)) unsafeAtomicAdd(&cut.acc[2 * (size_t)s], r1);
+    }
+    if (!TRIM && cutting && lane == 0 && !(cut.probe & 2)) {
+        unsafeAtomicAdd(&cut.acc[2 * (size_t)s], lb_fix);
+        if (sb.dual) unsafeAtomicAdd(&cut.acc[2 * (size_t)s + 1], lb_rot);
     }
 }

@@ -115,7 +115,13 @@ static int tick_launch_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
     // kernel reads the descriptors straight from the pinned staging buffers and takes the items in submission order —
     // two copies and four sort launches fewer on the critical path.  Results do not depend on the item order.
     const int um = sl.win_units > 0 ? c->unit_m : 1;
-    const size_t nitems = (size_t)(neval - sl.win_units * (um - 1)) * c->nchunk1;
+    // windows with thresholds: an item may span several chunks (fewer workgroups to dispatch for the items that end early)
+    int span = sl.win_cut ? c->cut_span : 1;
+#ifdef FGOICP_DEV_KNOBS
+    if (span > 1 && bounds_dev_variant_selected(c->d_lut_zp, c->lut_layout, c->unit_m)) span = 1;  // round 3's kernels take one chunk per item
+#endif
+    const int per_eval = (c->nchunk1 + span - 1) / span;  // work items per evaluation
+    const size_t nitems = (size_t)(neval - sl.win_units * (um - 1)) * (size_t)per_eval;
     const bool small = nitems <= (size_t)c->small_tick_items;
     const TickGroup* dev_groups = small ? sl.hd_groups : sl.d_groups;
     const TickSub* dev_subs = small ? sl.hd_subs : sl.d_subs;
@@ -134,7 +140,7 @@ static int tick_launch_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
         const int fault = c->sort_fault_tick && c->sorted_ticks == (uint64_t)c->sort_fault_tick;
         // FGOICP_SEPARATE_CHECK=1 (development build): the permutation check as round 3's launch behind the scatter instead of inside the bounds kernel
         static const bool separate_check = [] { const char* e = dev_env("FGOICP_SEPARATE_CHECK"); return e && std::atoi(e) != 0; }();
-        launch_tick_sort(c->geom, c->d_chunk_cen, c->nchunk1, sl.d_groups, sl.d_subs, neval, c->cell_shift, sl.d_keys, sl.d_ranks, sl.d_hist, sl.d_hist_xcd, sl.d_xoff, sl.d_block_sums, sl.d_cursor, sl.d_sorted,
+        launch_tick_sort(c->geom, span > 1 ? c->d_span_cen : c->d_chunk_cen, per_eval, sl.d_groups, sl.d_subs, neval, c->cell_shift, sl.d_keys, sl.d_ranks, sl.d_hist, sl.d_hist_xcd, sl.d_xoff, sl.d_block_sums, sl.d_cursor, sl.d_sorted,
                          c->sort_xcd ? 1 : 0, c->sort_check ? 1 : 0, separate_check && c->sort_check ? sl.hd_sort_err : nullptr, fault, sl.sort_stream, sl.win_units, um);
         if (separate_check) fused_err = nullptr;
         HIPCHK(hipEventRecord(sl.sorted_ev, sl.sort_stream));
@@ -161,8 +167,8 @@ static int tick_launch_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
     static const int cut_probe = [] { const char* e = dev_env("FGOICP_CUT_PROBE"); return e ? std::atoi(e) : 0; }();  // measurement of the early exit's own cost (tools/op_bench.py)
     cut.probe = cut_probe;
     const bool cut_on = launch_bounds_sorted(c->d_src, (int)c->ns, c->d_lut, c->d_lut_zp, c->lut_layout, c->geom, c->nchunk1, c->chunk_pts, dev_groups, dev_subs, neval, small ? nullptr : sl.d_sorted,
-                                             sl.d_partials, c->inliers ? sl.d_evals : nullptr, c->erow, c->trim_samp_shift, fused_err, cut, e0, e1, sl.stream, sl.win_units, um);
-    if (cut_on) c->cut_items_offered += nitems;
+                                             sl.d_partials, c->inliers ? sl.d_evals : nullptr, c->erow, c->trim_samp_shift, fused_err, cut, span, e0, e1, sl.stream, sl.win_units, um);
+    if (cut_on) c->cut_items_offered += (size_t)neval * c->nchunk1;  // (counted in chunks, like the skipped ones: bounds_finalize_kernel)
     // the per-subcube sums run on the slot's side stream, so the main stream holds nothing but bounds kernels back to back
     hipStream_t fin = c->finalize_on_side ? sl.sort_stream : sl.stream;
     if (fin != sl.stream) {
@@ -1534,28 +1540,47 @@ static int ctx_create_impl(const float* tgt_xyz, size_t nt, const float* src_xyz
         int maxd = std::max(g.dx, std::max(g.dy, g.dz));
         c->cell_shift = 0;
         while ((maxd >> c->cell_shift) > 32) ++c->cell_shift;  // 5 bits per axis
-        std::vector<float4> cen(2 * (size_t)c->nchunk1);  // [0, nchunk): patch centres; [nchunk, 2 nchunk): patch normals (direction of least variance)
-        for (int k = 0; k < c->nchunk1; ++k) {
-            double sx = 0, sy = 0, sz = 0;
-            const size_t a = (size_t)k * c->chunk_pts, b = std::min(ns, a + (size_t)c->chunk_pts);
-            for (size_t i = a; i < b; ++i) {
-                const float* p = src_xyz + 3 * (size_t)c->perm[i];
-                sx += p[0]; sy += p[1]; sz += p[2];
+        // [0, n): centres of the runs of `pts` consecutive points; [n, 2 n): their normals (direction of least variance)
+        const auto run_centres = [&](size_t pts) {
+            const size_t n = (ns + pts - 1) / pts;
+            std::vector<float4> cen(2 * n);
+            for (size_t k = 0; k < n; ++k) {
+                double sx = 0, sy = 0, sz = 0;
+                const size_t a = k * pts, b = std::min(ns, a + pts);
+                for (size_t i = a; i < b; ++i) {
+                    const float* p = src_xyz + 3 * (size_t)c->perm[i];
+                    sx += p[0]; sy += p[1]; sz += p[2];
+                }
+                const double inv = 1.0 / (double)(b - a);
+                const double m[3] = {sx * inv, sy * inv, sz * inv};
+                cen[k] = make_float4((float)m[0], (float)m[1], (float)m[2], 0.f);
+                double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, U[3][3], S[3], V[3][3];
+                for (size_t i = a; i < b; ++i) {
+                    const float* p = src_xyz + 3 * (size_t)c->perm[i];
+                    const double d[3] = {p[0] - m[0], p[1] - m[1], p[2] - m[2]};
+                    for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) H[r][q] += d[r] * d[q];
+                }
+                svd3_jacobi(H, U, S, V);  // symmetric positive semi-definite: the last column belongs to the smallest eigenvalue
+                cen[n + k] = make_float4((float)V[0][2], (float)V[1][2], (float)V[2][2], 0.f);
             }
-            const double inv = 1.0 / (double)(b - a);
-            const double m[3] = {sx * inv, sy * inv, sz * inv};
-            cen[k] = make_float4((float)m[0], (float)m[1], (float)m[2], 0.f);
-            double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, U[3][3], S[3], V[3][3];
-            for (size_t i = a; i < b; ++i) {
-                const float* p = src_xyz + 3 * (size_t)c->perm[i];
-                const double d[3] = {p[0] - m[0], p[1] - m[1], p[2] - m[2]};
-                for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) H[r][q] += d[r] * d[q];
-            }
-            svd3_jacobi(H, U, S, V);  // symmetric positive semi-definite: the last column belongs to the smallest eigenvalue
-            cen[(size_t)c->nchunk1 + k] = make_float4((float)V[0][2], (float)V[1][2], (float)V[2][2], 0.f);
+            return cen;
+        };
+        {
+            const std::vector<float4> cen = run_centres((size_t)c->chunk_pts);
+            CHK(hipMalloc(&c->d_chunk_cen, sizeof(float4) * cen.size()));
+            CHK(hipMemcpy(c->d_chunk_cen, cen.data(), sizeof(float4) * cen.size(), hipMemcpyHostToDevice));
         }
-        CHK(hipMalloc(&c->d_chunk_cen, sizeof(float4) * cen.size()));
-        CHK(hipMemcpy(c->d_chunk_cen, cen.data(), sizeof(float4) * cen.size(), hipMemcpyHostToDevice));
+        // Windows with thresholds (fgoicp_bounds_submit_cut) on sparse clouds: two chunks per work item.  Half of such a window's items end
+        // after three loads, and what they cost is their workgroup's dispatch (profiles/r04_dispatch_rate.txt); measured on the bunny
+        // shape with the early exit, 256 / 512 / 1024 points per item: 243 / 220 / 245 ms per certify run — while without thresholds
+        // 512 points are 8 % slower than 256 (above).  The sums stay per chunk, so both kinds of window return the same bits.
+        c->cut_span = c->chunk_pts == 256 ? 2 : 1;
+        if (const char* e = dev_env("FGOICP_CUT_SPAN")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) c->cut_span = v; }  // tuning knob
+        if (c->cut_span > 1) {
+            const std::vector<float4> cen = run_centres((size_t)c->chunk_pts * c->cut_span);
+            CHK(hipMalloc(&c->d_span_cen, sizeof(float4) * cen.size()));
+            CHK(hipMemcpy(c->d_span_cen, cen.data(), sizeof(float4) * cen.size(), hipMemcpyHostToDevice));
+        }
         const size_t max_items = (size_t)c->max_subcubes * c->nchunk1;
         for (int k = 0; k < 2; ++k) {
             fgoicp_ctx::TickSlot& sl = c->slots[k];
@@ -1737,6 +1762,7 @@ void fgoicp_ctx_destroy(fgoicp_ctx* c) {
     }
     bvh_free(&c->bvh_tgt);
     (void)hipFree(c->d_chunk_cen);
+    (void)hipFree(c->d_span_cen);
     (void)hipFree(c->d_orig_of_slot);
     for (int k = 0; k < 2; ++k) {
         fgoicp_ctx::TickSlot& sl = c->slots[k];

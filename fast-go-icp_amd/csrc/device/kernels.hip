@@ -2970,6 +2970,13 @@ void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, con
 }
 
 #ifdef FGOICP_DEV_KNOBS
+// development build: does a knob select one of round 3's kernels (which know neither thresholds nor chunk spans) for this context's windows?
+bool bounds_dev_variant_selected(const float2* zp, int layout, int unit_m) {
+    const int lds_rows = [] { const char* e = dev_env("FGOICP_LDS_TILES"); return e ? std::atoi(e) : 0; }();
+    const int item_kernel = [] { const char* e = dev_env("FGOICP_BOUNDS_ITEM"); return e ? std::atoi(e) : 1; }();
+    return lds_rows == 128 || lds_rows == 192 || unit_m > 1 || !item_kernel || dev_env("FGOICP_BOUNDS_VARIANT") || dev_env("FGOICP_ITEMS_PER_WG") || dev_env("FGOICP_NT_SOURCE") ||
+           dev_env("FGOICP_TRIM_VARIANT") || dev_env("FGOICP_QUAD_PAIRED") || dev_env("FGOICP_LDS_PAD") || !zp || layout == 3;
+}
 // Round 3's launch logic with every variant behind its knob; false = nothing launched (the shipped kernel follows).
 static bool launch_bounds_sorted_dev(const float4* src, int ns, const float* lut, const float2* zp, int layout, const LutGeom& g, int nchunk, int chunk_pts,
                                      const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials, float* evals, size_t erow, int samp_shift,
@@ -3075,18 +3082,21 @@ static bool launch_bounds_sorted_dev(const float4* src, int ns, const float* lut
 // sibling units, LDS tiles, several items per workgroup, other thread / point shapes — stay selectable by their knobs (NOTES.md).
 template <int LAYOUT, int TRIM>
 static void launch_item(const float4* src, int ns, const char* lutp, const LutGeom& g, bool wide, const TickGroup* groups, const TickSub* subs, const unsigned* sorted, int nchunk,
-                        int chunk_pts, double2* partials, float* evals, size_t erow, int samp_shift, unsigned nitems, unsigned* sort_err, const TickCut& cut, hipStream_t s) {
+                        int chunk_pts, double2* partials, float* evals, size_t erow, int samp_shift, unsigned nitems, unsigned* sort_err, const TickCut& cut, int span, hipStream_t s) {
     const dim3 grid(nitems), block(64);
-#define FGOICP_ITEM(W, Q) hipLaunchKernelGGL((bounds_item_kernel<LAYOUT, TRIM, W, Q>), grid, block, 0, s, src, ns, lutp, g, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, nitems, sort_err, cut)
-    if (wide) { if (g.quantize) FGOICP_ITEM(true, true); else FGOICP_ITEM(true, false); }
-    else { if (g.quantize) FGOICP_ITEM(false, true); else FGOICP_ITEM(false, false); }
+#define FGOICP_ITEM(W, Q, S) hipLaunchKernelGGL((bounds_item_kernel<LAYOUT, TRIM, W, Q, S>), grid, block, 0, s, src, ns, lutp, g, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, nitems, sort_err, cut, span)
+    if (!TRIM && span > 1) {  // (trimmed windows carry no thresholds, hence no spans)
+        if (wide) { if (g.quantize) FGOICP_ITEM(true, true, !TRIM); else FGOICP_ITEM(true, false, !TRIM); }
+        else { if (g.quantize) FGOICP_ITEM(false, true, !TRIM); else FGOICP_ITEM(false, false, !TRIM); }
+    } else if (wide) { if (g.quantize) FGOICP_ITEM(true, true, false); else FGOICP_ITEM(true, false, false); }
+    else { if (g.quantize) FGOICP_ITEM(false, true, false); else FGOICP_ITEM(false, false, false); }
 #undef FGOICP_ITEM
 }
 
 bool launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* zp, int layout, const LutGeom& g, int nchunk, int chunk_pts,
                           const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials, float* evals, size_t erow, int samp_shift,
-                          unsigned* sort_err, const TickCut& cut, hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s, int nunits, int unit_m) {
-    const size_t nitems = (size_t)(nsub - nunits * (unit_m - 1)) * nchunk;
+                          unsigned* sort_err, const TickCut& cut, int span, hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s, int nunits, int unit_m) {
+    const size_t nitems = (size_t)(nsub - nunits * (unit_m - 1)) * (size_t)((nchunk + span - 1) / span);
     if (ev_start) (void)hipEventRecord(ev_start, s);
     bool done = false, item_kernel = false;
 #ifdef FGOICP_DEV_KNOBS
@@ -3101,13 +3111,13 @@ bool launch_bounds_sorted(const float4* src, int ns, const float* lut, const flo
         const bool wide = (size_t)g.py * g.pz > ((size_t)1 << 23) || bytes + 64 > ((size_t)1 << 32);
         const char* lutp = reinterpret_cast<const char*>(zp);
         if (evals) {
-            if (layout == 1) launch_item<1, 1>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, cut, s);
-            else if (layout == 2) launch_item<3, 1>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, cut, s);
-            else launch_item<5, 1>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, cut, s);
+            if (layout == 1) launch_item<1, 1>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, cut, span, s);
+            else if (layout == 2) launch_item<3, 1>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, cut, span, s);
+            else launch_item<5, 1>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, cut, span, s);
         } else {
-            if (layout == 1) launch_item<1, 0>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, cut, s);
-            else if (layout == 2) launch_item<3, 0>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, cut, s);
-            else launch_item<5, 0>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, cut, s);
+            if (layout == 1) launch_item<1, 0>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, cut, span, s);
+            else if (layout == 2) launch_item<3, 0>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, cut, span, s);
+            else launch_item<5, 0>(src, ns, lutp, g, wide, groups, subs, sorted, nchunk, chunk_pts, partials, evals, erow, samp_shift, (unsigned)nitems, sort_err, cut, span, s);
         }
         done = item_kernel = true;
     }

@@ -88,12 +88,16 @@ void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, con
                       int nunits = 0, int unit_m = 1 /* sibling units: the first nunits * unit_m evaluations form nunits items per chunk (bounds_units_kernel) */);
 // descriptors of a tick: pinned staging (device-visible addresses) -> device arrays, one launch
 void launch_tick_upload(const TickGroup* hd_groups, TickGroup* d_groups, int ngroups, const TickSub* hd_subs, TickSub* d_subs, int nsubs, hipStream_t s);
+#ifdef FGOICP_DEV_KNOBS
+bool bounds_dev_variant_selected(const float2* packed_or_null, int layout, int unit_m);
+#endif
 bool launch_bounds_sorted(const float4* src, int ns, const float* lut, const float2* packed_or_null, int layout /* 1 z-pair, 2 yz-quad */, const LutGeom& g, int nchunk,
                           int chunk_pts /* 256 .. 2048 points per item */, const TickGroup* groups, const TickSub* subs, int nsub, const unsigned* sorted, double2* partials,
                           float* evals_or_null /* trimmed mode: row r = the per-point e = max(d, 0) of output row r */, size_t erow /* floats per row, multiple of 4 */,
                           int samp_shift /* trimmed mode: > 0 = every 2^samp_shift-th point once more in the sample behind the row (offset: ns rounded up to 64 floats) */,
                           unsigned* sort_err /* optional, host-visible: set to 1 unless `sorted` (prefilled, see launch_tick_sort) is a permutation of the items */,
                           const TickCut& cut /* early exit of evaluations whose lower bound has reached its group's cut_above */,
+                          int span /* chunks per work item: `sorted` then orders nsub * ceil(nchunk / span) items (1 unless the item kernel runs: bounds_dev_variant_selected) */,
                           hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t s, int nunits = 0, int unit_m = 1);
 // EXTENSION (trimmed Go-ICP): per output row the sums of ub = e*e and lb = max(e - sqrt3*span, 0)^2 over the row's k smallest e
 // (one exact selection per row, kernels.hip trim_rows_kernel); row_span[r] = translation span of row r (device-readable)
