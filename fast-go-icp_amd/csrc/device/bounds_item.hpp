@@ -221,7 +221,15 @@ __global__ __launch_bounds__(64) void bounds_item_kernel(const float4* __restric
                                                          const TickGroup* __restrict__ groups, const TickSub* __restrict__ subs, const unsigned* __restrict__ sorted,
                                                          int nchunk, int chunk_pts, double2* __restrict__ partials, float* __restrict__ evals, size_t erow, int samp_shift,
                                                          unsigned nitems, unsigned* __restrict__ sort_err, TickCut cut, int span /* chunks per work item (1: the rule) */) {
-    const unsigned slot = xcd_remap(blockIdx.x, gridDim.x);
+    // two tiers (windows with thresholds): workgroups are handed out in the order of their ids, so the first n0 of them take the first tier —
+    // each tier divided among the XCDs in contiguous runs like the whole list otherwise (a bijection either way: both parts are)
+    unsigned slot;
+    if (!TRIM && cut.tier_split && sorted) {
+        const unsigned n0 = min(*cut.tier_split, gridDim.x);
+        slot = blockIdx.x < n0 ? xcd_remap(blockIdx.x, n0) : n0 + xcd_remap(blockIdx.x - n0, gridDim.x - n0);
+    } else {
+        slot = xcd_remap(blockIdx.x, gridDim.x);
+    }
     const unsigned item = sorted ? sorted[slot] : slot;  // small ticks come unsorted
     // The sort's check, folded into its only consumer.  `sorted` was filled with 0xFFFFFFFF before the scatter and every in-range rank
     // is written by exactly the item that drew it, so if no slot still holds an out-of-range value every slot was written, hence written

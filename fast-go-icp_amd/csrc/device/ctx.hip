@@ -121,6 +121,10 @@ static int tick_launch_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
     if (span > 1 && bounds_dev_variant_selected(c->d_lut_zp, c->lut_layout, c->unit_m)) span = 1;  // round 3's kernels take one chunk per item
 #endif
     const int per_eval = (c->nchunk1 + span - 1) / span;  // work items per evaluation
+    bool tiers = sl.win_cut && c->cut_tier_level > 0.0f;   // ... and its items in two tiers, the heavy ones first (launch_tick_sort)
+#ifdef FGOICP_DEV_KNOBS
+    if (tiers && bounds_dev_variant_selected(c->d_lut_zp, c->lut_layout, c->unit_m)) tiers = false;
+#endif
     const size_t nitems = (size_t)(neval - sl.win_units * (um - 1)) * (size_t)per_eval;
     const bool small = nitems <= (size_t)c->small_tick_items;
     const TickGroup* dev_groups = small ? sl.hd_groups : sl.d_groups;
@@ -141,7 +145,8 @@ static int tick_launch_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
         // FGOICP_SEPARATE_CHECK=1 (development build): the permutation check as round 3's launch behind the scatter instead of inside the bounds kernel
         static const bool separate_check = [] { const char* e = dev_env("FGOICP_SEPARATE_CHECK"); return e && std::atoi(e) != 0; }();
         launch_tick_sort(c->geom, span > 1 ? c->d_span_cen : c->d_chunk_cen, per_eval, sl.d_groups, sl.d_subs, neval, c->cell_shift, sl.d_keys, sl.d_ranks, sl.d_hist, sl.d_hist_xcd, sl.d_xoff, sl.d_block_sums, sl.d_cursor, sl.d_sorted,
-                         c->sort_xcd ? 1 : 0, c->sort_check ? 1 : 0, separate_check && c->sort_check ? sl.hd_sort_err : nullptr, fault, sl.sort_stream, sl.win_units, um);
+                         c->sort_xcd ? 1 : 0, c->sort_check ? 1 : 0, separate_check && c->sort_check ? sl.hd_sort_err : nullptr, fault, sl.sort_stream, sl.win_units, um,
+                         tiers ? c->d_lut : nullptr, c->cut_tier_level / (float)c->ns);
         if (separate_check) fused_err = nullptr;
         HIPCHK(hipEventRecord(sl.sorted_ev, sl.sort_stream));
         HIPCHK(hipStreamWaitEvent(sl.stream, sl.sorted_ev, 0));
@@ -164,6 +169,7 @@ static int tick_launch_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
     }
     TickCut cut;  // early exit of evaluations that have reached their group's threshold (fgoicp_bounds_submit_cut)
     if (sl.win_cut) { cut.acc = sl.d_cut_acc; cut.done = sl.d_cut_done; cut.row_cut = sl.d_row_cut; cut.stat = c->d_cut_stat; }
+    if (tiers && !small) cut.tier_split = sl.d_cursor + kTickTierSplit;
     static const int cut_probe = [] { const char* e = dev_env("FGOICP_CUT_PROBE"); return e ? std::atoi(e) : 0; }();  // measurement of the early exit's own cost (tools/op_bench.py)
     cut.probe = cut_probe;
     const bool cut_on = launch_bounds_sorted(c->d_src, (int)c->ns, c->d_lut, c->d_lut_zp, c->lut_layout, c->geom, c->nchunk1, c->chunk_pts, dev_groups, dev_subs, neval, small ? nullptr : sl.d_sorted,
@@ -1575,6 +1581,7 @@ static int ctx_create_impl(const float* tgt_xyz, size_t nt, const float* src_xyz
         // shape with the early exit, 256 / 512 / 1024 points per item: 243 / 220 / 245 ms per certify run — while without thresholds
         // 512 points are 8 % slower than 256 (above).  The sums stay per chunk, so both kinds of window return the same bits.
         c->cut_span = c->chunk_pts == 256 ? 2 : 1;
+        if (const char* e = dev_env("FGOICP_CUT_TIERS")) c->cut_tier_level = (float)std::atof(e);  // tuning knob: 0 = one tier
         if (const char* e = dev_env("FGOICP_CUT_SPAN")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) c->cut_span = v; }  // tuning knob
         if (c->cut_span > 1) {
             const std::vector<float4> cen = run_centres((size_t)c->chunk_pts * c->cut_span);

@@ -94,6 +94,7 @@ struct fgoicp_ctx {
     size_t coop_split_trim_min = 262144;     // ... trimmed contexts split from this size on: a trimmed iteration is long (1.5 ms at 1M points, 85 % of it the walk) and splitting pays — 8-rank replay of the 1M trimmed run 1.84x -> 2.69x (2.45x with the 632 gathers charged)
     bool icp_seeding = true;                 // ICP passes seed their exact NN search with the previous pass's correspondences
     float4* d_chunk_cen = nullptr;           // centroid of every chunk (source frame)
+    float cut_tier_level = 0.5f;             // windows with thresholds: items whose per-point term at the patch centre reaches this multiple of T / ns go first (0: one tier)
     int cut_span = 1;                        // chunks per work item in windows with thresholds (2 on sparse clouds: see bounds_item_kernel)
     float4* d_span_cen = nullptr;            // centroid of every run of cut_span chunks
     TickSlot slots[2];

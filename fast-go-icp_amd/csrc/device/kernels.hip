@@ -401,7 +401,8 @@ __global__ __launch_bounds__(64) void tick_keys_kernel(const float4* __restrict_
                                                            unsigned short* __restrict__ keys, unsigned* __restrict__ ranks, unsigned* __restrict__ hist,
                                                            unsigned* __restrict__ prefill /* optional: `sorted`, filled with 0xFFFFFFFF for the permutation check of the bounds kernel */,
                                                            int nunits, int unit_m /* sibling units: the first nunits * unit_m evaluations, unit_m per item */,
-                                                           int orient /* experimental: 1 = 12-bit cell index + 3 bits of the rotated patch normal (chunk_cen[nchunk + c]) */) {
+                                                           int orient /* experimental: 1 = 12-bit cell index + 3 bits of the rotated patch normal (chunk_cen[nchunk + c]) */,
+                                                           const float* __restrict__ tier_lut /* windows with thresholds: the plain LUT; nullptr = one tier */, float tier_level) {
     const size_t unit_items = (size_t)nunits * nchunk;
     const size_t nitems = unit_items + (size_t)(nsub - nunits * unit_m) * nchunk;
     for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < nitems; i += (size_t)gridDim.x * 64) {
@@ -440,6 +441,23 @@ __global__ __launch_bounds__(64) void tick_keys_kernel(const float4* __restrict_
             if (nz < 0.0f) { nx = -nx; ny = -ny; }
             const unsigned oc = (nx >= 0.0f ? 1u : 0u) | (ny >= 0.0f ? 2u : 0u) | (nz * nz > 0.5f ? 4u : 0u);
             key = (hilbert15((unsigned)vx >> 1, (unsigned)vy >> 1, (unsigned)vz >> 1) << 3) | oc;
+        }
+        if (tier_lut) {
+            // Windows with thresholds (fgoicp_bounds_submit_cut): an evaluation is over as soon as the lower-bound sums of its finished items
+            // reach its threshold T, so the items likely to carry much of the sum go FIRST (tier 0: the top key bit clear; inside a tier the
+            // Hilbert order at half the cell resolution).  The guess: the bound's per-point term at the patch centre, from the nearest LUT
+            // node, against the level a point contributes on average when the sum is T — tier_level * T / ns.  Only the order depends
+            // on it; a wrong guess costs time, never a bit.
+            const int ix = (int)fminf(fmaxf((rx + sb.tx + g.off_x) * g.scale, 0.0f), (float)(g.dx - 1));
+            const int iy = (int)fminf(fmaxf((ry + sb.ty + g.off_y) * g.scale, 0.0f), (float)(g.dy - 1));
+            const int iz = (int)fminf(fmaxf((rz + sb.tz + g.off_z) * g.scale, 0.0f), (float)(g.dz - 1));
+            const float d = sqrtf(tier_lut[((size_t)(iz + 1) * g.py + (size_t)(iy + 1)) * g.px + (size_t)(ix + 1)]);
+            const float e_fix = fmaxf(d - kSqrt3 * sb.span, 0.0f);
+            const float e_rot = fmaxf(d - kSqrt3 * sb.span - 2.0f * gr.sin_half * sqrtf(cc.x * cc.x + cc.y * cc.y + cc.z * cc.z), 0.0f);
+            bool heavy;
+            if (sb.dual) heavy = e_fix * e_fix >= tier_level * sb.cut0 && e_rot * e_rot >= tier_level * sb.cut1;
+            else heavy = (gr.fix_rot ? e_fix * e_fix : e_rot * e_rot) >= tier_level * sb.cut0;
+            key = (key >> 1) | (heavy ? 0u : 1u << 14);
         }
         keys[i] = (unsigned short)key;
         if (XCD) {
@@ -2927,7 +2945,7 @@ void launch_bounds(const float4* src, int ns, const float* lut, const LutGeom& g
 // The locality sort of one tick (descriptors must already be on the device): keys + histogram, scan, scatter.
 void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, const TickGroup* groups, const TickSub* subs, int nsub, int cell_shift,
                       unsigned short* keys, unsigned* ranks, unsigned* hist, unsigned* hist_xcd, unsigned* xoff, unsigned* block_sums, unsigned* cursor, unsigned* sorted,
-                      int allow_xcd, int prefill, unsigned* check_err, int inject_fault, hipStream_t s, int nunits, int unit_m) {
+                      int allow_xcd, int prefill, unsigned* check_err, int inject_fault, hipStream_t s, int nunits, int unit_m, const float* tier_lut, float tier_level) {
     const size_t nitems = (size_t)(nsub - nunits * (unit_m - 1)) * nchunk;
     const unsigned kb = (unsigned)std::min<size_t>((nitems + 63) / 64, 8192);  // `hist` / `hist_xcd` are zero here: the scan / fold kernels re-zero them
 #ifdef FGOICP_DEV_KNOBS
@@ -2944,17 +2962,17 @@ void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, con
         ;  // allow_xcd: per context, cleared by a failed permutation check
     if (xcd) {
 #ifdef FGOICP_DEV_KNOBS
-        if (!hilbert) hipLaunchKernelGGL((tick_keys_kernel<0, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd, prefill ? sorted : nullptr, nunits, unit_m, orient);
+        if (!hilbert) hipLaunchKernelGGL((tick_keys_kernel<0, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd, prefill ? sorted : nullptr, nunits, unit_m, orient, tier_lut, tier_level);
         else
 #endif
-        hipLaunchKernelGGL((tick_keys_kernel<1, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd, prefill ? sorted : nullptr, nunits, unit_m, orient);
+        hipLaunchKernelGGL((tick_keys_kernel<1, 1>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist_xcd, prefill ? sorted : nullptr, nunits, unit_m, orient, tier_lut, tier_level);
         hipLaunchKernelGGL(tick_fold_sums_kernel, dim3(kScanBlocks), dim3(64), 0, s, hist_xcd, xoff, hist, block_sums);
     } else {
 #ifdef FGOICP_DEV_KNOBS
-        if (!hilbert) hipLaunchKernelGGL((tick_keys_kernel<0, 0>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist, prefill ? sorted : nullptr, nunits, unit_m, orient);
+        if (!hilbert) hipLaunchKernelGGL((tick_keys_kernel<0, 0>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist, prefill ? sorted : nullptr, nunits, unit_m, orient, tier_lut, tier_level);
         else
 #endif
-        hipLaunchKernelGGL((tick_keys_kernel<1, 0>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist, prefill ? sorted : nullptr, nunits, unit_m, orient);
+        hipLaunchKernelGGL((tick_keys_kernel<1, 0>), dim3(kb), dim3(64), 0, s, chunk_cen, nchunk, groups, subs, nsub, g, cell_shift, keys, ranks, hist, prefill ? sorted : nullptr, nunits, unit_m, orient, tier_lut, tier_level);
     }
     if (!xcd) hipLaunchKernelGGL(tick_scan_sums_kernel, dim3(kScanBlocks), dim3(64), 0, s, hist, block_sums);
     hipLaunchKernelGGL(tick_scan_apply_kernel, dim3(kScanBlocks), dim3(64), 0, s, hist, block_sums, cursor);

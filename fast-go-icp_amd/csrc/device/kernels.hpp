@@ -75,6 +75,7 @@ struct TickCut {
     unsigned* done = nullptr;             // per evaluation: 1 = an item has seen the running sums at their thresholds (a cached hint, zero between windows)
     float* row_cut = nullptr;
     unsigned long long* stat = nullptr;   // [kCutStatSlots]
+    const unsigned* tier_split = nullptr; // items of the first tier of `sorted` (launch_tick_sort with tier_lut): the grid walks them before the others
     int probe = 0;                        // development build, FGOICP_CUT_PROBE: 1 = the running sums are not read (nothing is ever cut), 2 = not added to, 4 = no `done` hint
 };
 constexpr int kTickNumKeys = 1 << 15;
@@ -85,7 +86,11 @@ void launch_tick_sort(const LutGeom& g, const float4* chunk_cen, int nchunk, con
                       int allow_xcd /* 0: device-scope histogram atomics */, int prefill /* 1: `sorted` is filled with 0xFFFFFFFF first, for the permutation check in launch_bounds_sorted */,
                       unsigned* check_err /* development build, A/B only: the check as a launch of its own behind the scatter */,
                       int inject_fault /* test hook */, hipStream_t s,
-                      int nunits = 0, int unit_m = 1 /* sibling units: the first nunits * unit_m evaluations form nunits items per chunk (bounds_units_kernel) */);
+                      int nunits = 0, int unit_m = 1 /* sibling units: the first nunits * unit_m evaluations form nunits items per chunk (bounds_units_kernel) */,
+                      const float* tier_lut = nullptr /* windows with thresholds: the plain LUT — items likely to carry much of their evaluation's lower bound are sorted
+                                                         in front of the others (two tiers; cursor[kTickTierSplit] = items of the first) */,
+                      float tier_level = 0.0f /* ... those whose per-point term at the patch centre reaches tier_level * T */);
+constexpr int kTickTierSplit = 1 << 14;
 // descriptors of a tick: pinned staging (device-visible addresses) -> device arrays, one launch
 void launch_tick_upload(const TickGroup* hd_groups, TickGroup* d_groups, int ngroups, const TickSub* hd_subs, TickSub* d_subs, int nsubs, hipStream_t s);
 #ifdef FGOICP_DEV_KNOBS
