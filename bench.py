@@ -201,6 +201,9 @@ def run_leg(env, fg, tgt, src, res, mse, sched, K, steps, warmup, trim=0.0, earl
     sums, maxes = env.sum_max([sub, elapsed])
     if stats is not None and steps > 1:  # ICP figures over all timed steps (stats() describes the last run only)
         stats = dict(stats)
+    info = reg.info()
+    prof["chunks_per_evaluation"] = info["items_per_evaluation"]
+    prof["chunks_per_work_item"] = info["chunks_per_item_with_thresholds"] if (early_exit and not env.no_early_exit and trim == 0.0) else 1
     out = dict(solver=solver, reg=reg, R=R, t=t, stats=stats, prof=prof, elapsed=maxes[1], subcubes=sums[0], subcubes_rank=sub, steps=steps, setup_s=setup_s, trim=trim,
                best_sse=float(solver.get_best_error()), ns=reg.ns, nt=reg.nt, lut_dims=list(reg.lut_dims()))
     return out
@@ -227,6 +230,7 @@ def roofline(leg, pmc, extra=None):
          "subcubes_per_launch": leg["subcubes_rank"] / launches, "output_rows_per_launch": p["subcubes"] / launches, "algorithmic_bytes_per_evaluation": ub,
          "algorithmic_bytes_per_launch": p["evaluations"] * done_frac * ub / launches,
          "work_items_evaluated_frac": done_frac,
+         "early_exit": bool(offered),
          "subcubes_served_per_evaluation": leg["subcubes_rank"] / max(1.0, float(p["evaluations"])),
          "note": "achieved = algorithmic bytes of the EVALUATIONS (SURVEY 8d unit x evaluations per launch x the fraction of their work items the kernel evaluated: a subcube "
                  "whose lower bound has reached the threshold its inner BnB drops it at is not evaluated further, fgoicp_bounds_submit_cut; counted on the device) / launch duration, "
@@ -235,17 +239,28 @@ def roofline(leg, pmc, extra=None):
                  "its memo) — subcubes_served_per_evaluation; output rows include the memo's look-ahead rows.  `traffic` and everything under `utilisation` are per-launch "
                  "counter figures of separate rocprofv3 --pmc passes of the same deterministic step on this tree (profiles/bench_pmc.json, bench_pmc_extra.json), NOT measured "
                  "in this run; rates derived from them use this run's launch duration"}
+    # the launch against the two floors it is made of when subcubes end early: the evaluated work items at the rate the kernel reaches when it
+    # evaluates everything (the same tree's full-evaluation figure is in the line), and one workgroup dispatch per work item
+    # (tools/calib/dispatch_rate.hip, profiles/r04_dispatch_rate.txt: 0.212 ns per 64-thread workgroup, whatever it does)
+    span = max(1, int(p.get("chunks_per_work_item", 1)))
+    wgs = p["evaluations"] / launches * (-(-int(p.get("chunks_per_evaluation", 0)) // span)) if p.get("chunks_per_evaluation") else None
+    if wgs:
+        r["workgroups_per_launch"] = wgs
+        r["workgroup_dispatch_floor_us"] = wgs * 0.212e-3
     if pmc:
         r["traffic"] = pmc.get("hbm_bytes_per_launch")
         r["traffic_source"] = pmc.get("source")
         r["traffic_read_bytes_per_launch"] = pmc.get("read_bytes_per_launch")
         r["traffic_write_bytes_per_launch"] = pmc.get("write_bytes_per_launch")
         r["l2_hit_rate"] = pmc.get("l2_hit_rate")
-        if pmc.get("hbm_bytes_per_launch"):  # the passes run the same deterministic step: bytes per launch carry over, durations are this run's
+        if pmc.get("hbm_bytes_per_launch"):  # the passes run the same step on the same tree: bytes per launch carry over, durations are this run's
             act = pmc["hbm_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9
-            r["hbm_actual_GBps"] = act
-            r["hbm_actual_frac"] = act / HBM_PEAK_GBS
-            r["traffic_over_algorithmic"] = pmc["hbm_bytes_per_launch"] / r["algorithmic_bytes_per_launch"]
+            if act <= HBM_PEAK_GBS:
+                r["hbm_actual_GBps"] = act
+                r["hbm_actual_frac"] = act / HBM_PEAK_GBS
+                r["traffic_over_algorithmic"] = pmc["hbm_bytes_per_launch"] / r["algorithmic_bytes_per_launch"]
+            else:  # bytes of a slower kernel over this one's duration: the counter file is of another tree — no rate is derived from it
+                r["traffic_stale"] = "profiles/bench_pmc.json was recorded on a tree whose launches move more bytes than this run's duration allows: re-run tools/gpu_profile.sh"
         if pmc.get("limited_by"):
             r["limited_by"] = pmc["limited_by"]
     if extra:
@@ -268,13 +283,13 @@ def utilisation(r, x):
         ach = x["valu_insts_per_launch"] / dur / 1e9
         u["valu"] = {"achieved": ach, "peak": VALU_PEAK_GINST, "unit": "G wave64 VALU instructions/s", "frac": ach / VALU_PEAK_GINST,
                      "frac_cycle_based": x.get("valu_issue_utilisation"), "insts_per_launch": x["valu_insts_per_launch"],
-                     "insts_per_point_evaluation": x["valu_insts_per_launch"] * 64.0 / (r["evaluations_per_launch"] * r["algorithmic_bytes_per_evaluation"] / 32.375)}
+                     "insts_per_point_evaluation": x["valu_insts_per_launch"] * 64.0 / (r["evaluations_per_launch"] * r.get("work_items_evaluated_frac", 1.0) * r["algorithmic_bytes_per_evaluation"] / 32.375)}
     for k in ("l1_hit_rate", "l1_miss_latency_cycles", "l1_pending_stall_frac", "l1_accesses_per_clock_cu", "ta_busy_frac", "ta_addr_stalled_frac", "ta_data_stalled_frac", "wave_wait_frac",
               "wave_issue_stall_frac"):
         if x.get(k) is not None:
             u[k] = x[k]
     if x.get("l1_accesses_per_launch"):
-        u["l1_accesses_per_point_evaluation"] = x["l1_accesses_per_launch"] / (r["evaluations_per_launch"] * r["algorithmic_bytes_per_evaluation"] / 32.375)
+        u["l1_accesses_per_point_evaluation"] = x["l1_accesses_per_launch"] / (r["evaluations_per_launch"] * r.get("work_items_evaluated_frac", 1.0) * r["algorithmic_bytes_per_evaluation"] / 32.375)
     r["utilisation"] = u
     # every candidate is a fraction of something that cannot exceed 1: HBM bytes moved / peak, VALU issue cycles / cycles, texture-addresser busy cycles / cycles,
     # L1 cache-line accesses per clock and CU (the TCP looks up one line per clock)
@@ -421,12 +436,18 @@ def main():
         utilisation(line["roofline"], pmc_extra.get("headline"))
         u = line["roofline"].get("utilisation") or {}
         if u.get("valu"):  # the counters of THIS kernel build (profiles/bench_pmc_extra.json [headline]), not a remembered figure
-            line["roofline"]["limited_by"] = (
-                f"L1-miss concurrency x L2 latency and VALU issue, not HBM bytes (counters of this kernel, profiles/bench_pmc_extra.json [headline]: L1 hit rate "
-                f"{100 * u.get('l1_hit_rate', 0):.0f} %, the L1 in pending-stall {100 * u.get('l1_pending_stall_frac', 0):.0f} % of its cycles, {u.get('l1_miss_latency_cycles', 0):.0f} cycles per L1 miss, "
-                f"VALU issue {100 * (u['valu'].get('frac_cycle_based') or u['valu']['frac']):.0f} %, measured HBM traffic {100 * (line['roofline'].get('hbm_actual_frac') or 0):.0f} % of the peak); round 2: a build whose "
-                "gathers all hit on chip ran 1.71x faster (profiles/r02_ablation_fixed_tick.txt), the plain LUT that fits the Infinity Cache moved 37 % fewer bytes and was 1.58x slower "
-                "(profiles/r03_ab_lut_layout_final_ticks.txt); round 3: the k-d order of the source cloud cut the traffic by a third and the launch by 9 % (profiles/r03_ab_kd_order.txt)")
+            r = line["roofline"]
+            fe = (line.get("full_evaluation") or {}).get("roofline") or {}
+            floors = ""
+            if fe.get("avg_launch_us") and r.get("workgroup_dispatch_floor_us"):
+                floors = (f"; a launch = {r['avg_launch_us']:.0f} us against {r['work_items_evaluated_frac'] * fe['avg_launch_us']:.0f} us for the evaluated work items at the full-evaluation "
+                          f"kernel's rate (this run: {fe['avg_launch_us']:.0f} us, {fe['frac']:.2f} of the HBM roof) and a floor of {r['workgroup_dispatch_floor_us']:.0f} us for dispatching its "
+                          f"{r['workgroups_per_launch']:.0f} workgroups — the ones that end early cost little else")
+            r["limited_by"] = (
+                f"evaluated work items: L1-miss concurrency x L2 latency, as without the early exit; items that end early: the workgroup dispatch rate (counters of this kernel, "
+                f"profiles/bench_pmc_extra.json [headline]: L1 hit rate {100 * u.get('l1_hit_rate', 0):.0f} %, the L1 in pending-stall {100 * u.get('l1_pending_stall_frac', 0):.0f} % of its cycles, "
+                f"{u.get('l1_miss_latency_cycles', 0):.0f} cycles per L1 miss, VALU issue {100 * (u['valu'].get('frac_cycle_based') or u['valu']['frac']):.0f} %, TA busy {100 * (u.get('ta_busy_frac') or 0):.0f} %, "
+                f"measured HBM traffic {100 * (r.get('hbm_actual_frac') or 0):.0f} % of the peak){floors}")
 
     # BASELINE.md's parameters (mse_threshold 1e-3) on the same clouds
     dflt = None

@@ -12,7 +12,7 @@ c_int_p = C.POINTER(C.c_int)
 class CtxInfo(C.Structure):
     _fields_ = [("struct_size", C.c_size_t), ("lut_dims", C.c_int * 3), ("lut_layout", C.c_int), ("lut_nodes", C.c_uint64), ("lut_bytes", C.c_uint64),
                 ("source_points_per_face_voxel", C.c_double), ("points_per_item", C.c_int), ("items_per_evaluation", C.c_int),
-                ("max_subcubes_per_window", C.c_int), ("source_order", C.c_int), ("tree_order", C.c_int)]
+                ("max_subcubes_per_window", C.c_int), ("source_order", C.c_int), ("tree_order", C.c_int), ("chunks_per_item_with_thresholds", C.c_int)]
 
 
 class CloudStats(C.Structure):

@@ -1828,6 +1828,7 @@ int fgoicp_ctx_get_info(const fgoicp_ctx* c, fgoicp_ctx_info* out) {
     out->max_subcubes_per_window = c->max_subcubes;
     out->source_order = c->source_order;
     out->tree_order = c->tree_order;
+    out->chunks_per_item_with_thresholds = c->cut_span;
     full.struct_size = caller < sizeof(full) ? caller : sizeof(full);
     std::memcpy(user_out, &full, full.struct_size);
     return FGOICP_OK;

@@ -92,7 +92,7 @@ class Registration:
         return dict(lut_dims=tuple(i.lut_dims), lut_layout=i.lut_layout, lut_nodes=i.lut_nodes, lut_bytes=i.lut_bytes,
                     source_points_per_face_voxel=i.source_points_per_face_voxel, points_per_item=i.points_per_item,
                     items_per_evaluation=i.items_per_evaluation, max_subcubes_per_window=i.max_subcubes_per_window,
-                    source_order=i.source_order, tree_order=i.tree_order)
+                    source_order=i.source_order, tree_order=i.tree_order, chunks_per_item_with_thresholds=i.chunks_per_item_with_thresholds)
 
     def lut_read(self):
         dx, dy, dz = self.lut_dims()

@@ -95,6 +95,7 @@ typedef struct fgoicp_ctx_info {
     int max_subcubes_per_window;
     int source_order;            /* order of the source cloud on the device: 0 = caller / Z-order, 1 = Hilbert curve, 2 = k-d cells of 64 points, 3 = density split */
     int tree_order;              /* leaves of the target tree: 1 = k-d cells of 32 points, 0 = runs of the space-filling curve */
+    int chunks_per_item_with_thresholds; /* fgoicp_bounds_submit_cut: a work item of such a submission spans this many chunks of points_per_item points (1 or 2).  Appended within revision 2: a caller built with the shorter struct is served as before (struct_size) */
 } fgoicp_ctx_info;
 int fgoicp_ctx_get_info(const fgoicp_ctx* ctx, fgoicp_ctx_info* out);
 /* n single nodes of the LUT: out[i] = node (x, y, z) = xyz[3i..3i+2] (the value buildLUTKernel, registration.cu:258-278, stores at
