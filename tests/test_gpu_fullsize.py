@@ -398,6 +398,18 @@ def test_tick_sort_is_checked_on_the_device_and_falls_back(fg, tiny_case, gpu_re
     ticks, fb = reg.sort_fallbacks()
     assert ticks >= 3 and fb == 1
     reg.close()
+    # the same with thresholds (fgoicp_bounds_submit_cut: two tiers, running sums, early exits): the repeated window starts from clean sums
+    reg = fg.Registration(c["pct"], c["pcs"], c["bounds"], c["res"])
+    cut = np.array([np.median(lbw) for lbw, _ in want], np.float32)
+    reg.test_sort_fault(2)
+    for rep in range(3):
+        got = reg.compute_bounds_cut(*args, cut)
+        for g, ((lb, ub), (lbw, ubw)) in enumerate(zip(got, want)):
+            below = lbw < cut[g]
+            assert np.array_equal(lb[below], lbw[below]) and np.array_equal(ub[below], ubw[below]) and np.all(lb[~below] == cut[g]) and np.all(ub[~below] == cut[g])
+    ticks, fb = reg.sort_fallbacks()
+    assert ticks >= 3 and fb == 1
+    reg.close()
 
 
 # ------------------------------------------------------------------------------------------------

@@ -99,6 +99,15 @@ def check_case(c):
             lb, ub = out[g]
             scale = max(float(np.abs(ubo).max()), 1e-12)
             assert np.allclose(ub, ubo, rtol=2e-6, atol=1e-6 * scale) and np.allclose(lb, lbo, rtol=2e-6, atol=1e-6 * scale), f"tick bounds, group {g} (fix_rot={fixes[g]})"
+        if not k:  # the same tick with thresholds (fgoicp_bounds_submit_cut): rows below theirs keep every bit, the others report the threshold
+            q = np.random.default_rng(len(Rs) * 7919 + len(src)).uniform(0.0, 1.0, len(Rs))
+            cut = np.array([np.inf if qq > 0.9 else np.quantile(out[g][0], qq) for g, qq in enumerate(q)], f32)
+            for rep in range(2):
+                got = hip.compute_bounds_cut(Rs, spans, fixes, groups, cut, slot=rep)
+                for g in range(len(Rs)):
+                    below = out[g][0] < cut[g]
+                    assert np.array_equal(got[g][0][below], out[g][0][below]) and np.array_equal(got[g][1][below], out[g][1][below]), f"thresholds, group {g}: a row below its threshold changed"
+                    assert np.all(got[g][0][~below] == cut[g]) and np.all(got[g][1][~below] == cut[g]), f"thresholds, group {g}: a row at or above its threshold does not report it"
         rn = fg.RotNode(0.2, -0.1, 0.3, 0.25)
         tn = c["batch_tn"]
         for fix in (True, False):
@@ -173,10 +182,20 @@ def run_case(rng, idx):
             assert float(m.get_best_error(rk)) == e, f"SERIAL on {W} ranks, rank {rk}: sse {m.get_best_error(rk)} vs {e}"
         assert np.array_equal(Rm, R) and np.array_equal(tm, t), f"SERIAL on {W} ranks: transform differs from the one-GPU run's"
         m.close()
-        r = fg.FastGoICP(tgt, src, res, mse, schedule=fg.SCHEDULE_ROUND, round_width=int(rng.choice([0, 1, 3])), trim_fraction=trim)
-        r.run()
-        er = float(r.get_best_error())
+        K = int(rng.choice([0, 1, 3]))
+        r = fg.FastGoICP(tgt, src, res, mse, schedule=fg.SCHEDULE_ROUND, round_width=K, trim_fraction=trim)
+        Rr, tr = r.run()
+        er, str_ = float(r.get_best_error()), r.stats()
         r.close()
+        # ... and with every subcube evaluated in full (fgoicp_solver_set_early_exit(0)): the same run, counter for counter and bit for bit
+        r = fg.FastGoICP(tgt, src, res, mse, schedule=fg.SCHEDULE_ROUND, round_width=K, trim_fraction=trim)
+        r.set_early_exit(False)
+        Rf, tf = r.run()
+        ef, stf = float(r.get_best_error()), r.stats()
+        r.close()
+        assert ef == er and np.array_equal(Rf, Rr) and np.array_equal(tf, tr), f"ROUND with / without the early exit: sse {er} vs {ef}"
+        assert all(int(str_[k]) == int(stf[k]) for k in o["stats"]), "ROUND with / without the early exit: counters differ"
+
         band = mse * (len(src) if not trim else int(len(src) * (1 - trim))) + 2e-3 * e  # epsilon-optimal + ICP stop band
         if not (er <= e + band and e <= er + band):
             # Not a defect by itself: the search is truncated at rotation span 0.05 / translation span 0.1 (fgoicp.cpp:56, :155) and
