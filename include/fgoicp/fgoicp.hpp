@@ -35,6 +35,9 @@ public:
     Result_t get_best_transform() const { mat3 R; vec3 t; check_status(fgoicp_solver_best_transform(s_, R.data(), &t.x), "fgoicp_solver_best_transform"); return {R, t}; }
     Result_t get_last_transform() const { mat3 R; vec3 t; check_status(fgoicp_solver_last_transform(s_, R.data(), &t.x), "fgoicp_solver_last_transform"); return {R, t}; }
 
+    // not in the reference: false = every subcube is evaluated in full, as kernComputeBounds does (default: the inner BnBs tell the bounds
+    // operator what they do not need to know, fgoicp_bounds_submit_cut — same trajectory, counters and result)
+    void set_early_exit(bool on) { check_status(fgoicp_solver_set_early_exit(s_, on ? 1 : 0), "fgoicp_solver_set_early_exit"); }
     fgoicp_run_stats stats() const { fgoicp_run_stats st{}; check_status(fgoicp_solver_stats(s_, &st), "fgoicp_solver_stats"); return st; }
     fgoicp_solver* handle() const { return s_; }
     // the reference's own lines while the search runs (fgoicp.cpp:15-17 Info, :85-87 Debug), from the driver's log events
