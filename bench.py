@@ -433,6 +433,16 @@ def main():
                 "same_incumbent_bits_as_headline": bool(np.array_equal(full["R"], head["R"]) and np.array_equal(full["t"], head["t"]) and full["best_sse"] == head["best_sse"]),
                 "roofline": None if rf is None else {k: rf[k] for k in ("achieved", "peak", "unit", "frac", "avg_launch_us", "launches", "evaluations_per_launch", "work_items_evaluated_frac")}}
             full["solver"].close()
+            line["value_every_subcube_evaluated_in_full"] = line["full_evaluation"]["value"]
+        line["early_exit"] = {
+            "on": bool(line["roofline"] and line["roofline"].get("early_exit")),
+            "what": "`value` is measured with the library's default: every inner branch-and-bound tells the bounds kernel the value above which it drops a subcube whatever its exact "
+                    "bounds are (fgoicp.cpp:151; the results it passes on are only ever compared: :74, :92), and the kernel stops evaluating a subcube once the lower-bound sums "
+                    "(all terms >= 0) of its finished work items have reached that value.  No subcube is skipped and none is answered approximately where the search looks: "
+                    "trajectory, counters and incumbent are those of the full evaluation, bit for bit (checked in this run: full_evaluation.same_counters_as_headline / "
+                    "same_incumbent_bits_as_headline; tests/test_host_logic.py, tests/test_gpu_fullsize.py).  `value_every_subcube_evaluated_in_full` is the same run with "
+                    "fgoicp_solver_set_early_exit(0), as the reference's kernComputeBounds evaluates; `roofline` prices the kernel on the work items it evaluated.",
+            "work_items_evaluated_frac": line["roofline"].get("work_items_evaluated_frac") if line["roofline"] else None}
         utilisation(line["roofline"], pmc_extra.get("headline"))
         u = line["roofline"].get("utilisation") or {}
         if u.get("valu"):  # the counters of THIS kernel build (profiles/bench_pmc_extra.json [headline]), not a remembered figure
