@@ -336,6 +336,42 @@ static int tick_wait_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
         HIPCHK(hipEventSynchronize(sl.done));
         if (*sl.h_sort_err) { set_error("tick sort did not produce a permutation of the work items (device-scope atomics)"); return FGOICP_ERR_HIP; }
     }
+#ifdef FGOICP_DEV_KNOBS
+    // FGOICP_CUT_VERIFY=1 (development build): every window that carried thresholds is evaluated once more WITHOUT them and each row is checked against
+    // the contract of fgoicp_bounds_submit_cut — at or above its threshold T in the exact evaluation: {T, T} was reported; below: the exact bits.
+    // The answers handed on are the first run's, so the search goes on as it would; the tally is printed when the context is destroyed.
+    static const bool cut_verify = [] { const char* e = dev_env("FGOICP_CUT_VERIFY"); return e && std::atoi(e) != 0; }();
+    if (cut_verify && sl.win_cut) {
+        const int rows = sl.win_rows;
+        std::vector<float> lb(sl.h_lb, sl.h_lb + rows), ub(sl.h_ub, sl.h_ub + rows);
+        sl.win_cut = false;
+        int rc = tick_launch_window(c, sl);
+        sl.win_cut = true;
+        if (rc) return rc;
+        HIPCHK(hipEventSynchronize(sl.done));
+        if (*sl.h_sort_err) { set_error("FGOICP_CUT_VERIFY: the repeated window's sort failed"); return FGOICP_ERR_HIP; }
+        for (int e = 0; e < sl.win_evals; ++e) {
+            const TickSub& ts = sl.h_subs[e];
+            for (int v = 0; v < (ts.dual ? 2 : 1); ++v) {
+                const int r = v ? ts.out1 : ts.out0;
+                const float T = v ? ts.cut1 : ts.cut0;
+                const bool above = sl.h_lb[r] >= T;
+                const bool ok = above ? (lb[(size_t)r] == T && ub[(size_t)r] == T)
+                                      : (std::memcmp(&lb[(size_t)r], &sl.h_lb[r], 4) == 0 && std::memcmp(&ub[(size_t)r], &sl.h_ub[r], 4) == 0);
+                c->cut_verify_rows++;
+                c->cut_verify_above += above ? 1 : 0;
+                if (!ok) {
+                    if (c->cut_verify_bad++ < 5)
+                        std::fprintf(stderr, "[fgoicp cut verify] row %d: threshold %.9g, exact {%.9g, %.9g}, reported {%.9g, %.9g}\n", r, (double)T, (double)sl.h_lb[r], (double)sl.h_ub[r],
+                                     (double)lb[(size_t)r], (double)ub[(size_t)r]);
+                }
+            }
+        }
+        c->cut_verify_windows++;
+        std::memcpy(sl.h_lb, lb.data(), sizeof(float) * rows);
+        std::memcpy(sl.h_ub, ub.data(), sizeof(float) * rows);
+    }
+#endif
     const double t3 = g_tt.on ? now_s() : 0;
     std::memcpy(sl.lb.data() + sl.win_pos, sl.h_lb, sizeof(float) * sl.win_rows);
     std::memcpy(sl.ub.data() + sl.win_pos, sl.h_ub, sizeof(float) * sl.win_rows);
@@ -1724,6 +1760,9 @@ static int ctx_create_impl(const float* tgt_xyz, size_t nt, const float* src_xyz
 
 void fgoicp_ctx_destroy(fgoicp_ctx* c) {
     if (!c) return;
+    if (c->cut_verify_windows)
+        std::fprintf(stderr, "[fgoicp cut verify] %llu windows with thresholds evaluated again without them: %llu rows, %llu of them at or above their threshold, %llu violations of the contract\n",
+                     (unsigned long long)c->cut_verify_windows, (unsigned long long)c->cut_verify_rows, (unsigned long long)c->cut_verify_above, (unsigned long long)c->cut_verify_bad);
     if (g_tt.on && g_tt.ticks) {
         std::fprintf(stderr, "[fgoicp timing] ticks %llu: pack %.1f us, enqueue %.1f us, wait %.1f us, copyout %.1f us per tick\n", (unsigned long long)g_tt.ticks,
                      1e6 * g_tt.pack / g_tt.ticks, 1e6 * g_tt.enqueue / g_tt.ticks, 1e6 * g_tt.wait / g_tt.ticks, 1e6 * g_tt.copyout / g_tt.ticks);

@@ -76,6 +76,7 @@ struct fgoicp_ctx {
     };
     unsigned long long* d_cut_stat = nullptr;    // items the early exit did not evaluate, since creation (device counter)
     uint64_t cut_items_offered = 0;              // items of the windows submitted with thresholds
+    uint64_t cut_verify_windows = 0, cut_verify_rows = 0, cut_verify_above = 0, cut_verify_bad = 0;  // development build, FGOICP_CUT_VERIFY
     uint64_t cut_stat_base = 0;                  // value of *d_cut_stat at the last reset
     bool sorted_bounds = true;
     bool sort_xcd = true;                    // XCD-private histograms for the tick sort (cleared for good if a permutation check fails)

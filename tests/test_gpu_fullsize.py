@@ -370,6 +370,25 @@ def test_early_exit_leaves_the_search_alone_on_the_benchmark_run(fg, gpu_require
     assert ang_deg(R1, R_gt) < 0.5
 
 
+def test_every_window_with_thresholds_keeps_the_contract(fg, gpu_required, monkeypatch, capfd):
+    """Development build, FGOICP_CUT_VERIFY=1: every window of a certify run that carried thresholds is evaluated once more without them, and
+    every row is checked — at or above its threshold T in the exact evaluation: {T, T} was reported; below: the exact bits (ctx.hip
+    tick_wait_window).  (profiles/r04_early_exit_contract_verified.txt: the four benchmark runs, 6.8 M rows, 0 violations.)"""
+    import re
+    monkeypatch.setenv("FGOICP_CUT_VERIFY", "1")
+    tgt, src, R_gt, t_gt = fg.synth.workload("small", angle_deg=150.0, min_angle_deg=110.0)
+    for sched, K in ((fg.SCHEDULE_SERIAL, 1), (fg.SCHEDULE_ROUND, 0)):
+        s = fg.FastGoICP(tgt, src, 0.02, 2e-5, schedule=sched, round_width=K)
+        s.run()
+        assert s.stats()["trans_cubes"] > 1000
+        s.close()
+        err = capfd.readouterr().err
+        m = re.search(r"cut verify\] (\d+) windows .*: (\d+) rows, (\d+) of them at or above their threshold, (\d+) violations", err)
+        assert m, err[-400:]
+        windows, rows, above, bad = map(int, m.groups())
+        assert windows > 0 and rows > 1000 and above > 0 and bad == 0
+
+
 # ------------------------------------------------------------------------------------------------
 # the tick sort's permutation check (ADVICE r01, VERDICT r01 #9)
 # ------------------------------------------------------------------------------------------------
