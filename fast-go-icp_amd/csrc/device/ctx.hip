@@ -340,7 +340,7 @@ static int tick_wait_window(fgoicp_ctx* c, fgoicp_ctx::TickSlot& sl) {
     // FGOICP_CUT_VERIFY=1 (development build): every window that carried thresholds is evaluated once more WITHOUT them and each row is checked against
     // the contract of fgoicp_bounds_submit_cut — at or above its threshold T in the exact evaluation: {T, T} was reported; below: the exact bits.
     // The answers handed on are the first run's, so the search goes on as it would; the tally is printed when the context is destroyed.
-    static const bool cut_verify = [] { const char* e = dev_env("FGOICP_CUT_VERIFY"); return e && std::atoi(e) != 0; }();
+    const bool cut_verify = [] { const char* e = dev_env("FGOICP_CUT_VERIFY"); return e && std::atoi(e) != 0; }();  // (read per window: a test toggles it)
     if (cut_verify && sl.win_cut) {
         const int rows = sl.win_rows;
         std::vector<float> lb(sl.h_lb, sl.h_lb + rows), ub(sl.h_ub, sl.h_ub + rows);
