@@ -3,8 +3,8 @@
 // kernComputeBounds + the two reductions (fgoicp/registration.cu:27-60, :126-140): a work item is (evaluation s, chunk c of 256 ... 2048
 // consecutive source points) = ONE wave, four points per lane and pass.  Same per-point fp32 values and the same fp64 sums, in the same
 // order, as round 3's bounds_sorted_kernel<64, 4, ...> (kept in the development build as the A/B and bit reference) — rewritten against
-// the instruction stream, because the dense-cloud leg is bound by VALU issue (profiles/r03_dragon_pmc_extra.json: 120 VALU instructions
-// per point-evaluation at 0.6-0.67 of the issue peak):
+// the instruction stream (120 -> 77 VALU instructions per point-evaluation; the launches did not get shorter for it: the texture
+// addresser / L1 path binds both the sparse and the dense leg):
 //   * everything wave-uniform is read once (rotation, sin, kind of the item: round 3 re-read `sin_half` and `fix_rot` through the scalar
 //     cache for every point — the compiler could not prove that the stores of the kernel do not alias the descriptors);
 //   * the three kinds of item (fix_rot = 1, fix_rot = 0, dual) and "every point of the pass exists" are decided per pass, outside the
@@ -17,6 +17,7 @@
 //     (tools/calib/valu_rate.hip, profiles/r04_valu_rate.txt): a packed instruction issues in the time of TWO plain ones (0.49-0.55 against
 //     0.85-0.94 instructions per SIMD and ns), so packing buys 15-19 % of the packed instructions' issue time, not half of it —
 //     the instruction COUNT falls further than the time does.
+// What did shorten the runs is not evaluating what the search drops anyway: the early exit further down (fgoicp_bounds_submit_cut).
 #pragma once
 
 constexpr float kCutNone = 3.0e38f;       // thresholds at or above this (fgoicp_bounds_submit_cut: +inf) switch the early exit off
