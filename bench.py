@@ -439,9 +439,9 @@ def main():
             "what": "`value` is measured with the library's default: every inner branch-and-bound tells the bounds kernel the value above which it drops a subcube whatever its exact "
                     "bounds are (fgoicp.cpp:151; the results it passes on are only ever compared: :74, :92), and the kernel stops evaluating a subcube once the lower-bound sums "
                     "(all terms >= 0) of its finished work items have reached that value.  No subcube is skipped and none is answered approximately where the search looks: "
-                    "trajectory, counters and incumbent are those of the full evaluation, bit for bit (checked in this run: full_evaluation.same_counters_as_headline / "
-                    "same_incumbent_bits_as_headline; tests/test_host_logic.py, tests/test_gpu_fullsize.py).  `value_every_subcube_evaluated_in_full` is the same run with "
-                    "fgoicp_solver_set_early_exit(0), as the reference's kernComputeBounds evaluates; `roofline` prices the kernel on the work items it evaluated.",
+                    "trajectory, counters and incumbent are those of the full evaluation, bit for bit (tests/test_host_logic.py, tests/test_gpu_fullsize.py; on one GPU also "
+                    "checked in this run: full_evaluation.same_counters_as_headline / same_incumbent_bits_as_headline, with `value_every_subcube_evaluated_in_full` = the same "
+                    "steps under fgoicp_solver_set_early_exit(0), as the reference's kernComputeBounds evaluates).  `roofline` prices the kernel on the work items it evaluated.",
             "work_items_evaluated_frac": line["roofline"].get("work_items_evaluated_frac") if line["roofline"] else None}
         utilisation(line["roofline"], pmc_extra.get("headline"))
         u = line["roofline"].get("utilisation") or {}
